@@ -1,0 +1,122 @@
+"""ctypes binding of libfedm_hip.so (include/fedm_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).
+There is no CPU fallback: a missing library or a missing GPU is an error.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+MAX_SPECIES, MAX_TERMS, MAX_REACTIONS, MAX_TAGS = 4, 6, 8, 8
+MAX_QP, MAX_FQP, MAX_EXT_NODES = 32, 8, 10
+
+EQ_TYPES = {"reaction": 0, "diffusion-reaction": 1, "drift-diffusion-reaction": 2}
+BC_KINDS = {"zero flux": 0, "Neumann": 1}
+DIVERGED = {1: "maximum number of Newton iterations reached",
+            2: "NaN or Inf in the residual", 3: "linear solve (GMRES) did not converge"}
+
+
+class TermSumC(C.Structure):
+    _fields_ = [("n_terms", C.c_int32), ("pad_", C.c_int32),
+                ("c", C.c_double * MAX_TERMS), ("p", C.c_double * MAX_TERMS),
+                ("q", C.c_double * MAX_TERMS), ("r", C.c_double * MAX_TERMS)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("n_species", C.c_int32), ("poisson", C.c_int32), ("axisymmetric", C.c_int32),
+        ("n_reactions", C.c_int32),
+        ("eq_type", C.c_int32 * MAX_SPECIES), ("Z", C.c_double * MAX_SPECIES),
+        ("mu", TermSumC * MAX_SPECIES), ("D", TermSumC * MAX_SPECIES),
+        ("has_drift_w", C.c_int32 * MAX_SPECIES), ("drift_w", (C.c_double * 2) * MAX_SPECIES),
+        ("k", TermSumC * MAX_REACTIONS),
+        ("power", (C.c_int32 * MAX_SPECIES) * MAX_REACTIONS),
+        ("net", (C.c_int32 * MAX_SPECIES) * MAX_REACTIONS),
+        ("charge_over_eps", C.c_double),
+        ("n_tags", C.c_int32),
+        ("bc_kind", (C.c_int32 * MAX_SPECIES) * MAX_TAGS),
+        ("n_qp", C.c_int32), ("n_fqp", C.c_int32),
+        ("qp_x", C.c_double * MAX_QP), ("qp_y", C.c_double * MAX_QP), ("qp_w", C.c_double * MAX_QP),
+        ("fqp_t", C.c_double * MAX_FQP), ("fqp_w", C.c_double * MAX_FQP),
+        ("ext_nodes", C.c_int32 * MAX_SPECIES),
+        ("ext_B", (C.c_double * MAX_EXT_NODES) * MAX_QP),
+    ]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("n_cells", C.c_int32),
+                ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
+                ("facet_tags", C.POINTER(C.c_int8)),
+                ("n_dirichlet", C.c_int32),
+                ("dirichlet_dofs", C.POINTER(C.c_int32)),
+                ("dirichlet_vals", C.POINTER(C.c_double))]
+
+
+class NewtonOpts(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("stol", C.c_double),
+                ("max_it", C.c_int32), ("ksp_restart", C.c_int32),
+                ("ksp_rtol", C.c_double), ("ksp_atol", C.c_double),
+                ("ksp_max_it", C.c_int32), ("pad_", C.c_int32)]
+
+
+class NewtonReport(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
+                ("linear_iterations", C.c_int32), ("reason", C.c_int32),
+                ("fnorm0", C.c_double), ("fnorm", C.c_double)]
+
+
+LIB_PATH = Path(__file__).resolve().parent / "libfedm_hip.so"
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_SIGNATURES = {
+    "fedm_last_error": (C.c_char_p, []),
+    "fedm_abi_version": (C.c_int, []),
+    "fedm_ctx_create": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(ModelDesc), C.c_int, C.POINTER(_P)]),
+    "fedm_ctx_destroy": (None, [_P]),
+    "fedm_set_state": (C.c_int, [_P, _D, _D, _D]),
+    "fedm_get_state": (C.c_int, [_P, _D]),
+    "fedm_shift_state": (C.c_int, [_P]),
+    "fedm_reset_state": (C.c_int, [_P]),
+    "fedm_set_step": (C.c_int, [_P, C.c_double, C.c_double]),
+    "fedm_set_dirichlet_values": (C.c_int, [_P, _D]),
+    "fedm_set_ext_source": (C.c_int, [_P, C.c_int, _D]),
+    "fedm_residual": (C.c_int, [_P, _D, _D]),
+    "fedm_jacobian": (C.c_int, [_P]),
+    "fedm_jacobian_nnz": (C.c_int64, [_P]),
+    "fedm_jacobian_csr": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _D]),
+    "fedm_spmv": (C.c_int, [_P, _D, _D]),
+    "fedm_newton_solve": (C.c_int, [_P, C.POINTER(NewtonOpts), C.POINTER(NewtonReport)]),
+    "fedm_poisson_solve": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_int)]),
+    "fedm_field_error": (C.c_int, [_P, C.c_int, _D]),
+    "fedm_time_kernel": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "fedm_sizes": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 6),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libfedm_hip.so and attach signatures.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  fedm_amd has no CPU fallback.")
+    lib = C.CDLL(os.fspath(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().fedm_last_error().decode()

@@ -1,0 +1,122 @@
+"""Positive streamer in air (Bagheri et al. 2018) on the device path.
+
+Counterpart of examples/streamer_discharge/fedm-streamer.py: same deck
+(file_input/benchmark_model), same boundary list, boundary-condition table,
+initial conditions, Dirichlet values and solver settings.  The reference's
+mesh.xml is not in its checkout, so the mesh is ours (tensor-product, optional
+geometric grading towards the axis).
+"""
+from pathlib import Path
+
+import numpy as np
+
+from ..device import DeviceProblem, Model, Reaction
+from ..mesh import Marking_boundaries, Mesh, RectangleMesh, geometric_lines
+from ..termsum import TermSum, parse
+
+U_W = 18750.0                 # fedm-streamer.py:39
+BOX = 0.0125                  # :96-97
+BOUNDARIES = [["line", 0.0, 0.0, 0.0, BOX], ["line", BOX, BOX, 0.0, BOX],
+              ["line", 0.0, BOX, 0.0, 0.0], ["line", 0.0, BOX, BOX, BOX]]          # :98-101
+BC_TYPE = [["zero flux", "Neumann"], ["zero flux", "Neumann"],
+           ["zero flux", "zero flux"], ["zero flux", "zero flux"]]                 # :103-107
+DECK = Path(__file__).resolve().parent.parent / "decks" / "streamer_discharge" / "file_input"
+# deck strings, transport_coefficients/{e_Nb,e_ND,alpha}.dat:12 (used when no deck dir is given)
+MU_E = "2.3987*E_m**(-0.26)"
+D_E = "4.3628e-3*E_m**(0.22)"
+ALPHA = "(1.1944e6 + 4.3666e26 * E_m**(-3))*exp(-2.73e7/E_m)-340.75"
+
+
+def model(mu_e=MU_E, D_e=D_E, alpha=ALPHA, quadrature_degree=2):
+    """LFA model of fedm-streamer.py:235-271."""
+    mu = parse(mu_e)
+    rate = parse(alpha) * mu * TermSum.field()          # alpha*mu[1]*E_m, :244-245
+    return Model(n_species=2, poisson=True,
+                 eq_type=["reaction", "drift-diffusion-reaction"], Z=[1.0, -1.0],
+                 mu=[TermSum.const(0.0), mu], D=[TermSum.const(0.0), parse(D_e)],
+                 reactions=[Reaction(rate, power=[0, 1], net=[1, 1])],
+                 bc_kind=BC_TYPE, quadrature_degree=quadrature_degree)
+
+
+def mesh(n, grading=1.0):
+    """n x n "right" mesh of the 1.25 cm box; grading>1 refines towards the axis."""
+    x_lines = geometric_lines(BOX, n, grading) if grading != 1.0 else None
+    return RectangleMesh((0.0, 0.0), (BOX, BOX), n, n, "right", x_lines=x_lines)
+
+
+def dirichlet(coords):
+    """Phi = 0 at z = 0 and Phi = U_w at z = box height (fedm-streamer.py:186-200,233)."""
+    z = coords[:, 1]
+    cathode = np.nonzero(np.abs(z) < 3e-16)[0]
+    anode = np.nonzero(np.abs(z - BOX) < 3e-16)[0]
+    dofs = np.concatenate([cathode, anode]) * 3 + 2
+    vals = np.concatenate([np.zeros(cathode.size), np.full(anode.size, U_W)])
+    return dofs.astype(np.int32), vals
+
+
+def initial_log_densities(coords):
+    """fedm-streamer.py:169-172."""
+    r, z = coords[:, 0], coords[:, 1]
+    u_ion = np.log(1e13 + 5e18 * np.exp(-(r ** 2 + (z - 1e-2) ** 2) / (0.4e-3) ** 2))
+    return u_ion, np.full_like(u_ion, np.log(1e13))
+
+
+def device_problem(coords, cells, device=0, **model_kw):
+    msh = Mesh(coords, cells)
+    tags = Marking_boundaries(msh, BOUNDARIES)
+    dofs, vals = dirichlet(msh.coords)
+    return DeviceProblem(msh.coords, msh.cells, model(**model_kw), facet_tags=tags,
+                         dirichlet_dofs=dofs, dirichlet_vals=vals, device=device)
+
+
+def initialise(prob):
+    """Initial densities + the initial Poisson solve (fedm-streamer.py:169-225) on the device."""
+    U = np.zeros((prob.nv, 3))
+    U[:, 0], U[:, 1] = initial_log_densities(prob.coords)
+    prob.set_state(U, U, U)
+    its = prob.poisson_solve(rtol=1e-12)
+    U = prob.get_state()
+    prob.set_state(U, U, U)
+    return U, its
+
+
+def run(prob, T_final=1e-10, dt_init=5e-12, dt_max=5e-12, dt_min=1e-15, ttol=1e-3,
+        relative_tolerance=1e-4, maximum_iterations=20, max_steps=None, error_file=None,
+        initialise_state=True):
+    """Time loop of fedm-streamer.py:304-340 on the device.  Returns the error-log rows."""
+    import tempfile
+    from .. import functions as ff
+    from ..forms import DeviceState, Expression, FunctionAssigner
+
+    if initialise_state:
+        initialise(prob)
+    solver = ff.PETScSNESSolver()
+    solver.parameters["relative_tolerance"] = relative_tolerance
+    solver.parameters["maximum_iterations"] = maximum_iterations
+    problem = ff.Problem(None, None, [], device_problem=prob)
+    dt = Expression("time_step", time_step=dt_init, degree=0)
+    dt_old = Expression("time_step", time_step=1e30, degree=0)
+    u_new, u_old = DeviceState(prob, "new"), DeviceState(prob, "old")
+    assigner = FunctionAssigner()
+    error, max_error = [0.0] * 2, [1] * 3
+    own_file = error_file is None
+    if own_file:
+        error_file = Path(tempfile.mkdtemp(prefix="fedm_amd_")) / "relative error.log"
+    open(error_file, "w").close()
+    t, steps, newton, linear = 0.0, 0, 0, 0
+    while abs(t - T_final) / T_final > 1e-6:
+        prob.shift_state()                                  # :306-307
+        t = ff.adaptive_solver(solver, problem, t, dt, dt_old, u_new, u_old, None, None,
+                               assigner, error, error_file, max_error, ttol, dt_min,
+                               time_dependent_arguments=[], approximation="LFA")
+        newton += prob.last_report.iterations
+        linear += prob.last_report.linear_iterations
+        dt_old.time_step = dt.time_step                     # :335
+        dt.time_step = ff.adaptive_timestep(dt.time_step, max_error, ttol, dt_min, dt_max)
+        max_error[2] = max_error[1]
+        max_error[1] = max_error[0]
+        steps += 1
+        if max_steps is not None and steps >= max_steps:
+            break
+    rows = [tuple(float(v) for v in line.split()) for line in open(error_file)]
+    return dict(log=rows, t=t, steps=steps, newton_iterations=newton, linear_iterations=linear)

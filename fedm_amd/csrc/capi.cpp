@@ -1,0 +1,601 @@
+// C ABI of libfedm_hip.so (include/fedm_hip.h): context, state, Newton / GMRES drivers.
+// Host logic only; every flop of the hot path runs in kernels.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "fedm_internal.hpp"
+
+struct fedm_ctx {
+    fedm::Ctx c;
+};
+
+namespace fedm {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+template <class T>
+static int upload(T *&dst, const T *src, size_t n) {
+    FEDM_HIP_CHECK(hipMalloc((void **)&dst, sizeof(T) * std::max<size_t>(n, 1)));
+    if (n) FEDM_HIP_CHECK(hipMemcpy(dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int alloc_zero(double *&p, size_t n, hipStream_t st) {
+    FEDM_HIP_CHECK(hipMalloc((void **)&p, sizeof(double) * std::max<size_t>(n, 1)));
+    FEDM_HIP_CHECK(hipMemsetAsync(p, 0, sizeof(double) * std::max<size_t>(n, 1), st));
+    return 0;
+}
+
+static int check_model(const fedm_model_desc &m) {
+    if (m.n_species < 1 || m.n_species > FEDM_MAX_SPECIES) return 1;
+    if (m.n_reactions < 0 || m.n_reactions > FEDM_MAX_REACTIONS) return 1;
+    if (m.n_qp < 1 || m.n_qp > FEDM_MAX_QP || m.n_fqp < 0 || m.n_fqp > FEDM_MAX_FQP) return 1;
+    if (m.n_tags < 0 || m.n_tags > FEDM_MAX_TAGS) return 1;
+    const int ns = m.n_species, po = m.poisson ? 1 : 0;
+    const bool ok = (ns == 1) || (ns == 2) || (ns == 3 && po);
+    if (!ok) return 1;
+    for (int s = 0; s < ns; ++s) {
+        if (m.eq_type[s] < 0 || m.eq_type[s] > 2) return 1;
+        if (m.mu[s].n_terms < 0 || m.mu[s].n_terms > FEDM_MAX_TERMS) return 1;
+        if (m.D[s].n_terms < 0 || m.D[s].n_terms > FEDM_MAX_TERMS) return 1;
+        if (m.ext_nodes[s] < 0 || m.ext_nodes[s] > FEDM_MAX_EXT_NODES) return 1;
+    }
+    for (int j = 0; j < m.n_reactions; ++j)
+        if (m.k[j].n_terms < 0 || m.k[j].n_terms > FEDM_MAX_TERMS) return 1;
+    return 0;
+}
+
+static int ensure_krylov(Ctx &c, int restart) {
+    if (restart + 1 <= c.krylov_cap) return 0;
+    if (c.d_V) hipFree(c.d_V);
+    c.d_V = nullptr;
+    FEDM_HIP_CHECK(hipMalloc((void **)&c.d_V, sizeof(double) * (size_t)c.np * (restart + 1)));
+    c.krylov_cap = restart + 1;
+    return 0;
+}
+
+// ---- GMRES(m), left-preconditioned with the point-block Jacobi inverse ---------------------
+// Solves  Dinv J delta = Dinv rhs  (rhs in c.d_rhs, already scaled), delta starts at 0.
+// Classical Gram-Schmidt (PETSc's KSPGMRES default), convergence on the preconditioned
+// residual norm: |r| <= max(rtol*|r0|, atol).
+static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int *its_out,
+                 double *rnorm_out) {
+    if (ensure_krylov(c, restart)) return -1;
+    const int m = restart;
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gvec(m + 1), yv(m);
+    std::vector<const double *> vp(m + 1);
+    for (int i = 0; i <= m; ++i) vp[i] = c.d_V + (size_t)i * c.np;
+    hipMemsetAsync(c.d_delta, 0, sizeof(double) * c.np, c.stream);
+    int its = 0;
+    double r0 = -1.0, rnorm = 0.0;
+    bool first = true;
+    while (true) {
+        // r = rhs - A delta  (delta == 0 on the first cycle)
+        double *v0 = c.d_V;
+        if (first) {
+            hipMemcpyAsync(v0, c.d_rhs, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
+        } else {
+            launch_spmv(c, c.d_delta, c.d_w, true);
+            hipMemcpyAsync(v0, c.d_rhs, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
+            launch_axpy(c, -1.0, c.d_w, v0);
+        }
+        launch_norm2(c, v0, 0);
+        read_red(c, 1);
+        double beta = std::sqrt(c.h_red[0]);
+        if (!std::isfinite(beta)) {
+            *its_out = its;
+            *rnorm_out = beta;
+            return FEDM_DIVERGED_NAN;
+        }
+        if (first) {
+            r0 = beta;
+            first = false;
+        }
+        rnorm = beta;
+        const double tol = std::max(rtol * r0, atol);
+        if (beta <= tol || its >= max_it) break;
+        launch_scale_copy(c, 1.0 / beta, v0, v0);
+        std::fill(gvec.begin(), gvec.end(), 0.0);
+        gvec[0] = beta;
+        int j = 0;
+        bool done = false;
+        for (; j < m && its < max_it; ++j) {
+            double *w = c.d_V + (size_t)(j + 1) * c.np;
+            launch_spmv(c, vp[j], w, true);
+            launch_dots(c, vp.data(), w, j + 1);  // h_i = v_i . w
+            read_red(c, j + 1);
+            for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = c.h_red[i];
+            launch_multi_axpy(c, c.h_red, j + 1, vp.data(), w, -1.0);
+            launch_norm2(c, w, 0);
+            read_red(c, 1);
+            const double hn = std::sqrt(c.h_red[0]);
+            H[(size_t)(j + 1) * m + j] = hn;
+            if (!std::isfinite(hn)) {
+                *its_out = its;
+                *rnorm_out = hn;
+                return FEDM_DIVERGED_NAN;
+            }
+            if (hn > 0.0) launch_scale_copy(c, 1.0 / hn, w, w);
+            // Givens rotations on column j
+            for (int i = 0; i < j; ++i) {
+                const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+                H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+                H[(size_t)i * m + j] = t;
+            }
+            const double a = H[(size_t)j * m + j], b = H[(size_t)(j + 1) * m + j];
+            const double d = std::hypot(a, b);
+            cs[j] = d > 0.0 ? a / d : 1.0;
+            sn[j] = d > 0.0 ? b / d : 0.0;
+            H[(size_t)j * m + j] = d;
+            H[(size_t)(j + 1) * m + j] = 0.0;
+            gvec[j + 1] = -sn[j] * gvec[j];
+            gvec[j] = cs[j] * gvec[j];
+            ++its;
+            rnorm = std::fabs(gvec[j + 1]);
+            if (rnorm <= tol || hn == 0.0) {
+                ++j;
+                done = true;
+                break;
+            }
+        }
+        // back substitution, delta += V y
+        const int k = j;
+        for (int i = k - 1; i >= 0; --i) {
+            double s = gvec[i];
+            for (int l = i + 1; l < k; ++l) s -= H[(size_t)i * m + l] * yv[l];
+            yv[i] = s / H[(size_t)i * m + i];
+        }
+        if (k > 0) launch_multi_axpy(c, yv.data(), k, vp.data(), c.d_delta, 1.0);
+        if (done || its >= max_it) {
+            if (!done) {  // recompute the true preconditioned residual for the report
+                launch_spmv(c, c.d_delta, c.d_w, true);
+                hipMemcpyAsync(c.d_tmp, c.d_rhs, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
+                launch_axpy(c, -1.0, c.d_w, c.d_tmp);
+                launch_norm2(c, c.d_tmp, 0);
+                read_red(c, 1);
+                rnorm = std::sqrt(c.h_red[0]);
+            }
+            break;
+        }
+    }
+    *its_out = its;
+    *rnorm_out = rnorm;
+    const double tol = std::max(rtol * r0, atol);
+    return rnorm <= tol ? 0 : FEDM_DIVERGED_LINEAR;
+}
+
+static int eval_residual(Ctx &c, int mode, double *fnorm) {
+    launch_assemble(c, false, mode);
+    launch_finalize(c, false, mode);
+    launch_norm2(c, c.d_F, 0);
+    read_red(c, 1);
+    *fnorm = std::sqrt(c.h_red[0]);
+    return 0;
+}
+
+static void eval_jacobian(Ctx &c, int mode) {
+    launch_assemble(c, true, mode);
+    launch_finalize(c, true, mode);
+}
+
+}  // namespace fedm
+
+using namespace fedm;
+
+extern "C" {
+
+const char *fedm_last_error(void) { return g_error.c_str(); }
+int fedm_abi_version(void) { return 1; }
+
+int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, int device,
+                    fedm_ctx **out) {
+    if (!mesh || !model || !out) {
+        set_error("null argument");
+        return -2;
+    }
+    if (check_model(*model)) {
+        set_error("unsupported model descriptor (species/reaction/quadrature counts)");
+        return -2;
+    }
+    if (mesh->n_vertices < 3 || mesh->n_cells < 1) {
+        set_error("empty mesh");
+        return -2;
+    }
+    for (int i = 0; i < 3 * mesh->n_cells; ++i)
+        if (mesh->cells[i] < 0 || mesh->cells[i] >= mesh->n_vertices) {
+            set_error("cell vertex index out of range");
+            return -2;
+        }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: libfedm_hip has no CPU fallback");
+        return -3;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(device));
+    fedm_ctx *h = new fedm_ctx();
+    Ctx &c = h->c;
+    c.device = device;
+    c.model = *model;
+    c.ns = model->n_species;
+    c.poisson = model->poisson != 0;
+    c.neq = c.ns + (c.poisson ? 1 : 0);
+    c.nv = mesh->n_vertices;
+    c.nc = mesh->n_cells;
+    build_pattern(*mesh, c.pat);
+    c.nvp = c.pat.nvp;
+    c.n = (int64_t)c.nv * c.neq;
+    c.np = (int64_t)c.nvp * c.neq;
+    for (int i = 0; i < mesh->n_dirichlet; ++i)
+        if (mesh->dirichlet_dofs[i] < 0 || mesh->dirichlet_dofs[i] >= c.n) {
+            set_error("Dirichlet dof out of range");
+            delete h;
+            return -2;
+        }
+    FEDM_HIP_CHECK(hipStreamCreate(&c.stream));
+    if (upload(c.d_coords, mesh->coords, (size_t)2 * c.nv)) return -1;
+    if (upload(c.d_cells, mesh->cells, (size_t)3 * c.nc)) return -1;
+    std::vector<int8_t> zero_tags;
+    const int8_t *tags = mesh->facet_tags;
+    if (!tags) {
+        zero_tags.assign((size_t)3 * c.nc, 0);
+        tags = zero_tags.data();
+    }
+    for (size_t i = 0; i < (size_t)3 * c.nc; ++i)
+        if (tags[i] < 0 || tags[i] > model->n_tags) {
+            set_error("facet tag out of range");
+            return -2;
+        }
+    if (upload(c.d_ftags, tags, (size_t)3 * c.nc)) return -1;
+    if (upload(c.d_cell_slots, c.pat.cell_slots.data(), c.pat.cell_slots.size())) return -1;
+    if (upload(c.d_colour_cells, c.pat.colour_cells.data(), c.pat.colour_cells.size())) return -1;
+    if (upload(c.d_model, model, 1)) return -1;
+    if (upload(c.d_slice_boff, c.pat.slice_boff.data(), c.pat.slice_boff.size())) return -1;
+    if (upload(c.d_colidx, c.pat.colidx.data(), c.pat.colidx.size())) return -1;
+    if (upload(c.d_diag_slot, c.pat.diag_slot.data(), c.pat.diag_slot.size())) return -1;
+    c.n_dir = mesh->n_dirichlet;
+    if (upload(c.d_dir_dofs, mesh->dirichlet_dofs, (size_t)c.n_dir)) return -1;
+    if (upload(c.d_dir_vals, mesh->dirichlet_vals, (size_t)c.n_dir)) return -1;
+    const size_t nval = (size_t)c.pat.total_bc * SLICE * c.neq * c.neq;
+    if (alloc_zero(c.d_val, nval, c.stream)) return -1;
+    if (alloc_zero(c.d_dinv, (size_t)c.nvp * c.neq * c.neq, c.stream)) return -1;
+    double **vecs[] = {&c.d_u, &c.d_uold, &c.d_uold1, &c.d_F, &c.d_delta, &c.d_w, &c.d_rhs, &c.d_tmp};
+    for (auto v : vecs)
+        if (alloc_zero(*v, (size_t)c.np, c.stream)) return -1;
+    if (alloc_zero(c.d_partials, (size_t)RED_BLOCKS * RED_K, c.stream)) return -1;
+    if (alloc_zero(c.d_red, RED_K, c.stream)) return -1;
+    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_red, sizeof(double) * RED_K));
+    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_stage, sizeof(double) * (size_t)c.np));
+    for (int s = 0; s < c.ns; ++s)
+        if (model->ext_nodes[s] > 0)
+            if (alloc_zero(c.d_ext[s], (size_t)c.nc * model->ext_nodes[s], c.stream)) return -1;
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    *out = h;
+    return 0;
+}
+
+void fedm_ctx_destroy(fedm_ctx *h) {
+    if (!h) return;
+    Ctx &c = h->c;
+    hipSetDevice(c.device);
+    if (c.stream) hipStreamSynchronize(c.stream);
+    void *ptrs[] = {c.d_coords, c.d_cells, c.d_ftags, c.d_cell_slots, c.d_colour_cells, c.d_model,
+                    c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.d_val, c.d_dinv, c.d_dir_dofs,
+                    c.d_dir_vals, c.d_u, c.d_uold, c.d_uold1, c.d_F, c.d_delta, c.d_w, c.d_rhs,
+                    c.d_tmp, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
+                    c.d_ext[3]};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (c.h_red) hipHostFree(c.h_red);
+    if (c.h_stage) hipHostFree(c.h_stage);
+    if (c.stream) hipStreamDestroy(c.stream);
+    delete h;
+}
+
+static int put_vec(Ctx &c, double *dst, const double *src) {
+    if (!src) return 0;
+    std::memcpy(c.h_stage, src, sizeof(double) * c.n);
+    FEDM_HIP_CHECK(hipMemcpyAsync(dst, c.h_stage, sizeof(double) * c.n, hipMemcpyHostToDevice, c.stream));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+static int get_vec(Ctx &c, double *dst, const double *src) {
+    FEDM_HIP_CHECK(hipMemcpyAsync(c.h_stage, src, sizeof(double) * c.n, hipMemcpyDeviceToHost, c.stream));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    std::memcpy(dst, c.h_stage, sizeof(double) * c.n);
+    return 0;
+}
+
+int fedm_set_state(fedm_ctx *h, const double *u_new, const double *u_old, const double *u_old1) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (put_vec(c, c.d_u, u_new) || put_vec(c, c.d_uold, u_old) || put_vec(c, c.d_uold1, u_old1)) return -1;
+    return 0;
+}
+
+int fedm_get_state(fedm_ctx *h, double *u_new) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    return get_vec(c, u_new, c.d_u);
+}
+
+int fedm_shift_state(fedm_ctx *h) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    std::swap(c.d_uold1, c.d_uold);  // old1 <- old (by rotation), then old <- new
+    FEDM_HIP_CHECK(hipMemcpyAsync(c.d_uold, c.d_u, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream));
+    return 0;
+}
+
+int fedm_reset_state(fedm_ctx *h) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipMemcpyAsync(c.d_u, c.d_uold, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream));
+    return 0;
+}
+
+int fedm_set_step(fedm_ctx *h, double dt, double dt_old) {
+    h->c.dt = dt;
+    h->c.dt_old = dt_old;
+    return 0;
+}
+
+int fedm_set_dirichlet_values(fedm_ctx *h, const double *vals) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (c.n_dir)
+        FEDM_HIP_CHECK(hipMemcpy(c.d_dir_vals, vals, sizeof(double) * c.n_dir, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int fedm_set_ext_source(fedm_ctx *h, int species, const double *nodal) {
+    Ctx &c = h->c;
+    if (species < 0 || species >= c.ns || !c.d_ext[species]) {
+        set_error("species has no Expression source");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipMemcpyAsync(c.d_ext[species], nodal,
+                                  sizeof(double) * (size_t)c.nc * c.model.ext_nodes[species],
+                                  hipMemcpyHostToDevice, c.stream));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int fedm_residual(fedm_ctx *h, double *F_out, double *fnorm) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    double fn = 0.0;
+    eval_residual(c, 0, &fn);
+    if (fnorm) *fnorm = fn;
+    if (F_out) return get_vec(c, F_out, c.d_F);
+    FEDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int fedm_jacobian(fedm_ctx *h) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    eval_jacobian(c, 0);
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    FEDM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int64_t fedm_jacobian_nnz(fedm_ctx *h) {
+    return h->c.pat.nnz_blocks * h->c.neq * h->c.neq;
+}
+
+int fedm_jacobian_csr(fedm_ctx *h, int64_t *indptr, int32_t *indices, double *values) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    const int neq = c.neq, neq2 = neq * neq;
+    const size_t nval = (size_t)c.pat.total_bc * SLICE * neq2;
+    std::vector<double> val(nval);
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    FEDM_HIP_CHECK(hipMemcpy(val.data(), c.d_val, sizeof(double) * nval, hipMemcpyDeviceToHost));
+    int64_t pos = 0;
+    indptr[0] = 0;
+    for (int v = 0; v < c.nv; ++v) {
+        const int s = v / SLICE, l = v % SLICE;
+        const int len = c.pat.row_len[v];
+        for (int cr = 0; cr < neq; ++cr) {
+            for (int j = 0; j < len; ++j) {
+                const size_t bc = (size_t)c.pat.slice_boff[s] + j;
+                const int col = c.pat.colidx[bc * SLICE + l];
+                for (int cc = 0; cc < neq; ++cc) {
+                    indices[pos] = col * neq + cc;
+                    values[pos] = val[(bc * neq2 + cr * neq + cc) * SLICE + l];
+                    ++pos;
+                }
+            }
+            indptr[(size_t)v * neq + cr + 1] = pos;
+        }
+    }
+    return 0;
+}
+
+int fedm_spmv(fedm_ctx *h, const double *x, double *y) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipMemsetAsync(c.d_tmp, 0, sizeof(double) * c.np, c.stream));
+    if (put_vec(c, c.d_tmp, x)) return -1;
+    launch_spmv(c, c.d_tmp, c.d_w, false);
+    return get_vec(c, y, c.d_w);
+}
+
+int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report *rep) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    fedm_newton_report r{};
+    int it = 0, lin_total = 0, rc = 0;
+    double fnorm = 0.0, fnorm0 = 0.0, snorm = 0.0;
+    while (true) {
+        eval_residual(c, 0, &fnorm);
+        if (!std::isfinite(fnorm)) {
+            rc = FEDM_DIVERGED_NAN;
+            break;
+        }
+        if (it == 0) {
+            fnorm0 = fnorm;
+            if (fnorm < o->atol) break;
+        } else {
+            if (fnorm < o->atol || fnorm <= o->rtol * fnorm0) break;
+            launch_norm2(c, c.d_u, 0);
+            read_red(c, 1);
+            if (snorm < o->stol * std::sqrt(c.h_red[0])) break;
+        }
+        if (it >= o->max_it) {
+            rc = FEDM_DIVERGED_MAX_IT;
+            break;
+        }
+        eval_jacobian(c, 0);
+        launch_block_inverse(c);
+        launch_apply_dinv(c, c.d_F, c.d_rhs, -1.0);
+        int lits = 0;
+        double lres = 0.0;
+        const int lrc = gmres(c, o->ksp_restart, o->ksp_rtol, o->ksp_atol, o->ksp_max_it, &lits, &lres);
+        lin_total += lits;
+        if (lrc != 0) {
+            rc = lrc < 0 ? lrc : (lrc == FEDM_DIVERGED_NAN ? FEDM_DIVERGED_NAN : FEDM_DIVERGED_LINEAR);
+            break;
+        }
+        launch_axpy(c, 1.0, c.d_delta, c.d_u);
+        launch_norm2(c, c.d_delta, 0);
+        read_red(c, 1);
+        snorm = std::sqrt(c.h_red[0]);
+        ++it;
+    }
+    r.iterations = it;
+    r.linear_iterations = lin_total;
+    r.fnorm0 = fnorm0;
+    r.fnorm = fnorm;
+    r.reason = rc > 0 ? rc : 0;
+    r.converged = rc == 0 ? 1 : 0;
+    if (rep) *rep = r;
+    if (hipGetLastError() != hipSuccess) {
+        set_error("HIP error during Newton solve");
+        return -1;
+    }
+    return rc;
+}
+
+// Jacobi-preconditioned CG on the potential rows with the species frozen.  The matrix has
+// identity rows for species / Dirichlet / padding dofs and their residual is zero once the
+// state satisfies the boundary values, so CG runs on the symmetric positive definite
+// remainder.  Replaces assemble(a), assemble(L), solve() of fedm-streamer.py:205-215.
+int fedm_poisson_solve(fedm_ctx *h, double rtol, int max_it, int *iterations) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (!c.poisson) {
+        set_error("model has no Poisson row");
+        return -2;
+    }
+    launch_set_dirichlet_state(c);
+    launch_assemble(c, true, 1);
+    launch_finalize(c, true, 1);
+    launch_block_inverse(c);
+    double *r = c.d_rhs, *z = c.d_tmp, *p = c.d_delta, *q = c.d_w;
+    // r = -F, x = 0 (correction), z = Dinv r, p = z
+    launch_scale_copy(c, -1.0, c.d_F, r);
+    launch_apply_dinv(c, r, z, 1.0);
+    hipMemcpyAsync(p, z, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
+    const double *rz_ptr[1] = {r};
+    launch_dots(c, rz_ptr, z, 1);
+    read_red(c, 1);
+    double rz = c.h_red[0];
+    launch_norm2(c, r, 0);
+    read_red(c, 1);
+    const double r0 = std::sqrt(c.h_red[0]);
+    double rn = r0;
+    int it = 0;
+    if (ensure_krylov(c, 1)) return -1;
+    double *x = c.d_V;  // accumulated correction
+    hipMemsetAsync(x, 0, sizeof(double) * c.np, c.stream);
+    while (rn > rtol * r0 && it < max_it && r0 > 0.0) {
+        launch_spmv(c, p, q, false);
+        const double *pp[1] = {p};
+        launch_dots(c, pp, q, 1);
+        read_red(c, 1);
+        const double alpha = rz / c.h_red[0];
+        launch_axpy(c, alpha, p, x);
+        launch_axpy(c, -alpha, q, r);
+        launch_apply_dinv(c, r, z, 1.0);
+        launch_dots(c, rz_ptr, z, 1);
+        launch_norm2(c, r, 1);
+        read_red(c, 2);
+        const double rz_new = c.h_red[0];
+        rn = std::sqrt(c.h_red[1]);
+        if (!std::isfinite(rn)) break;
+        const double beta = rz_new / rz;
+        rz = rz_new;
+        // p = z + beta p
+        launch_scale_copy(c, beta, p, p);
+        launch_axpy(c, 1.0, z, p);
+        ++it;
+    }
+    launch_axpy(c, 1.0, x, c.d_u);
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    if (iterations) *iterations = it;
+    if (!std::isfinite(rn)) return FEDM_DIVERGED_NAN;
+    return rn <= rtol * r0 || r0 == 0.0 ? 0 : FEDM_DIVERGED_LINEAR;
+}
+
+int fedm_field_error(fedm_ctx *h, int component, double *rel_err) {
+    Ctx &c = h->c;
+    if (component < 0 || component >= c.neq) {
+        set_error("component out of range");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    launch_field_error(c, component);
+    read_red(c, 2);
+    *rel_err = std::sqrt(c.h_red[0]) / std::sqrt(c.h_red[1]);
+    return 0;
+}
+
+int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    hipEvent_t e0, e1;
+    FEDM_HIP_CHECK(hipEventCreate(&e0));
+    FEDM_HIP_CHECK(hipEventCreate(&e1));
+    auto run = [&]() {
+        if (kind == 0) {
+            launch_assemble(c, true, 0);
+        } else if (kind == 1) {
+            launch_spmv(c, c.d_u, c.d_w, false);
+        } else {
+            launch_assemble(c, false, 0);
+        }
+    };
+    run();  // warm-up
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    FEDM_HIP_CHECK(hipEventRecord(e0, c.stream));
+    for (int i = 0; i < repeats; ++i) run();
+    FEDM_HIP_CHECK(hipEventRecord(e1, c.stream));
+    FEDM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FEDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = (double)ms / repeats;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 0;
+}
+
+int fedm_sizes(fedm_ctx *h, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq,
+               int64_t *nnz_blocks, int64_t *stored_blocks, int64_t *n_colours) {
+    Ctx &c = h->c;
+    if (n_vertices) *n_vertices = c.nv;
+    if (n_cells) *n_cells = c.nc;
+    if (n_eq) *n_eq = c.neq;
+    if (nnz_blocks) *nnz_blocks = c.pat.nnz_blocks;
+    if (stored_blocks) *stored_blocks = c.pat.total_bc * SLICE;
+    if (n_colours) *n_colours = (int64_t)c.pat.colour_ptr.size() - 1;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+// Per-cell evaluation of FEDM's LFA weak forms on a P1 triangle (device code, gfx950).
+//
+// What FFC's generated tabulate_tensor does for the forms of fedm/functions.py:350-368
+// (balance equation, log variables, variable-step BDF2), :219-237 (drift-diffusion flux),
+// :401 (Poisson) and :523-524 (Neumann boundary flux), with the exact Gateaux derivative
+// that `derivative(F, u_new, u)` (fedm-streamer.py:289) produces, hand-derived.
+//
+// P1 makes grad(u) and grad(Phi) -- hence E, |E| and every |E|-dependent coefficient --
+// constant per cell.  The quadrature loop therefore only accumulates weighted moments of
+// the P1 basis (sum_q W g(q) phi_a phi_b, sum_q W g(q) phi_a, sum_q W g(q)); the element
+// residual and the n_eq x n_eq Jacobian blocks are closed-form combinations of them.
+#pragma once
+#include "fedm_internal.hpp"
+
+namespace fedm {
+
+__device__ __forceinline__ int sym6(int a, int b) {
+    // (0,0)=0 (1,1)=1 (2,2)=2 (0,1)=3 (0,2)=4 (1,2)=5
+    return a == b ? a : (a + b + 2);
+}
+
+__device__ __forceinline__ void termsum_eval(const fedm_termsum &ts, double E, double lnE,
+                                             double &val, double &der) {
+    val = 0.0;
+    der = 0.0;
+    for (int i = 0; i < ts.n_terms; ++i) {
+        const double c = ts.c[i], p = ts.p[i], q = ts.q[i], r = ts.r[i];
+        if (c == 0.0) continue;
+        if (p == 0.0 && q == 0.0) {
+            val += c;
+            continue;
+        }
+        const double g = (q != 0.0) ? q * exp(r * lnE) : 0.0;
+        const double t = c * exp(p * lnE + g);
+        val += t;
+        der += t * (p + r * g) / E;
+    }
+}
+
+struct StepCoef {  // fedm/functions.py:350-356
+    double dt, tr2p1, trp1sq, trsq, trp1;
+};
+
+__host__ __device__ inline StepCoef step_coef(double dt, double dt_old) {
+    StepCoef s;
+    const double tr = dt / dt_old;
+    s.dt = dt;
+    s.trp1 = 1.0 + tr;
+    s.tr2p1 = 1.0 + 2.0 * tr;
+    s.trp1sq = s.trp1 * s.trp1;
+    s.trsq = tr * tr;
+    return s;
+}
+
+template <int NS, bool PO>
+struct Element {
+    static constexpr int NEQ = NS + (PO ? 1 : 0);
+    static constexpr int IPHI = NEQ - 1;
+
+    double G[3][2];
+    double GG[6];
+    double gradPhi[2];
+    double dEm[3];
+    double Dv[NS], velG[NS][3];
+    double gradu[NS][2];
+    double E[2];
+    double muv[NS], mud[NS], Dd[NS];
+    double M2g[NEQ][NS][6];
+    double M1h[NEQ][3];
+    double M1n[NS][3];
+    double M0n[NS];
+    double M1Sp[NS][3];
+    double BV[NS][3][2];
+    double M01;
+    bool flux[NS], fdrift[NS];
+
+    // ext: pointer to this cell's P_k nodal values per species (or nullptr)
+    __device__ void compute(const fedm_model_desc *__restrict__ md, const double x[3][2],
+                            const double Uc[3][NEQ], const double Uo[3][NEQ],
+                            const double Uo1[3][NEQ], const StepCoef sc,
+                            const double *const ext[NS], const int8_t tags[3], int mode) {
+        const double two_pi = 6.283185307179586476925286766559;
+        // ---- geometry ----------------------------------------------------------------
+        const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
+        const double d2x = x[2][0] - x[0][0], d2y = x[2][1] - x[0][1];
+        const double det = d1x * d2y - d1y * d2x;
+        const double detJ = fabs(det);
+        G[0][0] = (x[1][1] - x[2][1]) / det;
+        G[0][1] = (x[2][0] - x[1][0]) / det;
+        G[1][0] = (x[2][1] - x[0][1]) / det;
+        G[1][1] = (x[0][0] - x[2][0]) / det;
+        G[2][0] = (x[0][1] - x[1][1]) / det;
+        G[2][1] = (x[1][0] - x[0][0]) / det;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) GG[sym6(a, b)] = G[a][0] * G[b][0] + G[a][1] * G[b][1];
+        double rn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rn[a] = md->axisymmetric ? x[a][0] : 0.5 / 3.14159265358979323846;
+
+        // ---- cell-constant fields -----------------------------------------------------
+        double Em = 1.0;
+        E[0] = E[1] = 0.0;
+        gradPhi[0] = gradPhi[1] = 0.0;
+        dEm[0] = dEm[1] = dEm[2] = 0.0;
+        const bool full = (mode == 0);
+        if (PO) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                gradPhi[0] += Uc[a][IPHI] * G[a][0];
+                gradPhi[1] += Uc[a][IPHI] * G[a][1];
+            }
+            E[0] = -gradPhi[0];
+            E[1] = -gradPhi[1];
+            if (full) {
+                Em = sqrt(E[0] * E[0] + E[1] * E[1]);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) dEm[b] = -(E[0] * G[b][0] + E[1] * G[b][1]) / Em;
+            }
+        }
+        const double lnE = log(Em);
+        double kv[FEDM_MAX_REACTIONS], kd[FEDM_MAX_REACTIONS];
+        const int nreac = full ? md->n_reactions : 0;
+#pragma unroll
+        for (int j = 0; j < FEDM_MAX_REACTIONS; ++j) {
+            kv[j] = kd[j] = 0.0;
+            if (j < nreac) termsum_eval(md->k[j], Em, lnE, kv[j], kd[j]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            gradu[s][0] = gradu[s][1] = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                gradu[s][0] += Uc[a][s] * G[a][0];
+                gradu[s][1] += Uc[a][s] * G[a][1];
+            }
+            muv[s] = mud[s] = Dv[s] = Dd[s] = 0.0;
+            flux[s] = full && md->eq_type[s] != FEDM_EQ_REACTION;
+            fdrift[s] = false;
+            double vel0 = 0.0, vel1 = 0.0;
+            if (flux[s]) {
+                termsum_eval(md->D[s], Em, lnE, Dv[s], Dd[s]);
+                vel0 = -Dv[s] * gradu[s][0];
+                vel1 = -Dv[s] * gradu[s][1];
+                if (md->eq_type[s] == FEDM_EQ_DRIFT_DIFFUSION_REACTION) {
+                    if (md->has_drift_w[s]) {
+                        vel0 += md->drift_w[s][0];
+                        vel1 += md->drift_w[s][1];
+                    } else if (PO) {
+                        termsum_eval(md->mu[s], Em, lnE, muv[s], mud[s]);
+                        vel0 += md->Z[s] * muv[s] * E[0];
+                        vel1 += md->Z[s] * muv[s] * E[1];
+                        fdrift[s] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) velG[s][a] = vel0 * G[a][0] + vel1 * G[a][1];
+        }
+
+        // ---- quadrature: weighted P1 moments ----------------------------------------------
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) M1h[s][a] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) M2g[s][i][k] = 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            M0n[s] = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                M1n[s][a] = 0.0;
+                M1Sp[s][a] = 0.0;
+                BV[s][a][0] = BV[s][a][1] = 0.0;
+            }
+        }
+        M01 = 0.0;
+
+        const int nq = md->n_qp;
+        for (int q = 0; q < nq; ++q) {
+            const double xq = md->qp_x[q], yq = md->qp_y[q];
+            double phi[3] = {1.0 - xq - yq, xq, yq};
+            const double rq = rn[0] * phi[0] + rn[1] * phi[1] + rn[2] * phi[2];
+            const double W = md->qp_w[q] * detJ * two_pi * rq;
+            double nq_[NS], g[NEQ][NS], h[NEQ], Sp[NS];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) {
+                h[s] = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) g[s][i] = 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double u = Uc[0][s] * phi[0] + Uc[1][s] * phi[1] + Uc[2][s] * phi[2];
+                const double n = exp(u);
+                nq_[s] = n;
+                Sp[s] = 0.0;
+                if (full) {
+                    const double uo = Uo[0][s] * phi[0] + Uo[1][s] * phi[1] + Uo[2][s] * phi[2];
+                    const double uo1 = Uo1[0][s] * phi[0] + Uo1[1][s] * phi[1] + Uo1[2][s] * phi[2];
+                    const double u_part = (u * sc.tr2p1 - sc.trp1sq * uo + sc.trsq * uo1) / sc.trp1;
+                    h[s] = n * u_part / sc.dt;
+                    g[s][s] = n * (u_part / sc.dt + sc.tr2p1 / (sc.trp1 * sc.dt));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FEDM_MAX_REACTIONS; ++j) {
+                if (j >= nreac) break;
+                double prod = 1.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int P = md->power[j][i];
+                    for (int e = 0; e < P; ++e) prod *= nq_[i];
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double nu = (double)md->net[j][s];
+                    if (nu == 0.0) continue;
+                    h[s] -= nu * kv[j] * prod;
+                    Sp[s] += nu * kd[j] * prod;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const int P = md->power[j][i];
+                        if (P) g[s][i] -= nu * kv[j] * (double)P * prod;
+                    }
+                }
+            }
+            if (full) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int nn = md->ext_nodes[s];
+                    if (nn && ext[s]) {
+                        double f = 0.0;
+                        for (int m = 0; m < nn; ++m) f += ext[s][m] * md->ext_B[q][m];
+                        h[s] -= f;
+                    }
+                }
+            }
+            if (PO) {
+                double rho = 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double cz = md->Z[s] * nq_[s] * md->charge_over_eps;
+                    rho += cz;
+                    if (full) g[IPHI][s] = -cz;
+                }
+                h[IPHI] = -rho;
+            }
+            double pp[6];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = a; b < 3; ++b) pp[sym6(a, b)] = W * phi[a] * phi[b];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) M1h[s][a] += W * phi[a] * h[s];
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) M2g[s][i][k] += pp[k] * g[s][i];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                M0n[s] += W * nq_[s];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    M1n[s][a] += W * phi[a] * nq_[s];
+                    M1Sp[s][a] += W * phi[a] * Sp[s];
+                }
+            }
+            M01 += W;
+        }
+
+        // ---- Neumann boundary facets, fedm/functions.py:523-524 -------------------------
+        if (PO && full && (tags[0] | tags[1] | tags[2])) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int tag = tags[i];
+                if (tag <= 0) continue;
+                const int j = (i == 0) ? 1 : 0, k = (i == 2) ? 1 : 2;
+                const double gi = sqrt(G[i][0] * G[i][0] + G[i][1] * G[i][1]);
+                const double nrm[2] = {-G[i][0] / gi, -G[i][1] / gi};
+                const double ex = x[j][0] - x[k][0], ey = x[j][1] - x[k][1];
+                const double L = sqrt(ex * ex + ey * ey);
+                const double En = E[0] * nrm[0] + E[1] * nrm[1];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (!fdrift[s] || md->bc_kind[tag - 1][s] != FEDM_BC_NEUMANN) continue;
+                    double EM1[3] = {0.0, 0.0, 0.0}, EM2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                    for (int t = 0; t < md->n_fqp; ++t) {
+                        double phi[3] = {0.0, 0.0, 0.0};
+                        phi[j] = 1.0 - md->fqp_t[t];
+                        phi[k] = md->fqp_t[t];
+                        const double rq = rn[0] * phi[0] + rn[1] * phi[1] + rn[2] * phi[2];
+                        const double n = exp(Uc[0][s] * phi[0] + Uc[1][s] * phi[1] + Uc[2][s] * phi[2]);
+                        const double We = md->fqp_w[t] * L * two_pi * rq * n;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            EM1[a] += We * phi[a];
+#pragma unroll
+                            for (int b = a; b < 3; ++b) EM2[sym6(a, b)] += We * phi[a] * phi[b];
+                        }
+                    }
+                    const double zm = md->Z[s] * muv[s], zd = md->Z[s] * mud[s];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        M1h[s][a] += zm * En * EM1[a];
+                        M1Sp[s][a] -= zd * En * EM1[a];
+                        BV[s][a][0] += zm * nrm[0] * EM1[a];
+                        BV[s][a][1] += zm * nrm[1] * EM1[a];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 6; ++kk) M2g[s][s][kk] += zm * En * EM2[kk];
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void residual(const fedm_model_desc *__restrict__ md, int a,
+                                             double R[NEQ]) const {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            R[s] = M1h[s][a];
+            if (flux[s]) R[s] -= velG[s][a] * M0n[s];
+        }
+        if (PO) R[IPHI] = (gradPhi[0] * G[a][0] + gradPhi[1] * G[a][1]) * M01 + M1h[IPHI][a];
+    }
+
+    // row-major NEQ x NEQ block d R[a][.] / d U[b][.]
+    __device__ __forceinline__ void block(const fedm_model_desc *__restrict__ md, int a, int b,
+                                          double B[NEQ * NEQ]) const {
+        const int k = sym6(a, b);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) B[s * NEQ + i] = M2g[s][i][k];
+            if (flux[s]) B[s * NEQ + s] -= velG[s][a] * M1n[s][b] - Dv[s] * GG[k] * M0n[s];
+            if (PO) {
+                double v = -dEm[b] * M1Sp[s][a] - (G[b][0] * BV[s][a][0] + G[b][1] * BV[s][a][1]);
+                if (flux[s]) {
+                    double dv0 = -Dd[s] * dEm[b] * gradu[s][0];
+                    double dv1 = -Dd[s] * dEm[b] * gradu[s][1];
+                    if (fdrift[s]) {
+                        dv0 += md->Z[s] * (mud[s] * dEm[b] * E[0] - muv[s] * G[b][0]);
+                        dv1 += md->Z[s] * (mud[s] * dEm[b] * E[1] - muv[s] * G[b][1]);
+                    }
+                    v -= (dv0 * G[a][0] + dv1 * G[a][1]) * M0n[s];
+                }
+                B[s * NEQ + IPHI] = v;
+            }
+        }
+        if (PO) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) B[IPHI * NEQ + i] = M2g[IPHI][i][k];
+            B[IPHI * NEQ + IPHI] = GG[k] * M01;
+        }
+    }
+};
+
+}  // namespace fedm

@@ -1,0 +1,105 @@
+// Internal declarations shared by the host side and the HIP kernels of libfedm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fedm_hip.h"
+
+namespace fedm {
+
+constexpr int SLICE = 64;  // vertices per matrix slice = one wavefront
+
+// Sliced block-ELL pattern of the P1 vertex graph (host copy).
+//   slice S holds vertices [64 S, 64 S + 64); its rows are padded to the widest row of
+//   the slice; block column bc = slice_boff[S] + j is the j-th neighbour of every vertex
+//   of the slice.  Values of block entry (cr, cc) of (bc, lane) live at
+//   val[(bc * NEQ*NEQ + cr*NEQ + cc) * 64 + lane]  -> lanes are contiguous (coalesced).
+struct Pattern {
+    int nv = 0, nc = 0, nvp = 0, n_slices = 0;
+    int64_t total_bc = 0;    // stored block columns (x 64 lanes = stored blocks incl. padding)
+    int64_t nnz_blocks = 0;  // structural blocks without padding
+    std::vector<int> slice_boff;        // n_slices + 1
+    std::vector<int> colidx;            // total_bc * 64, padded entries point at the row itself
+    std::vector<int> row_len;           // nvp
+    std::vector<uint32_t> diag_slot;    // nvp : slot of the diagonal block
+    std::vector<uint32_t> cell_slots;   // nc * 9 : slot of block (a, b) of every cell
+    std::vector<int> colour_ptr;        // n_colours + 1
+    std::vector<int> colour_cells;      // cells grouped by colour
+};
+
+void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat);
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nv = 0, nc = 0, nvp = 0, ns = 0, neq = 0;
+    bool poisson = false;
+    int64_t n = 0, np = 0;  // nv*neq, nvp*neq
+    fedm_model_desc model{};
+    Pattern pat;
+    double dt = 1.0, dt_old = 1e30;
+    // device mesh
+    double *d_coords = nullptr;
+    int *d_cells = nullptr;
+    int8_t *d_ftags = nullptr;
+    uint32_t *d_cell_slots = nullptr;
+    int *d_colour_cells = nullptr;
+    fedm_model_desc *d_model = nullptr;
+    double *d_ext[FEDM_MAX_SPECIES] = {nullptr, nullptr, nullptr, nullptr};
+    // matrix
+    int *d_slice_boff = nullptr;
+    int *d_colidx = nullptr;
+    uint32_t *d_diag_slot = nullptr;
+    double *d_val = nullptr;
+    double *d_dinv = nullptr;  // sliced: [(slice*NEQ2 + e)*64 + lane]
+    // Dirichlet
+    int n_dir = 0;
+    int *d_dir_dofs = nullptr;
+    double *d_dir_vals = nullptr;
+    // vectors (np doubles each)
+    double *d_u = nullptr, *d_uold = nullptr, *d_uold1 = nullptr, *d_F = nullptr;
+    double *d_delta = nullptr, *d_w = nullptr, *d_rhs = nullptr, *d_tmp = nullptr;
+    double *d_V = nullptr;  // (restart+1) Krylov vectors
+    int krylov_cap = 0;
+    // reductions
+    double *d_partials = nullptr;  // [RED_BLOCKS][RED_K]
+    double *d_red = nullptr;       // [RED_K]
+    double *h_red = nullptr;       // pinned
+    double *h_stage = nullptr;     // pinned staging, np doubles
+};
+
+constexpr int RED_BLOCKS = 512;
+constexpr int RED_K = 40;
+
+// ---- kernel launchers (kernels.hip) -----------------------------------------------------
+// mode: 0 = full model, 1 = Poisson row only (species rows become identity)
+void launch_assemble(Ctx &c, bool jacobian, int mode);
+void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
+void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks
+void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv);
+void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
+void launch_dots(Ctx &c, const double *const *xs, const double *y, int k);  // d_red[i] = xs[i].y
+void launch_norm2(Ctx &c, const double *x, int slot);                       // d_red[slot] = x.x
+void launch_axpy(Ctx &c, double a, const double *x, double *y);             // y += a x
+void launch_scale_copy(Ctx &c, double a, const double *x, double *y);       // y = a x
+void launch_multi_axpy(Ctx &c, const double *coef_host, int k, const double *const *xs,
+                       double *y, double sign);                             // y += sign*sum c_i x_i
+void launch_field_error(Ctx &c, int comp);  // d_red[0]=|new-old+eps|^2, d_red[1]=|old+eps|^2
+void launch_set_dirichlet_state(Ctx &c);    // u[dof] = g
+void read_red(Ctx &c, int k);               // d_red -> h_red, synchronises the stream
+
+#define FEDM_HIP_CHECK(expr)                                                          \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            fedm::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+            return -1;                                                                \
+        }                                                                             \
+    } while (0)
+
+void set_error(const std::string &msg);
+
+}  // namespace fedm

@@ -1,0 +1,541 @@
+// HIP kernels (gfx950) of the FEDM hot path: coloured element assembly into the sliced
+// block-ELL Jacobian, Dirichlet rows, block-Jacobi inverse, SpMV and the vector kernels
+// that GMRES / Newton need.  All of it is fp64 and HBM-bound; no MFMA.
+#include "element.hpp"
+#include "fedm_internal.hpp"
+
+namespace fedm {
+
+// =============================================================================================
+// Assembly, one thread per cell, one launch per colour (cells of a colour share no vertex, so
+// the read-modify-write of matrix blocks and residual entries is conflict-free and the
+// summation order is fixed -> bitwise reproducible).     Problem.F / Problem.J,
+// fedm/functions.py:188-202
+// =============================================================================================
+template <int NS, bool PO>
+__global__ __launch_bounds__(256) void assemble_colour_kernel(
+    const fedm_model_desc *__restrict__ md, const int *__restrict__ cell_list, int n_cells,
+    const int *__restrict__ cells, const double *__restrict__ coords,
+    const int8_t *__restrict__ ftags, const uint32_t *__restrict__ cell_slots,
+    const double *__restrict__ u, const double *__restrict__ uold,
+    const double *__restrict__ uold1, StepCoef sc, const double *ext0, const double *ext1,
+    const double *ext2, const double *ext3, double *__restrict__ val, double *__restrict__ F,
+    int jacobian, int mode) {
+    constexpr int NEQ = NS + (PO ? 1 : 0);
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_cells) return;
+    const int c = cell_list[t];
+    int v[3];
+    double x[3][2], Uc[3][NEQ], Uo[3][NEQ], Uo1[3][NEQ];
+    int8_t tags[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        v[a] = cells[3 * c + a];
+        tags[a] = ftags[3 * c + a];
+        x[a][0] = coords[2 * v[a]];
+        x[a][1] = coords[2 * v[a] + 1];
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) {
+            Uc[a][s] = u[(size_t)v[a] * NEQ + s];
+            Uo[a][s] = uold[(size_t)v[a] * NEQ + s];
+            Uo1[a][s] = uold1[(size_t)v[a] * NEQ + s];
+        }
+    }
+    const double *extp[4] = {ext0, ext1, ext2, ext3};
+    const double *ext[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)c * md->ext_nodes[s] : nullptr;
+
+    Element<NS, PO> el;
+    el.compute(md, x, Uc, Uo, Uo1, sc, ext, tags, mode);
+
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double R[NEQ];
+        el.residual(md, a, R);
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) F[(size_t)v[a] * NEQ + s] += R[s];
+    }
+    if (!jacobian) return;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double B[NEQ2];
+            el.block(md, a, b, B);
+            const uint32_t slot = cell_slots[(size_t)c * 9 + a * 3 + b];
+            double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
+#pragma unroll
+            for (int e = 0; e < NEQ2; ++e) dst[(size_t)e * SLICE] += B[e];
+        }
+}
+
+template <int NS, bool PO>
+static void assemble_t(Ctx &c, bool jacobian, int mode) {
+    constexpr int NEQ = NS + (PO ? 1 : 0);
+    hipMemsetAsync(c.d_F, 0, sizeof(double) * c.np, c.stream);
+    if (jacobian)
+        hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * NEQ * NEQ, c.stream);
+    const StepCoef sc = step_coef(c.dt, c.dt_old);
+    const int ncol = (int)c.pat.colour_ptr.size() - 1;
+    for (int k = 0; k < ncol; ++k) {
+        const int n = c.pat.colour_ptr[k + 1] - c.pat.colour_ptr[k];
+        if (n == 0) continue;
+        hipLaunchKernelGGL((assemble_colour_kernel<NS, PO>), dim3((n + 255) / 256), dim3(256), 0,
+                           c.stream, c.d_model, c.d_colour_cells + c.pat.colour_ptr[k], n,
+                           c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots, c.d_u, c.d_uold,
+                           c.d_uold1, sc, c.d_ext[0], c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val,
+                           c.d_F, jacobian ? 1 : 0, mode);
+    }
+}
+
+void launch_assemble(Ctx &c, bool jacobian, int mode) {
+    if (c.ns == 1 && !c.poisson) return assemble_t<1, false>(c, jacobian, mode);
+    if (c.ns == 1 && c.poisson) return assemble_t<1, true>(c, jacobian, mode);
+    if (c.ns == 2 && c.poisson) return assemble_t<2, true>(c, jacobian, mode);
+    if (c.ns == 2 && !c.poisson) return assemble_t<2, false>(c, jacobian, mode);
+    if (c.ns == 3 && c.poisson) return assemble_t<3, true>(c, jacobian, mode);
+}
+
+// =============================================================================================
+// Dirichlet rows (bc.apply(b, x): b_i = x_i - g_i; bc.apply(A): identity row), padding
+// vertices and -- in Poisson-only mode -- frozen species rows.
+// =============================================================================================
+__device__ __forceinline__ void identity_row(double *val, const int *boff, const int *colidx,
+                                             int neq, int vtx, int cr) {
+    const int slice = vtx >> 6, lane = vtx & 63;
+    const int neq2 = neq * neq;
+    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+        const int col = colidx[(size_t)bc * SLICE + lane];
+        for (int cc = 0; cc < neq; ++cc)
+            val[((size_t)bc * neq2 + cr * neq + cc) * SLICE + lane] = (col == vtx && cc == cr) ? 1.0 : 0.0;
+    }
+    // padded duplicates of the diagonal column (col == vtx beyond row_len) must stay zero:
+    // they are only ever produced for j >= row_len where the first match already got the 1.
+}
+
+__global__ void dirichlet_kernel(int n_dir, const int *__restrict__ dofs,
+                                 const double *__restrict__ vals, const double *__restrict__ u,
+                                 double *__restrict__ F, double *__restrict__ val,
+                                 const int *__restrict__ boff, const int *__restrict__ colidx,
+                                 const uint32_t *__restrict__ diag_slot, int neq, int jacobian) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_dir) return;
+    const int dof = dofs[t];
+    F[dof] = u[dof] - vals[t];
+    if (!jacobian) return;
+    const int vtx = dof / neq, cr = dof % neq;
+    const int slice = vtx >> 6, lane = vtx & 63;
+    const int neq2 = neq * neq;
+    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc)
+        for (int cc = 0; cc < neq; ++cc)
+            val[((size_t)bc * neq2 + cr * neq + cc) * SLICE + lane] = 0.0;
+    const uint32_t ds = diag_slot[vtx];
+    val[((size_t)(ds >> 6) * neq2 + cr * neq + cr) * SLICE + (ds & 63)] = 1.0;
+}
+
+// rows that are identity by construction: padding vertices (all components) and, in
+// Poisson-only mode, every species component of every vertex
+__global__ void identity_rows_kernel(int nv, int nvp, int neq, int ns_frozen,
+                                     double *__restrict__ F, double *__restrict__ val,
+                                     const int *__restrict__ boff,
+                                     const uint32_t *__restrict__ diag_slot, int jacobian) {
+    const int vtx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vtx >= nvp) return;
+    const int neq2 = neq * neq;
+    const int slice = vtx >> 6, lane = vtx & 63;
+    const int n_rows = (vtx >= nv) ? neq : ns_frozen;
+    for (int cr = 0; cr < n_rows; ++cr) {
+        F[(size_t)vtx * neq + cr] = 0.0;
+        if (!jacobian) continue;
+        for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc)
+            for (int cc = 0; cc < neq; ++cc)
+                val[((size_t)bc * neq2 + cr * neq + cc) * SLICE + lane] = 0.0;
+        const uint32_t ds = diag_slot[vtx];
+        val[((size_t)(ds >> 6) * neq2 + cr * neq + cr) * SLICE + (ds & 63)] = 1.0;
+    }
+}
+
+void launch_finalize(Ctx &c, bool jacobian, int mode) {
+    const int ns_frozen = (mode == 1) ? c.ns : 0;
+    if (c.nvp > c.nv || ns_frozen > 0)
+        hipLaunchKernelGGL(identity_rows_kernel, dim3((c.nvp + 255) / 256), dim3(256), 0, c.stream,
+                           c.nv, c.nvp, c.neq, ns_frozen, c.d_F, c.d_val, c.d_slice_boff,
+                           c.d_diag_slot, jacobian ? 1 : 0);
+    if (c.n_dir > 0)
+        hipLaunchKernelGGL(dirichlet_kernel, dim3((c.n_dir + 255) / 256), dim3(256), 0, c.stream,
+                           c.n_dir, c.d_dir_dofs, c.d_dir_vals, c.d_u, c.d_F, c.d_val,
+                           c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.neq, jacobian ? 1 : 0);
+}
+
+__global__ void set_dirichlet_state_kernel(int n_dir, const int *__restrict__ dofs,
+                                           const double *__restrict__ vals, double *__restrict__ u) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_dir) u[dofs[t]] = vals[t];
+}
+
+void launch_set_dirichlet_state(Ctx &c) {
+    if (c.n_dir > 0)
+        hipLaunchKernelGGL(set_dirichlet_state_kernel, dim3((c.n_dir + 255) / 256), dim3(256), 0,
+                           c.stream, c.n_dir, c.d_dir_dofs, c.d_dir_vals, c.d_u);
+}
+
+// =============================================================================================
+// Point-block Jacobi: inverse of every vertex's n_eq x n_eq diagonal block (Gauss-Jordan with
+// partial pivoting), stored sliced so that lanes are contiguous.
+// =============================================================================================
+template <int NEQ>
+__global__ void block_inverse_kernel(int nvp, const double *__restrict__ val,
+                                     const uint32_t *__restrict__ diag_slot,
+                                     double *__restrict__ dinv) {
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int vtx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vtx >= nvp) return;
+    const uint32_t ds = diag_slot[vtx];
+    double A[NEQ][NEQ], I[NEQ][NEQ];
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r)
+#pragma unroll
+        for (int cidx = 0; cidx < NEQ; ++cidx) {
+            A[r][cidx] = val[((size_t)(ds >> 6) * NEQ2 + r * NEQ + cidx) * SLICE + (ds & 63)];
+            I[r][cidx] = (r == cidx) ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int k = 0; k < NEQ; ++k) {
+        // partial pivoting without dynamic register indexing: swap rows by predication
+        int piv = k;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < NEQ; ++r)
+            if (fabs(A[r][k]) > best) {
+                best = fabs(A[r][k]);
+                piv = r;
+            }
+#pragma unroll
+        for (int r = k + 1; r < NEQ; ++r)
+            if (piv == r) {
+#pragma unroll
+                for (int cidx = 0; cidx < NEQ; ++cidx) {
+                    double t = A[k][cidx];
+                    A[k][cidx] = A[r][cidx];
+                    A[r][cidx] = t;
+                    t = I[k][cidx];
+                    I[k][cidx] = I[r][cidx];
+                    I[r][cidx] = t;
+                }
+            }
+        const double inv = 1.0 / A[k][k];
+#pragma unroll
+        for (int cidx = 0; cidx < NEQ; ++cidx) {
+            A[k][cidx] *= inv;
+            I[k][cidx] *= inv;
+        }
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) {
+            if (r == k) continue;
+            const double f = A[r][k];
+#pragma unroll
+            for (int cidx = 0; cidx < NEQ; ++cidx) {
+                A[r][cidx] -= f * A[k][cidx];
+                I[r][cidx] -= f * I[k][cidx];
+            }
+        }
+    }
+    const int slice = vtx >> 6, lane = vtx & 63;
+#pragma unroll
+    for (int e = 0; e < NEQ2; ++e) dinv[((size_t)slice * NEQ2 + e) * SLICE + lane] = I[e / NEQ][e % NEQ];
+}
+
+void launch_block_inverse(Ctx &c) {
+    const dim3 g((c.nvp + 255) / 256), b(256);
+    switch (c.neq) {
+        case 1: hipLaunchKernelGGL(block_inverse_kernel<1>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 2: hipLaunchKernelGGL(block_inverse_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 3: hipLaunchKernelGGL(block_inverse_kernel<3>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 4: hipLaunchKernelGGL(block_inverse_kernel<4>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+    }
+}
+
+// =============================================================================================
+// SpMV on the sliced block-ELL matrix: one wavefront per slice, one lane per vertex.
+// Matrix values and column indices stream in coalesced (lanes contiguous); x is gathered per
+// neighbour (n_eq contiguous doubles).  Optional fused block-Jacobi scaling y = Dinv (A x).
+// =============================================================================================
+template <int NEQ>
+__global__ __launch_bounds__(256) void spmv_kernel(int n_slices, const int *__restrict__ boff,
+                                                   const int *__restrict__ colidx,
+                                                   const double *__restrict__ val,
+                                                   const double *__restrict__ x,
+                                                   double *__restrict__ y,
+                                                   const double *__restrict__ dinv) {
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slice >= n_slices) return;
+    const int b0 = boff[slice], b1 = boff[slice + 1];
+    double acc[NEQ];
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
+    for (int bc = b0; bc < b1; ++bc) {
+        const int col = colidx[(size_t)bc * SLICE + lane];
+        double xj[NEQ];
+#pragma unroll
+        for (int cc = 0; cc < NEQ; ++cc) xj[cc] = x[(size_t)col * NEQ + cc];
+        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NEQ; ++cc) acc[r] += vp[(size_t)(r * NEQ + cc) * SLICE] * xj[cc];
+    }
+    const size_t vtx = (size_t)slice * SLICE + lane;
+    if (dinv) {
+        const double *dp = dinv + (size_t)slice * NEQ2 * SLICE + lane;
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) {
+            double z = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NEQ; ++cc) z += dp[(size_t)(r * NEQ + cc) * SLICE] * acc[cc];
+            y[vtx * NEQ + r] = z;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) y[vtx * NEQ + r] = acc[r];
+    }
+}
+
+void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv) {
+    const int n = c.pat.n_slices;
+    const dim3 g((n + 3) / 4), b(256);
+    const double *dinv = scale_dinv ? c.d_dinv : nullptr;
+    switch (c.neq) {
+        case 1: hipLaunchKernelGGL(spmv_kernel<1>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 2: hipLaunchKernelGGL(spmv_kernel<2>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 3: hipLaunchKernelGGL(spmv_kernel<3>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 4: hipLaunchKernelGGL(spmv_kernel<4>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+    }
+}
+
+// y = alpha * Dinv x
+template <int NEQ>
+__global__ void apply_dinv_kernel(int nvp, const double *__restrict__ dinv,
+                                  const double *__restrict__ x, double *__restrict__ y, double alpha) {
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int vtx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vtx >= nvp) return;
+    const int slice = vtx >> 6, lane = vtx & 63;
+    const double *dp = dinv + (size_t)slice * NEQ2 * SLICE + lane;
+    double xv[NEQ];
+#pragma unroll
+    for (int cc = 0; cc < NEQ; ++cc) xv[cc] = x[(size_t)vtx * NEQ + cc];
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r) {
+        double z = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NEQ; ++cc) z += dp[(size_t)(r * NEQ + cc) * SLICE] * xv[cc];
+        y[(size_t)vtx * NEQ + r] = alpha * z;
+    }
+}
+
+void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha) {
+    const dim3 g((c.nvp + 255) / 256), b(256);
+    switch (c.neq) {
+        case 1: hipLaunchKernelGGL(apply_dinv_kernel<1>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
+        case 2: hipLaunchKernelGGL(apply_dinv_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
+        case 3: hipLaunchKernelGGL(apply_dinv_kernel<3>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
+        case 4: hipLaunchKernelGGL(apply_dinv_kernel<4>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
+    }
+}
+
+// =============================================================================================
+// Reductions: deterministic two-stage (per-block partials in a fixed grid, then one block).
+// =============================================================================================
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[K], double *partials, int kbase) {
+    __shared__ double sm[4][K];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const double s = wave_sum(acc[i]);
+        if (lane == 0) sm[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const double s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+        partials[(size_t)blockIdx.x * RED_K + kbase + threadIdx.x] = s;
+    }
+}
+
+struct PtrPack8 {
+    const double *p[8];
+};
+
+// partials[block][kbase + i] = sum over the block's grid-stride range of xs[i] * y
+template <int K>
+__global__ __launch_bounds__(256) void dots_kernel(PtrPack8 xs, const double *__restrict__ y,
+                                                   size_t n, double *__restrict__ partials, int kbase) {
+    double acc[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[i] = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const double yv = y[idx];
+#pragma unroll
+        for (int i = 0; i < K; ++i) acc[i] += xs.p[i][idx] * yv;
+    }
+    block_reduce_store<K>(acc, partials, kbase);
+}
+
+__global__ void reduce_partials_kernel(const double *__restrict__ partials, int nblocks, int k,
+                                       double *__restrict__ out) {
+    // one wave per output; fixed summation order
+    const int i = blockIdx.x;
+    if (i >= k) return;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[i] = s;
+}
+
+static int red_grid(const Ctx &c) {
+    const size_t blocks = ((size_t)c.np + 255) / 256;
+    return (int)(blocks < (size_t)RED_BLOCKS ? blocks : (size_t)RED_BLOCKS);
+}
+
+void launch_dots(Ctx &c, const double *const *xs, const double *y, int k) {
+    const int grid = red_grid(c);
+    int done = 0;
+    while (done < k) {
+        const int kk = (k - done) >= 8 ? 8 : (k - done);
+        PtrPack8 pk;
+        for (int i = 0; i < 8; ++i) pk.p[i] = xs[done + (i < kk ? i : 0)];
+        switch (kk) {
+            case 1: hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            case 2: hipLaunchKernelGGL(dots_kernel<2>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            case 3: hipLaunchKernelGGL(dots_kernel<3>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            case 4: hipLaunchKernelGGL(dots_kernel<4>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            case 5: hipLaunchKernelGGL(dots_kernel<5>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            case 6: hipLaunchKernelGGL(dots_kernel<6>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            case 7: hipLaunchKernelGGL(dots_kernel<7>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            default: hipLaunchKernelGGL(dots_kernel<8>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+        }
+        done += kk;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
+}
+
+__global__ void reduce_partials_slot_kernel(const double *__restrict__ partials, int nblocks,
+                                            int k_src, double *__restrict__ out, int slot) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + k_src];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[slot] = s;
+}
+
+void launch_norm2(Ctx &c, const double *x, int slot) {
+    const int grid = red_grid(c);
+    PtrPack8 pk;
+    for (int i = 0; i < 8; ++i) pk.p[i] = x;
+    hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, x, (size_t)c.np, c.d_partials, RED_K - 1);
+    hipLaunchKernelGGL(reduce_partials_slot_kernel, dim3(1), dim3(64), 0, c.stream, c.d_partials, grid, RED_K - 1, c.d_red, slot);
+}
+
+void read_red(Ctx &c, int k) {
+    hipMemcpyAsync(c.h_red, c.d_red, sizeof(double) * k, hipMemcpyDeviceToHost, c.stream);
+    hipStreamSynchronize(c.stream);
+}
+
+// =============================================================================================
+// Vector updates
+// =============================================================================================
+__global__ void axpy_kernel(size_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+__global__ void scale_copy_kernel(size_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i];
+}
+
+static dim3 vec_grid(const Ctx &c) {
+    size_t blocks = ((size_t)c.np + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    return dim3((unsigned)blocks);
+}
+
+void launch_axpy(Ctx &c, double a, const double *x, double *y) {
+    hipLaunchKernelGGL(axpy_kernel, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, a, x, y);
+}
+void launch_scale_copy(Ctx &c, double a, const double *x, double *y) {
+    hipLaunchKernelGGL(scale_copy_kernel, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, a, x, y);
+}
+
+struct CoefPack8 {
+    double c[8];
+};
+
+template <int K>
+__global__ void multi_axpy_kernel(size_t n, CoefPack8 cf, PtrPack8 xs, double *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double s = y[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) s += cf.c[k] * xs.p[k][i];
+        y[i] = s;
+    }
+}
+
+void launch_multi_axpy(Ctx &c, const double *coef_host, int k, const double *const *xs, double *y, double sign) {
+    int done = 0;
+    while (done < k) {
+        const int kk = (k - done) >= 8 ? 8 : (k - done);
+        PtrPack8 pk;
+        CoefPack8 cf;
+        for (int i = 0; i < 8; ++i) {
+            pk.p[i] = xs[done + (i < kk ? i : 0)];
+            cf.c[i] = i < kk ? sign * coef_host[done + i] : 0.0;
+        }
+        switch (kk) {
+            case 1: hipLaunchKernelGGL(multi_axpy_kernel<1>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+            case 2: hipLaunchKernelGGL(multi_axpy_kernel<2>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+            case 3: hipLaunchKernelGGL(multi_axpy_kernel<3>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+            case 4: hipLaunchKernelGGL(multi_axpy_kernel<4>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+            case 5: hipLaunchKernelGGL(multi_axpy_kernel<5>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+            case 6: hipLaunchKernelGGL(multi_axpy_kernel<6>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+            case 7: hipLaunchKernelGGL(multi_axpy_kernel<7>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+            default: hipLaunchKernelGGL(multi_axpy_kernel<8>, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, cf, pk, y); break;
+        }
+        done += kk;
+    }
+}
+
+// |new - old + eps|^2 and |old + eps|^2 over one component (fedm/functions.py:1062-1064)
+__global__ __launch_bounds__(256) void field_error_kernel(int nv, int neq, int comp,
+                                                          const double *__restrict__ u,
+                                                          const double *__restrict__ uold,
+                                                          double *__restrict__ partials) {
+    const double eps = 3.0e-16;  // DOLFIN_EPS
+    double acc[2] = {0.0, 0.0};
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
+        const double a = u[(size_t)v * neq + comp], b = uold[(size_t)v * neq + comp];
+        const double d = a - b + eps, o = b + eps;
+        acc[0] += d * d;
+        acc[1] += o * o;
+    }
+    block_reduce_store<2>(acc, partials, 0);
+}
+
+void launch_field_error(Ctx &c, int comp) {
+    int grid = (c.nv + 255) / 256;
+    if (grid > RED_BLOCKS) grid = RED_BLOCKS;
+    hipLaunchKernelGGL(field_error_kernel, dim3(grid), dim3(256), 0, c.stream, c.nv, c.neq, comp, c.d_u, c.d_uold, c.d_partials);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, 2, c.d_red);
+}
+
+}  // namespace fedm

@@ -1,0 +1,117 @@
+// Host-side mesh preprocessing: vertex graph -> sliced block-ELL pattern, per-cell block
+// slots, greedy cell colouring.  Replaces what DOLFIN builds when it creates the
+// FunctionSpace / sparsity pattern for `assemble` (fedm/functions.py:192,200).
+#include <algorithm>
+#include <numeric>
+
+#include "fedm_internal.hpp"
+
+namespace fedm {
+
+void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
+    const int nv = mesh.n_vertices, nc = mesh.n_cells;
+    const int32_t *cells = mesh.cells;
+    pat.nv = nv;
+    pat.nc = nc;
+    pat.n_slices = (nv + SLICE - 1) / SLICE;
+    pat.nvp = pat.n_slices * SLICE;
+
+    // --- vertex adjacency (including self), sorted ----------------------------------
+    std::vector<int64_t> cnt(nv + 1, 0);
+    for (int c = 0; c < nc; ++c)
+        for (int a = 0; a < 3; ++a) cnt[cells[3 * c + a] + 1] += 3;
+    for (int v = 0; v < nv; ++v) cnt[v + 1] += cnt[v];
+    std::vector<int> cand(cnt[nv]);
+    {
+        std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+        for (int c = 0; c < nc; ++c)
+            for (int a = 0; a < 3; ++a) {
+                int v = cells[3 * c + a];
+                for (int b = 0; b < 3; ++b) cand[pos[v]++] = cells[3 * c + b];
+            }
+    }
+    std::vector<int64_t> rowptr(pat.nvp + 1, 0);
+    std::vector<int> adj;
+    adj.reserve(cnt[nv] / 2);
+    pat.row_len.assign(pat.nvp, 1);
+    for (int v = 0; v < nv; ++v) {
+        auto b = cand.begin() + cnt[v], e = cand.begin() + cnt[v + 1];
+        if (b == e) {  // isolated vertex: diagonal only
+            adj.push_back(v);
+        } else {
+            std::sort(b, e);
+            e = std::unique(b, e);
+            adj.insert(adj.end(), b, e);
+        }
+        rowptr[v + 1] = (int64_t)adj.size();
+        pat.row_len[v] = (int)(rowptr[v + 1] - rowptr[v]);
+    }
+    for (int v = nv; v < pat.nvp; ++v) {  // padding vertices: diagonal only
+        adj.push_back(v);
+        rowptr[v + 1] = (int64_t)adj.size();
+    }
+    pat.nnz_blocks = rowptr[nv];
+
+    // --- slices ---------------------------------------------------------------------
+    pat.slice_boff.assign(pat.n_slices + 1, 0);
+    for (int s = 0; s < pat.n_slices; ++s) {
+        int w = 0;
+        for (int l = 0; l < SLICE; ++l) w = std::max(w, pat.row_len[s * SLICE + l]);
+        pat.slice_boff[s + 1] = pat.slice_boff[s] + w;
+    }
+    pat.total_bc = pat.slice_boff[pat.n_slices];
+    pat.colidx.resize((size_t)pat.total_bc * SLICE);
+    pat.diag_slot.resize(pat.nvp);
+    for (int s = 0; s < pat.n_slices; ++s) {
+        int w = pat.slice_boff[s + 1] - pat.slice_boff[s];
+        for (int l = 0; l < SLICE; ++l) {
+            int v = s * SLICE + l;
+            int len = pat.row_len[v];
+            const int *row = adj.data() + rowptr[v];
+            for (int j = 0; j < w; ++j) {
+                size_t slot = (size_t)(pat.slice_boff[s] + j) * SLICE + l;
+                pat.colidx[slot] = j < len ? row[j] : v;
+                if (j < len && row[j] == v) pat.diag_slot[v] = (uint32_t)slot;
+            }
+        }
+    }
+
+    // --- slot of block (a, b) for every cell ------------------------------------------
+    pat.cell_slots.resize((size_t)nc * 9);
+    for (int c = 0; c < nc; ++c)
+        for (int a = 0; a < 3; ++a) {
+            int v = cells[3 * c + a];
+            int s = v / SLICE, l = v % SLICE;
+            const int *row = adj.data() + rowptr[v];
+            int len = pat.row_len[v];
+            for (int b = 0; b < 3; ++b) {
+                int w = cells[3 * c + b];
+                int j = (int)(std::lower_bound(row, row + len, w) - row);
+                pat.cell_slots[(size_t)c * 9 + a * 3 + b] =
+                    (uint32_t)((size_t)(pat.slice_boff[s] + j) * SLICE + l);
+            }
+        }
+
+    // --- greedy colouring: cells of one colour share no vertex -------------------------
+    std::vector<uint64_t> used(nv, 0);
+    std::vector<int> colour(nc);
+    int n_colours = 0;
+    for (int c = 0; c < nc; ++c) {
+        uint64_t m = used[cells[3 * c]] | used[cells[3 * c + 1]] | used[cells[3 * c + 2]];
+        int k = 0;
+        while (k < 63 && ((m >> k) & 1ULL)) ++k;
+        colour[c] = k;
+        n_colours = std::max(n_colours, k + 1);
+        for (int a = 0; a < 3; ++a) used[cells[3 * c + a]] |= (1ULL << k);
+    }
+    pat.colour_ptr.assign(n_colours + 1, 0);
+    for (int c = 0; c < nc; ++c) pat.colour_ptr[colour[c] + 1]++;
+    for (int k = 0; k < n_colours; ++k) pat.colour_ptr[k + 1] += pat.colour_ptr[k];
+    pat.colour_cells.resize(nc);
+    {
+        std::vector<int> pos(pat.colour_ptr.begin(), pat.colour_ptr.end() - 1);
+        for (int c = 0; c < nc; ++c) pat.colour_cells[pos[colour[c]]++] = c;
+    }
+}
+
+}  // namespace fedm

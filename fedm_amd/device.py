@@ -1,0 +1,269 @@
+"""Device context: the Python face of libfedm_hip.so.
+
+One :class:`DeviceProblem` holds a mesh, a model descriptor and the state
+vectors in HBM and offers what the reference reaches through DOLFIN:
+
+* ``residual`` / ``jacobian``   <- ``Problem.F`` / ``Problem.J``  (fedm/functions.py:188-202)
+* ``newton_solve``              <- ``PETScSNESSolver.solve``      (fedm/functions.py:1047)
+* ``field_error``               <- the two ``df.norm`` calls      (fedm/functions.py:1062-1064)
+
+Numerical failure (non-convergence, NaN) raises ``RuntimeError`` exactly where
+DOLFIN's ``error_on_nonconvergence`` would, so ``adaptive_solver``'s catch-all
+retry (fedm/functions.py:1080) keeps working.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, quadrature
+from .physical_constants import elementary_charge, epsilon_0
+from .termsum import TermSum
+
+
+@dataclass
+class Reaction:
+    k: TermSum                 # rate coefficient as a function of |E|
+    power: Sequence[int]       # power-matrix row over the solved species
+    net: Sequence[int]         # gain - loss row
+
+
+@dataclass
+class Model:
+    """What fedm.functions' weak-form builders describe (see functions.py)."""
+    n_species: int
+    poisson: bool
+    eq_type: Sequence[str]
+    Z: Sequence[float]
+    mu: Sequence[TermSum] = ()
+    D: Sequence[TermSum] = ()
+    drift_w: Sequence[Optional[Tuple[float, float]]] = ()
+    reactions: Sequence[Reaction] = ()
+    bc_kind: Sequence[Sequence[str]] = ()      # [tag-1][species]
+    quadrature_degree: int = 2
+    ext_source_degree: Sequence[int] = ()      # 0 = none, k = Expression(degree=k) source
+    axisymmetric: bool = True
+
+    @property
+    def n_eq(self):
+        return self.n_species + (1 if self.poisson else 0)
+
+    def to_c(self):
+        md = _lib.ModelDesc()
+        ns = self.n_species
+        if not 1 <= ns <= _lib.MAX_SPECIES:
+            raise ValueError(f"n_species must be 1..{_lib.MAX_SPECIES}")
+        md.n_species, md.poisson, md.axisymmetric = ns, int(self.poisson), int(self.axisymmetric)
+        mu = list(self.mu) or [TermSum.const(0.0)] * ns
+        D = list(self.D) or [TermSum.const(0.0)] * ns
+        w = list(self.drift_w) or [None] * ns
+        for s in range(ns):
+            md.eq_type[s] = _lib.EQ_TYPES[self.eq_type[s]]
+            md.Z[s] = float(self.Z[s])
+            TermSum.coerce(mu[s]).fill(md.mu[s])
+            TermSum.coerce(D[s]).fill(md.D[s])
+            if w[s] is not None:
+                md.has_drift_w[s] = 1
+                md.drift_w[s][0], md.drift_w[s][1] = float(w[s][0]), float(w[s][1])
+        if len(self.reactions) > _lib.MAX_REACTIONS:
+            raise ValueError(f"at most {_lib.MAX_REACTIONS} reactions")
+        md.n_reactions = len(self.reactions)
+        for j, rc in enumerate(self.reactions):
+            TermSum.coerce(rc.k).fill(md.k[j])
+            for s in range(ns):
+                md.power[j][s] = int(rc.power[s])
+                md.net[j][s] = int(rc.net[s])
+        md.charge_over_eps = elementary_charge / epsilon_0
+        md.n_tags = len(self.bc_kind)
+        if md.n_tags > _lib.MAX_TAGS:
+            raise ValueError(f"at most {_lib.MAX_TAGS} boundary tags")
+        for t, row in enumerate(self.bc_kind):
+            for s in range(ns):
+                md.bc_kind[t][s] = _lib.BC_KINDS[row[s]]
+        xq, wq = quadrature.triangle(self.quadrature_degree)
+        if len(wq) > _lib.MAX_QP:
+            raise ValueError("quadrature rule too large")
+        md.n_qp = len(wq)
+        for q in range(len(wq)):
+            md.qp_x[q], md.qp_y[q], md.qp_w[q] = xq[q, 0], xq[q, 1], wq[q]
+        tq, wt = quadrature.interval(self.quadrature_degree)
+        md.n_fqp = len(wt)
+        for q in range(len(wt)):
+            md.fqp_t[q], md.fqp_w[q] = tq[q], wt[q]
+        ext = list(self.ext_source_degree) or [0] * ns
+        degs = {k for k in ext if k}
+        if len(degs) > 1:
+            raise ValueError("all Expression sources must share one degree")
+        for s in range(ns):
+            md.ext_nodes[s] = (ext[s] + 1) * (ext[s] + 2) // 2 if ext[s] else 0
+        if degs:
+            B, _ = quadrature.lagrange_interpolation_matrix(degs.pop(), xq)
+            for q in range(B.shape[0]):
+                for m in range(B.shape[1]):
+                    md.ext_B[q][m] = B[q, m]
+        return md
+
+
+@dataclass
+class NewtonReport:
+    iterations: int
+    converged: bool
+    linear_iterations: int
+    fnorm0: float
+    fnorm: float
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class DeviceProblem:
+    """Mesh + model + state resident on one MI355X."""
+
+    def __init__(self, coords, cells, model: Model, facet_tags=None,
+                 dirichlet_dofs=(), dirichlet_vals=(), device=0):
+        self.lib = _lib.load()
+        self.model = model
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self.nv, self.nc = self.coords.shape[0], self.cells.shape[0]
+        self.n_eq = model.n_eq
+        self.n = self.nv * self.n_eq
+        self._tags = None if facet_tags is None else np.ascontiguousarray(facet_tags, dtype=np.int8)
+        self._ddofs = np.ascontiguousarray(dirichlet_dofs, dtype=np.int32)
+        self._dvals = np.ascontiguousarray(dirichlet_vals, dtype=np.float64)
+        md = model.to_c()
+        mesh = _lib.MeshDesc()
+        mesh.n_vertices, mesh.n_cells = self.nv, self.nc
+        mesh.coords = _dp(self.coords)
+        mesh.cells = self.cells.ctypes.data_as(C.POINTER(C.c_int32))
+        mesh.facet_tags = (self._tags.ctypes.data_as(C.POINTER(C.c_int8))
+                           if self._tags is not None else None)
+        mesh.n_dirichlet = self._ddofs.size
+        mesh.dirichlet_dofs = self._ddofs.ctypes.data_as(C.POINTER(C.c_int32))
+        mesh.dirichlet_vals = _dp(self._dvals)
+        handle = C.c_void_p()
+        rc = self.lib.fedm_ctx_create(C.byref(mesh), C.byref(md), int(device), C.byref(handle))
+        if rc != 0:
+            raise RuntimeError(f"fedm_ctx_create failed ({rc}): {_lib.last_error()}")
+        self._h = handle
+
+    # -- lifetime ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fedm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed ({rc}): {_lib.last_error()}")
+        if rc > 0:
+            raise RuntimeError(f"{what}: {_lib.DIVERGED.get(rc, rc)}")
+
+    # -- state --------------------------------------------------------------
+    def _vec(self, a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        if a.size != self.n:
+            raise ValueError(f"state vector must have {self.n} entries, got {a.size}")
+        return a
+
+    def set_state(self, u_new=None, u_old=None, u_old1=None):
+        vs = [self._vec(v) for v in (u_new, u_old, u_old1)]
+        self._check(self.lib.fedm_set_state(self._h, *[_dp(v) if v is not None else None for v in vs]),
+                    "fedm_set_state")
+
+    def get_state(self):
+        out = np.empty(self.n)
+        self._check(self.lib.fedm_get_state(self._h, _dp(out)), "fedm_get_state")
+        return out.reshape(self.nv, self.n_eq)
+
+    def shift_state(self):
+        self._check(self.lib.fedm_shift_state(self._h), "fedm_shift_state")
+
+    def reset_state(self):
+        self._check(self.lib.fedm_reset_state(self._h), "fedm_reset_state")
+
+    def set_step(self, dt, dt_old):
+        self._check(self.lib.fedm_set_step(self._h, float(dt), float(dt_old)), "fedm_set_step")
+
+    def set_dirichlet_values(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        if v.size != self._ddofs.size:
+            raise ValueError("wrong number of Dirichlet values")
+        self._check(self.lib.fedm_set_dirichlet_values(self._h, _dp(v)), "fedm_set_dirichlet_values")
+
+    def set_ext_source(self, species, nodal):
+        v = np.ascontiguousarray(nodal, dtype=np.float64)
+        self._check(self.lib.fedm_set_ext_source(self._h, int(species), _dp(v)), "fedm_set_ext_source")
+
+    # -- Problem.F / Problem.J ------------------------------------------------
+    def residual(self, download=True):
+        F = np.empty(self.n) if download else None
+        fn = C.c_double()
+        self._check(self.lib.fedm_residual(self._h, _dp(F) if download else None, C.byref(fn)),
+                    "fedm_residual")
+        return (F, fn.value) if download else fn.value
+
+    def jacobian(self):
+        self._check(self.lib.fedm_jacobian(self._h), "fedm_jacobian")
+
+    def jacobian_csr(self):
+        import scipy.sparse as sp
+        nnz = self.lib.fedm_jacobian_nnz(self._h)
+        indptr = np.empty(self.n + 1, dtype=np.int64)
+        indices = np.empty(nnz, dtype=np.int32)
+        values = np.empty(nnz)
+        self._check(self.lib.fedm_jacobian_csr(
+            self._h, indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+            indices.ctypes.data_as(C.POINTER(C.c_int32)), _dp(values)), "fedm_jacobian_csr")
+        return sp.csr_matrix((values, indices, indptr), shape=(self.n, self.n))
+
+    def spmv(self, x):
+        x = self._vec(x)
+        y = np.empty(self.n)
+        self._check(self.lib.fedm_spmv(self._h, _dp(x), _dp(y)), "fedm_spmv")
+        return y
+
+    # -- solves --------------------------------------------------------------
+    def newton_solve(self, rtol=1e-9, max_it=50, atol=1e-10, stol=1e-16,
+                     ksp_restart=30, ksp_rtol=1e-5, ksp_atol=1e-50, ksp_max_it=10000):
+        o = _lib.NewtonOpts(rtol, atol, stol, max_it, ksp_restart, ksp_rtol, ksp_atol, ksp_max_it, 0)
+        r = _lib.NewtonReport()
+        rc = self.lib.fedm_newton_solve(self._h, C.byref(o), C.byref(r))
+        self.last_report = NewtonReport(r.iterations, bool(r.converged), r.linear_iterations,
+                                        r.fnorm0, r.fnorm)
+        self._check(rc, "fedm_newton_solve")
+        return r.iterations, True
+
+    def poisson_solve(self, rtol=1e-10, max_it=20000):
+        its = C.c_int()
+        self._check(self.lib.fedm_poisson_solve(self._h, float(rtol), int(max_it), C.byref(its)),
+                    "fedm_poisson_solve")
+        return its.value
+
+    def field_error(self, component):
+        e = C.c_double()
+        self._check(self.lib.fedm_field_error(self._h, int(component), C.byref(e)), "fedm_field_error")
+        return e.value
+
+    # -- measurement ----------------------------------------------------------
+    def time_kernel(self, kind, repeats=20):
+        ms = C.c_double()
+        self._check(self.lib.fedm_time_kernel(self._h, int(kind), int(repeats), C.byref(ms)),
+                    "fedm_time_kernel")
+        return ms.value
+
+    def sizes(self):
+        v = [C.c_int64() for _ in range(6)]
+        self.lib.fedm_sizes(self._h, *[C.byref(x) for x in v])
+        keys = ("n_vertices", "n_cells", "n_eq", "nnz_blocks", "stored_blocks", "n_colours")
+        return dict(zip(keys, (x.value for x in v)))

@@ -1,0 +1,171 @@
+/*
+ * fedm_hip.h -- C ABI of libfedm_hip.so: the MI355X (gfx950) replacement for
+ * the assemble()/solve() hot path of INP-PM/FEDM.
+ *
+ * The reference has no FFI; its seam is the DOLFIN subclass protocol
+ *     class Problem(df.NonlinearProblem)   F(b, x), J(A, x)   fedm/functions.py:174-202
+ * driven by
+ *     PETScSNESSolver.solve(problem, x)                       fedm/functions.py:1047
+ * Every entry point below names the reference call it replaces.  Plain
+ * pointers and sizes only; host pointers are borrowed for the duration of the
+ * call; all device memory lives behind the opaque context.
+ *
+ * Return codes: 0 = ok, <0 = hard error (HIP failure, bad descriptor; see
+ * fedm_last_error), >0 = numerical failure (FEDM_DIVERGED_*), which the Python
+ * facade turns into RuntimeError so that adaptive_solver's
+ * `except Exception` branch (fedm/functions.py:1080-1127) behaves as in the
+ * reference.
+ *
+ * DOF layout: interleaved per vertex, dof = vertex * n_eq + component,
+ * species first, potential last (if the model has a Poisson row).
+ */
+#ifndef FEDM_HIP_H
+#define FEDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEDM_MAX_SPECIES 4
+#define FEDM_MAX_TERMS 6
+#define FEDM_MAX_REACTIONS 8
+#define FEDM_MAX_TAGS 8
+#define FEDM_MAX_QP 32
+#define FEDM_MAX_FQP 8
+#define FEDM_MAX_EXT_NODES 10
+
+#define FEDM_EQ_REACTION 0                 /* 'reaction'                 functions.py:333 */
+#define FEDM_EQ_DIFFUSION_REACTION 1       /* 'diffusion-reaction'                       */
+#define FEDM_EQ_DRIFT_DIFFUSION_REACTION 2 /* 'drift-diffusion-reaction'                 */
+
+#define FEDM_BC_ZERO_FLUX 0                /* 'zero flux'                functions.py:472 */
+#define FEDM_BC_NEUMANN 1                  /* 'Neumann'                  functions.py:523 */
+
+#define FEDM_DIVERGED_MAX_IT 1
+#define FEDM_DIVERGED_NAN 2
+#define FEDM_DIVERGED_LINEAR 3
+
+/* f(E) = sum_i c[i] * E^p[i] * exp(q[i] * E^r[i]); normal form of the deck's
+ * 'fun:E' strings (file_input/benchmark_model/transport_coefficients/e_Nb.dat:12) */
+typedef struct {
+    int32_t n_terms;
+    int32_t pad_;
+    double c[FEDM_MAX_TERMS], p[FEDM_MAX_TERMS], q[FEDM_MAX_TERMS], r[FEDM_MAX_TERMS];
+} fedm_termsum;
+
+/* What the weak-form builders of fedm/functions.py:219-528 describe symbolically. */
+typedef struct {
+    int32_t n_species;                       /* balance equations (log variables)          */
+    int32_t poisson;                         /* 1: last component is the potential  :379   */
+    int32_t axisymmetric;                    /* 1: r = x[0]; 0: r = 0.5/pi          :251   */
+    int32_t n_reactions;
+    int32_t eq_type[FEDM_MAX_SPECIES];
+    double Z[FEDM_MAX_SPECIES];              /* charge number ("sign")              :232   */
+    fedm_termsum mu[FEDM_MAX_SPECIES];       /* mobility(|E|)                               */
+    fedm_termsum D[FEDM_MAX_SPECIES];        /* diffusion(|E|)                              */
+    int32_t has_drift_w[FEDM_MAX_SPECIES];   /* 1: drift velocity is the constant drift_w   */
+    double drift_w[FEDM_MAX_SPECIES][2];
+    fedm_termsum k[FEDM_MAX_REACTIONS];      /* rate coefficient(|E|)               :839   */
+    int32_t power[FEDM_MAX_REACTIONS][FEDM_MAX_SPECIES];   /* power matrix                  */
+    int32_t net[FEDM_MAX_REACTIONS][FEDM_MAX_SPECIES];     /* gain - loss           :841    */
+    double charge_over_eps;                  /* e/eps0, fedm-streamer.py:248                */
+    int32_t n_tags;
+    int32_t bc_kind[FEDM_MAX_TAGS][FEDM_MAX_SPECIES];      /* per boundary tag, species     */
+    /* quadrature on the reference triangle / unit interval (FIAT "default") */
+    int32_t n_qp;
+    int32_t n_fqp;
+    double qp_x[FEDM_MAX_QP], qp_y[FEDM_MAX_QP], qp_w[FEDM_MAX_QP];
+    double fqp_t[FEDM_MAX_FQP], fqp_w[FEDM_MAX_FQP];
+    /* Expression sources (P_k nodal values per cell), fedm-tof.py:116 */
+    int32_t ext_nodes[FEDM_MAX_SPECIES];     /* 0: none, else nodes per cell (6 for P2)     */
+    double ext_B[FEDM_MAX_QP][FEDM_MAX_EXT_NODES];         /* interpolant at qp_x/qp_y      */
+} fedm_model_desc;
+
+typedef struct {
+    int32_t n_vertices;
+    int32_t n_cells;
+    const double *coords;        /* [n_vertices][2] = (r, z)                               */
+    const int32_t *cells;        /* [n_cells][3]                                           */
+    const int8_t *facet_tags;    /* [n_cells][3], facet i opposite vertex i; 0 = none      */
+    int32_t n_dirichlet;         /* DirichletBC rows, fedm-streamer.py:233                 */
+    const int32_t *dirichlet_dofs;
+    const double *dirichlet_vals;
+} fedm_mesh_desc;
+
+typedef struct {
+    double rtol, atol, stol;     /* SNES: fedm-streamer.py:295; DOLFIN defaults 1e-10, 1e-16 */
+    int32_t max_it;              /* :297                                                    */
+    int32_t ksp_restart;         /* GMRES restart (PETSc default 30)                        */
+    double ksp_rtol;             /* PETSc default 1e-5, on the preconditioned residual      */
+    double ksp_atol;
+    int32_t ksp_max_it;          /* PETSc default 10000                                     */
+    int32_t pad_;
+} fedm_newton_opts;
+
+typedef struct {
+    int32_t iterations;          /* Newton iterations taken                                */
+    int32_t converged;
+    int32_t linear_iterations;   /* total GMRES iterations                                 */
+    int32_t reason;              /* 0 or FEDM_DIVERGED_*                                   */
+    double fnorm0, fnorm;        /* |F| before / after                                     */
+} fedm_newton_report;
+
+typedef struct fedm_ctx fedm_ctx;
+
+const char *fedm_last_error(void);
+int fedm_abi_version(void);
+
+/* mesh + model -> device: colouring, sliced block-ELL pattern, buffers.
+ * Replaces FunctionSpace/derivative/Problem set-up, fedm-streamer.py:133-291. */
+int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, int device,
+                    fedm_ctx **out);
+void fedm_ctx_destroy(fedm_ctx *ctx);
+
+/* u_new / u_old / u_old1 (N doubles each, any may be NULL to leave unchanged).
+ * Replaces Function.assign / rev_assigner.assign, fedm-streamer.py:282-283,306-307. */
+int fedm_set_state(fedm_ctx *ctx, const double *u_new, const double *u_old, const double *u_old1);
+int fedm_get_state(fedm_ctx *ctx, double *u_new);
+/* u_old1 <- u_old; u_old <- u_new on the device (fedm-streamer.py:306-307) */
+int fedm_shift_state(fedm_ctx *ctx);
+/* u_new <- u_old (step rejection, fedm/functions.py:1103) */
+int fedm_reset_state(fedm_ctx *ctx);
+
+/* dt.time_step / dt_old.time_step, fedm/functions.py:350 */
+int fedm_set_step(fedm_ctx *ctx, double dt, double dt_old);
+/* time-dependent Dirichlet values (time_dependent_arguments, functions.py:1042-1044) */
+int fedm_set_dirichlet_values(fedm_ctx *ctx, const double *vals);
+/* Expression source of one species for this step: [n_cells][ext_nodes] */
+int fedm_set_ext_source(fedm_ctx *ctx, int species, const double *nodal);
+
+/* Problem.F: assemble(F) then bc.apply(b, x)              fedm/functions.py:188-194 */
+int fedm_residual(fedm_ctx *ctx, double *F_out /* N or NULL */, double *fnorm /* or NULL */);
+/* Problem.J: assemble(J) then bc.apply(A)                 fedm/functions.py:196-202
+ * (also assembles F).  csr_* NULL -> stay on device. */
+int fedm_jacobian(fedm_ctx *ctx);
+/* pattern/values of the assembled Jacobian as scalar CSR, for parity tests */
+int64_t fedm_jacobian_nnz(fedm_ctx *ctx);
+int fedm_jacobian_csr(fedm_ctx *ctx, int64_t *indptr, int32_t *indices, double *values);
+/* y = J x with the assembled Jacobian (KSP mat-vec), for parity tests and bench */
+int fedm_spmv(fedm_ctx *ctx, const double *x, double *y);
+
+/* nonlinear_solver.solve(problem, u_new.vector())         fedm/functions.py:1047 */
+int fedm_newton_solve(fedm_ctx *ctx, const fedm_newton_opts *opts, fedm_newton_report *rep);
+/* Poisson row only, species frozen (initial potential, fedm-streamer.py:205-215) */
+int fedm_poisson_solve(fedm_ctx *ctx, double rtol, int max_it, int *iterations);
+
+/* |new - old + eps| / |old + eps| on one component        fedm/functions.py:1062-1064 */
+int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
+
+/* timed micro-benchmarks on the resident state (HIP events on the library's stream):
+ * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only.  ms per launch. */
+int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
+/* sizes the roofline model needs */
+int fedm_sizes(fedm_ctx *ctx, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq,
+               int64_t *nnz_blocks, int64_t *stored_blocks, int64_t *n_colours);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEDM_HIP_H */
