@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BDF2 time steps of the streamer_discharge case on MI355X.
+
+``python bench.py --gpus N --steps K --warmup W``.  A *step* is one accepted
+adaptive BDF2 time step of examples/streamer_discharge/fedm-streamer.py:304-340
+(shift states, Newton solve with F/J assembly and GMRES, error norm, step
+controller) on the state resident in HBM.  Workload (BASELINE.json configs[3]):
+2-D axisymmetric streamer, 576x576 "right" mesh graded towards the axis
+(332 929 vertices x 3 equations = 998 787 DOFs).  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md, chip-level parameters (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mesh", type=int, default=576, help="cells per side (per GPU)")
+    ap.add_argument("--grading", type=float, default=4.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-mesh", type=int, default=144)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def spmv_bytes(sz):
+    """Algorithmic bytes of one SpMV in the sliced block-ELL layout:
+    every structural block once (n_eq^2 values + one column index), x read once,
+    y written once, one slice offset per 64 vertices."""
+    neq, nnzb, nv = sz["n_eq"], sz["nnz_blocks"], sz["n_vertices"]
+    return nnzb * (neq * neq * 8 + 4) + nv * neq * 16 + (nv // 64 + 1) * 4
+
+
+def assembly_bytes(sz):
+    """coords + 3 state vectors + connectivity + cell slots + matrix values
+    written once + residual."""
+    neq, nnzb, nv, nc = sz["n_eq"], sz["nnz_blocks"], sz["n_vertices"], sz["n_cells"]
+    return nv * (16 + 24 * neq) + nc * (12 + 36) + nnzb * neq * neq * 8 + nv * neq * 8
+
+
+def cpu_baseline(n, steps):
+    """The oracle (numpy assembly + SuperLU, 'CPU restatement, not FEniCS') on a bounded
+    sample of the same workload, timed on this box's host cores."""
+    from oracle import streamer as ost
+    from oracle.mesh import graded_axis, rectangle_right
+    import warnings
+    mesh = rectangle_right(0.0, 0.0, ost.BOX, ost.BOX, n, n, xs=graded_axis(ost.BOX, n, 4.0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = ost.build(mesh)
+        ost.initial_state(model)          # untimed warm-up of the code path
+        t0 = time.perf_counter()
+        _, st, _, _ = ost.run(mesh=mesh, max_steps=steps)
+        el = time.perf_counter() - t0
+    ndof = mesh.nv * 3
+    return {"value": ndof * steps / el, "unit": "DOF-updates/s", "cores": 1, "kind": "port",
+            "timesteps_per_sec": steps / el,
+            "sample": f"{steps} accepted BDF2 steps (incl. initial Poisson solve) of the same "
+                      f"streamer case on a {n}x{n} graded mesh ({ndof} DOFs); oracle = numpy "
+                      f"assembly + SuperLU direct solve, single thread; host has "
+                      f"{os.cpu_count()} cores"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    if not entry.LIB.exists():
+        entry.build()
+    from fedm_amd.cases import streamer
+    from fedm_amd import functions as ff
+
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = args.mesh
+    msh = streamer.mesh(n, args.grading)
+    if distributed:
+        from fedm_amd.cases import streamer_distributed
+        runner = streamer_distributed.Runner(msh, rank, world, local_rank, args.grading)
+    else:
+        prob = streamer.device_problem(msh.coords, msh.cells, device=local_rank)
+        runner = streamer.Stepper(prob)
+    runner.initialise()
+    for _ in range(args.warmup):
+        runner.step()
+
+    barrier()
+    t0 = time.perf_counter()
+    n0 = (runner.newton_iterations, runner.linear_iterations)
+    for _ in range(args.steps):
+        runner.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_dofs = runner.total_dofs
+    sz = runner.sizes()
+    # live kernel timings (HIP events on the library's stream) for the roofline
+    ms_spmv = runner.time_kernel(1, 50)
+    ms_asm = runner.time_kernel(0, 10)
+    ms_res = runner.time_kernel(2, 10)
+    b_spmv, b_asm = spmv_bytes(sz), assembly_bytes(sz)
+    gbs_spmv = b_spmv / (ms_spmv * 1e-3) / 1e9
+    gbs_asm = b_asm / (ms_asm * 1e-3) / 1e9
+
+    out = {
+        "metric": "BDF2 DOF-updates/sec (streamer_discharge 2D axisym)",
+        "value": total_dofs * args.steps / elapsed,
+        "unit": "DOF-updates/s",
+        "timesteps_per_sec": args.steps / elapsed,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "streamer_discharge 2D axisymmetric, LFA, 3 equations "
+                               "(ions, electrons, Poisson), analytic Bagheri-2018 seed",
+                   "mesh": f"{n}x{n} right-diagonal, geometric grading {args.grading} towards "
+                           f"the axis, per GPU",
+                   "dofs_total": total_dofs, "vertices_per_gpu": sz["n_vertices"],
+                   "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": "restart 30, rtol 1e-5, "
+                   "point-block Jacobi", "partition": runner.partition_name},
+        "newton_iterations_per_step": (runner.newton_iterations - n0[0]) / args.steps,
+        "gmres_iterations_per_step": (runner.linear_iterations - n0[1]) / args.steps,
+        "roofline": {"bound": "hbm", "kernel": "spmv_kernel<3> (sliced block-ELL SpMV)",
+                     "achieved": gbs_spmv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs_spmv / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": b_spmv, "ms_per_launch": ms_spmv},
+        "roofline_assembly": {"bound": "hbm", "kernel": "assemble_colour_kernel<2,true> "
+                              "(all colours, F+J)", "achieved": gbs_asm, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": gbs_asm / HBM_PEAK_GBS,
+                              "algorithmic_bytes": b_asm, "ms_per_launch": ms_asm,
+                              "ms_residual_only": ms_res},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_mesh, args.cpu_steps)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

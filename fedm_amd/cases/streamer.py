@@ -80,43 +80,78 @@ def initialise(prob):
     return U, its
 
 
-def run(prob, T_final=1e-10, dt_init=5e-12, dt_max=5e-12, dt_min=1e-15, ttol=1e-3,
-        relative_tolerance=1e-4, maximum_iterations=20, max_steps=None, error_file=None,
-        initialise_state=True):
-    """Time loop of fedm-streamer.py:304-340 on the device.  Returns the error-log rows."""
-    import tempfile
-    from .. import functions as ff
-    from ..forms import DeviceState, Expression, FunctionAssigner
 
+class Stepper:
+    """The script-level time loop of fedm-streamer.py:304-340 around one device problem."""
+
+    partition_name = "single GPU"
+
+    def __init__(self, prob, dt_init=5e-12, dt_max=5e-12, dt_min=1e-15, ttol=1e-3,
+                 relative_tolerance=1e-4, maximum_iterations=20, error_file=None, quiet=True):
+        import tempfile
+        from .. import functions as ff
+        from ..forms import DeviceState, Expression, FunctionAssigner
+        self.ff, self.prob = ff, prob
+        self.solver = ff.PETScSNESSolver()
+        self.solver.parameters["relative_tolerance"] = relative_tolerance
+        self.solver.parameters["maximum_iterations"] = maximum_iterations
+        self.problem = ff.Problem(None, None, [], device_problem=prob)
+        self.dt = Expression("time_step", time_step=dt_init, degree=0)
+        self.dt_old = Expression("time_step", time_step=1e30, degree=0)
+        self.u_new, self.u_old = DeviceState(prob, "new"), DeviceState(prob, "old")
+        self.assigner = FunctionAssigner()
+        self.error, self.max_error = [0.0] * 2, [1] * 3
+        self.ttol, self.dt_min, self.dt_max = ttol, dt_min, dt_max
+        if error_file is None:
+            error_file = Path(tempfile.mkdtemp(prefix="fedm_amd_")) / "relative error.log"
+        self.error_file = Path(error_file)
+        open(self.error_file, "w").close()
+        self.t, self.steps, self.newton_iterations, self.linear_iterations = 0.0, 0, 0, 0
+        self.quiet = quiet
+        self.total_dofs = prob.n
+
+    def initialise(self):
+        return initialise(self.prob)
+
+    def step(self):
+        import contextlib, io
+        ff = self.ff
+        self.prob.shift_state()                              # :306-307
+        sink = io.StringIO() if self.quiet else None
+        with (contextlib.redirect_stdout(sink) if sink else contextlib.nullcontext()):
+            self.t = ff.adaptive_solver(self.solver, self.problem, self.t, self.dt, self.dt_old,
+                                        self.u_new, self.u_old, None, None, self.assigner,
+                                        self.error, self.error_file, self.max_error, self.ttol,
+                                        self.dt_min, time_dependent_arguments=[],
+                                        approximation="LFA")
+        self.newton_iterations += self.prob.last_report.iterations
+        self.linear_iterations += self.prob.last_report.linear_iterations
+        self.dt_old.time_step = self.dt.time_step            # :335
+        self.dt.time_step = ff.adaptive_timestep(self.dt.time_step, self.max_error, self.ttol,
+                                                 self.dt_min, self.dt_max)
+        self.max_error[2] = self.max_error[1]
+        self.max_error[1] = self.max_error[0]
+        self.steps += 1
+        return self.t
+
+    def log_rows(self):
+        return [tuple(float(v) for v in line.split()) for line in open(self.error_file)]
+
+    def sizes(self):
+        return self.prob.sizes()
+
+    def time_kernel(self, kind, repeats):
+        return self.prob.time_kernel(kind, repeats)
+
+
+def run(prob, T_final=1e-10, max_steps=None, initialise_state=True, **kw):
+    """Time loop of fedm-streamer.py:304-340 on the device.  Returns the error-log rows."""
+    st = Stepper(prob, **kw)
     if initialise_state:
-        initialise(prob)
-    solver = ff.PETScSNESSolver()
-    solver.parameters["relative_tolerance"] = relative_tolerance
-    solver.parameters["maximum_iterations"] = maximum_iterations
-    problem = ff.Problem(None, None, [], device_problem=prob)
-    dt = Expression("time_step", time_step=dt_init, degree=0)
-    dt_old = Expression("time_step", time_step=1e30, degree=0)
-    u_new, u_old = DeviceState(prob, "new"), DeviceState(prob, "old")
-    assigner = FunctionAssigner()
-    error, max_error = [0.0] * 2, [1] * 3
-    own_file = error_file is None
-    if own_file:
-        error_file = Path(tempfile.mkdtemp(prefix="fedm_amd_")) / "relative error.log"
-    open(error_file, "w").close()
-    t, steps, newton, linear = 0.0, 0, 0, 0
-    while abs(t - T_final) / T_final > 1e-6:
-        prob.shift_state()                                  # :306-307
-        t = ff.adaptive_solver(solver, problem, t, dt, dt_old, u_new, u_old, None, None,
-                               assigner, error, error_file, max_error, ttol, dt_min,
-                               time_dependent_arguments=[], approximation="LFA")
-        newton += prob.last_report.iterations
-        linear += prob.last_report.linear_iterations
-        dt_old.time_step = dt.time_step                     # :335
-        dt.time_step = ff.adaptive_timestep(dt.time_step, max_error, ttol, dt_min, dt_max)
-        max_error[2] = max_error[1]
-        max_error[1] = max_error[0]
-        steps += 1
-        if max_steps is not None and steps >= max_steps:
+        st.initialise()
+    while abs(st.t - T_final) / T_final > 1e-6:
+        st.step()
+        if max_steps is not None and st.steps >= max_steps:
             break
-    rows = [tuple(float(v) for v in line.split()) for line in open(error_file)]
-    return dict(log=rows, t=t, steps=steps, newton_iterations=newton, linear_iterations=linear)
+    return dict(log=st.log_rows(), t=st.t, steps=st.steps,
+                newton_iterations=st.newton_iterations, linear_iterations=st.linear_iterations)
