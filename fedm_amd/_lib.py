@@ -65,6 +65,12 @@ class NewtonReport(C.Structure):
                 ("fnorm0", C.c_double), ("fnorm", C.c_double)]
 
 
+class Csr(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("n_cols", C.c_int32),
+                ("indptr", C.POINTER(C.c_int64)), ("indices", C.POINTER(C.c_int32)),
+                ("values", C.POINTER(C.c_double))]
+
+
 LIB_PATH = Path(__file__).resolve().parent / "libfedm_hip.so"
 
 _P = C.c_void_p
@@ -88,6 +94,15 @@ _SIGNATURES = {
     "fedm_spmv": (C.c_int, [_P, _D, _D]),
     "fedm_newton_solve": (C.c_int, [_P, C.POINTER(NewtonOpts), C.POINTER(NewtonReport)]),
     "fedm_poisson_solve": (C.c_int, [_P, C.c_double, C.c_int, C.POINTER(C.c_int)]),
+    "fedm_block_nnz": (C.c_int64, [_P]),
+    "fedm_block_csr": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _D]),
+    "fedm_jacobian_poisson_only": (C.c_int, [_P]),
+    "fedm_amg_setup": (C.c_int, [_P, C.c_int, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), _D,
+                                 C.c_int, C.c_double]),
+    "fedm_amg_clear": (C.c_int, [_P]),
+    "fedm_amg_aggregate": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32)]),
     "fedm_field_error": (C.c_int, [_P, C.c_int, _D]),
     "fedm_time_kernel": (C.c_int, [_P, C.c_int, C.c_int, _D]),
     "fedm_sizes": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 6),

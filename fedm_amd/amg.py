@@ -1,0 +1,97 @@
+"""Set-up of the smoothed-aggregation multigrid hierarchy for the potential block.
+
+The Poisson stiffness block of FEDM's coupled system,
+``2*pi*r*inner(grad(u), grad(v))*dx`` (fedm/functions.py:401) with Dirichlet
+rows, does not change during a run, so its hierarchy is built once per mesh on
+the host (cold path, numpy/scipy + a native greedy aggregation) and uploaded;
+every V-cycle then runs on the device as sliced-ELL SpMV kernels.  The
+reference leaves this work to MUMPS (examples) or PETSc's default PC (test
+harness, fedm_streamer.py:32); see DESIGN.md "Linear solver".
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+
+def aggregate(A, theta):
+    """Greedy aggregation on the strength graph |a_ij| >= theta*sqrt(a_ii a_jj)."""
+    A = A.tocsr()
+    n = A.shape[0]
+    d = np.abs(A.diagonal())
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    strong = (np.abs(A.data) >= theta * np.sqrt(d[rows] * d[A.indices])).astype(np.uint8)
+    strong[A.indices == rows] = 0
+    agg = np.empty(n, dtype=np.int32)
+    nagg = C.c_int32()
+    fn = _lib.load().fedm_amg_aggregate
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    rc = fn(C.c_int32(n), indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+            indices.ctypes.data_as(C.POINTER(C.c_int32)),
+            strong.ctypes.data_as(C.POINTER(C.c_uint8)),
+            agg.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nagg))
+    if rc != 0:
+        raise RuntimeError("fedm_amg_aggregate failed")
+    return agg, nagg.value
+
+
+def build_hierarchy(A, theta=0.08, omega=4.0 / 3.0, max_coarse=600, max_levels=12,
+                    fixed=None):
+    """Levels [(A_l, P_l)] of a smoothed-aggregation hierarchy; the last A is coarsest.
+
+    ``fixed``: boolean mask of identity rows (Dirichlet / padding); they are kept out of
+    the aggregates (their prolongator rows are zero) so the coarse problems stay SPD."""
+    A = sp.csr_matrix(A)
+    levels = []
+    free = np.ones(A.shape[0], dtype=bool) if fixed is None else ~np.asarray(fixed, dtype=bool)
+    while A.shape[0] > max_coarse and len(levels) < max_levels - 1:
+        n = A.shape[0]
+        idx = np.nonzero(free)[0]
+        Af = A[idx][:, idx].tocsr()
+        agg_f, nagg = aggregate(Af, theta)
+        if nagg >= 0.8 * idx.size:          # coarsening stalled
+            break
+        T = sp.csr_matrix((np.ones(idx.size), (idx, agg_f)), shape=(n, nagg))
+        d = A.diagonal()
+        DinvA = sp.diags(1.0 / d) @ A
+        rho = np.abs(DinvA).sum(axis=1).max()          # Gershgorin bound on rho(D^-1 A)
+        P = (T - (omega / rho) * (DinvA @ T)).tocsr()
+        P = sp.diags(free.astype(np.float64)) @ P       # fixed rows interpolate nothing
+        P.eliminate_zeros()
+        Ac = (P.T @ A @ P).tocsr()
+        levels.append((A, P.tocsr()))
+        A = Ac
+        free = np.ones(A.shape[0], dtype=bool)
+    levels.append((A, None))
+    return levels
+
+
+def _csr_struct(M, keep):
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    indptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(M.indices, dtype=np.int32)
+    values = np.ascontiguousarray(M.data, dtype=np.float64)
+    keep.extend([indptr, indices, values])
+    return _lib.Csr(M.shape[0], M.shape[1], indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                    indices.ctypes.data_as(C.POINTER(C.c_int32)),
+                    values.ctypes.data_as(C.POINTER(C.c_double)))
+
+
+def install(handle, levels, nu=2, omega=0.67):
+    """Upload a hierarchy built by :func:`build_hierarchy` into a device context."""
+    lib = _lib.load()
+    keep = []
+    n = len(levels)
+    A = (_lib.Csr * n)(*[_csr_struct(a, keep) for a, _ in levels])
+    P = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p, keep) for _, p in levels[:-1]])
+    R = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p.T, keep) for _, p in levels[:-1]])
+    coarse = np.ascontiguousarray(np.linalg.inv(levels[-1][0].toarray()))
+    rc = lib.fedm_amg_setup(handle, n, A, P, R, coarse.ctypes.data_as(C.POINTER(C.c_double)),
+                            int(nu), float(omega))
+    if rc != 0:
+        raise RuntimeError(f"fedm_amg_setup failed ({rc}): {_lib.last_error()}")
+    return [a.shape[0] for a, _ in levels]

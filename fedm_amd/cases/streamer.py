@@ -69,11 +69,13 @@ def device_problem(coords, cells, device=0, **model_kw):
                          dirichlet_dofs=dofs, dirichlet_vals=vals, device=device)
 
 
-def initialise(prob):
+def initialise(prob, multigrid=True):
     """Initial densities + the initial Poisson solve (fedm-streamer.py:169-225) on the device."""
     U = np.zeros((prob.nv, 3))
     U[:, 0], U[:, 1] = initial_log_densities(prob.coords)
     prob.set_state(U, U, U)
+    if multigrid:
+        prob.setup_multigrid()
     its = prob.poisson_solve(rtol=1e-12)
     U = prob.get_state()
     prob.set_state(U, U, U)

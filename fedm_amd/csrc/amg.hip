@@ -1,0 +1,324 @@
+// Device side of the multigrid preconditioner for the potential block and the field-split
+// (block-triangular) combination with point-block Jacobi on the species rows.
+// Every operator is a scalar sliced-ELL matrix (64 rows per slice, lanes contiguous), so the
+// V-cycle is a sequence of coalesced, HBM/L2-bound SpMV kernels with fused epilogues.
+#include "amg.hpp"
+
+#include <algorithm>
+
+namespace fedm {
+
+// ---- scalar sliced-ELL --------------------------------------------------------------------
+int EllMat::from_csr(const fedm_csr &m, bool want_dinv) {
+    n_rows = m.n_rows;
+    n_cols = m.n_cols;
+    n_slices = (n_rows + SLICE - 1) / SLICE;
+    n_rows_p = n_slices * SLICE;
+    std::vector<int> boff_h(n_slices + 1, 0);
+    for (int s = 0; s < n_slices; ++s) {
+        int w = 0;
+        for (int l = 0; l < SLICE; ++l) {
+            const int r = s * SLICE + l;
+            if (r < n_rows) w = std::max(w, (int)(m.indptr[r + 1] - m.indptr[r]));
+        }
+        boff_h[s + 1] = boff_h[s] + w;
+    }
+    total_bc = boff_h[n_slices];
+    std::vector<int> col_h((size_t)total_bc * SLICE, 0);
+    std::vector<double> val_h((size_t)total_bc * SLICE, 0.0);
+    std::vector<double> dinv_h(n_rows_p, 1.0);
+    for (int s = 0; s < n_slices; ++s)
+        for (int l = 0; l < SLICE; ++l) {
+            const int r = s * SLICE + l;
+            if (r >= n_rows) continue;
+            int j = 0;
+            for (int64_t k = m.indptr[r]; k < m.indptr[r + 1]; ++k, ++j) {
+                const size_t slot = (size_t)(boff_h[s] + j) * SLICE + l;
+                if (m.indices[k] < 0 || m.indices[k] >= n_cols) return -2;
+                col_h[slot] = m.indices[k];
+                val_h[slot] = m.values[k];
+                if (want_dinv && m.indices[k] == r && m.values[k] != 0.0) dinv_h[r] = 1.0 / m.values[k];
+            }
+        }
+    if (hipMalloc((void **)&boff, sizeof(int) * boff_h.size()) != hipSuccess) return -1;
+    if (hipMalloc((void **)&col, sizeof(int) * std::max<size_t>(col_h.size(), 1)) != hipSuccess) return -1;
+    if (hipMalloc((void **)&val, sizeof(double) * std::max<size_t>(val_h.size(), 1)) != hipSuccess) return -1;
+    hipMemcpy(boff, boff_h.data(), sizeof(int) * boff_h.size(), hipMemcpyHostToDevice);
+    hipMemcpy(col, col_h.data(), sizeof(int) * col_h.size(), hipMemcpyHostToDevice);
+    hipMemcpy(val, val_h.data(), sizeof(double) * val_h.size(), hipMemcpyHostToDevice);
+    if (want_dinv) {
+        if (hipMalloc((void **)&dinv, sizeof(double) * n_rows_p) != hipSuccess) return -1;
+        hipMemcpy(dinv, dinv_h.data(), sizeof(double) * n_rows_p, hipMemcpyHostToDevice);
+    }
+    return 0;
+}
+
+void EllMat::release() {
+    if (boff) hipFree(boff);
+    if (col) hipFree(col);
+    if (val) hipFree(val);
+    if (dinv) hipFree(dinv);
+    boff = col = nullptr;
+    val = dinv = nullptr;
+}
+
+// MODE 0: y = A x      1: y = b - A x      2: y = x + omega*dinv*(b - A x)     3: y += A x
+template <int MODE>
+__global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *__restrict__ boff,
+                                                       const int *__restrict__ col,
+                                                       const double *__restrict__ val,
+                                                       const double *__restrict__ dinv,
+                                                       const double *__restrict__ x,
+                                                       const double *__restrict__ b,
+                                                       double *__restrict__ y, double omega) {
+    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slice >= n_slices) return;
+    double acc = 0.0;
+    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+        const size_t k = (size_t)bc * SLICE + lane;
+        acc += val[k] * x[col[k]];
+    }
+    const size_t r = (size_t)slice * SLICE + lane;
+    if (MODE == 0) y[r] = acc;
+    if (MODE == 1) y[r] = b[r] - acc;
+    if (MODE == 2) y[r] = x[r] + omega * dinv[r] * (b[r] - acc);
+    if (MODE == 3) y[r] += acc;
+}
+
+static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const double *b,
+                       double *y, double omega) {
+    const dim3 g((A.n_slices + 3) / 4), bl(256);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(ell_spmv_kernel<0>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
+        case 1: hipLaunchKernelGGL(ell_spmv_kernel<1>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
+        case 2: hipLaunchKernelGGL(ell_spmv_kernel<2>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
+        default: hipLaunchKernelGGL(ell_spmv_kernel<3>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
+    }
+}
+
+__global__ void jacobi_first_kernel(int n, const double *__restrict__ dinv,
+                                    const double *__restrict__ b, double *__restrict__ x, double omega) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = omega * dinv[i] * b[i];
+}
+
+// y = Minv b for the dense coarsest operator: one wave per row
+__global__ __launch_bounds__(256) void dense_gemv_kernel(int n, int ld, const double *__restrict__ M,
+                                                         const double *__restrict__ b, double *__restrict__ y) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s += M[(size_t)row * ld + j] * b[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) y[row] = s;
+}
+
+void Amg::vcycle(Ctx &c, int l) {
+    Level &L = levels[l];
+    if (l == (int)levels.size() - 1) {
+        hipLaunchKernelGGL(dense_gemv_kernel, dim3((n_coarse + 3) / 4), dim3(256), 0, c.stream,
+                           n_coarse, n_coarse, coarse_inv, L.b, L.x);
+        return;
+    }
+    const int np = L.A.n_rows_p;
+    double *x = L.x, *x2 = L.x2;
+    hipLaunchKernelGGL(jacobi_first_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, np,
+                       L.A.dinv, L.b, x, omega);
+    for (int s = 1; s < nu; ++s) {
+        ell_launch(c, L.A, 2, x, L.b, x2, omega);
+        std::swap(x, x2);
+    }
+    ell_launch(c, L.A, 1, x, L.b, L.r, 0.0);                   // r = b - A x
+    ell_launch(c, L.R, 0, L.r, nullptr, levels[l + 1].b, 0.0);  // b_c = R r
+    vcycle(c, l + 1);
+    ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c
+    for (int s = 0; s < nu; ++s) {
+        ell_launch(c, L.A, 2, x, L.b, x2, omega);
+        std::swap(x, x2);
+    }
+    if (x != L.x) {  // odd number of swaps: make L.x the result buffer
+        std::swap(L.x, L.x2);
+    }
+}
+
+void Amg::release() {
+    for (auto &L : levels) {
+        L.A.release();
+        L.P.release();
+        L.R.release();
+        for (double *p : {L.x, L.x2, L.b, L.r})
+            if (p) hipFree(p);
+    }
+    levels.clear();
+    if (coarse_inv) hipFree(coarse_inv);
+    coarse_inv = nullptr;
+    n_coarse = 0;
+}
+
+// ---- field split -----------------------------------------------------------------------------
+// z_u = Duu^-1 t_u per vertex; b0 = t_phi
+template <int NS>
+__global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
+                                  const double *__restrict__ t, double *__restrict__ z,
+                                  double *__restrict__ b0, double alpha) {
+    constexpr int NEQ = NS + 1;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvp) return;
+    const int slice = v >> 6, lane = v & 63;
+    const double *dp = dinv_uu + (size_t)slice * NS * NS * SLICE + lane;
+    double tv[NEQ];
+#pragma unroll
+    for (int s = 0; s < NEQ; ++s) tv[s] = alpha * t[(size_t)v * NEQ + s];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) acc += dp[(size_t)(r * NS + cidx) * SLICE] * tv[cidx];
+        z[(size_t)v * NEQ + r] = acc;
+    }
+    b0[v] = tv[NS];
+}
+
+// b0 -= J_phi,u z_u   (reads only the n_species value planes of the potential row)
+template <int NS>
+__global__ __launch_bounds__(256) void fs_coupling_kernel(int n_slices, const int *__restrict__ boff,
+                                                          const int *__restrict__ colidx,
+                                                          const double *__restrict__ val,
+                                                          const double *__restrict__ z,
+                                                          double *__restrict__ b0) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slice >= n_slices) return;
+    double acc = 0.0;
+    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+        const int col = colidx[(size_t)bc * SLICE + lane];
+        const double *vp = val + ((size_t)bc * NEQ2 + NS * NEQ) * SLICE + lane;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc += vp[(size_t)s * SLICE] * z[(size_t)col * NEQ + s];
+    }
+    b0[(size_t)slice * SLICE + lane] -= acc;
+}
+
+template <int NS>
+__global__ void fs_scatter_kernel(int nvp, const double *__restrict__ x0, double *__restrict__ z) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nvp) z[(size_t)v * (NS + 1) + NS] = x0[v];
+}
+
+// inverse of the leading NS x NS (species) part of every diagonal block
+template <int NS>
+__global__ void species_block_inverse_kernel(int nvp, const double *__restrict__ val,
+                                             const uint32_t *__restrict__ diag_slot,
+                                             double *__restrict__ dinv_uu) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    const int vtx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vtx >= nvp) return;
+    const uint32_t ds = diag_slot[vtx];
+    double A[NS][NS], I[NS][NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) {
+            A[r][cidx] = val[((size_t)(ds >> 6) * NEQ2 + r * NEQ + cidx) * SLICE + (ds & 63)];
+            I[r][cidx] = (r == cidx) ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        int piv = k;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < NS; ++r)
+            if (fabs(A[r][k]) > best) {
+                best = fabs(A[r][k]);
+                piv = r;
+            }
+#pragma unroll
+        for (int r = k + 1; r < NS; ++r)
+            if (piv == r) {
+#pragma unroll
+                for (int cidx = 0; cidx < NS; ++cidx) {
+                    double t = A[k][cidx];
+                    A[k][cidx] = A[r][cidx];
+                    A[r][cidx] = t;
+                    t = I[k][cidx];
+                    I[k][cidx] = I[r][cidx];
+                    I[r][cidx] = t;
+                }
+            }
+        const double inv = 1.0 / A[k][k];
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) {
+            A[k][cidx] *= inv;
+            I[k][cidx] *= inv;
+        }
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            if (r == k) continue;
+            const double f = A[r][k];
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx) {
+                A[r][cidx] -= f * A[k][cidx];
+                I[r][cidx] -= f * I[k][cidx];
+            }
+        }
+    }
+    const int slice = vtx >> 6, lane = vtx & 63;
+#pragma unroll
+    for (int e = 0; e < NS * NS; ++e)
+        dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = I[e / NS][e % NS];
+}
+
+template <int NS>
+static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+    const dim3 gv((c.nvp + 255) / 256), bv(256);
+    Amg::Level &L0 = amg.levels[0];
+    hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, z, L0.b, alpha);
+    hipLaunchKernelGGL(fs_coupling_kernel<NS>, dim3((c.pat.n_slices + 3) / 4), dim3(256), 0, c.stream,
+                       c.pat.n_slices, c.d_slice_boff, c.d_colidx, c.d_val, z, L0.b);
+    amg.vcycle(c, 0);
+    hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
+}
+
+void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+    switch (c.ns) {
+        case 1: fs_apply_t<1>(c, amg, t, z, alpha); break;
+        case 2: fs_apply_t<2>(c, amg, t, z, alpha); break;
+        case 3: fs_apply_t<3>(c, amg, t, z, alpha); break;
+    }
+}
+
+void fieldsplit_setup(Ctx &c) {
+    const dim3 g((c.nvp + 255) / 256), b(256);
+    switch (c.ns) {
+        case 1: hipLaunchKernelGGL(species_block_inverse_kernel<1>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 2: hipLaunchKernelGGL(species_block_inverse_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 3: hipLaunchKernelGGL(species_block_inverse_kernel<3>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+    }
+}
+
+// z = [0, V-cycle(t_phi)] : preconditioner of the Poisson-only CG (species rows are identity
+// with zero residual there)
+__global__ void gather_comp_kernel(int nvp, int neq, int comp, const double *__restrict__ t,
+                                   double *__restrict__ b0) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nvp) b0[v] = t[(size_t)v * neq + comp];
+}
+__global__ void scatter_comp_kernel(int nvp, int neq, int comp, const double *__restrict__ x0,
+                                    double *__restrict__ z) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvp) return;
+    for (int s = 0; s < neq; ++s) z[(size_t)v * neq + s] = (s == comp) ? x0[v] : 0.0;
+}
+
+void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z) {
+    const dim3 g((c.nvp + 255) / 256), b(256);
+    hipLaunchKernelGGL(gather_comp_kernel, g, b, 0, c.stream, c.nvp, c.neq, c.neq - 1, r, amg.levels[0].b);
+    amg.vcycle(c, 0);
+    hipLaunchKernelGGL(scatter_comp_kernel, g, b, 0, c.stream, c.nvp, c.neq, c.neq - 1, amg.levels[0].x, z);
+}
+
+}  // namespace fedm

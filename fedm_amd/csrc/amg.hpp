@@ -1,0 +1,36 @@
+// Multigrid hierarchy for the potential block + field-split preconditioner (see amg.hip).
+#pragma once
+#include <vector>
+
+#include "fedm_internal.hpp"
+
+namespace fedm {
+
+struct EllMat {  // scalar sliced-ELL, 64 rows per slice
+    int n_rows = 0, n_rows_p = 0, n_cols = 0, n_slices = 0;
+    int64_t total_bc = 0;
+    int *boff = nullptr, *col = nullptr;
+    double *val = nullptr, *dinv = nullptr;
+    int from_csr(const fedm_csr &m, bool want_dinv);
+    void release();
+};
+
+struct Amg {
+    struct Level {
+        EllMat A, P, R;
+        double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
+    };
+    std::vector<Level> levels;
+    double *coarse_inv = nullptr;
+    int n_coarse = 0;
+    int nu = 2;
+    double omega = 0.67;
+    void vcycle(Ctx &c, int level);  // levels[level].b -> levels[level].x
+    void release();
+};
+
+void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
+void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha);  // z = alpha*Minv t
+void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z);
+
+}  // namespace fedm

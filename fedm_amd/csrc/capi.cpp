@@ -5,6 +5,7 @@
 #include <cstring>
 #include <mutex>
 
+#include "amg.hpp"
 #include "fedm_internal.hpp"
 
 struct fedm_ctx {
@@ -57,6 +58,27 @@ static int ensure_krylov(Ctx &c, int restart) {
     return 0;
 }
 
+// w = Minv (J v): point-block Jacobi (fused in the SpMV) or field split with multigrid
+static void apply_operator(Ctx &c, const double *v, double *w) {
+    if (c.amg && c.poisson) {
+        launch_spmv(c, v, c.d_tmp, false);
+        fieldsplit_apply(c, *c.amg, c.d_tmp, w, 1.0);
+    } else {
+        launch_spmv(c, v, w, true);
+    }
+}
+
+// rhs = -Minv F, after the Jacobian has been assembled
+static void prepare_preconditioner_and_rhs(Ctx &c) {
+    if (c.amg && c.poisson) {
+        fieldsplit_setup(c);
+        fieldsplit_apply(c, *c.amg, c.d_F, c.d_rhs, -1.0);
+    } else {
+        launch_block_inverse(c);
+        launch_apply_dinv(c, c.d_F, c.d_rhs, -1.0);
+    }
+}
+
 // ---- GMRES(m), left-preconditioned with the point-block Jacobi inverse ---------------------
 // Solves  Dinv J delta = Dinv rhs  (rhs in c.d_rhs, already scaled), delta starts at 0.
 // Classical Gram-Schmidt (PETSc's KSPGMRES default), convergence on the preconditioned
@@ -78,7 +100,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         if (first) {
             hipMemcpyAsync(v0, c.d_rhs, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
         } else {
-            launch_spmv(c, c.d_delta, c.d_w, true);
+            apply_operator(c, c.d_delta, c.d_w);
             hipMemcpyAsync(v0, c.d_rhs, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
             launch_axpy(c, -1.0, c.d_w, v0);
         }
@@ -104,7 +126,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         bool done = false;
         for (; j < m && its < max_it; ++j) {
             double *w = c.d_V + (size_t)(j + 1) * c.np;
-            launch_spmv(c, vp[j], w, true);
+            apply_operator(c, vp[j], w);
             launch_dots(c, vp.data(), w, j + 1);  // h_i = v_i . w
             read_red(c, j + 1);
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = c.h_red[i];
@@ -151,10 +173,9 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         if (k > 0) launch_multi_axpy(c, yv.data(), k, vp.data(), c.d_delta, 1.0);
         if (done || its >= max_it) {
             if (!done) {  // recompute the true preconditioned residual for the report
-                launch_spmv(c, c.d_delta, c.d_w, true);
-                hipMemcpyAsync(c.d_tmp, c.d_rhs, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
-                launch_axpy(c, -1.0, c.d_w, c.d_tmp);
-                launch_norm2(c, c.d_tmp, 0);
+                apply_operator(c, c.d_delta, c.d_w);
+                launch_axpy(c, -1.0, c.d_rhs, c.d_w);
+                launch_norm2(c, c.d_w, 0);
                 read_red(c, 1);
                 rnorm = std::sqrt(c.h_red[0]);
             }
@@ -288,6 +309,10 @@ void fedm_ctx_destroy(fedm_ctx *h) {
                     c.d_ext[3]};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (c.amg) {
+        c.amg->release();
+        delete c.amg;
+    }
     if (c.h_red) hipHostFree(c.h_red);
     if (c.h_stage) hipHostFree(c.h_stage);
     if (c.stream) hipStreamDestroy(c.stream);
@@ -453,8 +478,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             break;
         }
         eval_jacobian(c, 0);
-        launch_block_inverse(c);
-        launch_apply_dinv(c, c.d_F, c.d_rhs, -1.0);
+        prepare_preconditioner_and_rhs(c);
         int lits = 0;
         double lres = 0.0;
         const int lrc = gmres(c, o->ksp_restart, o->ksp_rtol, o->ksp_atol, o->ksp_max_it, &lits, &lres);
@@ -499,9 +523,13 @@ int fedm_poisson_solve(fedm_ctx *h, double rtol, int max_it, int *iterations) {
     launch_finalize(c, true, 1);
     launch_block_inverse(c);
     double *r = c.d_rhs, *z = c.d_tmp, *p = c.d_delta, *q = c.d_w;
-    // r = -F, x = 0 (correction), z = Dinv r, p = z
+    auto precondition = [&](const double *rr, double *zz) {
+        if (c.amg) poisson_precondition(c, *c.amg, rr, zz);
+        else launch_apply_dinv(c, rr, zz, 1.0);
+    };
+    // r = -F, x = 0 (correction), z = Minv r, p = z
     launch_scale_copy(c, -1.0, c.d_F, r);
-    launch_apply_dinv(c, r, z, 1.0);
+    precondition(r, z);
     hipMemcpyAsync(p, z, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
     const double *rz_ptr[1] = {r};
     launch_dots(c, rz_ptr, z, 1);
@@ -523,7 +551,7 @@ int fedm_poisson_solve(fedm_ctx *h, double rtol, int max_it, int *iterations) {
         const double alpha = rz / c.h_red[0];
         launch_axpy(c, alpha, p, x);
         launch_axpy(c, -alpha, q, r);
-        launch_apply_dinv(c, r, z, 1.0);
+        precondition(r, z);
         launch_dots(c, rz_ptr, z, 1);
         launch_norm2(c, r, 1);
         read_red(c, 2);
@@ -595,6 +623,118 @@ int fedm_sizes(fedm_ctx *h, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq
     if (nnz_blocks) *nnz_blocks = c.pat.nnz_blocks;
     if (stored_blocks) *stored_blocks = c.pat.total_bc * SLICE;
     if (n_colours) *n_colours = (int64_t)c.pat.colour_ptr.size() - 1;
+    return 0;
+}
+
+int64_t fedm_block_nnz(fedm_ctx *h) { return h->c.pat.nnz_blocks; }
+
+int fedm_block_csr(fedm_ctx *h, int cr, int cc, int64_t *indptr, int32_t *indices, double *values) {
+    Ctx &c = h->c;
+    if (cr < 0 || cr >= c.neq || cc < 0 || cc >= c.neq) {
+        set_error("block component out of range");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    const int neq2 = c.neq * c.neq;
+    const size_t nplane = (size_t)c.pat.total_bc * SLICE;
+    std::vector<double> plane(nplane);
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    // one strided 2-D copy: plane e of every block column
+    FEDM_HIP_CHECK(hipMemcpy2D(plane.data(), sizeof(double) * SLICE,
+                               c.d_val + (size_t)(cr * c.neq + cc) * SLICE,
+                               sizeof(double) * SLICE * neq2, sizeof(double) * SLICE,
+                               (size_t)c.pat.total_bc, hipMemcpyDeviceToHost));
+    int64_t pos = 0;
+    indptr[0] = 0;
+    for (int v = 0; v < c.nv; ++v) {
+        const int s = v / SLICE, l = v % SLICE;
+        for (int j = 0; j < c.pat.row_len[v]; ++j) {
+            const size_t bc = (size_t)c.pat.slice_boff[s] + j;
+            indices[pos] = c.pat.colidx[bc * SLICE + l];
+            values[pos] = plane[bc * SLICE + l];
+            ++pos;
+        }
+        indptr[v + 1] = pos;
+    }
+    return 0;
+}
+
+int fedm_jacobian_poisson_only(fedm_ctx *h) {
+    Ctx &c = h->c;
+    if (!c.poisson) {
+        set_error("model has no Poisson row");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    launch_set_dirichlet_state(c);
+    eval_jacobian(c, 1);
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int fedm_amg_clear(fedm_ctx *h) {
+    Ctx &c = h->c;
+    if (c.amg) {
+        hipSetDevice(c.device);
+        hipStreamSynchronize(c.stream);
+        c.amg->release();
+        delete c.amg;
+        c.amg = nullptr;
+    }
+    return 0;
+}
+
+int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr *P,
+                   const fedm_csr *R, const double *coarse_inverse, int nu, double omega) {
+    Ctx &c = h->c;
+    if (n_levels < 1 || !A || !coarse_inverse || (n_levels > 1 && (!P || !R)) || nu < 1) {
+        set_error("bad multigrid description");
+        return -2;
+    }
+    if (A[0].n_rows != c.nv || A[0].n_cols != c.nv) {
+        set_error("finest multigrid operator must have n_vertices rows");
+        return -2;
+    }
+    for (int l = 0; l + 1 < n_levels; ++l)
+        if (P[l].n_rows != A[l].n_rows || P[l].n_cols != A[l + 1].n_rows ||
+            R[l].n_rows != A[l + 1].n_rows || R[l].n_cols != A[l].n_rows) {
+            set_error("inconsistent multigrid level shapes");
+            return -2;
+        }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    fedm_amg_clear(h);
+    Amg *amg = new Amg();
+    amg->nu = nu;
+    amg->omega = omega;
+    amg->levels.resize(n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+        Amg::Level &L = amg->levels[l];
+        int rc = 0;
+        if (l + 1 < n_levels) {
+            rc |= L.A.from_csr(A[l], true);
+            rc |= L.P.from_csr(P[l], false);
+            rc |= L.R.from_csr(R[l], false);
+        } else {
+            L.A.n_rows = A[l].n_rows;
+            L.A.n_rows_p = ((A[l].n_rows + SLICE - 1) / SLICE) * SLICE;
+        }
+        if (rc) {
+            set_error("multigrid level upload failed (bad CSR or out of memory)");
+            amg->release();
+            delete amg;
+            return rc < -1 ? -2 : -1;
+        }
+        const size_t n = (size_t)L.A.n_rows_p;
+        for (double **p : {&L.x, &L.x2, &L.b, &L.r}) {
+            FEDM_HIP_CHECK(hipMalloc((void **)p, sizeof(double) * n));
+            FEDM_HIP_CHECK(hipMemset(*p, 0, sizeof(double) * n));
+        }
+    }
+    amg->n_coarse = A[n_levels - 1].n_rows;
+    const size_t nc2 = (size_t)amg->n_coarse * amg->n_coarse;
+    FEDM_HIP_CHECK(hipMalloc((void **)&amg->coarse_inv, sizeof(double) * nc2));
+    FEDM_HIP_CHECK(hipMemcpy(amg->coarse_inv, coarse_inverse, sizeof(double) * nc2, hipMemcpyHostToDevice));
+    c.amg = amg;
     return 0;
 }
 

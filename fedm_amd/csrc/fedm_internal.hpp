@@ -32,7 +32,10 @@ struct Pattern {
 
 void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat);
 
+struct Amg;
+
 struct Ctx {
+    Amg *amg = nullptr;  // potential-block multigrid (optional)
     int device = 0;
     hipStream_t stream = nullptr;
     int nv = 0, nc = 0, nvp = 0, ns = 0, neq = 0;

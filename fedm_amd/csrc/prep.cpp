@@ -115,3 +115,60 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
 }
 
 }  // namespace fedm
+
+// ---------------------------------------------------------------------------------------------
+// Greedy aggregation (Vanek, Mandel, Brezina 1996) on the strength graph of a scalar CSR
+// matrix; set-up step of the algebraic multigrid used for the constant Poisson block.
+// Host code, cold path (once per mesh).
+// ---------------------------------------------------------------------------------------------
+extern "C" int fedm_amg_aggregate(int32_t n, const int64_t *indptr, const int32_t *indices,
+                                  const uint8_t *strong, int32_t *agg, int32_t *n_agg_out) {
+    if (n < 0 || !indptr || !indices || !strong || !agg || !n_agg_out) return -2;
+    std::vector<int32_t> a(n, -1);
+    int32_t na = 0;
+    // pass 1: roots whose strong neighbourhood is still free
+    for (int32_t i = 0; i < n; ++i) {
+        if (a[i] >= 0) continue;
+        bool free_nbhd = true;
+        int cnt = 0;
+        for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const int32_t j = indices[k];
+            if (j == i || !strong[k]) continue;
+            ++cnt;
+            if (a[j] >= 0) {
+                free_nbhd = false;
+                break;
+            }
+        }
+        if (!free_nbhd || cnt == 0) continue;
+        a[i] = na;
+        for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k)
+            if (strong[k] && indices[k] != i) a[indices[k]] = na;
+        ++na;
+    }
+    // pass 2: attach leftovers to a neighbouring pass-1 aggregate
+    std::vector<int32_t> b(a);
+    for (int32_t i = 0; i < n; ++i) {
+        if (a[i] >= 0) continue;
+        for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const int32_t j = indices[k];
+            if (j != i && strong[k] && a[j] >= 0) {
+                b[i] = a[j];
+                break;
+            }
+        }
+    }
+    // pass 3: whatever is left forms aggregates with its free strong neighbours
+    for (int32_t i = 0; i < n; ++i) {
+        if (b[i] >= 0) continue;
+        b[i] = na;
+        for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const int32_t j = indices[k];
+            if (j != i && strong[k] && b[j] < 0) b[j] = na;
+        }
+        ++na;
+    }
+    for (int32_t i = 0; i < n; ++i) agg[i] = b[i];
+    *n_agg_out = na;
+    return 0;
+}

@@ -233,6 +233,38 @@ class DeviceProblem:
         self._check(self.lib.fedm_spmv(self._h, _dp(x), _dp(y)), "fedm_spmv")
         return y
 
+    # -- linear-solver set-up ---------------------------------------------------
+    def block_csr(self, cr, cc):
+        import scipy.sparse as sp
+        nnz = self.lib.fedm_block_nnz(self._h)
+        indptr = np.empty(self.nv + 1, dtype=np.int64)
+        indices = np.empty(nnz, dtype=np.int32)
+        values = np.empty(nnz)
+        self._check(self.lib.fedm_block_csr(
+            self._h, int(cr), int(cc), indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+            indices.ctypes.data_as(C.POINTER(C.c_int32)), _dp(values)), "fedm_block_csr")
+        return sp.csr_matrix((values, indices, indptr), shape=(self.nv, self.nv))
+
+    def setup_multigrid(self, theta=0.08, nu=2, omega=0.67, max_coarse=600):
+        """Build (host, once) and install the multigrid hierarchy of the constant potential
+        block; afterwards Newton uses GMRES + field split (block Jacobi on the species,
+        one V-cycle on the potential) and poisson_solve uses V-cycle-preconditioned CG."""
+        from . import amg
+        if not self.model.poisson:
+            raise ValueError("the model has no potential equation")
+        self._check(self.lib.fedm_jacobian_poisson_only(self._h), "fedm_jacobian_poisson_only")
+        ip = self.n_eq - 1
+        K = self.block_csr(ip, ip)
+        fixed = np.zeros(self.nv, dtype=bool)
+        d = self._ddofs[self._ddofs % self.n_eq == ip] // self.n_eq
+        fixed[d] = True
+        levels = amg.build_hierarchy(K, theta=theta, max_coarse=max_coarse, fixed=fixed)
+        self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
+        return self.multigrid_levels
+
+    def clear_multigrid(self):
+        self.lib.fedm_amg_clear(self._h)
+
     # -- solves --------------------------------------------------------------
     def newton_solve(self, rtol=1e-9, max_it=50, atol=1e-10, stol=1e-16,
                      ksp_restart=30, ksp_rtol=1e-5, ksp_atol=1e-50, ksp_max_it=10000):

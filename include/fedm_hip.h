@@ -155,6 +155,34 @@ int fedm_newton_solve(fedm_ctx *ctx, const fedm_newton_opts *opts, fedm_newton_r
 /* Poisson row only, species frozen (initial potential, fedm-streamer.py:205-215) */
 int fedm_poisson_solve(fedm_ctx *ctx, double rtol, int max_it, int *iterations);
 
+/* ---- linear solver set-up -----------------------------------------------------------------
+ * The reference hands J dx = -F to MUMPS (examples) or to PETSc GMRES + default PC (test
+ * harness, tests/integrated_tests/streamer_discharge/fedm_streamer.py:32).  Here: GMRES with
+ * point-block Jacobi on the species rows and, when a hierarchy has been installed, one
+ * multigrid V-cycle on the (constant) potential block, combined block-triangularly. */
+typedef struct {
+    int32_t n_rows, n_cols;
+    const int64_t *indptr;
+    const int32_t *indices;
+    const double *values;
+} fedm_csr;
+
+/* scalar CSR of block component (cr, cc) of the assembled Jacobian (n_vertices rows) */
+int64_t fedm_block_nnz(fedm_ctx *ctx);
+int fedm_block_csr(fedm_ctx *ctx, int cr, int cc, int64_t *indptr, int32_t *indices,
+                   double *values);
+/* assemble only the Poisson row with the species frozen (identity species rows) */
+int fedm_jacobian_poisson_only(fedm_ctx *ctx);
+/* install a multigrid hierarchy for the potential block: n_levels operators A[l]
+ * (A[0] = fine), n_levels-1 prolongators P[l] (rows of level l, cols of level l+1) and
+ * their transposes R[l]; dense inverse of the coarsest operator; nu damped-Jacobi sweeps. */
+int fedm_amg_setup(fedm_ctx *ctx, int n_levels, const fedm_csr *A, const fedm_csr *P,
+                   const fedm_csr *R, const double *coarse_inverse, int nu, double omega);
+int fedm_amg_clear(fedm_ctx *ctx);
+/* host-side greedy aggregation on a strength graph (set-up helper, no GPU needed) */
+int fedm_amg_aggregate(int32_t n, const int64_t *indptr, const int32_t *indices,
+                       const uint8_t *strong, int32_t *agg, int32_t *n_agg);
+
 /* |new - old + eps| / |old + eps| on one component        fedm/functions.py:1062-1064 */
 int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
 

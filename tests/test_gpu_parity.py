@@ -141,3 +141,33 @@ def test_tof_golden(golden_dir):
     assert np.mean(np.abs(err)) < 1e-5
     assert np.sqrt(np.mean(err ** 2)) < 1e-5
     assert np.max(np.abs(err)) < 1e-3
+
+
+def test_streamer_multigrid_fieldsplit(streamer_setup):
+    """Field-split + V-cycle preconditioning changes the Krylov path, not the answer."""
+    from oracle.newton import newton_solve
+    mesh, omodel, U0, prob = streamer_setup
+    levels = prob.setup_multigrid(max_coarse=40)
+    assert len(levels) >= 2
+    try:
+        U = U0.copy()
+        U[:, 2] = 0.0
+        prob.set_state(U, U, U)
+        its_cg = prob.poisson_solve(rtol=1e-13)
+        Phi = prob.get_state()[:, 2]
+        assert its_cg < 40
+        assert np.abs(Phi - U0[:, 2]).max() / np.abs(U0[:, 2]).max() < 1e-9
+        prob.set_state(U0, U0, U0)
+        prob.set_step(5e-12, 1e30)
+        prob.newton_solve(rtol=1e-8, max_it=20, ksp_rtol=1e-10)
+        lin_amg = prob.last_report.linear_iterations
+        U_gpu = prob.get_state()
+        U_cpu = U0.copy()
+        newton_solve(omodel, U_cpu, U0, U0, 5e-12, 1e30, 1e-8, 20)
+        d = np.abs(U_gpu - U_cpu).max(axis=0) / np.abs(U_cpu).max(axis=0)
+        assert d.max() < 1e-9
+    finally:
+        prob.clear_multigrid()
+    prob.set_state(U0, U0, U0)
+    prob.newton_solve(rtol=1e-8, max_it=20, ksp_rtol=1e-10)
+    assert lin_amg < prob.last_report.linear_iterations
