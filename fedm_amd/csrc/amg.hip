@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(int n, int ld, const do
     if (lane == 0) y[row] = s;
 }
 
+// Buffers never swap on the host: with (nu-1) + nu Jacobi sweeps after the first one the
+// iterate ping-pongs an odd number of times, so it starts in x2 and always ends in x.  The
+// launch sequence is therefore static and is replayed as one hipGraph (Amg::run).
 void Amg::vcycle(Ctx &c, int l) {
     Level &L = levels[l];
     if (l == (int)levels.size() - 1) {
@@ -124,24 +127,41 @@ void Amg::vcycle(Ctx &c, int l) {
         return;
     }
     const int np = L.A.n_rows_p;
-    double *x = L.x, *x2 = L.x2;
+    double *x = L.x2, *y = L.x;  // x: current iterate, y: the other buffer
     hipLaunchKernelGGL(jacobi_first_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, np,
                        L.A.dinv, L.b, x, omega);
     for (int s = 1; s < nu; ++s) {
-        ell_launch(c, L.A, 2, x, L.b, x2, omega);
-        std::swap(x, x2);
+        ell_launch(c, L.A, 2, x, L.b, y, omega);
+        std::swap(x, y);
     }
     ell_launch(c, L.A, 1, x, L.b, L.r, 0.0);                   // r = b - A x
     ell_launch(c, L.R, 0, L.r, nullptr, levels[l + 1].b, 0.0);  // b_c = R r
     vcycle(c, l + 1);
     ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c
     for (int s = 0; s < nu; ++s) {
-        ell_launch(c, L.A, 2, x, L.b, x2, omega);
-        std::swap(x, x2);
+        ell_launch(c, L.A, 2, x, L.b, y, omega);
+        std::swap(x, y);
     }
-    if (x != L.x) {  // odd number of swaps: make L.x the result buffer
-        std::swap(L.x, L.x2);
+    // (2 nu - 1) swaps from x2 -> the result is in L.x
+}
+
+int Amg::capture(Ctx &c) {
+    if (graph_exec) {
+        hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
     }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
+    vcycle(c, 0);
+    if (hipStreamEndCapture(c.stream, &graph) != hipSuccess || !graph) return -1;
+    const hipError_t e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    return e == hipSuccess ? 0 : -1;
+}
+
+void Amg::run(Ctx &c) {
+    if (graph_exec) hipGraphLaunch(graph_exec, c.stream);
+    else vcycle(c, 0);
 }
 
 void Amg::release() {
@@ -153,6 +173,8 @@ void Amg::release() {
             if (p) hipFree(p);
     }
     levels.clear();
+    if (graph_exec) hipGraphExecDestroy(graph_exec);
+    graph_exec = nullptr;
     if (coarse_inv) hipFree(coarse_inv);
     coarse_inv = nullptr;
     n_coarse = 0;
@@ -279,7 +301,7 @@ static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alph
     hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, z, L0.b, alpha);
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, dim3((c.pat.n_slices + 3) / 4), dim3(256), 0, c.stream,
                        c.pat.n_slices, c.d_slice_boff, c.d_colidx, c.d_val, z, L0.b);
-    amg.vcycle(c, 0);
+    amg.run(c);
     hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
 }
 
@@ -317,7 +339,7 @@ __global__ void scatter_comp_kernel(int nvp, int neq, int comp, const double *__
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z) {
     const dim3 g((c.nvp + 255) / 256), b(256);
     hipLaunchKernelGGL(gather_comp_kernel, g, b, 0, c.stream, c.nvp, c.neq, c.neq - 1, r, amg.levels[0].b);
-    amg.vcycle(c, 0);
+    amg.run(c);
     hipLaunchKernelGGL(scatter_comp_kernel, g, b, 0, c.stream, c.nvp, c.neq, c.neq - 1, amg.levels[0].x, z);
 }
 

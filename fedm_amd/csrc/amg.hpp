@@ -25,7 +25,10 @@ struct Amg {
     int n_coarse = 0;
     int nu = 2;
     double omega = 0.67;
-    void vcycle(Ctx &c, int level);  // levels[level].b -> levels[level].x
+    hipGraphExec_t graph_exec = nullptr;
+    void vcycle(Ctx &c, int level);  // levels[level].b -> levels[level].x (kernel launches)
+    int capture(Ctx &c);             // record the V-cycle once as a hipGraph
+    void run(Ctx &c);                // levels[0].b -> levels[0].x
     void release();
 };
 

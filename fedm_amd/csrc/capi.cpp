@@ -735,6 +735,10 @@ int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr 
     FEDM_HIP_CHECK(hipMalloc((void **)&amg->coarse_inv, sizeof(double) * nc2));
     FEDM_HIP_CHECK(hipMemcpy(amg->coarse_inv, coarse_inverse, sizeof(double) * nc2, hipMemcpyHostToDevice));
     c.amg = amg;
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    if (amg->capture(c) != 0) {
+        hipGetLastError();  // graph capture unavailable: fall back to plain launches
+    }
     return 0;
 }
 

@@ -245,7 +245,7 @@ class DeviceProblem:
             indices.ctypes.data_as(C.POINTER(C.c_int32)), _dp(values)), "fedm_block_csr")
         return sp.csr_matrix((values, indices, indptr), shape=(self.nv, self.nv))
 
-    def setup_multigrid(self, theta=0.08, nu=2, omega=0.67, max_coarse=600):
+    def setup_multigrid(self, theta=0.08, nu=2, omega=0.67, max_coarse=2000):
         """Build (host, once) and install the multigrid hierarchy of the constant potential
         block; afterwards Newton uses GMRES + field split (block Jacobi on the species,
         one V-cycle on the potential) and poisson_solve uses V-cycle-preconditioned CG."""
