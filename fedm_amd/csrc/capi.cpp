@@ -2,6 +2,7 @@
 // Host logic only; every flop of the hot path runs in kernels.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -85,10 +86,14 @@ static void prepare_preconditioner_and_rhs(Ctx &c) {
 // residual norm: |r| <= max(rtol*|r0|, atol).
 static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int *its_out,
                  double *rnorm_out) {
+    if (restart < 1 || restart > RED_K - 10) {
+        set_error("GMRES restart must be between 1 and 30");
+        return -2;
+    }
     if (ensure_krylov(c, restart)) return -1;
     const int m = restart;
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gvec(m + 1), yv(m);
-    std::vector<const double *> vp(m + 1);
+    std::vector<const double *> vp(m + 1), dotp(m + 2);
     for (int i = 0; i <= m; ++i) vp[i] = c.d_V + (size_t)i * c.np;
     hipMemsetAsync(c.d_delta, 0, sizeof(double) * c.np, c.stream);
     int its = 0;
@@ -127,20 +132,38 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         for (; j < m && its < max_it; ++j) {
             double *w = c.d_V + (size_t)(j + 1) * c.np;
             apply_operator(c, vp[j], w);
-            launch_dots(c, vp.data(), w, j + 1);  // h_i = v_i . w
-            read_red(c, j + 1);
+            // classical Gram-Schmidt with ONE reduction and ONE host sync per iteration:
+            // h_i = v_i.w and ww = w.w together; |w - V h|^2 = ww - |h|^2 on the device;
+            // the update and the normalisation read their coefficients from device memory.
+            for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+            dotp[j + 1] = w;
+            launch_dots(c, dotp.data(), w, j + 2, true);
+            launch_cgs_update(c, j + 1, vp.data(), w);
+            read_red(c, RED_K);
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = c.h_red[i];
-            launch_multi_axpy(c, c.h_red, j + 1, vp.data(), w, -1.0);
-            launch_norm2(c, w, 0);
-            read_red(c, 1);
-            const double hn = std::sqrt(c.h_red[0]);
+            double hn2 = c.h_red[j + 1];
+            const double ww = c.h_red[RED_K - 2];
+            double hn;
+            if (!(hn2 > 1e-8 * ww && hn2 > 0.0) && std::isfinite(ww) && ww > 0.0) {
+                // strong cancellation: w was left unscaled; refine (second CGS pass) and
+                // take the norm explicitly
+                launch_dots(c, vp.data(), w, j + 1, false);
+                read_red(c, j + 1);
+                for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] += c.h_red[i];
+                launch_multi_axpy(c, c.h_red, j + 1, vp.data(), w, -1.0);
+                launch_norm2(c, w, 0);
+                read_red(c, 1);
+                hn = std::sqrt(c.h_red[0]);
+                if (hn > 0.0 && std::isfinite(hn)) launch_scale_copy(c, 1.0 / hn, w, w);
+            } else {
+                hn = std::sqrt(hn2);
+            }
             H[(size_t)(j + 1) * m + j] = hn;
             if (!std::isfinite(hn)) {
                 *its_out = its;
                 *rnorm_out = hn;
                 return FEDM_DIVERGED_NAN;
             }
-            if (hn > 0.0) launch_scale_copy(c, 1.0 / hn, w, w);
             // Givens rotations on column j
             for (int i = 0; i < j; ++i) {
                 const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
@@ -270,9 +293,32 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
             return -2;
         }
     if (upload(c.d_ftags, tags, (size_t)3 * c.nc)) return -1;
+    {
+        std::vector<int> bf;
+        for (int cell = 0; cell < c.nc; ++cell)
+            for (int i = 0; i < 3; ++i)
+                if (tags[3 * cell + i] > 0) {
+                    bf.push_back(cell);
+                    bf.push_back(i);
+                    bf.push_back(tags[3 * cell + i]);
+                }
+        c.n_bfacets = (int)bf.size() / 3;
+        if (upload(c.d_bfacets, bf.data(), bf.size())) return -1;
+    }
     if (upload(c.d_cell_slots, c.pat.cell_slots.data(), c.pat.cell_slots.size())) return -1;
     if (upload(c.d_colour_cells, c.pat.colour_cells.data(), c.pat.colour_cells.size())) return -1;
     if (upload(c.d_model, model, 1)) return -1;
+    if (upload(c.d_patch_cell_ptr, c.pat.patch_cell_ptr.data(), c.pat.patch_cell_ptr.size())) return -1;
+    if (upload(c.d_patch_halo_ptr, c.pat.patch_halo_ptr.data(), c.pat.patch_halo_ptr.size())) return -1;
+    if (upload(c.d_patch_halo, c.pat.patch_halo.data(), c.pat.patch_halo.size())) return -1;
+    if (upload(c.d_patch_cells, c.pat.patch_cells.data(), c.pat.patch_cells.size())) return -1;
+    {
+        // LDS patches need 8-bit local indices and <= 160 KiB of LDS per workgroup; the
+        // globally coloured kernel is the (deterministic, slower) alternative.
+        const char *env = getenv("FEDM_ASSEMBLY");
+        c.assembly_kind = (env && std::string(env) == "colour") ? 0 : 1;
+        if (!c.pat.patch_ok || patch_lds_bytes(c) > 160 * 1024) c.assembly_kind = 0;
+    }
     if (upload(c.d_slice_boff, c.pat.slice_boff.data(), c.pat.slice_boff.size())) return -1;
     if (upload(c.d_colidx, c.pat.colidx.data(), c.pat.colidx.size())) return -1;
     if (upload(c.d_diag_slot, c.pat.diag_slot.data(), c.pat.diag_slot.size())) return -1;
@@ -306,7 +352,8 @@ void fedm_ctx_destroy(fedm_ctx *h) {
                     c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.d_val, c.d_dinv, c.d_dir_dofs,
                     c.d_dir_vals, c.d_u, c.d_uold, c.d_uold1, c.d_F, c.d_delta, c.d_w, c.d_rhs,
                     c.d_tmp, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
-                    c.d_ext[3]};
+                    c.d_ext[3], c.d_patch_cell_ptr, c.d_patch_halo_ptr, c.d_patch_halo,
+                    c.d_patch_cells, c.d_bfacets};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c.amg) {
@@ -611,6 +658,20 @@ int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) 
     *ms_per_launch = (double)ms / repeats;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    return 0;
+}
+
+int fedm_set_assembly(fedm_ctx *h, int kind) {
+    Ctx &c = h->c;
+    if (kind == 1 && (!c.pat.patch_ok || patch_lds_bytes(c) > 160 * 1024)) {
+        set_error("LDS patch assembly unavailable for this mesh");
+        return -2;
+    }
+    if (kind != 0 && kind != 1) {
+        set_error("assembly kind must be 0 (colouring) or 1 (LDS patches)");
+        return -2;
+    }
+    c.assembly_kind = kind;
     return 0;
 }
 

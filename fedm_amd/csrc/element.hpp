@@ -37,22 +37,48 @@ __device__ __forceinline__ void termsum_eval(const fedm_termsum &ts, double E, d
     }
 }
 
-struct StepCoef {  // fedm/functions.py:350-356
-    double dt, tr2p1, trp1sq, trsq, trp1;
+// Variable-step BDF2 in the log variable, fedm/functions.py:350-357:
+//   u_part = (u*(1+2w) - (1+w)^2 u_old + w^2 u_old1) / (1+w),   w = dt/dt_old.
+// The history part is linear in the nodal values, so it is folded per node into
+//   hist = c_old * u_old + c_old1 * u_old1        and       u_part = c_new * u + hist.
+struct StepCoef {
+    double dt, c_new, c_old, c_old1;
 };
 
 __host__ __device__ inline StepCoef step_coef(double dt, double dt_old) {
     StepCoef s;
     const double tr = dt / dt_old;
+    const double trp1 = 1.0 + tr;
     s.dt = dt;
-    s.trp1 = 1.0 + tr;
-    s.tr2p1 = 1.0 + 2.0 * tr;
-    s.trp1sq = s.trp1 * s.trp1;
-    s.trsq = tr * tr;
+    s.c_new = (1.0 + 2.0 * tr) / trp1;
+    s.c_old = -(trp1 * trp1) / trp1;
+    s.c_old1 = (tr * tr) / trp1;
     return s;
 }
 
-template <int NS, bool PO>
+// cell geometry: gradients of the P1 basis, |det J|, vertex radii
+struct CellGeom {
+    double G[3][2];
+    double detJ;
+    double rn[3];
+    __device__ __forceinline__ void init(const double x[3][2], int axisymmetric) {
+        const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
+        const double d2x = x[2][0] - x[0][0], d2y = x[2][1] - x[0][1];
+        const double det = d1x * d2y - d1y * d2x;
+        detJ = fabs(det);
+        G[0][0] = (x[1][1] - x[2][1]) / det;
+        G[0][1] = (x[2][0] - x[1][0]) / det;
+        G[1][0] = (x[2][1] - x[0][1]) / det;
+        G[1][1] = (x[0][0] - x[2][0]) / det;
+        G[2][0] = (x[0][1] - x[1][1]) / det;
+        G[2][1] = (x[1][0] - x[0][0]) / det;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rn[a] = axisymmetric ? x[a][0] : 0.5 / 3.14159265358979323846;
+    }
+};
+
+// NR: compile-time bound on the number of reactions (keeps their coefficients in registers)
+template <int NS, bool PO, int NR>
 struct Element {
     static constexpr int NEQ = NS + (PO ? 1 : 0);
     static constexpr int IPHI = NEQ - 1;
@@ -70,34 +96,26 @@ struct Element {
     double M1n[NS][3];
     double M0n[NS];
     double M1Sp[NS][3];
-    double BV[NS][3][2];
     double M01;
     bool flux[NS], fdrift[NS];
 
-    // ext: pointer to this cell's P_k nodal values per species (or nullptr)
+    // Uc: nodal unknowns; Hc: nodal BDF history (see StepCoef); ext: this cell's P_k nodal
+    // source values per species (or nullptr); mode 1 = Poisson row only
     __device__ void compute(const fedm_model_desc *__restrict__ md, const double x[3][2],
-                            const double Uc[3][NEQ], const double Uo[3][NEQ],
-                            const double Uo1[3][NEQ], const StepCoef sc,
-                            const double *const ext[NS], const int8_t tags[3], int mode) {
+                            const double Uc[3][NEQ], const double Hc[3][NS > 0 ? NS : 1],
+                            const StepCoef sc, const double *const ext[NS], int mode) {
         const double two_pi = 6.283185307179586476925286766559;
-        // ---- geometry ----------------------------------------------------------------
-        const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
-        const double d2x = x[2][0] - x[0][0], d2y = x[2][1] - x[0][1];
-        const double det = d1x * d2y - d1y * d2x;
-        const double detJ = fabs(det);
-        G[0][0] = (x[1][1] - x[2][1]) / det;
-        G[0][1] = (x[2][0] - x[1][0]) / det;
-        G[1][0] = (x[2][1] - x[0][1]) / det;
-        G[1][1] = (x[0][0] - x[2][0]) / det;
-        G[2][0] = (x[0][1] - x[1][1]) / det;
-        G[2][1] = (x[1][0] - x[0][0]) / det;
+        CellGeom cg;
+        cg.init(x, md->axisymmetric);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            G[a][0] = cg.G[a][0];
+            G[a][1] = cg.G[a][1];
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = a; b < 3; ++b) GG[sym6(a, b)] = G[a][0] * G[b][0] + G[a][1] * G[b][1];
-        double rn[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) rn[a] = md->axisymmetric ? x[a][0] : 0.5 / 3.14159265358979323846;
 
         // ---- cell-constant fields -----------------------------------------------------
         double Em = 1.0;
@@ -120,10 +138,10 @@ struct Element {
             }
         }
         const double lnE = log(Em);
-        double kv[FEDM_MAX_REACTIONS], kd[FEDM_MAX_REACTIONS];
+        double kv[NR > 0 ? NR : 1], kd[NR > 0 ? NR : 1];
         const int nreac = full ? md->n_reactions : 0;
 #pragma unroll
-        for (int j = 0; j < FEDM_MAX_REACTIONS; ++j) {
+        for (int j = 0; j < NR; ++j) {
             kv[j] = kd[j] = 0.0;
             if (j < nreac) termsum_eval(md->k[j], Em, lnE, kv[j], kd[j]);
         }
@@ -176,7 +194,6 @@ struct Element {
             for (int a = 0; a < 3; ++a) {
                 M1n[s][a] = 0.0;
                 M1Sp[s][a] = 0.0;
-                BV[s][a][0] = BV[s][a][1] = 0.0;
             }
         }
         M01 = 0.0;
@@ -185,8 +202,8 @@ struct Element {
         for (int q = 0; q < nq; ++q) {
             const double xq = md->qp_x[q], yq = md->qp_y[q];
             double phi[3] = {1.0 - xq - yq, xq, yq};
-            const double rq = rn[0] * phi[0] + rn[1] * phi[1] + rn[2] * phi[2];
-            const double W = md->qp_w[q] * detJ * two_pi * rq;
+            const double rq = cg.rn[0] * phi[0] + cg.rn[1] * phi[1] + cg.rn[2] * phi[2];
+            const double W = md->qp_w[q] * cg.detJ * two_pi * rq;
             double nq_[NS], g[NEQ][NS], h[NEQ], Sp[NS];
 #pragma unroll
             for (int s = 0; s < NEQ; ++s) {
@@ -201,15 +218,14 @@ struct Element {
                 nq_[s] = n;
                 Sp[s] = 0.0;
                 if (full) {
-                    const double uo = Uo[0][s] * phi[0] + Uo[1][s] * phi[1] + Uo[2][s] * phi[2];
-                    const double uo1 = Uo1[0][s] * phi[0] + Uo1[1][s] * phi[1] + Uo1[2][s] * phi[2];
-                    const double u_part = (u * sc.tr2p1 - sc.trp1sq * uo + sc.trsq * uo1) / sc.trp1;
+                    const double hist = Hc[0][s] * phi[0] + Hc[1][s] * phi[1] + Hc[2][s] * phi[2];
+                    const double u_part = sc.c_new * u + hist;
                     h[s] = n * u_part / sc.dt;
-                    g[s][s] = n * (u_part / sc.dt + sc.tr2p1 / (sc.trp1 * sc.dt));
+                    g[s][s] = n * (u_part / sc.dt + sc.c_new / sc.dt);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < FEDM_MAX_REACTIONS; ++j) {
+            for (int j = 0; j < NR; ++j) {
                 if (j >= nreac) break;
                 double prod = 1.0;
 #pragma unroll
@@ -276,54 +292,9 @@ struct Element {
             }
             M01 += W;
         }
-
-        // ---- Neumann boundary facets, fedm/functions.py:523-524 -------------------------
-        if (PO && full && (tags[0] | tags[1] | tags[2])) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int tag = tags[i];
-                if (tag <= 0) continue;
-                const int j = (i == 0) ? 1 : 0, k = (i == 2) ? 1 : 2;
-                const double gi = sqrt(G[i][0] * G[i][0] + G[i][1] * G[i][1]);
-                const double nrm[2] = {-G[i][0] / gi, -G[i][1] / gi};
-                const double ex = x[j][0] - x[k][0], ey = x[j][1] - x[k][1];
-                const double L = sqrt(ex * ex + ey * ey);
-                const double En = E[0] * nrm[0] + E[1] * nrm[1];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if (!fdrift[s] || md->bc_kind[tag - 1][s] != FEDM_BC_NEUMANN) continue;
-                    double EM1[3] = {0.0, 0.0, 0.0}, EM2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                    for (int t = 0; t < md->n_fqp; ++t) {
-                        double phi[3] = {0.0, 0.0, 0.0};
-                        phi[j] = 1.0 - md->fqp_t[t];
-                        phi[k] = md->fqp_t[t];
-                        const double rq = rn[0] * phi[0] + rn[1] * phi[1] + rn[2] * phi[2];
-                        const double n = exp(Uc[0][s] * phi[0] + Uc[1][s] * phi[1] + Uc[2][s] * phi[2]);
-                        const double We = md->fqp_w[t] * L * two_pi * rq * n;
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            EM1[a] += We * phi[a];
-#pragma unroll
-                            for (int b = a; b < 3; ++b) EM2[sym6(a, b)] += We * phi[a] * phi[b];
-                        }
-                    }
-                    const double zm = md->Z[s] * muv[s], zd = md->Z[s] * mud[s];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        M1h[s][a] += zm * En * EM1[a];
-                        M1Sp[s][a] -= zd * En * EM1[a];
-                        BV[s][a][0] += zm * nrm[0] * EM1[a];
-                        BV[s][a][1] += zm * nrm[1] * EM1[a];
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < 6; ++kk) M2g[s][s][kk] += zm * En * EM2[kk];
-                }
-            }
-        }
     }
 
-    __device__ __forceinline__ void residual(const fedm_model_desc *__restrict__ md, int a,
-                                             double R[NEQ]) const {
+    __device__ __forceinline__ void residual(int a, double R[NEQ]) const {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             R[s] = M1h[s][a];
@@ -342,7 +313,7 @@ struct Element {
             for (int i = 0; i < NS; ++i) B[s * NEQ + i] = M2g[s][i][k];
             if (flux[s]) B[s * NEQ + s] -= velG[s][a] * M1n[s][b] - Dv[s] * GG[k] * M0n[s];
             if (PO) {
-                double v = -dEm[b] * M1Sp[s][a] - (G[b][0] * BV[s][a][0] + G[b][1] * BV[s][a][1]);
+                double v = -dEm[b] * M1Sp[s][a];
                 if (flux[s]) {
                     double dv0 = -Dd[s] * dEm[b] * gradu[s][0];
                     double dv1 = -Dd[s] * dEm[b] * gradu[s][1];
@@ -362,5 +333,69 @@ struct Element {
         }
     }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Neumann boundary flux of one tagged facet (fedm/functions.py:523-524):
+//   2*pi * (Z mu E.n) exp(u) v r ds     on the edge opposite local vertex `fi`.
+// Contributions are added with global fp64 atomics (a few thousand facets; adjacent facets
+// share a vertex).  R: [3][NEQ] residual, blocks via `add(a, b, s_row, s_col, value)`.
+// ---------------------------------------------------------------------------------------------
+template <int NS, class AddR, class AddJ>
+__device__ void boundary_facet(const fedm_model_desc *__restrict__ md, const double x[3][2],
+                               const double Uc[3][NS + 1], int fi, int tag, bool jacobian,
+                               AddR addR, AddJ addJ) {
+    constexpr int NEQ = NS + 1;
+    const double two_pi = 6.283185307179586476925286766559;
+    CellGeom cg;
+    cg.init(x, md->axisymmetric);
+    double E[2] = {0.0, 0.0};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        E[0] -= Uc[a][NS] * cg.G[a][0];
+        E[1] -= Uc[a][NS] * cg.G[a][1];
+    }
+    const double Em = sqrt(E[0] * E[0] + E[1] * E[1]);
+    const double lnE = log(Em);
+    double dEm[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) dEm[b] = -(E[0] * cg.G[b][0] + E[1] * cg.G[b][1]) / Em;
+    const int j = (fi == 0) ? 1 : 0, k = (fi == 2) ? 1 : 2;
+    const double gi = sqrt(cg.G[fi][0] * cg.G[fi][0] + cg.G[fi][1] * cg.G[fi][1]);
+    const double nrm[2] = {-cg.G[fi][0] / gi, -cg.G[fi][1] / gi};
+    const double ex = x[j][0] - x[k][0], ey = x[j][1] - x[k][1];
+    const double L = sqrt(ex * ex + ey * ey);
+    const double En = E[0] * nrm[0] + E[1] * nrm[1];
+    for (int s = 0; s < NS; ++s) {
+        if (md->eq_type[s] != FEDM_EQ_DRIFT_DIFFUSION_REACTION || md->has_drift_w[s] ||
+            md->bc_kind[tag - 1][s] != FEDM_BC_NEUMANN)
+            continue;
+        double muv, mud;
+        termsum_eval(md->mu[s], Em, lnE, muv, mud);
+        double EM1[3] = {0.0, 0.0, 0.0}, EM2[3][3] = {{0.0}};
+        for (int t = 0; t < md->n_fqp; ++t) {
+            double phi[3] = {0.0, 0.0, 0.0};
+            phi[j] = 1.0 - md->fqp_t[t];
+            phi[k] = md->fqp_t[t];
+            const double rq = cg.rn[0] * phi[0] + cg.rn[1] * phi[1] + cg.rn[2] * phi[2];
+            const double n = exp(Uc[0][s] * phi[0] + Uc[1][s] * phi[1] + Uc[2][s] * phi[2]);
+            const double We = md->fqp_w[t] * L * two_pi * rq * n;
+            for (int a = 0; a < 3; ++a) {
+                EM1[a] += We * phi[a];
+                for (int b = 0; b < 3; ++b) EM2[a][b] += We * phi[a] * phi[b];
+            }
+        }
+        const double zm = md->Z[s] * muv, zd = md->Z[s] * mud;
+        for (int a = 0; a < 3; ++a) {
+            if (a == fi) continue;  // phi_a vanishes on the facet
+            addR(a, s, zm * En * EM1[a]);
+            if (!jacobian) continue;
+            for (int b = 0; b < 3; ++b) {
+                addJ(a, b, s, s, zm * En * EM2[a][b]);
+                const double gbn = cg.G[b][0] * nrm[0] + cg.G[b][1] * nrm[1];
+                addJ(a, b, s, NEQ - 1, (zd * dEm[b] * En - zm * gbn) * EM1[a]);
+            }
+        }
+    }
+}
 
 }  // namespace fedm

@@ -17,6 +17,18 @@ constexpr int SLICE = 64;  // vertices per matrix slice = one wavefront
 //   the slice; block column bc = slice_boff[S] + j is the j-th neighbour of every vertex
 //   of the slice.  Values of block entry (cr, cc) of (bc, lane) live at
 //   val[(bc * NEQ*NEQ + cr*NEQ + cc) * 64 + lane]  -> lanes are contiguous (coalesced).
+// One cell as seen from one patch (slice of 64 owned vertices): local vertex ids (< 64 owned
+// lane, >= 64 halo), the local block column of every (a, b) pair whose row vertex a is owned
+// (0xFF otherwise), boundary tags and the global cell id.
+struct PatchCell {
+    int32_t cell;
+    uint8_t lv[3];
+    int8_t tag[3];
+    uint8_t j[9];
+    uint8_t pad_;
+};
+static_assert(sizeof(PatchCell) == 20, "PatchCell layout");
+
 struct Pattern {
     int nv = 0, nc = 0, nvp = 0, n_slices = 0;
     int64_t total_bc = 0;    // stored block columns (x 64 lanes = stored blocks incl. padding)
@@ -28,6 +40,13 @@ struct Pattern {
     std::vector<uint32_t> cell_slots;   // nc * 9 : slot of block (a, b) of every cell
     std::vector<int> colour_ptr;        // n_colours + 1
     std::vector<int> colour_cells;      // cells grouped by colour
+    // patch (= slice) lists for the LDS assembly kernel
+    std::vector<int> patch_cell_ptr;    // n_slices + 1
+    std::vector<PatchCell> patch_cells; // every cell touching a vertex of the slice
+    std::vector<int> patch_halo_ptr;    // n_slices + 1
+    std::vector<int> patch_halo;        // non-owned vertices referenced by the slice's cells
+    int max_patch_width = 0, max_patch_verts = 0, max_patch_cells = 0;
+    bool patch_ok = false;              // false: some patch exceeds the 8-bit local indices
 };
 
 void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat);
@@ -50,6 +69,11 @@ struct Ctx {
     int8_t *d_ftags = nullptr;
     uint32_t *d_cell_slots = nullptr;
     int *d_colour_cells = nullptr;
+    int *d_patch_cell_ptr = nullptr, *d_patch_halo_ptr = nullptr, *d_patch_halo = nullptr;
+    PatchCell *d_patch_cells = nullptr;
+    int assembly_kind = 1;  // 0: global colouring (deterministic), 1: LDS patches
+    int n_bfacets = 0;      // tagged boundary facets (cell, local facet, tag)
+    int *d_bfacets = nullptr;
     fedm_model_desc *d_model = nullptr;
     double *d_ext[FEDM_MAX_SPECIES] = {nullptr, nullptr, nullptr, nullptr};
     // matrix
@@ -80,11 +104,13 @@ constexpr int RED_K = 40;
 // ---- kernel launchers (kernels.hip) -----------------------------------------------------
 // mode: 0 = full model, 1 = Poisson row only (species rows become identity)
 void launch_assemble(Ctx &c, bool jacobian, int mode);
+size_t patch_lds_bytes(const Ctx &c);
 void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks
 void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
-void launch_dots(Ctx &c, const double *const *xs, const double *y, int k);  // d_red[i] = xs[i].y
+void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
+void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y);
 void launch_norm2(Ctx &c, const double *x, int slot);                       // d_red[slot] = x.x
 void launch_axpy(Ctx &c, double a, const double *x, double *y);             // y += a x
 void launch_scale_copy(Ctx &c, double a, const double *x, double *y);       // y = a x

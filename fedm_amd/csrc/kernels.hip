@@ -7,54 +7,50 @@
 namespace fedm {
 
 // =============================================================================================
-// Assembly, one thread per cell, one launch per colour (cells of a colour share no vertex, so
-// the read-modify-write of matrix blocks and residual entries is conflict-free and the
-// summation order is fixed -> bitwise reproducible).     Problem.F / Problem.J,
-// fedm/functions.py:188-202
+// Assembly, variant 0: one thread per cell, one launch per colour (cells of a colour share
+// no vertex, so the read-modify-write of matrix blocks and residual entries is conflict-free
+// and the summation order is fixed -> bitwise reproducible).
+// Problem.F / Problem.J, fedm/functions.py:188-202
 // =============================================================================================
-template <int NS, bool PO>
+template <int NS, bool PO, int NR>
 __global__ __launch_bounds__(256) void assemble_colour_kernel(
     const fedm_model_desc *__restrict__ md, const int *__restrict__ cell_list, int n_cells,
     const int *__restrict__ cells, const double *__restrict__ coords,
-    const int8_t *__restrict__ ftags, const uint32_t *__restrict__ cell_slots,
-    const double *__restrict__ u, const double *__restrict__ uold,
-    const double *__restrict__ uold1, StepCoef sc, const double *ext0, const double *ext1,
-    const double *ext2, const double *ext3, double *__restrict__ val, double *__restrict__ F,
-    int jacobian, int mode) {
+    const uint32_t *__restrict__ cell_slots, const double *__restrict__ u,
+    const double *__restrict__ uold, const double *__restrict__ uold1, StepCoef sc,
+    const double *ext0, const double *ext1, const double *ext2, const double *ext3,
+    double *__restrict__ val, double *__restrict__ F, int jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     constexpr int NEQ2 = NEQ * NEQ;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_cells) return;
     const int c = cell_list[t];
     int v[3];
-    double x[3][2], Uc[3][NEQ], Uo[3][NEQ], Uo1[3][NEQ];
-    int8_t tags[3];
+    double x[3][2], Uc[3][NEQ], Hc[3][NS];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         v[a] = cells[3 * c + a];
-        tags[a] = ftags[3 * c + a];
         x[a][0] = coords[2 * v[a]];
         x[a][1] = coords[2 * v[a] + 1];
 #pragma unroll
-        for (int s = 0; s < NEQ; ++s) {
-            Uc[a][s] = u[(size_t)v[a] * NEQ + s];
-            Uo[a][s] = uold[(size_t)v[a] * NEQ + s];
-            Uo1[a][s] = uold1[(size_t)v[a] * NEQ + s];
-        }
+        for (int s = 0; s < NEQ; ++s) Uc[a][s] = u[(size_t)v[a] * NEQ + s];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            Hc[a][s] = sc.c_old * uold[(size_t)v[a] * NEQ + s] + sc.c_old1 * uold1[(size_t)v[a] * NEQ + s];
     }
     const double *extp[4] = {ext0, ext1, ext2, ext3};
-    const double *ext[NS > 0 ? NS : 1];
+    const double *ext[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)c * md->ext_nodes[s] : nullptr;
 
-    Element<NS, PO> el;
-    el.compute(md, x, Uc, Uo, Uo1, sc, ext, tags, mode);
+    Element<NS, PO, NR> el;
+    el.compute(md, x, Uc, Hc, sc, ext, mode);
 
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         double R[NEQ];
-        el.residual(md, a, R);
+        el.residual(a, R);
 #pragma unroll
         for (int s = 0; s < NEQ; ++s) F[(size_t)v[a] * NEQ + s] += R[s];
     }
@@ -72,8 +68,8 @@ __global__ __launch_bounds__(256) void assemble_colour_kernel(
         }
 }
 
-template <int NS, bool PO>
-static void assemble_t(Ctx &c, bool jacobian, int mode) {
+template <int NS, bool PO, int NR>
+static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     hipMemsetAsync(c.d_F, 0, sizeof(double) * c.np, c.stream);
     if (jacobian)
@@ -83,20 +79,191 @@ static void assemble_t(Ctx &c, bool jacobian, int mode) {
     for (int k = 0; k < ncol; ++k) {
         const int n = c.pat.colour_ptr[k + 1] - c.pat.colour_ptr[k];
         if (n == 0) continue;
-        hipLaunchKernelGGL((assemble_colour_kernel<NS, PO>), dim3((n + 255) / 256), dim3(256), 0,
+        hipLaunchKernelGGL((assemble_colour_kernel<NS, PO, NR>), dim3((n + 255) / 256), dim3(256), 0,
                            c.stream, c.d_model, c.d_colour_cells + c.pat.colour_ptr[k], n,
-                           c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots, c.d_u, c.d_uold,
-                           c.d_uold1, sc, c.d_ext[0], c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val,
-                           c.d_F, jacobian ? 1 : 0, mode);
+                           c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_uold, c.d_uold1, sc,
+                           c.d_ext[0], c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val, c.d_F,
+                           jacobian ? 1 : 0, mode);
+    }
+}
+
+// =============================================================================================
+// Assembly, variant 1 (default): LDS patches.  One workgroup owns one matrix slice (64 vertex
+// rows).  It stages the patch's vertex data (owned + halo vertices: coordinates, u and the
+// folded BDF history) in LDS, evaluates every cell that touches an owned vertex (cells on
+// patch borders are evaluated by each patch they touch), accumulates the owned rows' blocks
+// and residual entries in LDS with ds_add_f64, and finally streams the finished slice out
+// with fully coalesced stores: every matrix value is written exactly once -- no
+// read-modify-write in HBM and no zero-fill pass.
+// =============================================================================================
+constexpr int PATCH_THREADS = 320;
+
+template <int NS, bool PO, int NR>
+__global__ __launch_bounds__(PATCH_THREADS) void assemble_patch_kernel(
+    const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
+    const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
+    const int *__restrict__ halo_ptr, const int *__restrict__ halo,
+    const double *__restrict__ coords, const double *__restrict__ u,
+    const double *__restrict__ uold, const double *__restrict__ uold1, StepCoef sc,
+    const double *ext0, const double *ext1, const double *ext2, const double *ext3,
+    double *__restrict__ val, double *__restrict__ F, int jacobian, int mode, int acc_doubles,
+    int max_verts) {
+    constexpr int NEQ = NS + (PO ? 1 : 0);
+    constexpr int NEQ2 = NEQ * NEQ;
+    extern __shared__ double lds[];
+    double *acc = lds;                          // [width][NEQ2][64]
+    double *Fl = acc + acc_doubles;             // [64][NEQ]
+    double *vx = Fl + SLICE * NEQ;              // [max_verts][2]
+    double *Ul = vx + 2 * max_verts;            // [max_verts][NEQ]
+    double *Hl = Ul + NEQ * max_verts;          // [max_verts][NS]
+
+    const int S = blockIdx.x;
+    const int b0 = boff[S], width = boff[S + 1] - b0;
+    const int n_acc = jacobian ? width * NEQ2 * SLICE : 0;
+    for (int k = threadIdx.x; k < n_acc; k += blockDim.x) acc[k] = 0.0;
+    for (int k = threadIdx.x; k < SLICE * NEQ; k += blockDim.x) Fl[k] = 0.0;
+    const int h0 = halo_ptr[S], n_local = SLICE + halo_ptr[S + 1] - h0;
+    for (int i = threadIdx.x; i < n_local; i += blockDim.x) {
+        const int g = (i < SLICE) ? S * SLICE + i : halo[h0 + i - SLICE];
+        if (g < nv) {
+            vx[2 * i] = coords[2 * (size_t)g];
+            vx[2 * i + 1] = coords[2 * (size_t)g + 1];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) Ul[i * NEQ + s] = u[(size_t)g * NEQ + s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                Hl[i * NS + s] = sc.c_old * uold[(size_t)g * NEQ + s] + sc.c_old1 * uold1[(size_t)g * NEQ + s];
+        }
+    }
+    __syncthreads();
+
+    const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
+    for (int i = threadIdx.x; i < n_cells; i += blockDim.x) {
+        const PatchCell pc = pcells[c0 + i];
+        double x[3][2], Uc[3][NEQ], Hc[3][NS];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int l = pc.lv[a];
+            x[a][0] = vx[2 * l];
+            x[a][1] = vx[2 * l + 1];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) Uc[a][s] = Ul[l * NEQ + s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Hc[a][s] = Hl[l * NS + s];
+        }
+        const double *extp[4] = {ext0, ext1, ext2, ext3};
+        const double *ext[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)pc.cell * md->ext_nodes[s] : nullptr;
+
+        Element<NS, PO, NR> el;
+        el.compute(md, x, Uc, Hc, sc, ext, mode);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int lane = pc.lv[a];
+            if (lane >= SLICE) continue;  // row vertex owned by another patch
+            double R[NEQ];
+            el.residual(a, R);
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) unsafeAtomicAdd(&Fl[lane * NEQ + s], R[s]);
+            if (!jacobian) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                double B[NEQ2];
+                el.block(md, a, b, B);
+                double *dst = acc + (size_t)pc.j[a * 3 + b] * NEQ2 * SLICE + lane;
+#pragma unroll
+                for (int e = 0; e < NEQ2; ++e) unsafeAtomicAdd(&dst[e * SLICE], B[e]);
+            }
+        }
+    }
+    __syncthreads();
+    double *vdst = val + (size_t)b0 * NEQ2 * SLICE;
+    for (int k = threadIdx.x; k < n_acc; k += blockDim.x) vdst[k] = acc[k];
+    double *fdst = F + (size_t)S * SLICE * NEQ;
+    for (int k = threadIdx.x; k < SLICE * NEQ; k += blockDim.x) fdst[k] = Fl[k];
+}
+
+size_t patch_lds_bytes(const Ctx &c) {
+    const int neq = c.neq, mv = c.pat.max_patch_verts;
+    return sizeof(double) * ((size_t)c.pat.max_patch_width * neq * neq * SLICE + SLICE * neq +
+                             2 * mv + (size_t)(neq + c.ns) * mv);
+}
+
+template <int NS, bool PO, int NR>
+static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
+    constexpr int NEQ = NS + (PO ? 1 : 0);
+    const StepCoef sc = step_coef(c.dt, c.dt_old);
+    const int acc_doubles = c.pat.max_patch_width * NEQ * NEQ * SLICE;
+    hipLaunchKernelGGL((assemble_patch_kernel<NS, PO, NR>), dim3(c.pat.n_slices), dim3(PATCH_THREADS),
+                       patch_lds_bytes(c), c.stream, c.d_model, c.nv, c.d_slice_boff,
+                       c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr, c.d_patch_halo,
+                       c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],
+                       c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, jacobian ? 1 : 0, mode, acc_doubles,
+                       c.pat.max_patch_verts);
+}
+
+// =============================================================================================
+// Neumann boundary facets (fedm/functions.py:523-524): one thread per tagged facet, added on
+// top of the volume assembly with global fp64 atomics.
+// =============================================================================================
+template <int NS>
+__global__ void boundary_kernel(const fedm_model_desc *__restrict__ md, int n_facets,
+                                const int *__restrict__ facets /* [n][3] = cell, local facet, tag */,
+                                const int *__restrict__ cells, const double *__restrict__ coords,
+                                const uint32_t *__restrict__ cell_slots,
+                                const double *__restrict__ u, double *__restrict__ val,
+                                double *__restrict__ F, int jacobian) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_facets) return;
+    const int c = facets[3 * t], fi = facets[3 * t + 1], tag = facets[3 * t + 2];
+    int v[3];
+    double x[3][2], Uc[3][NEQ];
+    for (int a = 0; a < 3; ++a) {
+        v[a] = cells[3 * c + a];
+        x[a][0] = coords[2 * v[a]];
+        x[a][1] = coords[2 * v[a] + 1];
+        for (int s = 0; s < NEQ; ++s) Uc[a][s] = u[(size_t)v[a] * NEQ + s];
+    }
+    auto addR = [&](int a, int s, double value) { unsafeAtomicAdd(&F[(size_t)v[a] * NEQ + s], value); };
+    auto addJ = [&](int a, int b, int sr, int scol, double value) {
+        const uint32_t slot = cell_slots[(size_t)c * 9 + a * 3 + b];
+        unsafeAtomicAdd(&val[((size_t)(slot >> 6) * NEQ2 + sr * NEQ + scol) * SLICE + (slot & 63)], value);
+    };
+    boundary_facet<NS>(md, x, Uc, fi, tag, jacobian != 0, addR, addJ);
+}
+
+static void launch_boundary(Ctx &c, bool jacobian) {
+    if (!c.poisson || c.n_bfacets == 0) return;
+    const dim3 g((c.n_bfacets + 127) / 128), b(128);
+    switch (c.ns) {
+        case 1: hipLaunchKernelGGL(boundary_kernel<1>, g, b, 0, c.stream, c.d_model, c.n_bfacets, c.d_bfacets, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+        case 2: hipLaunchKernelGGL(boundary_kernel<2>, g, b, 0, c.stream, c.d_model, c.n_bfacets, c.d_bfacets, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+        case 3: hipLaunchKernelGGL(boundary_kernel<3>, g, b, 0, c.stream, c.d_model, c.n_bfacets, c.d_bfacets, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+    }
+}
+
+template <int NS, bool PO>
+static void assemble_dispatch(Ctx &c, bool jacobian, int mode) {
+    const bool few = c.model.n_reactions <= 1;
+    if (c.assembly_kind == 1) {
+        if (few) assemble_patch_t<NS, PO, 1>(c, jacobian, mode);
+        else assemble_patch_t<NS, PO, FEDM_MAX_REACTIONS>(c, jacobian, mode);
+    } else {
+        if (few) assemble_colour_t<NS, PO, 1>(c, jacobian, mode);
+        else assemble_colour_t<NS, PO, FEDM_MAX_REACTIONS>(c, jacobian, mode);
     }
 }
 
 void launch_assemble(Ctx &c, bool jacobian, int mode) {
-    if (c.ns == 1 && !c.poisson) return assemble_t<1, false>(c, jacobian, mode);
-    if (c.ns == 1 && c.poisson) return assemble_t<1, true>(c, jacobian, mode);
-    if (c.ns == 2 && c.poisson) return assemble_t<2, true>(c, jacobian, mode);
-    if (c.ns == 2 && !c.poisson) return assemble_t<2, false>(c, jacobian, mode);
-    if (c.ns == 3 && c.poisson) return assemble_t<3, true>(c, jacobian, mode);
+    if (c.ns == 1 && !c.poisson) assemble_dispatch<1, false>(c, jacobian, mode);
+    else if (c.ns == 1 && c.poisson) assemble_dispatch<1, true>(c, jacobian, mode);
+    else if (c.ns == 2 && c.poisson) assemble_dispatch<2, true>(c, jacobian, mode);
+    else if (c.ns == 2 && !c.poisson) assemble_dispatch<2, false>(c, jacobian, mode);
+    else if (c.ns == 3 && c.poisson) assemble_dispatch<3, true>(c, jacobian, mode);
+    if (mode == 0) launch_boundary(c, jacobian);
 }
 
 // =============================================================================================
@@ -404,12 +571,56 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partials, int 
     if (threadIdx.x == 0) out[i] = s;
 }
 
+// GMRES orthogonalisation step in ONE reduction: the dots kernel has produced partials of
+// h_i = v_i . w (i < k-1) and of ww = w . w (slot k-1).  One block reduces all of them in a
+// fixed order and derives |w - sum h_i v_i|^2 = ww - sum h_i^2 (Pythagoras; V orthonormal).
+// out[k-1] <- that squared norm, out[RED_K-2] <- ww, out[RED_K-1] <- scale for the update
+// (1/norm, or 1 when cancellation is too strong to trust the formula -> host refines).
+__global__ __launch_bounds__(1024) void reduce_finish_kernel(const double *__restrict__ partials,
+                                                             int nblocks, int k,
+                                                             double *__restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < k; i += 16) {
+        double s = 0.0;
+        for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
+        s = wave_sum(s);
+        if (lane == 0) out[i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ww = out[k - 1];
+        double hh = 0.0;
+        for (int i = 0; i < k - 1; ++i) hh += out[i] * out[i];
+        const double hn2 = ww - hh;
+        out[RED_K - 2] = ww;
+        out[k - 1] = hn2;
+        out[RED_K - 1] = (hn2 > 1e-8 * ww && hn2 > 0.0) ? 1.0 / sqrt(hn2) : 1.0;
+    }
+}
+
+template <int K, bool FINAL>
+__global__ void cgs_update_kernel(size_t n, const double *__restrict__ coef, int base, PtrPack8 xs,
+                                  double *__restrict__ y) {
+    double cf[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cf[k] = coef[base + k];
+    const double scale = FINAL ? coef[RED_K - 1] : 1.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double s = y[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) s -= cf[k] * xs.p[k][i];
+        y[i] = FINAL ? s * scale : s;
+    }
+}
+
+static dim3 vec_grid(const Ctx &c);
+
 static int red_grid(const Ctx &c) {
     const size_t blocks = ((size_t)c.np + 255) / 256;
     return (int)(blocks < (size_t)RED_BLOCKS ? blocks : (size_t)RED_BLOCKS);
 }
 
-void launch_dots(Ctx &c, const double *const *xs, const double *y, int k) {
+void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish) {
     const int grid = red_grid(c);
     int done = 0;
     while (done < k) {
@@ -428,7 +639,38 @@ void launch_dots(Ctx &c, const double *const *xs, const double *y, int k) {
         }
         done += kk;
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
+    if (finish)
+        hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(1024), 0, c.stream, c.d_partials, grid, k, c.d_red);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
+}
+
+// y = (y - sum_i d_red[i] xs[i]) * d_red[RED_K-1], coefficients stay on the device
+void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y) {
+    int done = 0;
+    while (done < k) {
+        const int kk = (k - done) >= 8 ? 8 : (k - done);
+        const bool fin = (done + kk == k);
+        PtrPack8 pk;
+        for (int i = 0; i < 8; ++i) pk.p[i] = xs[done + (i < kk ? i : 0)];
+#define FEDM_CGS(K)                                                                               \
+    if (fin) hipLaunchKernelGGL((cgs_update_kernel<K, true>), vec_grid(c), dim3(256), 0, c.stream, \
+                                (size_t)c.np, c.d_red, done, pk, y);                               \
+    else hipLaunchKernelGGL((cgs_update_kernel<K, false>), vec_grid(c), dim3(256), 0, c.stream,     \
+                            (size_t)c.np, c.d_red, done, pk, y);
+        switch (kk) {
+            case 1: FEDM_CGS(1) break;
+            case 2: FEDM_CGS(2) break;
+            case 3: FEDM_CGS(3) break;
+            case 4: FEDM_CGS(4) break;
+            case 5: FEDM_CGS(5) break;
+            case 6: FEDM_CGS(6) break;
+            case 7: FEDM_CGS(7) break;
+            default: FEDM_CGS(8) break;
+        }
+#undef FEDM_CGS
+        done += kk;
+    }
 }
 
 __global__ void reduce_partials_slot_kernel(const double *__restrict__ partials, int nblocks,

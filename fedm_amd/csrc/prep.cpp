@@ -112,6 +112,72 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
         std::vector<int> pos(pat.colour_ptr.begin(), pat.colour_ptr.end() - 1);
         for (int c = 0; c < nc; ++c) pat.colour_cells[pos[colour[c]]++] = c;
     }
+
+    // --- patches: every slice with the cells that touch one of its vertices ---------------
+    {
+        std::vector<int64_t> vc_ptr(nv + 1, 0);
+        for (int c = 0; c < nc; ++c)
+            for (int a = 0; a < 3; ++a) vc_ptr[cells[3 * c + a] + 1]++;
+        for (int v = 0; v < nv; ++v) vc_ptr[v + 1] += vc_ptr[v];
+        std::vector<int> vc(vc_ptr[nv]);
+        std::vector<int64_t> pos(vc_ptr.begin(), vc_ptr.end() - 1);
+        for (int c = 0; c < nc; ++c)
+            for (int a = 0; a < 3; ++a) vc[pos[cells[3 * c + a]]++] = c;
+        pat.patch_cell_ptr.assign(pat.n_slices + 1, 0);
+        pat.patch_halo_ptr.assign(pat.n_slices + 1, 0);
+        pat.patch_cells.clear();
+        pat.patch_halo.clear();
+        pat.patch_ok = true;
+        std::vector<int> pc, halo;
+        for (int s = 0; s < pat.n_slices; ++s) {
+            const int v0 = s * SLICE, v1 = std::min(nv, v0 + SLICE);
+            pc.clear();
+            for (int v = v0; v < v1; ++v) pc.insert(pc.end(), vc.begin() + vc_ptr[v], vc.begin() + vc_ptr[v + 1]);
+            std::sort(pc.begin(), pc.end());
+            pc.erase(std::unique(pc.begin(), pc.end()), pc.end());
+            halo.clear();
+            for (int c : pc)
+                for (int a = 0; a < 3; ++a) {
+                    const int v = cells[3 * c + a];
+                    if (v < v0 || v >= v1) halo.push_back(v);
+                }
+            std::sort(halo.begin(), halo.end());
+            halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+            const int width = pat.slice_boff[s + 1] - pat.slice_boff[s];
+            if (halo.size() + SLICE > 255 || width > 254) pat.patch_ok = false;
+            for (int c : pc) {
+                PatchCell e{};
+                e.cell = c;
+                for (int a = 0; a < 3; ++a) {
+                    const int v = cells[3 * c + a];
+                    int lv;
+                    if (v >= v0 && v < v1) lv = v - v0;
+                    else lv = SLICE + (int)(std::lower_bound(halo.begin(), halo.end(), v) - halo.begin());
+                    e.lv[a] = (uint8_t)std::min(lv, 255);
+                    e.tag[a] = mesh.facet_tags ? mesh.facet_tags[3 * c + a] : 0;
+                }
+                for (int a = 0; a < 3; ++a) {
+                    const int v = cells[3 * c + a];
+                    for (int b = 0; b < 3; ++b) {
+                        if (v < v0 || v >= v1) {
+                            e.j[a * 3 + b] = 0xFF;
+                            continue;
+                        }
+                        const int *row = adj.data() + rowptr[v];
+                        const int j = (int)(std::lower_bound(row, row + pat.row_len[v], cells[3 * c + b]) - row);
+                        e.j[a * 3 + b] = (uint8_t)std::min(j, 254);
+                    }
+                }
+                pat.patch_cells.push_back(e);
+            }
+            pat.patch_halo.insert(pat.patch_halo.end(), halo.begin(), halo.end());
+            pat.patch_cell_ptr[s + 1] = (int)pat.patch_cells.size();
+            pat.patch_halo_ptr[s + 1] = (int)pat.patch_halo.size();
+            pat.max_patch_width = std::max(pat.max_patch_width, width);
+            pat.max_patch_verts = std::max(pat.max_patch_verts, SLICE + (int)halo.size());
+            pat.max_patch_cells = std::max(pat.max_patch_cells, (int)pc.size());
+        }
+    }
 }
 
 }  // namespace fedm

@@ -287,6 +287,11 @@ class DeviceProblem:
         self._check(self.lib.fedm_field_error(self._h, int(component), C.byref(e)), "fedm_field_error")
         return e.value
 
+    def set_assembly(self, kind):
+        """'patch' (LDS patches, default) or 'colour' (global colouring, bitwise reproducible)."""
+        code = {"colour": 0, "patch": 1}[kind]
+        self._check(self.lib.fedm_set_assembly(self._h, code), "fedm_set_assembly")
+
     # -- measurement ----------------------------------------------------------
     def time_kernel(self, kind, repeats=20):
         ms = C.c_double()

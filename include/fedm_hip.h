@@ -189,6 +189,9 @@ int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
 /* timed micro-benchmarks on the resident state (HIP events on the library's stream):
  * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only.  ms per launch. */
 int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
+/* assembly kernel: 0 = global graph colouring (bitwise reproducible), 1 = LDS patches
+ * (default; each matrix value written once, LDS fp64 atomics) */
+int fedm_set_assembly(fedm_ctx *ctx, int kind);
 /* sizes the roofline model needs */
 int fedm_sizes(fedm_ctx *ctx, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq,
                int64_t *nnz_blocks, int64_t *stored_blocks, int64_t *n_colours);
