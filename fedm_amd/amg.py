@@ -38,22 +38,43 @@ def aggregate(A, theta):
     return agg, nagg.value
 
 
+def _z_order(xy):
+    from .device import locality_order
+    return locality_order(xy)
+
+
 def build_hierarchy(A, theta=0.08, omega=4.0 / 3.0, max_coarse=600, max_levels=12,
-                    fixed=None):
+                    fixed=None, coords=None):
     """Levels [(A_l, P_l)] of a smoothed-aggregation hierarchy; the last A is coarsest.
 
     ``fixed``: boolean mask of identity rows (Dirichlet / padding); they are kept out of
-    the aggregates (their prolongator rows are zero) so the coarse problems stay SPD."""
+    the aggregates (their prolongator rows are zero) so the coarse problems stay SPD.
+    ``coords`` (n,2), optional: nodes are visited in a lexicographic sweep (compact, regular
+    aggregates whatever the numbering) and the aggregates of every level are numbered along
+    a Z-curve of their centroids, so that restriction/prolongation gathers stay within a
+    few cache lines on the device."""
     A = sp.csr_matrix(A)
     levels = []
     free = np.ones(A.shape[0], dtype=bool) if fixed is None else ~np.asarray(fixed, dtype=bool)
+    xy = None if coords is None else np.asarray(coords, dtype=np.float64)
     while A.shape[0] > max_coarse and len(levels) < max_levels - 1:
         n = A.shape[0]
         idx = np.nonzero(free)[0]
+        if xy is not None:                   # lexicographic sweep: by y, then x
+            idx = idx[np.lexsort((xy[idx, 0], xy[idx, 1]))]
         Af = A[idx][:, idx].tocsr()
         agg_f, nagg = aggregate(Af, theta)
         if nagg >= 0.8 * idx.size:          # coarsening stalled
             break
+        if xy is not None:
+            cnt = np.bincount(agg_f, minlength=nagg).astype(np.float64)
+            cxy = np.stack([np.bincount(agg_f, weights=xy[idx, d], minlength=nagg) / cnt
+                            for d in range(2)], axis=1)
+            order = _z_order(cxy)            # new -> old aggregate id
+            relabel = np.empty(nagg, dtype=np.int64)
+            relabel[order] = np.arange(nagg)
+            agg_f = relabel[agg_f]
+            xy_next = cxy[order]
         T = sp.csr_matrix((np.ones(idx.size), (idx, agg_f)), shape=(n, nagg))
         d = A.diagonal()
         DinvA = sp.diags(1.0 / d) @ A
@@ -65,6 +86,8 @@ def build_hierarchy(A, theta=0.08, omega=4.0 / 3.0, max_coarse=600, max_levels=1
         levels.append((A, P.tocsr()))
         A = Ac
         free = np.ones(A.shape[0], dtype=bool)
+        if xy is not None:
+            xy = xy_next
     levels.append((A, None))
     return levels
 

@@ -74,11 +74,26 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
-    double acc = 0.0;
-    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+    // four independent gather chains in flight: coarse levels have few waves and long rows,
+    // so the loop is latency-bound unless the loads of several entries overlap
+    const int b0 = boff[slice], b1 = boff[slice + 1];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int bc = b0;
+    for (; bc + 4 <= b1; bc += 4) {
         const size_t k = (size_t)bc * SLICE + lane;
-        acc += val[k] * x[col[k]];
+        const int c0 = col[k], c1 = col[k + SLICE], c2 = col[k + 2 * SLICE], c3 = col[k + 3 * SLICE];
+        const double v0 = val[k], v1 = val[k + SLICE], v2 = val[k + 2 * SLICE], v3 = val[k + 3 * SLICE];
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        a0 += v0 * x0;
+        a1 += v1 * x1;
+        a2 += v2 * x2;
+        a3 += v3 * x3;
     }
+    for (; bc < b1; ++bc) {
+        const size_t k = (size_t)bc * SLICE + lane;
+        a0 += val[k] * x[col[k]];
+    }
+    const double acc = (a0 + a1) + (a2 + a3);
     const size_t r = (size_t)slice * SLICE + lane;
     if (MODE == 0) y[r] = acc;
     if (MODE == 1) y[r] = b[r] - acc;

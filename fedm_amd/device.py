@@ -118,11 +118,36 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def _part1by1(v):
+    v = v.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    for shift, mask in ((16, 0x0000FFFF0000FFFF), (8, 0x00FF00FF00FF00FF),
+                        (4, 0x0F0F0F0F0F0F0F0F), (2, 0x3333333333333333),
+                        (1, 0x5555555555555555)):
+        v = (v | (v << np.uint64(shift))) & np.uint64(mask)
+    return v
+
+
+def locality_order(coords):
+    """Vertex order along a Z-curve over the rank-quantised coordinates.
+
+    64 consecutive vertices then form a compact 2-D patch (about 8x8 on a
+    tensor-product mesh, whatever its grading), which is what the slice-based kernels
+    want: few halo vertices per assembly patch, neighbours of a matrix slice within a
+    few cache lines, aggregates of the multigrid contiguous in memory.
+    Returns ``order`` (new -> old)."""
+    ranks = []
+    for d in range(2):
+        _, inv = np.unique(coords[:, d], return_inverse=True)
+        ranks.append(inv.astype(np.uint64))
+    key = _part1by1(ranks[0]) | (_part1by1(ranks[1]) << np.uint64(1))
+    return np.argsort(key, kind="stable")
+
+
 class DeviceProblem:
     """Mesh + model + state resident on one MI355X."""
 
     def __init__(self, coords, cells, model: Model, facet_tags=None,
-                 dirichlet_dofs=(), dirichlet_vals=(), device=0):
+                 dirichlet_dofs=(), dirichlet_vals=(), device=0, reorder=True):
         self.lib = _lib.load()
         self.model = model
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
@@ -131,13 +156,23 @@ class DeviceProblem:
         self.n_eq = model.n_eq
         self.n = self.nv * self.n_eq
         self._tags = None if facet_tags is None else np.ascontiguousarray(facet_tags, dtype=np.int8)
-        self._ddofs = np.ascontiguousarray(dirichlet_dofs, dtype=np.int32)
+        # internal vertex numbering (the caller keeps seeing its own numbering)
+        self._order = locality_order(self.coords) if reorder else np.arange(self.nv)
+        self._inv = np.empty(self.nv, dtype=np.int64)
+        self._inv[self._order] = np.arange(self.nv)
+        neq = self.n_eq
+        self._dof_new_of_old = (self._inv[:, None] * neq + np.arange(neq)[None, :]).ravel()
+        ddofs = np.asarray(dirichlet_dofs, dtype=np.int64)
+        self._ddofs = np.ascontiguousarray(self._dof_new_of_old[ddofs] if ddofs.size else ddofs,
+                                           dtype=np.int32)
         self._dvals = np.ascontiguousarray(dirichlet_vals, dtype=np.float64)
+        self._coords_dev = np.ascontiguousarray(self.coords[self._order])
+        self._cells_dev = np.ascontiguousarray(self._inv[self.cells], dtype=np.int32)
         md = model.to_c()
         mesh = _lib.MeshDesc()
         mesh.n_vertices, mesh.n_cells = self.nv, self.nc
-        mesh.coords = _dp(self.coords)
-        mesh.cells = self.cells.ctypes.data_as(C.POINTER(C.c_int32))
+        mesh.coords = _dp(self._coords_dev)
+        mesh.cells = self._cells_dev.ctypes.data_as(C.POINTER(C.c_int32))
         mesh.facet_tags = (self._tags.ctypes.data_as(C.POINTER(C.c_int8))
                            if self._tags is not None else None)
         mesh.n_dirichlet = self._ddofs.size
@@ -169,12 +204,17 @@ class DeviceProblem:
 
     # -- state --------------------------------------------------------------
     def _vec(self, a):
+        """caller's dof order -> device order"""
         if a is None:
             return None
-        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        a = np.asarray(a, dtype=np.float64).reshape(-1)
         if a.size != self.n:
             raise ValueError(f"state vector must have {self.n} entries, got {a.size}")
-        return a
+        return np.ascontiguousarray(a.reshape(self.nv, self.n_eq)[self._order]).reshape(-1)
+
+    def _back(self, a):
+        """device order -> caller's dof order"""
+        return np.ascontiguousarray(a.reshape(self.nv, self.n_eq)[self._inv]).reshape(-1)
 
     def set_state(self, u_new=None, u_old=None, u_old1=None):
         vs = [self._vec(v) for v in (u_new, u_old, u_old1)]
@@ -184,7 +224,7 @@ class DeviceProblem:
     def get_state(self):
         out = np.empty(self.n)
         self._check(self.lib.fedm_get_state(self._h, _dp(out)), "fedm_get_state")
-        return out.reshape(self.nv, self.n_eq)
+        return self._back(out).reshape(self.nv, self.n_eq)
 
     def shift_state(self):
         self._check(self.lib.fedm_shift_state(self._h), "fedm_shift_state")
@@ -211,7 +251,7 @@ class DeviceProblem:
         fn = C.c_double()
         self._check(self.lib.fedm_residual(self._h, _dp(F) if download else None, C.byref(fn)),
                     "fedm_residual")
-        return (F, fn.value) if download else fn.value
+        return (self._back(F), fn.value) if download else fn.value
 
     def jacobian(self):
         self._check(self.lib.fedm_jacobian(self._h), "fedm_jacobian")
@@ -225,13 +265,15 @@ class DeviceProblem:
         self._check(self.lib.fedm_jacobian_csr(
             self._h, indptr.ctypes.data_as(C.POINTER(C.c_int64)),
             indices.ctypes.data_as(C.POINTER(C.c_int32)), _dp(values)), "fedm_jacobian_csr")
-        return sp.csr_matrix((values, indices, indptr), shape=(self.n, self.n))
+        J = sp.csr_matrix((values, indices, indptr), shape=(self.n, self.n))
+        m = self._dof_new_of_old
+        return J[m][:, m].tocsr()
 
     def spmv(self, x):
         x = self._vec(x)
         y = np.empty(self.n)
         self._check(self.lib.fedm_spmv(self._h, _dp(x), _dp(y)), "fedm_spmv")
-        return y
+        return self._back(y)
 
     # -- linear-solver set-up ---------------------------------------------------
     def block_csr(self, cr, cc):
@@ -257,8 +299,9 @@ class DeviceProblem:
         K = self.block_csr(ip, ip)
         fixed = np.zeros(self.nv, dtype=bool)
         d = self._ddofs[self._ddofs % self.n_eq == ip] // self.n_eq
-        fixed[d] = True
-        levels = amg.build_hierarchy(K, theta=theta, max_coarse=max_coarse, fixed=fixed)
+        fixed[d] = True            # device numbering, like K itself
+        levels = amg.build_hierarchy(K, theta=theta, max_coarse=max_coarse, fixed=fixed,
+                                     coords=self._coords_dev)
         self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
         return self.multigrid_levels
 
