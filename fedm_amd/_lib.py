@@ -105,6 +105,8 @@ _SIGNATURES = {
                                      C.POINTER(C.c_int32)]),
     "fedm_field_error": (C.c_int, [_P, C.c_int, _D]),
     "fedm_time_kernel": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "fedm_profile": (C.c_int, [_P, C.c_int]),
+    "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
     "fedm_set_assembly": (C.c_int, [_P, C.c_int]),
     "fedm_sizes": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 6),
 }

@@ -87,6 +87,11 @@ class Stepper:
     """The script-level time loop of fedm-streamer.py:304-340 around one device problem."""
 
     partition_name = "single GPU"
+    assembly_kernel_name = "assemble_patch_kernel<2,true,1> (LDS patches, F+J)"
+
+    @property
+    def multigrid_levels(self):
+        return getattr(self.prob, "multigrid_levels", None)
 
     def __init__(self, prob, dt_init=5e-12, dt_max=5e-12, dt_min=1e-15, ttol=1e-3,
                  relative_tolerance=1e-4, maximum_iterations=20, error_file=None, quiet=True):
@@ -144,6 +149,12 @@ class Stepper:
 
     def time_kernel(self, kind, repeats):
         return self.prob.time_kernel(kind, repeats)
+
+    def profile(self, enable=True):
+        self.prob.profile(enable)
+
+    def profile_read(self):
+        return self.prob.profile_read()
 
 
 def run(prob, T_final=1e-10, max_steps=None, initialise_state=True, **kw):

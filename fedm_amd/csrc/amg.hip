@@ -175,8 +175,10 @@ int Amg::capture(Ctx &c) {
 }
 
 void Amg::run(Ctx &c) {
+    prof_begin(c, 3);
     if (graph_exec) hipGraphLaunch(graph_exec, c.stream);
     else vcycle(c, 0);
+    prof_end(c);
 }
 
 void Amg::release() {

@@ -18,6 +18,35 @@ namespace fedm {
 static thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
 
+void prof_collect(Ctx &c) {
+    Prof &p = c.prof;
+    if (p.used == 0) return;
+    hipStreamSynchronize(c.stream);
+    for (int i = 0; i + 1 < p.used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) {
+            p.ms[p.kind[i / 2]] += ms;
+            p.cnt[p.kind[i / 2]]++;
+        }
+    }
+    p.used = 0;
+}
+
+void prof_begin(Ctx &c, int kind) {
+    Prof &p = c.prof;
+    if (!p.on) return;
+    if (p.used + 2 > (int)p.ev.size()) prof_collect(c);
+    p.kind[p.used / 2] = kind;
+    hipEventRecord(p.ev[p.used], c.stream);
+}
+
+void prof_end(Ctx &c) {
+    Prof &p = c.prof;
+    if (!p.on) return;
+    hipEventRecord(p.ev[p.used + 1], c.stream);
+    p.used += 2;
+}
+
 template <class T>
 static int upload(T *&dst, const T *src, size_t n) {
     FEDM_HIP_CHECK(hipMalloc((void **)&dst, sizeof(T) * std::max<size_t>(n, 1)));
@@ -62,10 +91,14 @@ static int ensure_krylov(Ctx &c, int restart) {
 // w = Minv (J v): point-block Jacobi (fused in the SpMV) or field split with multigrid
 static void apply_operator(Ctx &c, const double *v, double *w) {
     if (c.amg && c.poisson) {
+        prof_begin(c, 1);
         launch_spmv(c, v, c.d_tmp, false);
+        prof_end(c);
         fieldsplit_apply(c, *c.amg, c.d_tmp, w, 1.0);
     } else {
+        prof_begin(c, 1);
         launch_spmv(c, v, w, true);
+        prof_end(c);
     }
 }
 
@@ -360,6 +393,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
         c.amg->release();
         delete c.amg;
     }
+    for (auto &e : c.prof.ev) hipEventDestroy(e);
     if (c.h_red) hipHostFree(c.h_red);
     if (c.h_stage) hipHostFree(c.h_stage);
     if (c.stream) hipStreamDestroy(c.stream);
@@ -658,6 +692,34 @@ int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) 
     *ms_per_launch = (double)ms / repeats;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    return 0;
+}
+
+int fedm_profile(fedm_ctx *h, int enable) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    Prof &p = c.prof;
+    prof_collect(c);
+    if (enable && p.ev.empty()) {
+        p.ev.resize(16384);
+        p.kind.resize(8192);
+        for (auto &e : p.ev) FEDM_HIP_CHECK(hipEventCreate(&e));
+    }
+    p.on = enable != 0;
+    if (enable)
+        for (int k = 0; k < 8; ++k) {
+            p.ms[k] = 0.0;
+            p.cnt[k] = 0;
+        }
+    return 0;
+}
+
+int fedm_profile_read(fedm_ctx *h, int kind, double *ms_total, int64_t *count) {
+    Ctx &c = h->c;
+    if (kind < 0 || kind >= 8) return -2;
+    prof_collect(c);
+    if (ms_total) *ms_total = c.prof.ms[kind];
+    if (count) *count = c.prof.cnt[kind];
     return 0;
 }
 

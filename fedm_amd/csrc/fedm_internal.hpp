@@ -53,8 +53,20 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat);
 
 struct Amg;
 
+// Optional in-run kernel timing with HIP events on the library's stream (bench.py roofline).
+// kinds: 0 assembly F+J, 1 Jacobian SpMV, 2 assembly F only, 3 multigrid V-cycle
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;
+    int used = 0;
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
 struct Ctx {
     Amg *amg = nullptr;  // potential-block multigrid (optional)
+    Prof prof;
     int device = 0;
     hipStream_t stream = nullptr;
     int nv = 0, nc = 0, nvp = 0, ns = 0, neq = 0;
@@ -130,5 +142,8 @@ void read_red(Ctx &c, int k);               // d_red -> h_red, synchronises the 
     } while (0)
 
 void set_error(const std::string &msg);
+void prof_begin(Ctx &c, int kind);
+void prof_end(Ctx &c);
+void prof_collect(Ctx &c);
 
 }  // namespace fedm

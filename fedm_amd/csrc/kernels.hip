@@ -258,11 +258,13 @@ static void assemble_dispatch(Ctx &c, bool jacobian, int mode) {
 }
 
 void launch_assemble(Ctx &c, bool jacobian, int mode) {
+    prof_begin(c, jacobian ? 0 : 2);  // the volume kernel only (all colours in variant 0)
     if (c.ns == 1 && !c.poisson) assemble_dispatch<1, false>(c, jacobian, mode);
     else if (c.ns == 1 && c.poisson) assemble_dispatch<1, true>(c, jacobian, mode);
     else if (c.ns == 2 && c.poisson) assemble_dispatch<2, true>(c, jacobian, mode);
     else if (c.ns == 2 && !c.poisson) assemble_dispatch<2, false>(c, jacobian, mode);
     else if (c.ns == 3 && c.poisson) assemble_dispatch<3, true>(c, jacobian, mode);
+    prof_end(c);
     if (mode == 0) launch_boundary(c, jacobian);
 }
 

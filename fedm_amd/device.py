@@ -342,6 +342,20 @@ class DeviceProblem:
                     "fedm_time_kernel")
         return ms.value
 
+    def profile(self, enable=True):
+        self._check(self.lib.fedm_profile(self._h, int(bool(enable))), "fedm_profile")
+
+    def profile_read(self):
+        """{kind: (total ms, launches)} of the kernels timed since profile(True)."""
+        names = {0: "assembly_FJ", 1: "spmv", 2: "assembly_F", 3: "vcycle"}
+        out = {}
+        for k, name in names.items():
+            ms, cnt = C.c_double(), C.c_int64()
+            self._check(self.lib.fedm_profile_read(self._h, k, C.byref(ms), C.byref(cnt)),
+                        "fedm_profile_read")
+            out[name] = (ms.value, cnt.value)
+        return out
+
     def sizes(self):
         v = [C.c_int64() for _ in range(6)]
         self.lib.fedm_sizes(self._h, *[C.byref(x) for x in v])

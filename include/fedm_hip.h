@@ -189,6 +189,10 @@ int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
 /* timed micro-benchmarks on the resident state (HIP events on the library's stream):
  * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only.  ms per launch. */
 int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
+/* in-run kernel timing with HIP events on the library's stream.  kind: 0 = assembly F+J,
+ * 1 = Jacobian SpMV, 2 = assembly F only, 3 = multigrid V-cycle (whole graph) */
+int fedm_profile(fedm_ctx *ctx, int enable);
+int fedm_profile_read(fedm_ctx *ctx, int kind, double *ms_total, int64_t *count);
 /* assembly kernel: 0 = global graph colouring (bitwise reproducible), 1 = LDS patches
  * (default; each matrix value written once, LDS fp64 atomics) */
 int fedm_set_assembly(fedm_ctx *ctx, int kind);
