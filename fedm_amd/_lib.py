@@ -49,7 +49,8 @@ class MeshDesc(C.Structure):
                 ("facet_tags", C.POINTER(C.c_int8)),
                 ("n_dirichlet", C.c_int32),
                 ("dirichlet_dofs", C.POINTER(C.c_int32)),
-                ("dirichlet_vals", C.POINTER(C.c_double))]
+                ("dirichlet_vals", C.POINTER(C.c_double)),
+                ("n_owned_vertices", C.c_int32)]
 
 
 class NewtonOpts(C.Structure):
@@ -70,6 +71,9 @@ class Csr(C.Structure):
                 ("indptr", C.POINTER(C.c_int64)), ("indices", C.POINTER(C.c_int32)),
                 ("values", C.POINTER(C.c_double))]
 
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_void_p)
 
 LIB_PATH = Path(__file__).resolve().parent / "libfedm_hip.so"
 
@@ -105,6 +109,12 @@ _SIGNATURES = {
                                      C.POINTER(C.c_int32)]),
     "fedm_field_error": (C.c_int, [_P, C.c_int, _D]),
     "fedm_time_kernel": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "fedm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "fedm_comm_init_rccl": (C.c_int, [_P, C.c_int] + [C.POINTER(C.c_int32)] * 4
+                            + [C.c_void_p, C.c_int, C.c_int]),
+    "fedm_comm_init_callbacks": (C.c_int, [_P, C.c_int] + [C.POINTER(C.c_int32)] * 4
+                                 + [ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p, C.c_int, C.c_int]),
+    "fedm_sync_ghosts": (C.c_int, [_P]),
     "fedm_profile": (C.c_int, [_P, C.c_int]),
     "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
     "fedm_set_assembly": (C.c_int, [_P, C.c_int]),

@@ -1,0 +1,49 @@
+"""Streamer case across several GPUs: one process per GPU, vertex partition by RCB,
+ghost exchange + all-reduces inside libfedm_hip.so (RCCL over xGMI).
+
+Weak scaling: the mesh handed in is the per-GPU mesh size; the global mesh has
+``world`` times as many cells (the box is fixed, the resolution grows).
+"""
+import numpy as np
+
+from .. import partition
+from ..device import DeviceProblem, rccl_unique_id
+from ..mesh import Marking_boundaries, Mesh, RectangleMesh, geometric_lines
+from . import streamer
+
+
+def global_mesh(n_per_gpu, world, grading):
+    """About world * n^2 * 2 cells: refine both directions by sqrt(world)."""
+    n = int(round(n_per_gpu * np.sqrt(world)))
+    return streamer.mesh(n, grading), n
+
+
+class Runner(streamer.Stepper):
+    def __init__(self, per_gpu_mesh, rank, world, local_rank, grading=4.0, transport="rccl",
+                 group=None, n_per_gpu=None, **kw):
+        import torch.distributed as dist
+        n_per_gpu = n_per_gpu or int(round(np.sqrt(per_gpu_mesh.num_cells() / 2)))
+        gmesh, n = global_mesh(n_per_gpu, world, grading)
+        part = partition.partition_rcb(gmesh.coords, world)
+        lm = partition.local_mesh(gmesh.coords, gmesh.cells, part, rank)
+        self.lm, self.world, self.rank = lm, world, rank
+        self.global_n = n
+        # boundary tags and Dirichlet rows from the global mesh, restricted to the local cells
+        gtags = Marking_boundaries(gmesh, streamer.BOUNDARIES)
+        tags = gtags[lm.cell_global]
+        ddofs, dvals = streamer.dirichlet(lm.coords)
+        prob = DeviceProblem(lm.coords, lm.cells, streamer.model(), facet_tags=tags,
+                             dirichlet_dofs=ddofs, dirichlet_vals=dvals, device=local_rank,
+                             n_owned=lm.n_owned)
+        if transport == "rccl":
+            import torch
+            uid = [rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, group=group)
+            prob.init_comm_rccl(lm, uid[0], rank, world)
+        else:
+            prob.init_comm_torch(lm, group)
+        super().__init__(prob, **kw)
+        self.total_dofs = gmesh.num_vertices() * 3
+        self.partition_name = (f"RCB vertex partition, {world} parts, global mesh {n}x{n}, "
+                               f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices on rank {rank}, "
+                               f"{len(lm.neighbours)} neighbours, transport {transport}")

@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "amg.hpp"
+#include "comm.hpp"
 #include "fedm_internal.hpp"
 
 struct fedm_ctx {
@@ -90,6 +91,7 @@ static int ensure_krylov(Ctx &c, int restart) {
 
 // w = Minv (J v): point-block Jacobi (fused in the SpMV) or field split with multigrid
 static void apply_operator(Ctx &c, const double *v, double *w) {
+    comm_halo(c, const_cast<double *>(v));  // ghost inputs from their owners (multi-GPU)
     if (c.amg && c.poisson) {
         prof_begin(c, 1);
         launch_spmv(c, v, c.d_tmp, false);
@@ -303,6 +305,8 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
     c.nc = mesh->n_cells;
     build_pattern(*mesh, c.pat);
     c.nvp = c.pat.nvp;
+    c.n_owned = (mesh->n_owned_vertices > 0 && mesh->n_owned_vertices <= c.nv) ? mesh->n_owned_vertices : c.nv;
+    c.n_dot = (int64_t)c.n_owned * c.neq;
     c.n = (int64_t)c.nv * c.neq;
     c.np = (int64_t)c.nvp * c.neq;
     for (int i = 0; i < mesh->n_dirichlet; ++i)
@@ -392,6 +396,10 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (c.amg) {
         c.amg->release();
         delete c.amg;
+    }
+    if (c.comm) {
+        c.comm->release();
+        delete c.comm;
     }
     for (auto &e : c.prof.ev) hipEventDestroy(e);
     if (c.h_red) hipHostFree(c.h_red);
@@ -569,6 +577,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             break;
         }
         launch_axpy(c, 1.0, c.d_delta, c.d_u);
+        comm_halo(c, c.d_u);
         launch_norm2(c, c.d_delta, 0);
         read_red(c, 1);
         snorm = std::sqrt(c.h_red[0]);
@@ -625,6 +634,7 @@ int fedm_poisson_solve(fedm_ctx *h, double rtol, int max_it, int *iterations) {
     double *x = c.d_V;  // accumulated correction
     hipMemsetAsync(x, 0, sizeof(double) * c.np, c.stream);
     while (rn > rtol * r0 && it < max_it && r0 > 0.0) {
+        comm_halo(c, p);
         launch_spmv(c, p, q, false);
         const double *pp[1] = {p};
         launch_dots(c, pp, q, 1);
@@ -647,6 +657,7 @@ int fedm_poisson_solve(fedm_ctx *h, double rtol, int max_it, int *iterations) {
         ++it;
     }
     launch_axpy(c, 1.0, x, c.d_u);
+    comm_halo(c, c.d_u);
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     if (iterations) *iterations = it;
     if (!std::isfinite(rn)) return FEDM_DIVERGED_NAN;
@@ -692,6 +703,71 @@ int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) 
     *ms_per_launch = (double)ms / repeats;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    return 0;
+}
+
+int fedm_comm_unique_id(void *out128) { return comm_unique_id(out128); }
+
+static int comm_common(Ctx &c, int n_nb, const int32_t *nb_rank, const int32_t *send_ptr,
+                       const int32_t *send_idx, const int32_t *recv_ptr) {
+    if (n_nb < 0 || (n_nb > 0 && (!nb_rank || !send_ptr || !recv_ptr))) {
+        set_error("bad halo plan");
+        return -2;
+    }
+    if (c.comm) {
+        c.comm->release();
+        delete c.comm;
+        c.comm = nullptr;
+    }
+    Comm *cm = new Comm();
+    static const int32_t zero2[2] = {0, 0};
+    const int rc = comm_setup_plan(c, *cm, n_nb, nb_rank, n_nb ? send_ptr : zero2, send_idx,
+                                   n_nb ? recv_ptr : zero2);
+    if (rc) {
+        cm->release();
+        delete cm;
+        return rc;
+    }
+    c.comm = cm;
+    return 0;
+}
+
+int fedm_comm_init_rccl(fedm_ctx *h, int n_nb, const int32_t *nb_rank, const int32_t *send_ptr,
+                        const int32_t *send_idx, const int32_t *recv_ptr, const void *unique_id,
+                        int rank, int n_ranks) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (int rc = comm_common(c, n_nb, nb_rank, send_ptr, send_idx, recv_ptr)) return rc;
+    return comm_init_rccl(c, *c.comm, unique_id, rank, n_ranks);
+}
+
+int fedm_comm_init_callbacks(fedm_ctx *h, int n_nb, const int32_t *nb_rank, const int32_t *send_ptr,
+                             const int32_t *send_idx, const int32_t *recv_ptr,
+                             fedm_allreduce_fn allreduce, fedm_exchange_fn exchange, void *user,
+                             int rank, int n_ranks) {
+    Ctx &c = h->c;
+    if (!allreduce || !exchange) {
+        set_error("null transport callback");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (int rc = comm_common(c, n_nb, nb_rank, send_ptr, send_idx, recv_ptr)) return rc;
+    c.comm->kind = 1;
+    c.comm->rank = rank;
+    c.comm->nranks = n_ranks;
+    c.comm->allreduce_cb = allreduce;
+    c.comm->exchange_cb = exchange;
+    c.comm->user = user;
+    return 0;
+}
+
+int fedm_sync_ghosts(fedm_ctx *h) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    comm_halo(c, c.d_u);
+    comm_halo(c, c.d_uold);
+    comm_halo(c, c.d_uold1);
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     return 0;
 }
 

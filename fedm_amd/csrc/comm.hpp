@@ -1,0 +1,39 @@
+// Multi-GPU plumbing: one process per GPU, each owning a vertex partition.  Rows of owned
+// vertices are assembled locally from every cell that touches them (ghost cells are evaluated
+// on both sides), so the only traffic is (i) ghost *input* values of a vector before an SpMV or
+// an assembly and (ii) small all-reduces for dot products and norms.
+// Transports: RCCL over xGMI (ncclSend/ncclRecv groups + ncclAllReduce on the library's
+// stream), or host-staged callbacks (any transport the caller owns, e.g. gloo; used by tests).
+#pragma once
+#include <vector>
+
+#include "fedm_internal.hpp"
+
+namespace fedm {
+
+struct Comm {
+    int kind = 0;  // 0 none, 1 host callbacks, 2 RCCL
+    int rank = 0, nranks = 1;
+    // halo plan (vertex units).  Ghost vertices follow the owned ones in local numbering,
+    // grouped by owner in neighbour order, so every receive lands contiguously in the vector.
+    int n_nb = 0;
+    std::vector<int> nb_rank, send_ptr, recv_ptr;
+    int n_send = 0, n_ghost = 0;
+    int *d_send_idx = nullptr;
+    double *d_sendbuf = nullptr;
+    double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;
+    fedm_allreduce_fn allreduce_cb = nullptr;
+    fedm_exchange_fn exchange_cb = nullptr;
+    void *user = nullptr;
+    void *nccl = nullptr;  // ncclComm_t
+    void release();
+};
+
+int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const int32_t *send_ptr,
+                    const int32_t *send_idx, const int32_t *recv_ptr);
+int comm_init_rccl(Ctx &c, Comm &cm, const void *unique_id, int rank, int nranks);
+int comm_unique_id(void *out128);
+void comm_allreduce(Ctx &c, double *d_buf, int n);  // sum over ranks, in place, stream-ordered
+void comm_halo(Ctx &c, double *d_vec);              // refresh ghost vertices of a block vector
+
+}  // namespace fedm

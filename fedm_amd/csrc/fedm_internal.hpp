@@ -52,6 +52,7 @@ struct Pattern {
 void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat);
 
 struct Amg;
+struct Comm;
 
 // Optional in-run kernel timing with HIP events on the library's stream (bench.py roofline).
 // kinds: 0 assembly F+J, 1 Jacobian SpMV, 2 assembly F only, 3 multigrid V-cycle
@@ -67,6 +68,9 @@ struct Prof {
 struct Ctx {
     Amg *amg = nullptr;  // potential-block multigrid (optional)
     Prof prof;
+    Comm *comm = nullptr;  // multi-GPU transport (optional)
+    int n_owned = 0;       // owned vertices (== nv on a single GPU)
+    int64_t n_dot = 0;     // vector entries that take part in reductions: n_owned * neq
     int device = 0;
     hipStream_t stream = nullptr;
     int nv = 0, nc = 0, nvp = 0, ns = 0, neq = 0;

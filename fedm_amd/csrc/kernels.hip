@@ -1,6 +1,7 @@
 // HIP kernels (gfx950) of the FEDM hot path: coloured element assembly into the sliced
 // block-ELL Jacobian, Dirichlet rows, block-Jacobi inverse, SpMV and the vector kernels
 // that GMRES / Newton need.  All of it is fp64 and HBM-bound; no MFMA.
+#include "comm.hpp"
 #include "element.hpp"
 #include "fedm_internal.hpp"
 
@@ -329,9 +330,9 @@ __global__ void identity_rows_kernel(int nv, int nvp, int neq, int ns_frozen,
 
 void launch_finalize(Ctx &c, bool jacobian, int mode) {
     const int ns_frozen = (mode == 1) ? c.ns : 0;
-    if (c.nvp > c.nv || ns_frozen > 0)
+    if (c.nvp > c.n_owned || ns_frozen > 0)  // padding + ghost vertices, frozen species
         hipLaunchKernelGGL(identity_rows_kernel, dim3((c.nvp + 255) / 256), dim3(256), 0, c.stream,
-                           c.nv, c.nvp, c.neq, ns_frozen, c.d_F, c.d_val, c.d_slice_boff,
+                           c.n_owned, c.nvp, c.neq, ns_frozen, c.d_F, c.d_val, c.d_slice_boff,
                            c.d_diag_slot, jacobian ? 1 : 0);
     if (c.n_dir > 0)
         hipLaunchKernelGGL(dirichlet_kernel, dim3((c.n_dir + 255) / 256), dim3(256), 0, c.stream,
@@ -433,7 +434,8 @@ void launch_block_inverse(Ctx &c) {
 // neighbour (n_eq contiguous doubles).  Optional fused block-Jacobi scaling y = Dinv (A x).
 // =============================================================================================
 template <int NEQ>
-__global__ __launch_bounds__(256) void spmv_kernel(int n_slices, const int *__restrict__ boff,
+__global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
+                                                   const int *__restrict__ boff,
                                                    const int *__restrict__ colidx,
                                                    const double *__restrict__ val,
                                                    const double *__restrict__ x,
@@ -459,6 +461,10 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, const int *__re
             for (int cc = 0; cc < NEQ; ++cc) acc[r] += vp[(size_t)(r * NEQ + cc) * SLICE] * xj[cc];
     }
     const size_t vtx = (size_t)slice * SLICE + lane;
+    if ((int)vtx >= n_owned) {  // ghost / padding rows belong to someone else (or to nobody)
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
+    }
     if (dinv) {
         const double *dp = dinv + (size_t)slice * NEQ2 * SLICE + lane;
 #pragma unroll
@@ -479,10 +485,10 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv) {
     const dim3 g((n + 3) / 4), b(256);
     const double *dinv = scale_dinv ? c.d_dinv : nullptr;
     switch (c.neq) {
-        case 1: hipLaunchKernelGGL(spmv_kernel<1>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 2: hipLaunchKernelGGL(spmv_kernel<2>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 3: hipLaunchKernelGGL(spmv_kernel<3>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 4: hipLaunchKernelGGL(spmv_kernel<4>, g, b, 0, c.stream, n, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 1: hipLaunchKernelGGL(spmv_kernel<1>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 2: hipLaunchKernelGGL(spmv_kernel<2>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 3: hipLaunchKernelGGL(spmv_kernel<3>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 4: hipLaunchKernelGGL(spmv_kernel<4>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
     }
 }
 
@@ -573,31 +579,20 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partials, int 
     if (threadIdx.x == 0) out[i] = s;
 }
 
-// GMRES orthogonalisation step in ONE reduction: the dots kernel has produced partials of
-// h_i = v_i . w (i < k-1) and of ww = w . w (slot k-1).  One block reduces all of them in a
-// fixed order and derives |w - sum h_i v_i|^2 = ww - sum h_i^2 (Pythagoras; V orthonormal).
+// GMRES orthogonalisation step in ONE reduction: the dots kernel has produced h_i = v_i . w
+// (i < k-1) and ww = w . w (slot k-1); after the (all-)reduction one thread derives
+// |w - sum h_i v_i|^2 = ww - sum h_i^2 (Pythagoras; V orthonormal).
 // out[k-1] <- that squared norm, out[RED_K-2] <- ww, out[RED_K-1] <- scale for the update
 // (1/norm, or 1 when cancellation is too strong to trust the formula -> host refines).
-__global__ __launch_bounds__(1024) void reduce_finish_kernel(const double *__restrict__ partials,
-                                                             int nblocks, int k,
-                                                             double *__restrict__ out) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < k; i += 16) {
-        double s = 0.0;
-        for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
-        s = wave_sum(s);
-        if (lane == 0) out[i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double ww = out[k - 1];
-        double hh = 0.0;
-        for (int i = 0; i < k - 1; ++i) hh += out[i] * out[i];
-        const double hn2 = ww - hh;
-        out[RED_K - 2] = ww;
-        out[k - 1] = hn2;
-        out[RED_K - 1] = (hn2 > 1e-8 * ww && hn2 > 0.0) ? 1.0 / sqrt(hn2) : 1.0;
-    }
+__global__ void cgs_finish_kernel(int k, double *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ww = out[k - 1];
+    double hh = 0.0;
+    for (int i = 0; i < k - 1; ++i) hh += out[i] * out[i];
+    const double hn2 = ww - hh;
+    out[RED_K - 2] = ww;
+    out[k - 1] = hn2;
+    out[RED_K - 1] = (hn2 > 1e-8 * ww && hn2 > 0.0) ? 1.0 / sqrt(hn2) : 1.0;
 }
 
 template <int K, bool FINAL>
@@ -618,7 +613,7 @@ __global__ void cgs_update_kernel(size_t n, const double *__restrict__ coef, int
 static dim3 vec_grid(const Ctx &c);
 
 static int red_grid(const Ctx &c) {
-    const size_t blocks = ((size_t)c.np + 255) / 256;
+    const size_t blocks = ((size_t)c.n_dot + 255) / 256;
     return (int)(blocks < (size_t)RED_BLOCKS ? blocks : (size_t)RED_BLOCKS);
 }
 
@@ -630,21 +625,20 @@ void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool f
         PtrPack8 pk;
         for (int i = 0; i < 8; ++i) pk.p[i] = xs[done + (i < kk ? i : 0)];
         switch (kk) {
-            case 1: hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
-            case 2: hipLaunchKernelGGL(dots_kernel<2>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
-            case 3: hipLaunchKernelGGL(dots_kernel<3>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
-            case 4: hipLaunchKernelGGL(dots_kernel<4>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
-            case 5: hipLaunchKernelGGL(dots_kernel<5>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
-            case 6: hipLaunchKernelGGL(dots_kernel<6>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
-            case 7: hipLaunchKernelGGL(dots_kernel<7>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
-            default: hipLaunchKernelGGL(dots_kernel<8>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.np, c.d_partials, done); break;
+            case 1: hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
+            case 2: hipLaunchKernelGGL(dots_kernel<2>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
+            case 3: hipLaunchKernelGGL(dots_kernel<3>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
+            case 4: hipLaunchKernelGGL(dots_kernel<4>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
+            case 5: hipLaunchKernelGGL(dots_kernel<5>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
+            case 6: hipLaunchKernelGGL(dots_kernel<6>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
+            case 7: hipLaunchKernelGGL(dots_kernel<7>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
+            default: hipLaunchKernelGGL(dots_kernel<8>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, c.d_partials, done); break;
         }
         done += kk;
     }
-    if (finish)
-        hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(1024), 0, c.stream, c.d_partials, grid, k, c.d_red);
-    else
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
+    comm_allreduce(c, c.d_red, k);
+    if (finish) hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red);
 }
 
 // y = (y - sum_i d_red[i] xs[i]) * d_red[RED_K-1], coefficients stay on the device
@@ -687,8 +681,9 @@ void launch_norm2(Ctx &c, const double *x, int slot) {
     const int grid = red_grid(c);
     PtrPack8 pk;
     for (int i = 0; i < 8; ++i) pk.p[i] = x;
-    hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, x, (size_t)c.np, c.d_partials, RED_K - 1);
+    hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, x, (size_t)c.n_dot, c.d_partials, RED_K - 1);
     hipLaunchKernelGGL(reduce_partials_slot_kernel, dim3(1), dim3(64), 0, c.stream, c.d_partials, grid, RED_K - 1, c.d_red, slot);
+    comm_allreduce(c, c.d_red + slot, 1);
 }
 
 void read_red(Ctx &c, int k) {
@@ -776,10 +771,11 @@ __global__ __launch_bounds__(256) void field_error_kernel(int nv, int neq, int c
 }
 
 void launch_field_error(Ctx &c, int comp) {
-    int grid = (c.nv + 255) / 256;
+    int grid = (c.n_owned + 255) / 256;
     if (grid > RED_BLOCKS) grid = RED_BLOCKS;
-    hipLaunchKernelGGL(field_error_kernel, dim3(grid), dim3(256), 0, c.stream, c.nv, c.neq, comp, c.d_u, c.d_uold, c.d_partials);
+    hipLaunchKernelGGL(field_error_kernel, dim3(grid), dim3(256), 0, c.stream, c.n_owned, c.neq, comp, c.d_u, c.d_uold, c.d_partials);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, 2, c.d_red);
+    comm_allreduce(c, c.d_red, 2);
 }
 
 }  // namespace fedm

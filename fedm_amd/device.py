@@ -147,7 +147,7 @@ class DeviceProblem:
     """Mesh + model + state resident on one MI355X."""
 
     def __init__(self, coords, cells, model: Model, facet_tags=None,
-                 dirichlet_dofs=(), dirichlet_vals=(), device=0, reorder=True):
+                 dirichlet_dofs=(), dirichlet_vals=(), device=0, reorder=True, n_owned=None):
         self.lib = _lib.load()
         self.model = model
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
@@ -157,7 +157,11 @@ class DeviceProblem:
         self.n = self.nv * self.n_eq
         self._tags = None if facet_tags is None else np.ascontiguousarray(facet_tags, dtype=np.int8)
         # internal vertex numbering (the caller keeps seeing its own numbering)
-        self._order = locality_order(self.coords) if reorder else np.arange(self.nv)
+        # multi-GPU: vertices [0, n_owned) are owned, the rest are ghosts (kept in place)
+        self.n_owned = self.nv if n_owned is None else int(n_owned)
+        self._order = np.arange(self.nv)
+        if reorder:
+            self._order[:self.n_owned] = locality_order(self.coords[:self.n_owned])
         self._inv = np.empty(self.nv, dtype=np.int64)
         self._inv[self._order] = np.arange(self.nv)
         neq = self.n_eq
@@ -178,6 +182,7 @@ class DeviceProblem:
         mesh.n_dirichlet = self._ddofs.size
         mesh.dirichlet_dofs = self._ddofs.ctypes.data_as(C.POINTER(C.c_int32))
         mesh.dirichlet_vals = _dp(self._dvals)
+        mesh.n_owned_vertices = self.n_owned
         handle = C.c_void_p()
         rc = self.lib.fedm_ctx_create(C.byref(mesh), C.byref(md), int(device), C.byref(handle))
         if rc != 0:
@@ -275,6 +280,59 @@ class DeviceProblem:
         self._check(self.lib.fedm_spmv(self._h, _dp(x), _dp(y)), "fedm_spmv")
         return self._back(y)
 
+    # -- multi-GPU transport ---------------------------------------------------------
+    def _plan_arrays(self, lm):
+        nb = np.ascontiguousarray(lm.neighbours, dtype=np.int32)
+        sp_ = np.ascontiguousarray(lm.send_ptr, dtype=np.int32)
+        si = np.ascontiguousarray(self._inv[lm.send_idx], dtype=np.int32)   # device numbering
+        rp = np.ascontiguousarray(lm.recv_ptr, dtype=np.int32)
+        self._plan_keep = (nb, sp_, si, rp)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        return len(nb), ip(nb), ip(sp_), ip(si), ip(rp)
+
+    def init_comm_rccl(self, lm, unique_id: bytes, rank, n_ranks):
+        """RCCL transport (ncclSend/ncclRecv halo groups + ncclAllReduce on the library's
+        stream).  ``unique_id``: 128 bytes from :func:`rccl_unique_id` on rank 0."""
+        uid = C.create_string_buffer(unique_id, 128)
+        self._check(self.lib.fedm_comm_init_rccl(self._h, *self._plan_arrays(lm), uid,
+                                                 int(rank), int(n_ranks)), "fedm_comm_init_rccl")
+
+    def init_comm_torch(self, lm, group=None):
+        """Host-staged transport through torch.distributed (gloo): the library copies the
+        packed halo / the reduction scalars to pinned host memory and calls back here.
+        Same algorithm as the RCCL path, used to test it where ranks share one GPU."""
+        import torch
+        import torch.distributed as dist
+        n_send, n_ghost = int(lm.send_ptr[-1]), int(lm.recv_ptr[-1])
+
+        def allreduce(buf, n, _user):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, group=group)
+
+        def exchange(send, recv, width, _user):
+            s = np.ctypeslib.as_array(send, shape=(max(n_send, 1), width))
+            r = np.ctypeslib.as_array(recv, shape=(max(n_ghost, 1), width))
+            reqs, bufs = [], []
+            for k, q in enumerate(lm.neighbours):
+                out = torch.from_numpy(np.ascontiguousarray(s[lm.send_ptr[k]:lm.send_ptr[k + 1]]))
+                reqs.append(dist.isend(out, int(q), group=group))
+                buf = torch.empty((int(lm.recv_ptr[k + 1] - lm.recv_ptr[k]), width), dtype=torch.float64)
+                bufs.append(buf)
+                reqs.append(dist.irecv(buf, int(q), group=group))
+            for q in reqs:
+                q.wait()
+            for k, buf in enumerate(bufs):
+                r[lm.recv_ptr[k]:lm.recv_ptr[k + 1]] = buf.numpy()
+
+        self._cb_keep = (_lib.ALLREDUCE_FN(allreduce), _lib.EXCHANGE_FN(exchange))
+        self._check(self.lib.fedm_comm_init_callbacks(
+            self._h, *self._plan_arrays(lm), self._cb_keep[0], self._cb_keep[1], None,
+            dist.get_rank(group), dist.get_world_size(group)), "fedm_comm_init_callbacks")
+
+    def sync_ghosts(self):
+        self._check(self.lib.fedm_sync_ghosts(self._h), "fedm_sync_ghosts")
+
     # -- linear-solver set-up ---------------------------------------------------
     def block_csr(self, cr, cc):
         import scipy.sparse as sp
@@ -300,6 +358,7 @@ class DeviceProblem:
         fixed = np.zeros(self.nv, dtype=bool)
         d = self._ddofs[self._ddofs % self.n_eq == ip] // self.n_eq
         fixed[d] = True            # device numbering, like K itself
+        fixed[self.n_owned:] = True  # ghost rows are identity rows of the local block
         levels = amg.build_hierarchy(K, theta=theta, max_coarse=max_coarse, fixed=fixed,
                                      coords=self._coords_dev)
         self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
@@ -361,3 +420,12 @@ class DeviceProblem:
         self.lib.fedm_sizes(self._h, *[C.byref(x) for x in v])
         keys = ("n_vertices", "n_cells", "n_eq", "nnz_blocks", "stored_blocks", "n_colours")
         return dict(zip(keys, (x.value for x in v)))
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId (call on one rank, broadcast to the others)."""
+    buf = C.create_string_buffer(128)
+    lib = _lib.load()
+    if lib.fedm_comm_unique_id(buf) != 0:
+        raise RuntimeError(f"fedm_comm_unique_id failed: {_lib.last_error()}")
+    return buf.raw

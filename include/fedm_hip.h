@@ -92,6 +92,8 @@ typedef struct {
     int32_t n_dirichlet;         /* DirichletBC rows, fedm-streamer.py:233                 */
     const int32_t *dirichlet_dofs;
     const double *dirichlet_vals;
+    int32_t n_owned_vertices;    /* multi-GPU: vertices [0, n_owned) are owned, the rest are
+                                    ghosts of neighbouring partitions; 0 = all owned        */
 } fedm_mesh_desc;
 
 typedef struct {
@@ -182,6 +184,27 @@ int fedm_amg_clear(fedm_ctx *ctx);
 /* host-side greedy aggregation on a strength graph (set-up helper, no GPU needed) */
 int fedm_amg_aggregate(int32_t n, const int64_t *indptr, const int32_t *indices,
                        const uint8_t *strong, int32_t *agg, int32_t *n_agg);
+
+/* ---- multi-GPU (one process per GPU; what DOLFIN/PETSc do implicitly under mpirun,
+ * README.md:63-67): ghost-value exchange before SpMV/assembly + all-reduces for dots/norms.
+ * Plan in local vertex numbering: for neighbour k (rank nb_rank[k]) send the owned vertices
+ * send_idx[send_ptr[k]..send_ptr[k+1]) and receive the ghost vertices
+ * n_owned + [recv_ptr[k], recv_ptr[k+1]).  Both sides list a shared vertex set in the same
+ * (global id) order. */
+typedef void (*fedm_allreduce_fn)(double *host_buf, int32_t n, void *user);
+typedef void (*fedm_exchange_fn)(const double *send_host, double *recv_host, int32_t width,
+                                 void *user);
+int fedm_comm_unique_id(void *out128 /* ncclUniqueId */);
+int fedm_comm_init_rccl(fedm_ctx *ctx, int n_neighbours, const int32_t *nb_rank,
+                        const int32_t *send_ptr, const int32_t *send_idx, const int32_t *recv_ptr,
+                        const void *unique_id, int rank, int n_ranks);
+/* host-staged transport owned by the caller (e.g. torch.distributed gloo); tests use it */
+int fedm_comm_init_callbacks(fedm_ctx *ctx, int n_neighbours, const int32_t *nb_rank,
+                             const int32_t *send_ptr, const int32_t *send_idx,
+                             const int32_t *recv_ptr, fedm_allreduce_fn allreduce,
+                             fedm_exchange_fn exchange, void *user, int rank, int n_ranks);
+/* refresh the ghost entries of u_new, u_old, u_old1 from their owners */
+int fedm_sync_ghosts(fedm_ctx *ctx);
 
 /* |new - old + eps| / |old + eps| on one component        fedm/functions.py:1062-1064 */
 int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
