@@ -20,7 +20,7 @@ BOUNDARIES = [["line", 0.0, 0.0, 0.0, BOX], ["line", BOX, BOX, 0.0, BOX],
               ["line", 0.0, BOX, 0.0, 0.0], ["line", 0.0, BOX, BOX, BOX]]          # :98-101
 BC_TYPE = [["zero flux", "Neumann"], ["zero flux", "Neumann"],
            ["zero flux", "zero flux"], ["zero flux", "zero flux"]]                 # :103-107
-DECK = Path(__file__).resolve().parent.parent / "decks" / "streamer_discharge" / "file_input"
+DECK = Path(__file__).resolve().parents[2] / "decks" / "streamer_discharge" / "file_input"
 # deck strings, transport_coefficients/{e_Nb,e_ND,alpha}.dat:12 (used when no deck dir is given)
 MU_E = "2.3987*E_m**(-0.26)"
 D_E = "4.3628e-3*E_m**(0.22)"
@@ -34,6 +34,29 @@ def model(mu_e=MU_E, D_e=D_E, alpha=ALPHA, quadrature_degree=2):
     return Model(n_species=2, poisson=True,
                  eq_type=["reaction", "drift-diffusion-reaction"], Z=[1.0, -1.0],
                  mu=[TermSum.const(0.0), mu], D=[TermSum.const(0.0), parse(D_e)],
+                 reactions=[Reaction(rate, power=[0, 1], net=[1, 1])],
+                 bc_kind=BC_TYPE, quadrature_degree=quadrature_degree)
+
+
+def model_from_deck(file_input=DECK, model_name="benchmark_model", quadrature_degree=2):
+    """The same model configured the way the script does it (fedm-streamer.py:47-53,
+    227-245): species list, particle properties and transport coefficients through the
+    deck readers; the 'fun:E' strings are parsed, never eval'd."""
+    from .. import file_io, functions
+    file_io.files.file_input = Path(file_input)
+    path = file_io.files.file_input / model_name
+    n_species, species, prop_files, _ = file_io.read_speclist(path)
+    M, sign = file_io.read_particle_properties(prop_files, model_name)
+    n_species, n_eq, species, M, sign = functions.modify_approximation_vars(
+        "LFA", n_species, species, M, sign)
+    _, D_y, _ = file_io.read_transport_coefficients(species, "Diffusion", model_name)
+    _, mu_y, _ = file_io.read_transport_coefficients(species, "mobility", model_name)
+    alpha = file_io.read_single_string(path / "transport_coefficients" / "alpha.dat")
+    mu = [TermSum.coerce(v) for v in mu_y]
+    D = [TermSum.coerce(v) for v in D_y]
+    rate = parse(alpha) * mu[1] * TermSum.field()
+    return Model(n_species=n_species, poisson=True,
+                 eq_type=["reaction", "drift-diffusion-reaction"], Z=sign, mu=mu, D=D,
                  reactions=[Reaction(rate, power=[0, 1], net=[1, 1])],
                  bc_kind=BC_TYPE, quadrature_degree=quadrature_degree)
 

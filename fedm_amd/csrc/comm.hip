@@ -129,7 +129,7 @@ int comm_init_rccl(Ctx &c, Comm &cm, const void *unique_id, int rank, int nranks
 
 void comm_allreduce(Ctx &c, double *d_buf, int n) {
     Comm *cm = c.comm;
-    if (!cm || cm->kind == 0 || cm->nranks <= 1) return;
+    if (!cm || cm->kind == 0) return;
     if (cm->kind == 2) {
         g_nccl.AllReduce(d_buf, d_buf, (size_t)n, kNcclDouble, kNcclSum, cm->nccl, c.stream);
         return;
@@ -150,7 +150,7 @@ __global__ void halo_pack_kernel(int n_send, int neq, const int *__restrict__ id
 
 void comm_halo(Ctx &c, double *d_vec) {
     Comm *cm = c.comm;
-    if (!cm || cm->kind == 0 || cm->nranks <= 1 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
+    if (!cm || cm->kind == 0 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
     const int w = c.neq;
     if (cm->n_send)
         hipLaunchKernelGGL(halo_pack_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, c.stream,

@@ -64,7 +64,8 @@ def initial_state(model):
     U[:, 0], U[:, 1] = initial_log_densities(mesh.coords)
     # Poisson is linear in Phi: one Newton step from Phi=0 with densities frozen
     phi_model = _PoissonOnly(model)
-    F, J = phi_model.system(U)
+    with np.errstate(all="ignore"):      # Phi = 0 -> |E| = 0: species rows are NaN and unused
+        F, J = phi_model.system(U)
     U[:, 2] = direct_solve(J, -F)
     return U
 

@@ -71,3 +71,27 @@ def test_two_ranks_match_single_gpu():
     ref_log = np.array(st.log_rows())
     for r in res:
         assert np.allclose(np.array(r[3]), ref_log, rtol=1e-6)
+
+
+def test_rccl_transport_single_rank():
+    """RCCL is resolved with dlopen and driven on the library's stream: a one-rank
+    communicator (self all-reduce, empty halo) must not change the solve."""
+    from fedm_amd import partition
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import rccl_unique_id
+    msh = streamer.mesh(16, 2.0)
+    part = partition.partition_rcb(msh.coords, 1)
+    lm = partition.local_mesh(msh.coords, msh.cells, part, 0)
+    assert lm.n_ghost == 0 and len(lm.neighbours) == 0
+    out = []
+    for use_rccl in (False, True):
+        prob = streamer.device_problem(msh.coords, msh.cells)
+        if use_rccl:
+            prob.init_comm_rccl(lm, rccl_unique_id(), 0, 1)
+        st = streamer.Stepper(prob)
+        st.initialise()
+        st.step()
+        out.append(prob.get_state())
+        prob.close()
+    # not bitwise: the LDS-atomic assembly sums in a run-dependent order
+    assert np.allclose(out[0], out[1], rtol=1e-9, atol=1e-9)

@@ -1,0 +1,214 @@
+"""CPU tests of the host layer: step controllers (bit-exact replay of the reference's golden
+error logs), deck readers and source terms against fixtures generated from the reference's own
+Python (tests/golden/make_fixtures.py), coefficient parser, façade error behaviour, and that the
+C-ABI library loads and exports every symbol include/fedm_hip.h declares."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+    return json.loads((golden_dir / "reference_values.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def logs(golden_dir):
+    return json.loads((golden_dir / "error_logs.json").read_text())
+
+
+# ---- step controllers ---------------------------------------------------------------------
+@pytest.mark.parametrize("impl", ["product", "oracle"])
+@pytest.mark.parametrize("case,ttol,dt_max", [("streamer_discharge", 1e-3, 5e-12),
+                                              ("glow_discharge", 2e-3, 1e-11)])
+def test_adaptive_timestep_replays_golden_logs(logs, impl, case, ttol, dt_max):
+    """Row k of `relative error.log` predicts dt of row k+1 (fedm-streamer.py:335-340)."""
+    if impl == "product":
+        from fedm_amd.functions import adaptive_timestep
+    else:
+        from oracle.controller import adaptive_timestep
+    rows = logs[case]
+    max_error = [1, 1, 1]
+    dt_min = 1e-15
+    for k, (err, dt_old, dt) in enumerate(rows[:-1]):
+        max_error[0] = err
+        nxt = adaptive_timestep(dt, max_error, ttol, dt_min, dt_max)
+        max_error[2], max_error[1] = max_error[1], max_error[0]
+        assert nxt == rows[k + 1][2], (k, nxt, rows[k + 1][2])      # bit-exact
+        assert rows[k + 1][1] == dt
+
+
+def test_controller_known_answers(ref):
+    from fedm_amd import functions as ff
+    for name in ("adaptive_timestep", "adaptive_timestep_PI34", "adaptive_timestep_H211b"):
+        assert getattr(ff, name)(*ref[name]["args"]) == ref[name]["value"]
+
+
+# ---- fedm.functions façade: the reference's own unit tests ---------------------------------
+def test_modify_approximation_vars(ref):
+    """tests/unit_tests/functions/test_modify_approximation_vars.py:6-54"""
+    from fedm_amd.functions import modify_approximation_vars
+    out = modify_approximation_vars("LFA", 3, ["a", "b", "c"], [1., 2., 3.], [0., 1., -1.])
+    assert list(out) == ref["modify_LFA"]
+    out = modify_approximation_vars("LMEA", 3, ["a", "b", "c"], [1., 2., 3.], [0., 1., -1.])
+    assert list(out) == ref["modify_LMEA"]
+    with pytest.raises(ValueError) as exc:
+        modify_approximation_vars("bad_type", 3, ["a"], [1.], [0.])
+    assert "bad_type" in str(exc.value)
+
+
+def test_facade_error_messages():
+    from fedm_amd import functions as ff
+    from fedm_amd.mesh import Marking_boundaries, RectangleMesh
+    with pytest.raises(ValueError, match="status 'later' not recognised"):
+        ff.Transport_coefficient_interpolation("later", [], 1.0, 300.0, [], [], [], None, None)
+    with pytest.raises(ValueError, match="dependence 'fun' not"):
+        ff.Rate_coefficient_interpolation("initial", ["fun"], [None], [0], [0], None, None)
+    with pytest.raises(ValueError, match="coupling must be"):
+        ff.Source_term("x", "LFA", [], [], [], [], 1.0, [])
+    with pytest.raises(ValueError, match="Invalid boundary_type 'arc'"):
+        Marking_boundaries(RectangleMesh((0, 0), (1, 1), 2, 2), [["arc", 0, 0, 0, 1]])
+    with pytest.raises(ValueError, match="Invalid function_type"):
+        ff.Function_definition(None, "Nope")
+
+
+# ---- deck readers ----------------------------------------------------------------------------
+def test_glow_discharge_deck(ref):
+    from fedm_amd import file_io as fio
+    g = ref["gd_deck"]
+    fio.files.file_input = ROOT / "decks" / "glow_discharge" / "file_input"
+    model = "4_particles"
+    path = fio.files.file_input / model
+    n, names, props, tc = fio.read_speclist(path)
+    assert (n, names, props, tc) == (g["n"], g["names"], g["props"], g["tc_names"])
+    M, Z = fio.read_particle_properties(props, model)
+    assert M == g["M"] and Z == g["Z"]
+    P, L, G = fio.reaction_matrices(path, names)
+    assert P.tolist() == g["power"] and L.tolist() == g["loss_m"] and G.tolist() == g["gain_m"]
+    kfiles = fio.rate_coefficient_file_names(path)
+    assert [f.name for f in kfiles] == g["kfiles"]
+    assert fio.read_energy_loss(path) == g["energy_loss"]
+    kdep = fio.read_dependences(kfiles)
+    assert kdep == g["kdep"]
+    kx, ky = fio.read_rate_coefficients(kfiles, kdep)
+    assert [int(np.size(a)) for a in kx] == g["k_len"]
+    summ = lambda v: [float(np.sum(a)) if np.ndim(a) else float(a) for a in v]
+    assert np.allclose(summ(kx), g["kx_sum"], rtol=1e-14) and np.allclose(summ(ky), g["ky_sum"], rtol=1e-14)
+    Dx, Dy, Ddep = fio.read_transport_coefficients(tc, "Diffusion", model)
+    mx, my, mdep = fio.read_transport_coefficients(tc, "mobility", model)
+    norm = lambda d: [str(x) for x in d]
+    assert norm(Ddep) == norm(g["Ddep"]) and norm(mdep) == norm(g["mdep"])
+    assert [int(np.size(a)) for a in Dx] == g["D_len"] and [int(np.size(a)) for a in mx] == g["m_len"]
+    assert np.allclose(summ(Dy), g["Dy_sum"], rtol=1e-14) and np.allclose(summ(my), g["my_sum"], rtol=1e-14)
+
+
+def test_streamer_deck_and_model(ref):
+    from fedm_amd import file_io as fio
+    from fedm_amd.cases import streamer
+    s = ref["streamer_deck"]
+    fio.files.file_input = ROOT / "decks" / "streamer_discharge" / "file_input"
+    n, names, props, tc = fio.read_speclist(fio.files.file_input / "benchmark_model")
+    assert (n, names, props, tc) == (s["n"], s["names"], s["props"], s["tc_names"])
+    M, Z = fio.read_particle_properties(props, "benchmark_model")
+    assert M == s["M"] and Z == s["Z"]
+    _, Dy, Ddep = fio.read_transport_coefficients(names, "Diffusion", "benchmark_model")
+    _, my, mdep = fio.read_transport_coefficients(names, "mobility", "benchmark_model")
+    assert Dy == s["Dy"] and Ddep == s["Ddep"] and my == s["my"] and mdep == s["mdep"]
+    a, b = streamer.model_from_deck(), streamer.model()
+    assert a.n_species == b.n_species == 2 and list(a.Z) == list(b.Z)
+    for E in (1e5, 1.5e6, 2e7):
+        for x, y in zip(list(a.mu) + list(a.D) + [a.reactions[0].k],
+                        list(b.mu) + list(b.D) + [b.reactions[0].k]):
+            assert x(E) == pytest.approx(y(E), rel=1e-15)
+    with pytest.raises(RuntimeError, match="is not a directory"):
+        fio.files.file_input = ROOT / "no_such_dir"
+
+
+def test_missing_files_raise_like_the_reference(tmp_path):
+    from fedm_amd import file_io as fio
+    with pytest.raises(FileNotFoundError, match="fedm.read_dependence"):
+        fio.read_dependence(tmp_path / "nope.dat")
+    assert fio.read_dependences([tmp_path / "nope.dat"], zero_if_file_missing=True) == [0]
+    with pytest.raises(ValueError, match="should be the same length"):
+        fio.read_rate_coefficients(["a"], [])
+    with pytest.raises(ValueError, match="dependence 'weird' is not"):
+        fio.read_rate_coefficients(["a"], ["weird"])
+
+
+# ---- source terms -----------------------------------------------------------------------------
+def test_source_terms_match_reference_values(ref):
+    from fedm_amd import functions as ff
+    g, s = ref["gd_deck"], ref["source_term"]
+    P, L, G = np.array(g["power"]), np.array(g["loss_m"]), np.array(g["gain_m"])
+    f = ff.Source_term("coupled", "LMEA", P, L, G, s["k"], s["N0"], s["u"])
+    assert np.allclose(f, s["f"], rtol=1e-14)
+    fen = ff.Energy_Source_term("coupled", P, L, G, s["k"], g["energy_loss"], s["mean_energy"],
+                                s["N0"], s["u"])
+    assert fen == pytest.approx(s["f_energy"], rel=1e-14)
+
+
+def test_interpolation_semantics():
+    from fedm_amd import functions as ff
+    from fedm_amd.forms import Function
+    from fedm_amd.physical_constants import elementary_charge, kB, kB_eV
+    N0, Tgas = 2.0, 300.0
+    energy, red = Function(values=[0.5, 2.0, 9.0]), Function(values=[10.0, 20.0, 30.0])
+    kx, ky = [1.0, 3.0, 5.0], [10.0, 30.0, 20.0]
+    ks = [Function(values=np.zeros(3)) for _ in range(4)]
+    mu = Function(values=[1.0, 2.0, 3.0])
+    ff.Transport_coefficient_interpolation("initial", ["const", "Umean", "E/N", "ESR"], N0, Tgas, ks,
+                                           [0, kx, [10.0, 30.0], 0], [8.0, ky, [1.0, 3.0], 0],
+                                           energy, red, [None, None, None, mu])
+    assert np.array_equal(ks[0].vector(), [4.0] * 3)
+    assert np.allclose(ks[1].vector(), np.interp([0.5, 2.0, 9.0], kx, ky) / N0)       # clamped ends
+    assert np.allclose(ks[2].vector(), [0.5, 1.0, 1.5])
+    assert np.allclose(ks[3].vector(), kB * Tgas * np.array([1.0, 2.0, 3.0]) / elementary_charge)
+    r = [Function(values=np.zeros(3))]
+    ff.Rate_coefficient_interpolation("update", ["Te"], r, [kx], [ky], energy, red)
+    assert np.allclose(r[0].vector(), np.interp(2 * np.array([0.5, 2.0, 9.0]) / (3 * kB_eV), kx, ky))
+
+
+# ---- coefficient expressions --------------------------------------------------------------------
+def test_termsum_parser():
+    import math
+    from fedm_amd.termsum import TermSum, parse
+    a = parse("(1.1944e6 + 4.3666e26 * E_m**(-3))*exp(-2.73e7/E_m)-340.75")
+    for E in (3e5, 1.5e6, 4e7):
+        assert a(E) == pytest.approx((1.1944e6 + 4.3666e26 * E ** -3) * math.exp(-2.73e7 / E) - 340.75, rel=1e-14)
+        h = E * 1e-6
+        assert a.derivative(E) == pytest.approx((a(E + h) - a(E - h)) / (2 * h), rel=1e-6)
+    assert parse("sqrt(E_m)*2")(4.0) == pytest.approx(4.0)
+    assert parse("0.00000E+00").is_const()
+    for bad in ("__import__('os').system('true')", "E_m.real", "exp(E_m + E_m**2)", "x*2",
+                "(1+E_m)**0.5", "exp(-1/E_m)*exp(-E_m)"):
+        with pytest.raises(ValueError):
+            parse(bad)
+
+
+# ---- C ABI -----------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as entry
+    entry.build()
+    from fedm_amd import _lib
+    header = (ROOT / "include" / "fedm_hip.h").read_text()
+    declared = set(re.findall(r"\b(fedm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fedm_allreduce_fn", "fedm_exchange_fn"}
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.exported_symbols())
+    assert lib.fedm_abi_version() == 1
+
+
+def test_product_and_oracle_quadrature_tables_agree():
+    from fedm_amd import quadrature as pq
+    from oracle import quadrature as oq
+    for d in (1, 2, 3, 4, 5, 6, 8):
+        a, b = pq.triangle(d), oq.triangle_rule(d)
+        assert np.allclose(a[0], b[0]) and np.allclose(a[1], b[1]) and a[1].sum() == pytest.approx(0.5)
+    assert np.allclose(pq.interval(2)[0], oq.interval_rule(2)[0])
