@@ -51,6 +51,21 @@ def assembly_bytes(sz):
     return nv * (16 + 24 * neq) + nc * (12 + 36) + nnzb * neq * neq * 8 + nv * neq * 8
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed PMC passes of this same workload
+    (profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied);
+    counters cannot be read from inside the run, so None when the file is absent."""
+    f = ROOT / "profiles" / "r01_pmc_traffic.json"
+    if not f.exists():
+        return {}
+    k = json.loads(f.read_text())["kernels"]
+    out = {}
+    for name, v in k.items():
+        if "traffic_bytes_corrected" in v:
+            out["spmv" if name.startswith("fedm::spmv_kernel") else name] = v["traffic_bytes_corrected"]
+    return out
+
+
 def cpu_baseline(n, steps):
     """The oracle (numpy assembly + SuperLU, 'CPU restatement, not FEniCS') on a bounded
     sample of the same workload, timed on this box's host cores."""
@@ -149,6 +164,9 @@ def main():
               "frac": gbs_asm / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": b_asm,
               "ms_per_launch": ms_asm, "launches": prof["assembly_FJ"][1],
               "ms_residual_only": ms_res, "share_of_timed_region": share["assembly_FJ"]}
+    tr = pmc_traffic() if (world == 1 and n == 576) else {}
+    rl_spmv["traffic"] = tr.get("spmv")
+    rl_asm["traffic"] = next((v for k, v in tr.items() if "assemble_patch" in k and "F+J" in k), None)
     dominant, other = (rl_asm, rl_spmv) if share["assembly_FJ"] >= share["spmv"] else (rl_spmv, rl_asm)
 
     out = {

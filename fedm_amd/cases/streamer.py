@@ -92,13 +92,16 @@ def device_problem(coords, cells, device=0, **model_kw):
                          dirichlet_dofs=dofs, dirichlet_vals=vals, device=device)
 
 
+MULTIGRID = dict(nu=1)      # V(1,1): measured as effective as V(2,2) here at 60 % of the cost
+
+
 def initialise(prob, multigrid=True):
     """Initial densities + the initial Poisson solve (fedm-streamer.py:169-225) on the device."""
     U = np.zeros((prob.nv, 3))
     U[:, 0], U[:, 1] = initial_log_densities(prob.coords)
     prob.set_state(U, U, U)
     if multigrid:
-        prob.setup_multigrid()
+        prob.setup_multigrid(**MULTIGRID)
     its = prob.poisson_solve(rtol=1e-12)
     U = prob.get_state()
     prob.set_state(U, U, U)

@@ -331,14 +331,37 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
         }
     if (upload(c.d_ftags, tags, (size_t)3 * c.nc)) return -1;
     {
-        std::vector<int> bf;
+        // tagged boundary facets, greedily coloured so that facets of one colour share no
+        // vertex of their cells: the boundary kernel can then add without atomics, in a
+        // fixed order (bitwise reproducible)
+        std::vector<int> fcell, floc, ftag, fcol;
+        std::vector<uint32_t> used(c.nv, 0);
+        int ncol = 0;
         for (int cell = 0; cell < c.nc; ++cell)
             for (int i = 0; i < 3; ++i)
                 if (tags[3 * cell + i] > 0) {
-                    bf.push_back(cell);
-                    bf.push_back(i);
-                    bf.push_back(tags[3 * cell + i]);
+                    const int32_t *v = mesh->cells + 3 * cell;
+                    const uint32_t m = used[v[0]] | used[v[1]] | used[v[2]];
+                    int k = 0;
+                    while (k < 31 && ((m >> k) & 1u)) ++k;
+                    for (int a = 0; a < 3; ++a) used[v[a]] |= (1u << k);
+                    ncol = std::max(ncol, k + 1);
+                    fcell.push_back(cell);
+                    floc.push_back(i);
+                    ftag.push_back(tags[3 * cell + i]);
+                    fcol.push_back(k);
                 }
+        std::vector<int> bf;
+        c.bfacet_colour_ptr.assign(ncol + 1, 0);
+        for (int k = 0; k < ncol; ++k) {
+            for (size_t f = 0; f < fcell.size(); ++f)
+                if (fcol[f] == k) {
+                    bf.push_back(fcell[f]);
+                    bf.push_back(floc[f]);
+                    bf.push_back(ftag[f]);
+                }
+            c.bfacet_colour_ptr[k + 1] = (int)bf.size() / 3;
+        }
         c.n_bfacets = (int)bf.size() / 3;
         if (upload(c.d_bfacets, bf.data(), bf.size())) return -1;
     }

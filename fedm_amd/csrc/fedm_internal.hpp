@@ -90,6 +90,7 @@ struct Ctx {
     int assembly_kind = 1;  // 0: global colouring (deterministic), 1: LDS patches
     int n_bfacets = 0;      // tagged boundary facets (cell, local facet, tag)
     int *d_bfacets = nullptr;
+    std::vector<int> bfacet_colour_ptr;  // facets grouped by colour
     fedm_model_desc *d_model = nullptr;
     double *d_ext[FEDM_MAX_SPECIES] = {nullptr, nullptr, nullptr, nullptr};
     // matrix

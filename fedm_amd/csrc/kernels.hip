@@ -206,8 +206,9 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
 }
 
 // =============================================================================================
-// Neumann boundary facets (fedm/functions.py:523-524): one thread per tagged facet, added on
-// top of the volume assembly with global fp64 atomics.
+// Neumann boundary facets (fedm/functions.py:523-524): one thread per tagged facet, one launch
+// per facet colour (facets of a colour share no vertex), plain adds on top of the volume
+// assembly -> fixed summation order.
 // =============================================================================================
 template <int NS>
 __global__ void boundary_kernel(const fedm_model_desc *__restrict__ md, int n_facets,
@@ -228,21 +229,27 @@ __global__ void boundary_kernel(const fedm_model_desc *__restrict__ md, int n_fa
         x[a][1] = coords[2 * v[a] + 1];
         for (int s = 0; s < NEQ; ++s) Uc[a][s] = u[(size_t)v[a] * NEQ + s];
     }
-    auto addR = [&](int a, int s, double value) { unsafeAtomicAdd(&F[(size_t)v[a] * NEQ + s], value); };
+    auto addR = [&](int a, int s, double value) { F[(size_t)v[a] * NEQ + s] += value; };
     auto addJ = [&](int a, int b, int sr, int scol, double value) {
         const uint32_t slot = cell_slots[(size_t)c * 9 + a * 3 + b];
-        unsafeAtomicAdd(&val[((size_t)(slot >> 6) * NEQ2 + sr * NEQ + scol) * SLICE + (slot & 63)], value);
+        val[((size_t)(slot >> 6) * NEQ2 + sr * NEQ + scol) * SLICE + (slot & 63)] += value;
     };
     boundary_facet<NS>(md, x, Uc, fi, tag, jacobian != 0, addR, addJ);
 }
 
 static void launch_boundary(Ctx &c, bool jacobian) {
     if (!c.poisson || c.n_bfacets == 0) return;
-    const dim3 g((c.n_bfacets + 127) / 128), b(128);
-    switch (c.ns) {
-        case 1: hipLaunchKernelGGL(boundary_kernel<1>, g, b, 0, c.stream, c.d_model, c.n_bfacets, c.d_bfacets, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
-        case 2: hipLaunchKernelGGL(boundary_kernel<2>, g, b, 0, c.stream, c.d_model, c.n_bfacets, c.d_bfacets, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
-        case 3: hipLaunchKernelGGL(boundary_kernel<3>, g, b, 0, c.stream, c.d_model, c.n_bfacets, c.d_bfacets, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+    const int ncol = (int)c.bfacet_colour_ptr.size() - 1;
+    for (int k = 0; k < ncol; ++k) {
+        const int f0 = c.bfacet_colour_ptr[k], n = c.bfacet_colour_ptr[k + 1] - f0;
+        if (n == 0) continue;
+        const dim3 g((n + 127) / 128), b(128);
+        const int *fl = c.d_bfacets + 3 * f0;
+        switch (c.ns) {
+            case 1: hipLaunchKernelGGL(boundary_kernel<1>, g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+            case 2: hipLaunchKernelGGL(boundary_kernel<2>, g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+            case 3: hipLaunchKernelGGL(boundary_kernel<3>, g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+        }
     }
 }
 
