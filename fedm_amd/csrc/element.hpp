@@ -77,52 +77,50 @@ struct CellGeom {
     }
 };
 
-// NR: compile-time bound on the number of reactions (keeps their coefficients in registers)
-template <int NS, bool PO, int NR>
+// NR: compile-time bound on the number of reactions (keeps their coefficients in registers).
+// CACHE: keep exp(u) and the BDF term at the (<= 3) quadrature points in registers and emit
+// the element tensors one equation row at a time, so that only one row's moments are live
+// (n_eq = 3: 22 instead of 60 doubles); without it every row pass re-evaluates exp(u).
+template <int NS, bool PO, int NR, bool CACHE>
 struct Element {
     static constexpr int NEQ = NS + (PO ? 1 : 0);
     static constexpr int IPHI = NEQ - 1;
+    static constexpr int NQC = 3;
 
-    double G[3][2];
-    double GG[6];
-    double gradPhi[2];
-    double dEm[3];
-    double Dv[NS], velG[NS][3];
-    double gradu[NS][2];
-    double E[2];
-    double muv[NS], mud[NS], Dd[NS];
-    double M2g[NEQ][NS][6];
-    double M1h[NEQ][3];
-    double M1n[NS][3];
-    double M0n[NS];
-    double M1Sp[NS][3];
-    double M01;
-    bool flux[NS], fdrift[NS];
+    // cell constants
+    double G[3][2], detJ, rn[3];
+    double gradPhi[2], E[2], invEm;
+    double Dv[NS], Dd[NS], muv[NS], mud[NS], vel[NS][2], gradu[NS][2];
+    double kv[NR > 0 ? NR : 1], kd[NR > 0 ? NR : 1];
+    double nq_c[NS][NQC], up_c[NS][NQC];
+    bool flux[NS], fdrift[NS], full;
+    int nreac;
+    // moments of the row being emitted
+    double m2[NS][6], m1h[3], m1n[3], m0n, m1sp[3], m01;
 
-    // Uc: nodal unknowns; Hc: nodal BDF history (see StepCoef); ext: this cell's P_k nodal
-    // source values per species (or nullptr); mode 1 = Poisson row only
-    __device__ void compute(const fedm_model_desc *__restrict__ md, const double x[3][2],
-                            const double Uc[3][NEQ], const double Hc[3][NS > 0 ? NS : 1],
-                            const StepCoef sc, const double *const ext[NS], int mode) {
-        const double two_pi = 6.283185307179586476925286766559;
+    __device__ __forceinline__ double dEm(int b) const {
+        return -(E[0] * G[b][0] + E[1] * G[b][1]) * invEm;
+    }
+    __device__ __forceinline__ double GG(int a, int b) const {
+        return G[a][0] * G[b][0] + G[a][1] * G[b][1];
+    }
+
+    __device__ void setup(const fedm_model_desc *__restrict__ md, const double x[3][2],
+                          const double Uc[3][NEQ], const double Hc[3][NS], const StepCoef sc,
+                          int mode) {
         CellGeom cg;
         cg.init(x, md->axisymmetric);
+        detJ = cg.detJ;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             G[a][0] = cg.G[a][0];
             G[a][1] = cg.G[a][1];
+            rn[a] = cg.rn[a];
         }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = a; b < 3; ++b) GG[sym6(a, b)] = G[a][0] * G[b][0] + G[a][1] * G[b][1];
-
-        // ---- cell-constant fields -----------------------------------------------------
         double Em = 1.0;
-        E[0] = E[1] = 0.0;
-        gradPhi[0] = gradPhi[1] = 0.0;
-        dEm[0] = dEm[1] = dEm[2] = 0.0;
-        const bool full = (mode == 0);
+        E[0] = E[1] = gradPhi[0] = gradPhi[1] = 0.0;
+        invEm = 0.0;
+        full = (mode == 0);
         if (PO) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -133,13 +131,11 @@ struct Element {
             E[1] = -gradPhi[1];
             if (full) {
                 Em = sqrt(E[0] * E[0] + E[1] * E[1]);
-#pragma unroll
-                for (int b = 0; b < 3; ++b) dEm[b] = -(E[0] * G[b][0] + E[1] * G[b][1]) / Em;
+                invEm = 1.0 / Em;
             }
         }
         const double lnE = log(Em);
-        double kv[NR > 0 ? NR : 1], kd[NR > 0 ? NR : 1];
-        const int nreac = full ? md->n_reactions : 0;
+        nreac = full ? md->n_reactions : 0;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             kv[j] = kd[j] = 0.0;
@@ -156,180 +152,186 @@ struct Element {
             muv[s] = mud[s] = Dv[s] = Dd[s] = 0.0;
             flux[s] = full && md->eq_type[s] != FEDM_EQ_REACTION;
             fdrift[s] = false;
-            double vel0 = 0.0, vel1 = 0.0;
+            vel[s][0] = vel[s][1] = 0.0;
             if (flux[s]) {
                 termsum_eval(md->D[s], Em, lnE, Dv[s], Dd[s]);
-                vel0 = -Dv[s] * gradu[s][0];
-                vel1 = -Dv[s] * gradu[s][1];
+                vel[s][0] = -Dv[s] * gradu[s][0];
+                vel[s][1] = -Dv[s] * gradu[s][1];
                 if (md->eq_type[s] == FEDM_EQ_DRIFT_DIFFUSION_REACTION) {
                     if (md->has_drift_w[s]) {
-                        vel0 += md->drift_w[s][0];
-                        vel1 += md->drift_w[s][1];
+                        vel[s][0] += md->drift_w[s][0];
+                        vel[s][1] += md->drift_w[s][1];
                     } else if (PO) {
                         termsum_eval(md->mu[s], Em, lnE, muv[s], mud[s]);
-                        vel0 += md->Z[s] * muv[s] * E[0];
-                        vel1 += md->Z[s] * muv[s] * E[1];
+                        vel[s][0] += md->Z[s] * muv[s] * E[0];
+                        vel[s][1] += md->Z[s] * muv[s] * E[1];
                         fdrift[s] = true;
                     }
                 }
             }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) velG[s][a] = vel0 * G[a][0] + vel1 * G[a][1];
         }
-
-        // ---- quadrature: weighted P1 moments ----------------------------------------------
+        if (CACHE) {
 #pragma unroll
-        for (int s = 0; s < NEQ; ++s) {
+            for (int q = 0; q < NQC; ++q) {
+                const double xq = md->qp_x[q], yq = md->qp_y[q];
+                const double p0 = 1.0 - xq - yq;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) M1h[s][a] = 0.0;
-#pragma unroll
-            for (int i = 0; i < NS; ++i)
-#pragma unroll
-                for (int k = 0; k < 6; ++k) M2g[s][i][k] = 0.0;
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            M0n[s] = 0.0;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                M1n[s][a] = 0.0;
-                M1Sp[s][a] = 0.0;
-            }
-        }
-        M01 = 0.0;
-
-        const int nq = md->n_qp;
-        for (int q = 0; q < nq; ++q) {
-            const double xq = md->qp_x[q], yq = md->qp_y[q];
-            double phi[3] = {1.0 - xq - yq, xq, yq};
-            const double rq = cg.rn[0] * phi[0] + cg.rn[1] * phi[1] + cg.rn[2] * phi[2];
-            const double W = md->qp_w[q] * cg.detJ * two_pi * rq;
-            double nq_[NS], g[NEQ][NS], h[NEQ], Sp[NS];
-#pragma unroll
-            for (int s = 0; s < NEQ; ++s) {
-                h[s] = 0.0;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) g[s][i] = 0.0;
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double u = Uc[0][s] * phi[0] + Uc[1][s] * phi[1] + Uc[2][s] * phi[2];
-                const double n = exp(u);
-                nq_[s] = n;
-                Sp[s] = 0.0;
-                if (full) {
-                    const double hist = Hc[0][s] * phi[0] + Hc[1][s] * phi[1] + Hc[2][s] * phi[2];
-                    const double u_part = sc.c_new * u + hist;
-                    h[s] = n * u_part / sc.dt;
-                    g[s][s] = n * (u_part / sc.dt + sc.c_new / sc.dt);
+                for (int s = 0; s < NS; ++s) {
+                    const double u = Uc[0][s] * p0 + Uc[1][s] * xq + Uc[2][s] * yq;
+                    nq_c[s][q] = exp(u);
+                    up_c[s][q] = sc.c_new * u + (Hc[0][s] * p0 + Hc[1][s] * xq + Hc[2][s] * yq);
                 }
             }
+        }
+    }
+
+    // moments of equation row `row` (compile-time constant after unrolling)
+    __device__ __forceinline__ void row_moments(const fedm_model_desc *__restrict__ md, int row,
+                                                const double Uc[3][NEQ], const double Hc[3][NS],
+                                                const StepCoef sc, const double *const ext[NS]) {
+        const double two_pi = 6.283185307179586476925286766559;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) m1h[a] = m1n[a] = m1sp[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m2[i][k] = 0.0;
+        m0n = m01 = 0.0;
+        const int nq = md->n_qp;
+        if (CACHE) {
+            // compile-time quadrature index: the cached values stay in registers
+#pragma unroll
+            for (int q = 0; q < NQC; ++q) {
+                if (q >= nq) break;
+                double n[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) n[i] = nq_c[i][q];
+                point(md, row, q, n, up_c[row < NS ? row : 0][q], sc, ext);
+            }
+        } else {
+            for (int q = 0; q < nq; ++q) {
+                const double xq = md->qp_x[q], yq = md->qp_y[q], p0 = 1.0 - xq - yq;
+                double n[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) n[i] = exp(Uc[0][i] * p0 + Uc[1][i] * xq + Uc[2][i] * yq);
+                const int s = row < NS ? row : 0;
+                const double u = Uc[0][s] * p0 + Uc[1][s] * xq + Uc[2][s] * yq;
+                const double u_part = sc.c_new * u + (Hc[0][s] * p0 + Hc[1][s] * xq + Hc[2][s] * yq);
+                point(md, row, q, n, u_part, sc, ext);
+            }
+        }
+    }
+
+    // contribution of quadrature point q to the moments of equation row `row`
+    __device__ __forceinline__ void point(const fedm_model_desc *__restrict__ md, int row, int q,
+                                          const double n[NS], double u_part, const StepCoef sc,
+                                          const double *const ext[NS]) {
+        const double two_pi = 6.283185307179586476925286766559;
+        const bool phi_row = PO && row == IPHI;
+        const double xq = md->qp_x[q], yq = md->qp_y[q];
+        const double phi[3] = {1.0 - xq - yq, xq, yq};
+        const double rq = rn[0] * phi[0] + rn[1] * phi[1] + rn[2] * phi[2];
+        const double W = md->qp_w[q] * detJ * two_pi * rq;
+        double g[NS], h = 0.0, sp = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) g[i] = 0.0;
+        if (phi_row) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double cz = md->Z[i] * n[i] * md->charge_over_eps;
+                h -= cz;
+                if (full) g[i] = -cz;
+            }
+        } else if (full) {
+            const int s = row < NS ? row : 0;
+            h = n[s] * u_part / sc.dt;
+            g[s] = n[s] * (u_part / sc.dt + sc.c_new / sc.dt);
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 if (j >= nreac) break;
+                const double nu = (double)md->net[j][s];
+                if (nu == 0.0) continue;
                 double prod = 1.0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const int P = md->power[j][i];
-                    for (int e = 0; e < P; ++e) prod *= nq_[i];
+                    for (int e = 0; e < P; ++e) prod *= n[i];
                 }
+                h -= nu * kv[j] * prod;
+                sp += nu * kd[j] * prod;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const double nu = (double)md->net[j][s];
-                    if (nu == 0.0) continue;
-                    h[s] -= nu * kv[j] * prod;
-                    Sp[s] += nu * kd[j] * prod;
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const int P = md->power[j][i];
-                        if (P) g[s][i] -= nu * kv[j] * (double)P * prod;
-                    }
+                for (int i = 0; i < NS; ++i) {
+                    const int P = md->power[j][i];
+                    if (P) g[i] -= nu * kv[j] * (double)P * prod;
                 }
             }
-            if (full) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int nn = md->ext_nodes[s];
-                    if (nn && ext[s]) {
-                        double f = 0.0;
-                        for (int m = 0; m < nn; ++m) f += ext[s][m] * md->ext_B[q][m];
-                        h[s] -= f;
-                    }
-                }
+            const int nn = md->ext_nodes[s];
+            if (nn && ext[s]) {
+                double f = 0.0;
+                for (int m = 0; m < nn; ++m) f += ext[s][m] * md->ext_B[q][m];
+                h -= f;
             }
-            if (PO) {
-                double rho = 0.0;
+        }
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const double cz = md->Z[s] * nq_[s] * md->charge_over_eps;
-                    rho += cz;
-                    if (full) g[IPHI][s] = -cz;
-                }
-                h[IPHI] = -rho;
+        for (int a = 0; a < 3; ++a) m1h[a] += W * phi[a] * h;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) {
+                const double pp = W * phi[a] * phi[b];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) m2[i][sym6(a, b)] += pp * g[i];
             }
-            double pp[6];
+        if (phi_row) {
+            m01 += W;
+        } else {
+            const double ns_ = n[row < NS ? row : 0];
+            m0n += W * ns_;
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = a; b < 3; ++b) pp[sym6(a, b)] = W * phi[a] * phi[b];
-#pragma unroll
-            for (int s = 0; s < NEQ; ++s) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) M1h[s][a] += W * phi[a] * h[s];
-#pragma unroll
-                for (int i = 0; i < NS; ++i)
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) M2g[s][i][k] += pp[k] * g[s][i];
+            for (int a = 0; a < 3; ++a) {
+                m1n[a] += W * phi[a] * ns_;
+                m1sp[a] += W * phi[a] * sp;
             }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                M0n[s] += W * nq_[s];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    M1n[s][a] += W * phi[a] * nq_[s];
-                    M1Sp[s][a] += W * phi[a] * Sp[s];
-                }
-            }
-            M01 += W;
         }
     }
 
-    __device__ __forceinline__ void residual(int a, double R[NEQ]) const {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            R[s] = M1h[s][a];
-            if (flux[s]) R[s] -= velG[s][a] * M0n[s];
-        }
-        if (PO) R[IPHI] = (gradPhi[0] * G[a][0] + gradPhi[1] * G[a][1]) * M01 + M1h[IPHI][a];
+    // residual entry (a, row) -- after row_moments(row)
+    __device__ __forceinline__ double residual(int row, int a) const {
+        if (PO && row == IPHI) return (gradPhi[0] * G[a][0] + gradPhi[1] * G[a][1]) * m01 + m1h[a];
+        const int s = row < NS ? row : 0;
+        double r = m1h[a];
+        if (flux[s]) r -= (vel[s][0] * G[a][0] + vel[s][1] * G[a][1]) * m0n;
+        return r;
     }
 
-    // row-major NEQ x NEQ block d R[a][.] / d U[b][.]
-    __device__ __forceinline__ void block(const fedm_model_desc *__restrict__ md, int a, int b,
-                                          double B[NEQ * NEQ]) const {
+    // entries d R[a][row] / d U[b][0..NEQ) -- after row_moments(row)
+    __device__ __forceinline__ void block_row(const fedm_model_desc *__restrict__ md, int row, int a,
+                                              int b, double B[NEQ]) const {
         const int k = sym6(a, b);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int i = 0; i < NS; ++i) B[s * NEQ + i] = M2g[s][i][k];
-            if (flux[s]) B[s * NEQ + s] -= velG[s][a] * M1n[s][b] - Dv[s] * GG[k] * M0n[s];
-            if (PO) {
-                double v = -dEm[b] * M1Sp[s][a];
-                if (flux[s]) {
-                    double dv0 = -Dd[s] * dEm[b] * gradu[s][0];
-                    double dv1 = -Dd[s] * dEm[b] * gradu[s][1];
-                    if (fdrift[s]) {
-                        dv0 += md->Z[s] * (mud[s] * dEm[b] * E[0] - muv[s] * G[b][0]);
-                        dv1 += md->Z[s] * (mud[s] * dEm[b] * E[1] - muv[s] * G[b][1]);
-                    }
-                    v -= (dv0 * G[a][0] + dv1 * G[a][1]) * M0n[s];
-                }
-                B[s * NEQ + IPHI] = v;
-            }
+        for (int i = 0; i < NS; ++i) B[i] = m2[i][k];
+        if (PO && row == IPHI) {
+            B[IPHI] = GG(a, b) * m01;
+            return;
+        }
+        const int s = row < NS ? row : 0;
+        if (flux[s]) {
+            const double velGa = vel[s][0] * G[a][0] + vel[s][1] * G[a][1];
+            B[s] -= velGa * m1n[b] - Dv[s] * GG(a, b) * m0n;
         }
         if (PO) {
-#pragma unroll
-            for (int i = 0; i < NS; ++i) B[IPHI * NEQ + i] = M2g[IPHI][i][k];
-            B[IPHI * NEQ + IPHI] = GG[k] * M01;
+            const double de = dEm(b);
+            double v = -de * m1sp[a];
+            if (flux[s]) {
+                double dv0 = -Dd[s] * de * gradu[s][0];
+                double dv1 = -Dd[s] * de * gradu[s][1];
+                if (fdrift[s]) {
+                    dv0 += md->Z[s] * (mud[s] * de * E[0] - muv[s] * G[b][0]);
+                    dv1 += md->Z[s] * (mud[s] * de * E[1] - muv[s] * G[b][1]);
+                }
+                v -= (dv0 * G[a][0] + dv1 * G[a][1]) * m0n;
+            }
+            B[IPHI] = v;
         }
     }
 };

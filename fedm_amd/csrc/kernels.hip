@@ -13,7 +13,7 @@ namespace fedm {
 // and the summation order is fixed -> bitwise reproducible).
 // Problem.F / Problem.J, fedm/functions.py:188-202
 // =============================================================================================
-template <int NS, bool PO, int NR>
+template <int NS, bool PO, int NR, bool CACHE>
 __global__ __launch_bounds__(256) void assemble_colour_kernel(
     const fedm_model_desc *__restrict__ md, const int *__restrict__ cell_list, int n_cells,
     const int *__restrict__ cells, const double *__restrict__ coords,
@@ -45,31 +45,35 @@ __global__ __launch_bounds__(256) void assemble_colour_kernel(
     for (int s = 0; s < NS; ++s)
         ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)c * md->ext_nodes[s] : nullptr;
 
-    Element<NS, PO, NR> el;
-    el.compute(md, x, Uc, Hc, sc, ext, mode);
-
+    Element<NS, PO, NR, CACHE> el;
+    el.setup(md, x, Uc, Hc, sc, mode);
+    uint32_t slot[9];
+    if (jacobian) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        double R[NEQ];
-        el.residual(a, R);
-#pragma unroll
-        for (int s = 0; s < NEQ; ++s) F[(size_t)v[a] * NEQ + s] += R[s];
+        for (int k = 0; k < 9; ++k) slot[k] = cell_slots[(size_t)c * 9 + k];
     }
-    if (!jacobian) return;
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int row = 0; row < NEQ; ++row) {
+        if (mode == 1 && PO && row != NEQ - 1) continue;  // Poisson-only: species rows are identity
+        el.row_moments(md, row, Uc, Hc, sc, ext);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            double B[NEQ2];
-            el.block(md, a, b, B);
-            const uint32_t slot = cell_slots[(size_t)c * 9 + a * 3 + b];
-            double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
+        for (int a = 0; a < 3; ++a) {
+            F[(size_t)v[a] * NEQ + row] += el.residual(row, a);
+            if (!jacobian) continue;
 #pragma unroll
-            for (int e = 0; e < NEQ2; ++e) dst[(size_t)e * SLICE] += B[e];
+            for (int b = 0; b < 3; ++b) {
+                double B[NEQ];
+                el.block_row(md, row, a, b, B);
+                const uint32_t sl = slot[a * 3 + b];
+                double *dst = val + ((size_t)(sl >> 6) * NEQ2 + row * NEQ) * SLICE + (sl & 63);
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) dst[(size_t)i * SLICE] += B[i];
+            }
         }
+    }
 }
 
-template <int NS, bool PO, int NR>
+template <int NS, bool PO, int NR, bool CACHE>
 static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     hipMemsetAsync(c.d_F, 0, sizeof(double) * c.np, c.stream);
@@ -80,7 +84,7 @@ static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
     for (int k = 0; k < ncol; ++k) {
         const int n = c.pat.colour_ptr[k + 1] - c.pat.colour_ptr[k];
         if (n == 0) continue;
-        hipLaunchKernelGGL((assemble_colour_kernel<NS, PO, NR>), dim3((n + 255) / 256), dim3(256), 0,
+        hipLaunchKernelGGL((assemble_colour_kernel<NS, PO, NR, CACHE>), dim3((n + 255) / 256), dim3(256), 0,
                            c.stream, c.d_model, c.d_colour_cells + c.pat.colour_ptr[k], n,
                            c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_uold, c.d_uold1, sc,
                            c.d_ext[0], c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val, c.d_F,
@@ -99,7 +103,7 @@ static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
 // =============================================================================================
 constexpr int PATCH_THREADS = 320;
 
-template <int NS, bool PO, int NR>
+template <int NS, bool PO, int NR, bool CACHE>
 __global__ __launch_bounds__(PATCH_THREADS) void assemble_patch_kernel(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
@@ -158,24 +162,26 @@ __global__ __launch_bounds__(PATCH_THREADS) void assemble_patch_kernel(
         for (int s = 0; s < NS; ++s)
             ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)pc.cell * md->ext_nodes[s] : nullptr;
 
-        Element<NS, PO, NR> el;
-        el.compute(md, x, Uc, Hc, sc, ext, mode);
+        Element<NS, PO, NR, CACHE> el;
+        el.setup(md, x, Uc, Hc, sc, mode);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int lane = pc.lv[a];
-            if (lane >= SLICE) continue;  // row vertex owned by another patch
-            double R[NEQ];
-            el.residual(a, R);
+        for (int row = 0; row < NEQ; ++row) {
+            if (mode == 1 && PO && row != NEQ - 1) continue;
+            el.row_moments(md, row, Uc, Hc, sc, ext);
 #pragma unroll
-            for (int s = 0; s < NEQ; ++s) unsafeAtomicAdd(&Fl[lane * NEQ + s], R[s]);
-            if (!jacobian) continue;
+            for (int a = 0; a < 3; ++a) {
+                const int lane = pc.lv[a];
+                if (lane >= SLICE) continue;  // row vertex owned by another patch
+                unsafeAtomicAdd(&Fl[lane * NEQ + row], el.residual(row, a));
+                if (!jacobian) continue;
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                double B[NEQ2];
-                el.block(md, a, b, B);
-                double *dst = acc + (size_t)pc.j[a * 3 + b] * NEQ2 * SLICE + lane;
+                for (int b = 0; b < 3; ++b) {
+                    double B[NEQ];
+                    el.block_row(md, row, a, b, B);
+                    double *dst = acc + ((size_t)pc.j[a * 3 + b] * NEQ2 + row * NEQ) * SLICE + lane;
 #pragma unroll
-                for (int e = 0; e < NEQ2; ++e) unsafeAtomicAdd(&dst[e * SLICE], B[e]);
+                    for (int i = 0; i < NEQ; ++i) unsafeAtomicAdd(&dst[i * SLICE], B[i]);
+                }
             }
         }
     }
@@ -192,12 +198,12 @@ size_t patch_lds_bytes(const Ctx &c) {
                              2 * mv + (size_t)(neq + c.ns) * mv);
 }
 
-template <int NS, bool PO, int NR>
+template <int NS, bool PO, int NR, bool CACHE>
 static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     const StepCoef sc = step_coef(c.dt, c.dt_old);
     const int acc_doubles = c.pat.max_patch_width * NEQ * NEQ * SLICE;
-    hipLaunchKernelGGL((assemble_patch_kernel<NS, PO, NR>), dim3(c.pat.n_slices), dim3(PATCH_THREADS),
+    hipLaunchKernelGGL((assemble_patch_kernel<NS, PO, NR, CACHE>), dim3(c.pat.n_slices), dim3(PATCH_THREADS),
                        patch_lds_bytes(c), c.stream, c.d_model, c.nv, c.d_slice_boff,
                        c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr, c.d_patch_halo,
                        c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],
@@ -253,16 +259,22 @@ static void launch_boundary(Ctx &c, bool jacobian) {
     }
 }
 
+template <int NS, bool PO, int NR, bool CACHE>
+static void assemble_variant(Ctx &c, bool jacobian, int mode) {
+    if (c.assembly_kind == 1) assemble_patch_t<NS, PO, NR, CACHE>(c, jacobian, mode);
+    else assemble_colour_t<NS, PO, NR, CACHE>(c, jacobian, mode);
+}
+
 template <int NS, bool PO>
 static void assemble_dispatch(Ctx &c, bool jacobian, int mode) {
+    constexpr int NEQ = NS + (PO ? 1 : 0);
     const bool few = c.model.n_reactions <= 1;
-    if (c.assembly_kind == 1) {
-        if (few) assemble_patch_t<NS, PO, 1>(c, jacobian, mode);
-        else assemble_patch_t<NS, PO, FEDM_MAX_REACTIONS>(c, jacobian, mode);
-    } else {
-        if (few) assemble_colour_t<NS, PO, 1>(c, jacobian, mode);
-        else assemble_colour_t<NS, PO, FEDM_MAX_REACTIONS>(c, jacobian, mode);
-    }
+    // cache exp(u) at the quadrature points when the tensors are emitted in several row passes
+    const bool cache = NEQ > 1 && c.model.n_qp <= 3;
+    if (few && cache) assemble_variant<NS, PO, 1, (NEQ > 1)>(c, jacobian, mode);
+    else if (few) assemble_variant<NS, PO, 1, false>(c, jacobian, mode);
+    else if (cache) assemble_variant<NS, PO, FEDM_MAX_REACTIONS, (NEQ > 1)>(c, jacobian, mode);
+    else assemble_variant<NS, PO, FEDM_MAX_REACTIONS, false>(c, jacobian, mode);
 }
 
 void launch_assemble(Ctx &c, bool jacobian, int mode) {
