@@ -44,11 +44,14 @@ def _z_order(xy):
 
 
 def build_hierarchy(A, theta=0.08, omega=4.0 / 3.0, max_coarse=600, max_levels=12,
-                    fixed=None, coords=None):
+                    fixed=None, coords=None, max_sparse_levels=None):
     """Levels [(A_l, P_l)] of a smoothed-aggregation hierarchy; the last A is coarsest.
 
     ``fixed``: boolean mask of identity rows (Dirichlet / padding); they are kept out of
     the aggregates (their prolongator rows are zero) so the coarse problems stay SPD.
+    ``max_sparse_levels``: once that many sparse levels exist, further coarsening steps are
+    composed into the last prolongator (P <- P P_next) instead of adding levels: every level
+    costs ~5 latency-bound kernel launches per cycle on the device.
     ``coords`` (n,2), optional: nodes are visited in a lexicographic sweep (compact, regular
     aggregates whatever the numbering) and the aggregates of every level are numbered along
     a Z-curve of their centroids, so that restriction/prolongation gathers stay within a
@@ -83,7 +86,11 @@ def build_hierarchy(A, theta=0.08, omega=4.0 / 3.0, max_coarse=600, max_levels=1
         P = sp.diags(free.astype(np.float64)) @ P       # fixed rows interpolate nothing
         P.eliminate_zeros()
         Ac = (P.T @ A @ P).tocsr()
-        levels.append((A, P.tocsr()))
+        if max_sparse_levels is not None and len(levels) >= max_sparse_levels:
+            A_prev, P_prev = levels[-1]
+            levels[-1] = (A_prev, (P_prev @ P).tocsr())
+        else:
+            levels.append((A, P.tocsr()))
         A = Ac
         free = np.ones(A.shape[0], dtype=bool)
         if xy is not None:

@@ -92,7 +92,7 @@ def device_problem(coords, cells, device=0, **model_kw):
                          dirichlet_dofs=dofs, dirichlet_vals=vals, device=device)
 
 
-MULTIGRID = dict(nu=1)      # V(1,1): measured as effective as V(2,2) here at 60 % of the cost
+MULTIGRID = dict(nu=1)      # V(1,1): as effective as V(2,2) here at 75 % of the cost
 
 
 def initialise(prob, multigrid=True):

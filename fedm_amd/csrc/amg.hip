@@ -63,6 +63,8 @@ void EllMat::release() {
 }
 
 // MODE 0: y = A x      1: y = b - A x      2: y = x + omega*dinv*(b - A x)     3: y += A x
+// MODE 4: first sweep from a zero guess fused with the residual:
+//         x1 = omega*dinv*b (written to `aux`),  y = b - A x1   (x is unused)
 template <int MODE>
 __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *__restrict__ boff,
                                                        const int *__restrict__ col,
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *
                                                        const double *__restrict__ dinv,
                                                        const double *__restrict__ x,
                                                        const double *__restrict__ b,
-                                                       double *__restrict__ y, double omega) {
+                                                       double *__restrict__ y, double omega,
+                                                       double *__restrict__ aux) {
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
@@ -83,7 +86,18 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *
         const size_t k = (size_t)bc * SLICE + lane;
         const int c0 = col[k], c1 = col[k + SLICE], c2 = col[k + 2 * SLICE], c3 = col[k + 3 * SLICE];
         const double v0 = val[k], v1 = val[k + SLICE], v2 = val[k + 2 * SLICE], v3 = val[k + 3 * SLICE];
-        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        double x0, x1, x2, x3;
+        if (MODE == 4) {
+            x0 = omega * dinv[c0] * b[c0];
+            x1 = omega * dinv[c1] * b[c1];
+            x2 = omega * dinv[c2] * b[c2];
+            x3 = omega * dinv[c3] * b[c3];
+        } else {
+            x0 = x[c0];
+            x1 = x[c1];
+            x2 = x[c2];
+            x3 = x[c3];
+        }
         a0 += v0 * x0;
         a1 += v1 * x1;
         a2 += v2 * x2;
@@ -91,7 +105,8 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *
     }
     for (; bc < b1; ++bc) {
         const size_t k = (size_t)bc * SLICE + lane;
-        a0 += val[k] * x[col[k]];
+        const int cc = col[k];
+        a0 += val[k] * (MODE == 4 ? omega * dinv[cc] * b[cc] : x[cc]);
     }
     const double acc = (a0 + a1) + (a2 + a3);
     const size_t r = (size_t)slice * SLICE + lane;
@@ -99,16 +114,21 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *
     if (MODE == 1) y[r] = b[r] - acc;
     if (MODE == 2) y[r] = x[r] + omega * dinv[r] * (b[r] - acc);
     if (MODE == 3) y[r] += acc;
+    if (MODE == 4) {
+        y[r] = b[r] - acc;
+        aux[r] = omega * dinv[r] * b[r];
+    }
 }
 
 static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const double *b,
-                       double *y, double omega) {
+                       double *y, double omega, double *aux = nullptr) {
     const dim3 g((A.n_slices + 3) / 4), bl(256);
     switch (mode) {
-        case 0: hipLaunchKernelGGL(ell_spmv_kernel<0>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
-        case 1: hipLaunchKernelGGL(ell_spmv_kernel<1>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
-        case 2: hipLaunchKernelGGL(ell_spmv_kernel<2>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
-        default: hipLaunchKernelGGL(ell_spmv_kernel<3>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega); break;
+        case 0: hipLaunchKernelGGL(ell_spmv_kernel<0>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 1: hipLaunchKernelGGL(ell_spmv_kernel<1>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 2: hipLaunchKernelGGL(ell_spmv_kernel<2>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 3: hipLaunchKernelGGL(ell_spmv_kernel<3>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        default: hipLaunchKernelGGL(ell_spmv_kernel<4>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
     }
 }
 
@@ -143,13 +163,17 @@ void Amg::vcycle(Ctx &c, int l) {
     }
     const int np = L.A.n_rows_p;
     double *x = L.x2, *y = L.x;  // x: current iterate, y: the other buffer
-    hipLaunchKernelGGL(jacobi_first_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, np,
-                       L.A.dinv, L.b, x, omega);
-    for (int s = 1; s < nu; ++s) {
-        ell_launch(c, L.A, 2, x, L.b, y, omega);
-        std::swap(x, y);
+    if (nu == 1) {
+        ell_launch(c, L.A, 4, nullptr, L.b, L.r, omega, x);    // x = w Dinv b;  r = b - A x
+    } else {
+        hipLaunchKernelGGL(jacobi_first_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, np,
+                           L.A.dinv, L.b, x, omega);
+        for (int s = 1; s < nu; ++s) {
+            ell_launch(c, L.A, 2, x, L.b, y, omega);
+            std::swap(x, y);
+        }
+        ell_launch(c, L.A, 1, x, L.b, L.r, 0.0);               // r = b - A x
     }
-    ell_launch(c, L.A, 1, x, L.b, L.r, 0.0);                   // r = b - A x
     ell_launch(c, L.R, 0, L.r, nullptr, levels[l + 1].b, 0.0);  // b_c = R r
     vcycle(c, l + 1);
     ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c

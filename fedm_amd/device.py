@@ -345,7 +345,7 @@ class DeviceProblem:
             indices.ctypes.data_as(C.POINTER(C.c_int32)), _dp(values)), "fedm_block_csr")
         return sp.csr_matrix((values, indices, indptr), shape=(self.nv, self.nv))
 
-    def setup_multigrid(self, theta=0.08, nu=2, omega=0.67, max_coarse=2000):
+    def setup_multigrid(self, theta=0.08, nu=2, omega=0.67, max_coarse=2000, max_sparse_levels=None):
         """Build (host, once) and install the multigrid hierarchy of the constant potential
         block; afterwards Newton uses GMRES + field split (block Jacobi on the species,
         one V-cycle on the potential) and poisson_solve uses V-cycle-preconditioned CG."""
@@ -360,7 +360,7 @@ class DeviceProblem:
         fixed[d] = True            # device numbering, like K itself
         fixed[self.n_owned:] = True  # ghost rows are identity rows of the local block
         levels = amg.build_hierarchy(K, theta=theta, max_coarse=max_coarse, fixed=fixed,
-                                     coords=self._coords_dev)
+                                     coords=self._coords_dev, max_sparse_levels=max_sparse_levels)
         self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
         return self.multigrid_levels
 
