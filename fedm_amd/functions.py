@@ -73,26 +73,265 @@ def Function_definition(function_space, function_type, eq_number=1):
 
 
 # ---------------------------------------------------------------------------
+# fedm/functions.py:219-528 -- weak-form builders.  They return descriptors that
+# Problem() compiles into the device model (fedm_amd.device.Model).
+# ---------------------------------------------------------------------------
+class FluxDesc:
+    def __init__(self, sign, u, D, mu, E, grad_diffusion, logarithm_representation):
+        self.sign, self.u, self.D, self.mu, self.E = sign, u, D, mu, E
+        self.grad_diffusion, self.log = grad_diffusion, logarithm_representation
+
+
+class FormPiece:
+    def __add__(self, other):
+        return FormSum([self]) + other
+
+    def __radd__(self, other):
+        return FormSum([self]).__radd__(other)
+
+
+class FormSum:
+    """F = 0.0; F += piece ... (fedm-streamer.py:252-271)"""
+
+    def __init__(self, pieces=()):
+        self.pieces = list(pieces)
+
+    def __add__(self, other):
+        if isinstance(other, FormSum):
+            return FormSum(self.pieces + other.pieces)
+        if isinstance(other, FormPiece):
+            return FormSum(self.pieces + [other])
+        if isinstance(other, (int, float)) and other == 0:
+            return self
+        return NotImplemented
+
+    __radd__ = __add__
+
+
+class BalanceEq(FormPiece):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class PoissonEq(FormPiece):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class BoundaryTerm(FormPiece):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def Flux(sign, u, D, mu, E, grad_diffusion=True, logarithm_representation=True):
+    """Drift-diffusion flux, fedm/functions.py:219-237: -grad(D exp(u)) [or -D grad(exp(u))]
+    + sign * mu * E * exp(u).  With P1 elements and coefficients that depend on |E| only,
+    D is constant per cell and both diffusion forms coincide."""
+    return FluxDesc(sign, u, D, mu, E, grad_diffusion, logarithm_representation)
+
+
+def weak_form_balance_equation(equation_type, dt, dt_old, dx, u, u_old, u_old1, v, f, Gamma,
+                               r=0.5 / np.pi, D=None, log_representation=False):
+    """Weak form of a particle balance equation, fedm/functions.py:240-368 (same positional
+    arguments, same ValueErrors)."""
+    equation_types = ["reaction", "diffusion-reaction", "drift-diffusion-reaction"]
+    if equation_type not in equation_types:
+        err_msg = dedent(
+            f"""\
+            fedm.weak_form_balance_equation_log_representation: The equation type
+            {equation_type}' is not recognised. Must be one of
+            {comma_separated(equation_types)}.
+            """
+        )
+        raise ValueError(err_msg.rstrip().replace("\n", " "))
+    if equation_type == "diffusion-reaction" and D is None:
+        raise ValueError(
+            "fedm.weak_form_balance_equation_log_representation: When 'equation_type' "
+            "is diffusion-reaction, must also supply the diffusion coefficient 'D'."
+        )
+    if not log_representation:
+        raise NotImplementedError(
+            "the device path implements the logarithmic representation "
+            "(weak_form_balance_equation_log_representation), the one every FEDM example uses")
+    return BalanceEq(equation_type=equation_type, dt=dt, dt_old=dt_old, dx=dx, u=u, u_old=u_old,
+                     u_old1=u_old1, v=v, f=f, Gamma=Gamma, r=r, D=D)
+
+
+def weak_form_balance_equation_log_representation(*args, **kwargs):
+    return weak_form_balance_equation(*args, **kwargs, log_representation=True)
+
+
+def weak_form_Poisson_equation(dx, u, v, f, r=0.5 / np.pi):
+    """2*pi*r*(inner(grad(u), grad(v)) - f*v)*dx, fedm/functions.py:379-401."""
+    return PoissonEq(dx=dx, u=u, v=v, f=f, r=r)
+
+
+def Boundary_flux(bc_type, equation_type, particle_type, sign, mu, E, normal, u, gamma, v,
+                  ds_temp, r=0.5 / np.pi, vth=0.0, ref=1.0, Ion_flux=0.0):
+    """Boundary terms, fedm/functions.py:404-528: same checks, warning and return
+    convention (a form piece, or 0.0 when the condition contributes nothing)."""
+    bc_types = ["zero flux", "flux source", "Neumann"]
+    equation_types = ["reaction", "diffusion-reaction", "drift-diffusion-reaction"]
+    particle_types = ["Heavy", "electrons"]
+    if "_" in bc_type:
+        warnings.warn("fedm.BoundaryFlux: bc_type should have spaces, not underscores")
+        bc_type = bc_type.replace("_", " ")
+    if bc_type not in bc_types:
+        err_msg = dedent(
+            f"""\
+            fedm.Boundary_flux: boundary condition type '{bc_type}' not recognised.
+            Must be one of {comma_separated(bc_types)}.
+            """
+        )
+        raise ValueError(err_msg.rstrip().replace("\n", " "))
+    if bc_type != "zero flux" and equation_type not in equation_types:
+        err_msg = dedent(
+            f"""\
+            fedm.Boundary_flux: equation type '{equation_type}' not recognised.
+            Must be one of {comma_separated(equation_types)}.
+            """
+        )
+        raise ValueError(err_msg.rstrip().replace("\n", " "))
+    if (bc_type == "flux source" and equation_type == "diffusion-reaction"
+            and particle_type not in particle_types):
+        err_msg = dedent(
+            f"""\
+            fedm.Boundary_flux: particle type '{particle_type}' not recognised.
+            Must be one of {comma_separated(particle_types)}.
+            """
+        )
+        raise ValueError(err_msg.rstrip())
+    if bc_type == "flux source" and equation_type != "reaction":
+        raise NotImplementedError(
+            "'flux source' boundaries (glow-discharge model) are not on the device path yet")
+    if bc_type == "Neumann" and equation_type == "drift-diffusion-reaction":
+        return BoundaryTerm(kind="Neumann", u=u, sign=sign, mu=mu, tag=ds_temp.tag,
+                            ds=ds_temp, r=r)
+    return 0.0
+
+
+def _axisymmetric(r):
+    """r = Expression('x[0]') (cylindrical) vs the default 0.5/pi (fedm/functions.py:251)."""
+    if isinstance(r, (int, float)):
+        if abs(r - 0.5 / np.pi) > 1e-15:
+            raise NotImplementedError("constant r other than the default 0.5/pi")
+        return False
+    return True
+
+
+def compile_forms(F, quadrature_degree=None):
+    """FormSum -> (device Model, mesh, facet tags).  The compiler of this façade: what
+    FFC does for the reference, restricted to the model family of the device kernels."""
+    from . import forms
+    from .device import Model, Reaction
+    from .physical_constants import elementary_charge as q_e, epsilon_0 as eps0
+    from .termsum import TermSum
+    pieces = F.pieces if isinstance(F, FormSum) else [F]
+    balances = sorted([p for p in pieces if isinstance(p, BalanceEq)], key=lambda p: p.u.index)
+    poissons = [p for p in pieces if isinstance(p, PoissonEq)]
+    bterms = [p for p in pieces if isinstance(p, BoundaryTerm)]
+    if not balances:
+        raise ValueError("no balance equation in the form")
+    if len(poissons) > 1:
+        raise ValueError("more than one Poisson equation in the form")
+    ns = len(balances)
+    if [p.u.index for p in balances] != list(range(ns)):
+        raise ValueError("balance equations must use the leading components of the mixed space")
+    space = balances[0].u.space
+    mesh = space.mesh
+    axis = _axisymmetric(balances[0].r)
+    eq_type = [p.equation_type for p in balances]
+    zero = TermSum.const(0.0)
+    mu, D, Z = [zero] * ns, [zero] * ns, [0.0] * ns
+    reactions = []
+    for s, p in enumerate(balances):
+        if p.equation_type == "drift-diffusion-reaction":
+            g = p.Gamma
+            if not isinstance(g, FluxDesc):
+                raise ValueError("drift-diffusion-reaction needs Gamma = Flux(...)")
+            mu[s], D[s], Z[s] = TermSum.coerce(g.mu), TermSum.coerce(g.D), float(g.sign)
+        elif p.equation_type == "diffusion-reaction":
+            D[s] = TermSum.coerce(p.D)
+        for term in forms.RateSum.coerce(p.f).terms:
+            power = [int(term.powers.get(i, 0)) for i in range(ns)]
+            if any(i >= ns for i in term.powers):
+                raise ValueError("source terms may only contain exp(u) of the species")
+            for rc in reactions:                       # same rate on several species rows
+                if rc.k.terms == term.coef.terms and list(rc.power) == power and rc.net[s] == 0:
+                    rc.net[s] = 1
+                    break
+            else:
+                net = [0] * ns
+                net[s] = 1
+                reactions.append(Reaction(term.coef, power, net))
+    if poissons:
+        ps = poissons[0]
+        if ps.u.index != ns:
+            raise ValueError("the potential must be the last component of the mixed space")
+        for term in forms.RateSum.coerce(ps.f).terms:
+            if len(term.powers) != 1 or list(term.powers.values()) != [1] or not term.coef.is_const():
+                raise ValueError("the Poisson source must be sum_i Z_i e/eps0 exp(u_i)")
+            i = next(iter(term.powers))
+            zi = term.coef.const_value() * eps0 / q_e
+            if abs(zi - round(zi)) < 1e-12:
+                zi = float(round(zi))            # charge numbers
+            if Z[i] not in (0.0,) and abs(Z[i] - zi) > 1e-9 * max(1.0, abs(zi)):
+                raise ValueError("charge in the Poisson source differs from the flux sign")
+            Z[i] = zi
+    n_tags = max([b.tag for b in bterms], default=0)
+    tags_mf = next((b.ds.subdomain_data for b in bterms if b.ds.subdomain_data is not None), None)
+    if tags_mf is not None:
+        n_tags = max(n_tags, int(np.max(tags_mf)))
+    bc_kind = [["zero flux"] * ns for _ in range(n_tags)]
+    for b in bterms:
+        bc_kind[b.tag - 1][b.u.index] = b.kind
+    qd = quadrature_degree
+    if qd is None:
+        qd = forms.parameters["form_compiler"]["quadrature_degree"]
+    if qd is None or qd < 0:
+        raise NotImplementedError(
+            "set parameters['form_compiler']['quadrature_degree'] (UFL's automatic degree "
+            "estimation is reproduced only for the time-of-flight case, see DESIGN.md)")
+    model = Model(n_species=ns, poisson=bool(poissons), eq_type=eq_type, Z=Z, mu=mu, D=D,
+                  reactions=reactions, bc_kind=bc_kind, quadrature_degree=int(qd),
+                  axisymmetric=axis)
+    return model, mesh, tags_mf
+
+
+# ---------------------------------------------------------------------------
 # fedm/functions.py:174-202 -- the drop-in seam
 # ---------------------------------------------------------------------------
 class Problem:
     """Nonlinear problem: ``Problem(J, F, bcs)`` as in the reference.
 
-    ``F``/``J`` here *are* the device kernels: ``F(b, x)`` assembles the residual
-    and applies the Dirichlet rows (functions.py:188-194), ``J(A, x)`` assembles the
-    Jacobian and applies them (functions.py:196-202).  ``b``/``A`` may be None to
-    keep the result on the device (what ``nonlinear_solver.solve`` does)."""
+    ``F`` is the sum of weak-form pieces built with the functions above (or anything already
+    bound to a device problem); ``J`` is accepted for signature compatibility -- the exact
+    Jacobian is part of the device kernels.  ``F(b, x)`` assembles the residual and applies
+    the Dirichlet rows (functions.py:188-194), ``J(A, x)`` the Jacobian (functions.py:196-202);
+    ``b``/``A`` may be None to keep the result on the device (what ``solve`` does)."""
 
-    def __init__(self, J, F, bcs, device_problem=None):
+    def __init__(self, J, F, bcs, device_problem=None, device=0):
         self.bilinear_form = J
         self.linear_form = F
         self.bcs = bcs
+        if device_problem is None and isinstance(F, (FormSum, FormPiece)):
+            from .device import DeviceProblem
+            model, mesh, tags = compile_forms(F)
+            dofs = [np.zeros(0, dtype=np.int64)]
+            vals = [np.zeros(0)]
+            for bc in bcs or []:
+                d, v = bc.rows(mesh, model.n_eq)
+                dofs.append(d)
+                vals.append(v)
+            device_problem = DeviceProblem(mesh.coords, mesh.cells, model, facet_tags=tags,
+                                           dirichlet_dofs=np.concatenate(dofs),
+                                           dirichlet_vals=np.concatenate(vals), device=device)
         self.device = device_problem if device_problem is not None else getattr(F, "device", None)
         if self.device is None:
             raise ValueError("fedm.Problem: the form is not bound to a device problem")
 
     def F(self, b=None, x=None):
-        if x is not None:
+        if x is not None and not hasattr(x, "device"):
             self.device.set_state(u_new=x)
         Fv, _ = self.device.residual()
         if b is not None:
@@ -100,10 +339,10 @@ class Problem:
         return Fv
 
     def J(self, A=None, x=None):
-        if x is not None:
+        if x is not None and not hasattr(x, "device"):
             self.device.set_state(u_new=x)
         self.device.jacobian()
-        return self.device.jacobian_csr() if A is not None else None
+        return self.device.jacobian_csr()
 
 
 class PETScSNESSolver:

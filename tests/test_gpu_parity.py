@@ -171,3 +171,22 @@ def test_streamer_multigrid_fieldsplit(streamer_setup):
     prob.set_state(U0, U0, U0)
     prob.newton_solve(rtol=1e-8, max_it=20, ksp_rtol=1e-10)
     assert lin_amg < prob.last_report.linear_iterations
+
+
+def test_example_script_in_fedm_shape(tmp_path):
+    """examples/streamer_discharge.py (the call sequence of fedm-streamer.py through the
+    fedm.functions façade) gives the same error log as the case module on the same mesh."""
+    import importlib.util
+    from pathlib import Path
+    from fedm_amd.cases import streamer
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("ex_streamer", root / "examples" / "streamer_discharge.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    state, log = mod.main(n=24, T_final=2e-11, output_dir=tmp_path, quiet=True)
+    rows = np.loadtxt(log).reshape(-1, 3)
+    msh = streamer.mesh(24, 4.0)
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    ref = streamer.run(prob, T_final=2e-11)
+    assert rows.shape == (4, 3) and np.allclose(rows, np.array(ref["log"]), rtol=1e-6)
+    assert np.allclose(state, prob.get_state(), rtol=1e-8, atol=1e-8)

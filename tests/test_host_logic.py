@@ -212,3 +212,77 @@ def test_product_and_oracle_quadrature_tables_agree():
         a, b = pq.triangle(d), oq.triangle_rule(d)
         assert np.allclose(a[0], b[0]) and np.allclose(a[1], b[1]) and a[1].sum() == pytest.approx(0.5)
     assert np.allclose(pq.interval(2)[0], oq.interval_rule(2)[0])
+
+
+# ---- weak-form façade -----------------------------------------------------------------------------
+def _streamer_forms(mesh):
+    from fedm_amd import forms, functions as ff
+    from fedm_amd.forms import (Expression, FiniteElement, Function, FunctionSpace, Measure,
+                                MixedElement, TestFunctions, TrialFunction, dx, exp, grad, inner, sqrt)
+    from fedm_amd.cases import streamer
+    from fedm_amd.physical_constants import elementary_charge, epsilon_0
+    from fedm_amd.termsum import parse
+    forms.parameters["form_compiler"]["quadrature_degree"] = 2
+    ME = FunctionSpace(mesh, MixedElement([FiniteElement()] * 3))
+    u, v = TrialFunction(ME), TestFunctions(ME)
+    E = -grad(u[2])
+    E_m = sqrt(inner(-grad(u[2]), -grad(u[2])))
+    mu1, D1 = parse(streamer.MU_E), parse(streamer.D_E)
+    alpha = (1.1944e6 + 4.3666e26 * E_m ** (-3)) * exp(-2.73e7 / E_m) - 340.75
+    f = [alpha * mu1 * E_m * exp(u[1]), alpha * mu1 * E_m * exp(u[1]),
+         Function(FunctionSpace(mesh, FiniteElement()))]
+    sign = [1.0, -1.0]
+    for i in range(2):
+        f[2] += sign[i] * exp(u[i]) * elementary_charge / epsilon_0
+    dt = Expression("time_step", time_step=5e-12)
+    r = Expression("x[0]", degree=1)
+    eqt = ["reaction", "drift-diffusion-reaction"]
+    F = 0.0
+    F += ff.weak_form_balance_equation_log_representation(eqt[0], dt, dt, dx, u[0], None, None, v[0], f[0], 0.0, r, 0.0)
+    F += ff.weak_form_balance_equation_log_representation(
+        eqt[1], dt, dt, dx, u[1], None, None, v[1], f[1],
+        ff.Flux(sign[1], u[1], D1, mu1, E, grad_diffusion=False), r, D1)
+    F += ff.weak_form_Poisson_equation(dx, u[2], v[2], f[2], r)
+    dsm = Measure("ds", domain=mesh, subdomain_data=ff.Marking_boundaries(mesh, streamer.BOUNDARIES))
+    for i in range(4):
+        for j in range(2):
+            F += ff.Boundary_flux(streamer.BC_TYPE[i][j], eqt[j], "x", sign[j], None, E, None, u[j],
+                                  0.0, v[j], dsm(i + 1), r)
+    return F
+
+
+def test_weak_forms_compile_to_the_streamer_model():
+    """The calls of fedm-streamer.py:235-271 produce the same device model as the case module."""
+    from fedm_amd import functions as ff
+    from fedm_amd.cases import streamer
+    from fedm_amd.mesh import RectangleMesh
+    mesh = RectangleMesh((0, 0), (0.0125, 0.0125), 4, 4)
+    m, mesh2, tags = ff.compile_forms(_streamer_forms(mesh))
+    ref = streamer.model()
+    assert mesh2 is mesh and tags.shape == (mesh.num_cells(), 3)
+    assert (m.n_species, m.poisson, list(m.eq_type), list(m.Z)) == (2, True, list(ref.eq_type), [1.0, -1.0])
+    assert m.bc_kind == ref.bc_kind and m.quadrature_degree == 2 and m.axisymmetric
+    assert len(m.reactions) == 1 and list(m.reactions[0].net) == [1, 1] and list(m.reactions[0].power) == [0, 1]
+    for E in (1e5, 2e6, 3e7):
+        assert m.reactions[0].k(E) == pytest.approx(ref.reactions[0].k(E), rel=1e-14)
+        assert m.mu[1](E) == pytest.approx(ref.mu[1](E), rel=1e-15)
+        assert m.D[1](E) == pytest.approx(ref.D[1](E), rel=1e-15)
+    a, b = m.to_c(), ref.to_c()
+    assert bytes(a)[:64] == bytes(b)[:64] and a.n_qp == b.n_qp == 3
+
+
+def test_weak_form_argument_checks():
+    """Same ValueErrors / warning as fedm/functions.py:333-348, 477-512."""
+    from fedm_amd import functions as ff
+    with pytest.raises(ValueError, match="is not recognised"):
+        ff.weak_form_balance_equation_log_representation("advection", 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    with pytest.raises(ValueError, match="must also supply the diffusion coefficient"):
+        ff.weak_form_balance_equation_log_representation("diffusion-reaction", 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    with pytest.raises(ValueError, match="boundary condition type 'wall' not recognised"):
+        ff.Boundary_flux("wall", "reaction", "Heavy", 1, 0, 0, 0, 0, 0, 0, None)
+    with pytest.raises(ValueError, match="equation type 'advection' not recognised"):
+        ff.Boundary_flux("Neumann", "advection", "Heavy", 1, 0, 0, 0, 0, 0, 0, None)
+    with pytest.warns(UserWarning, match="should have spaces"):
+        assert ff.Boundary_flux("zero_flux", "reaction", "Heavy", 1, 0, 0, 0, 0, 0, 0, None) == 0.0
+    assert ff.Boundary_flux("Neumann", "reaction", "Heavy", 1, 0, 0, 0, 0, 0, 0, None) == 0.0
+    assert ff.Max(3.0, 5.0) == 5.0 and ff.Min(3.0, 5.0) == 3.0
