@@ -19,8 +19,10 @@ __device__ __forceinline__ int sym6(int a, int b) {
     return a == b ? a : (a + b + 2);
 }
 
-__device__ __forceinline__ void termsum_eval(const fedm_termsum &ts, double E, double lnE,
-                                             double &val, double &der) {
+// value and d/dE of  sum_i c_i E^p_i exp(q_i E^r_i).  E^r needs no transcendental for the
+// integer r the decks use (exp(-2.73e7/E_m): r = -1); divisions are multiplications by 1/E.
+__device__ __forceinline__ void termsum_eval(const fedm_termsum &ts, double E, double invE,
+                                             double lnE, double &val, double &der) {
     val = 0.0;
     der = 0.0;
     for (int i = 0; i < ts.n_terms; ++i) {
@@ -30,10 +32,17 @@ __device__ __forceinline__ void termsum_eval(const fedm_termsum &ts, double E, d
             val += c;
             continue;
         }
-        const double g = (q != 0.0) ? q * exp(r * lnE) : 0.0;
+        double g = 0.0;
+        if (q != 0.0) {
+            if (r == -1.0) g = q * invE;
+            else if (r == 1.0) g = q * E;
+            else if (r == -2.0) g = q * invE * invE;
+            else if (r == 2.0) g = q * E * E;
+            else g = q * exp(r * lnE);
+        }
         const double t = c * exp(p * lnE + g);
         val += t;
-        der += t * (p + r * g) / E;
+        der += t * (p + r * g) * invE;
     }
 }
 
@@ -42,7 +51,7 @@ __device__ __forceinline__ void termsum_eval(const fedm_termsum &ts, double E, d
 // The history part is linear in the nodal values, so it is folded per node into
 //   hist = c_old * u_old + c_old1 * u_old1        and       u_part = c_new * u + hist.
 struct StepCoef {
-    double dt, c_new, c_old, c_old1;
+    double dt, inv_dt, c_new, c_old, c_old1;
 };
 
 __host__ __device__ inline StepCoef step_coef(double dt, double dt_old) {
@@ -50,6 +59,7 @@ __host__ __device__ inline StepCoef step_coef(double dt, double dt_old) {
     const double tr = dt / dt_old;
     const double trp1 = 1.0 + tr;
     s.dt = dt;
+    s.inv_dt = 1.0 / dt;
     s.c_new = (1.0 + 2.0 * tr) / trp1;
     s.c_old = -(trp1 * trp1) / trp1;
     s.c_old1 = (tr * tr) / trp1;
@@ -65,13 +75,14 @@ struct CellGeom {
         const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
         const double d2x = x[2][0] - x[0][0], d2y = x[2][1] - x[0][1];
         const double det = d1x * d2y - d1y * d2x;
+        const double idet = 1.0 / det;
         detJ = fabs(det);
-        G[0][0] = (x[1][1] - x[2][1]) / det;
-        G[0][1] = (x[2][0] - x[1][0]) / det;
-        G[1][0] = (x[2][1] - x[0][1]) / det;
-        G[1][1] = (x[0][0] - x[2][0]) / det;
-        G[2][0] = (x[0][1] - x[1][1]) / det;
-        G[2][1] = (x[1][0] - x[0][0]) / det;
+        G[0][0] = (x[1][1] - x[2][1]) * idet;
+        G[0][1] = (x[2][0] - x[1][0]) * idet;
+        G[1][0] = (x[2][1] - x[0][1]) * idet;
+        G[1][1] = (x[0][0] - x[2][0]) * idet;
+        G[2][0] = (x[0][1] - x[1][1]) * idet;
+        G[2][1] = (x[1][0] - x[0][0]) * idet;
 #pragma unroll
         for (int a = 0; a < 3; ++a) rn[a] = axisymmetric ? x[a][0] : 0.5 / 3.14159265358979323846;
     }
@@ -135,11 +146,12 @@ struct Element {
             }
         }
         const double lnE = log(Em);
+        const double invEm_ = full && PO ? invEm : 1.0;
         nreac = full ? md->n_reactions : 0;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             kv[j] = kd[j] = 0.0;
-            if (j < nreac) termsum_eval(md->k[j], Em, lnE, kv[j], kd[j]);
+            if (j < nreac) termsum_eval(md->k[j], Em, invEm_, lnE, kv[j], kd[j]);
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -154,7 +166,7 @@ struct Element {
             fdrift[s] = false;
             vel[s][0] = vel[s][1] = 0.0;
             if (flux[s]) {
-                termsum_eval(md->D[s], Em, lnE, Dv[s], Dd[s]);
+                termsum_eval(md->D[s], Em, invEm_, lnE, Dv[s], Dd[s]);
                 vel[s][0] = -Dv[s] * gradu[s][0];
                 vel[s][1] = -Dv[s] * gradu[s][1];
                 if (md->eq_type[s] == FEDM_EQ_DRIFT_DIFFUSION_REACTION) {
@@ -162,7 +174,7 @@ struct Element {
                         vel[s][0] += md->drift_w[s][0];
                         vel[s][1] += md->drift_w[s][1];
                     } else if (PO) {
-                        termsum_eval(md->mu[s], Em, lnE, muv[s], mud[s]);
+                        termsum_eval(md->mu[s], Em, invEm_, lnE, muv[s], mud[s]);
                         vel[s][0] += md->Z[s] * muv[s] * E[0];
                         vel[s][1] += md->Z[s] * muv[s] * E[1];
                         fdrift[s] = true;
@@ -244,8 +256,8 @@ struct Element {
             }
         } else if (full) {
             const int s = row < NS ? row : 0;
-            h = n[s] * u_part / sc.dt;
-            g[s] = n[s] * (u_part / sc.dt + sc.c_new / sc.dt);
+            h = n[s] * u_part * sc.inv_dt;
+            g[s] = n[s] * (u_part + sc.c_new) * sc.inv_dt;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 if (j >= nreac) break;
@@ -372,7 +384,7 @@ __device__ void boundary_facet(const fedm_model_desc *__restrict__ md, const dou
             md->bc_kind[tag - 1][s] != FEDM_BC_NEUMANN)
             continue;
         double muv, mud;
-        termsum_eval(md->mu[s], Em, lnE, muv, mud);
+        termsum_eval(md->mu[s], Em, 1.0 / Em, lnE, muv, mud);
         double EM1[3] = {0.0, 0.0, 0.0}, EM2[3][3] = {{0.0}};
         for (int t = 0; t < md->n_fqp; ++t) {
             double phi[3] = {0.0, 0.0, 0.0};
