@@ -101,10 +101,11 @@ static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
 // with fully coalesced stores: every matrix value is written exactly once -- no
 // read-modify-write in HBM and no zero-fill pass.
 // =============================================================================================
-constexpr int PATCH_THREADS = 320;
 
-template <int NS, bool PO, int NR, bool CACHE>
-__global__ __launch_bounds__(PATCH_THREADS) void assemble_patch_kernel(
+// THREADS: workgroup size = the patch's cell count rounded up (192 for Z-ordered meshes: two
+// 3-wave workgroups per CU at 2 waves/SIMD keep 6 waves busy; 320 covers 1-D strips)
+template <int NS, bool PO, int NR, bool CACHE, int THREADS>
+__global__ __launch_bounds__(THREADS) void assemble_patch_kernel(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
     const int *__restrict__ halo_ptr, const int *__restrict__ halo,
@@ -203,12 +204,16 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     const StepCoef sc = step_coef(c.dt, c.dt_old);
     const int acc_doubles = c.pat.max_patch_width * NEQ * NEQ * SLICE;
-    hipLaunchKernelGGL((assemble_patch_kernel<NS, PO, NR, CACHE>), dim3(c.pat.n_slices), dim3(PATCH_THREADS),
-                       patch_lds_bytes(c), c.stream, c.d_model, c.nv, c.d_slice_boff,
-                       c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr, c.d_patch_halo,
-                       c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],
-                       c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, jacobian ? 1 : 0, mode, acc_doubles,
-                       c.pat.max_patch_verts);
+#define FEDM_PATCH_LAUNCH(T)                                                                      \
+    hipLaunchKernelGGL((assemble_patch_kernel<NS, PO, NR, CACHE, T>), dim3(c.pat.n_slices), dim3(T), \
+                       patch_lds_bytes(c), c.stream, c.d_model, c.nv, c.d_slice_boff,               \
+                       c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr, c.d_patch_halo,     \
+                       c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],          \
+                       c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, jacobian ? 1 : 0, mode, acc_doubles, \
+                       c.pat.max_patch_verts)
+    if (c.pat.max_patch_cells <= 192) FEDM_PATCH_LAUNCH(192);
+    else FEDM_PATCH_LAUNCH(320);
+#undef FEDM_PATCH_LAUNCH
 }
 
 // =============================================================================================
