@@ -45,6 +45,28 @@ def error_logs():
     (OUT / "error_logs.json").write_text(json.dumps(logs, indent=1))
 
 
+def gd_golden():
+    """Glow-discharge checkpoint goldens (XDMF/HDF5) -> per-vertex ln n, vertex order."""
+    sys.path.insert(0, str(OUT))
+    from h5read import H5
+    h5 = H5()
+    res = IT / "glow_discharge/20220707_results"
+    out = {}
+    for key in ("electrons", "Ar_plus", "Ar_star"):
+        f = res / f"{key}.h5"
+        for snap in (0, 1):
+            g = f"/{key}/{key}_{snap}"
+            vec = h5.read(f, g + "/vector")[:, 0]
+            topo = h5.read(f, g + "/mesh/topology", np.int64)
+            cd = h5.read(f, g + "/cell_dofs", np.int64)[:, 0].reshape(-1, 3)
+            dof_of_vertex = np.empty(vec.size, dtype=np.int64)
+            dof_of_vertex[topo.ravel()] = cd.ravel()
+            out[f"{key}_{snap}"] = vec[dof_of_vertex]
+        out["coords"] = h5.read(f, f"/{key}/{key}_1/mesh/geometry")
+        out["cells"] = topo.astype(np.int32)
+    np.savez_compressed(OUT / "gd_golden.npz", **out)
+
+
 def import_reference():
     stub = tempfile.mkdtemp(prefix="dolfin_stub_")
     Path(stub, "dolfin.py").write_text(textwrap.dedent("""
@@ -135,6 +157,7 @@ def controller_and_sources():
 
 if __name__ == "__main__":
     tof_golden()
+    gd_golden()
     error_logs()
     controller_and_sources()
     print("fixtures written to", OUT)
