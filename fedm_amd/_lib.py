@@ -43,6 +43,27 @@ class ModelDesc(C.Structure):
     ]
 
 
+GD_MAX_SPECIES, GD_MAX_REACTIONS = 6, 16
+
+
+class GdDesc(C.Structure):
+    _fields_ = [
+        ("n_species", C.c_int32), ("n_reactions", C.c_int32), ("n_tags", C.c_int32),
+        ("axisymmetric", C.c_int32), ("N0", C.c_double), ("charge_over_eps", C.c_double),
+        ("eq_type", C.c_int32 * GD_MAX_SPECIES), ("grad_diffusion", C.c_int32 * GD_MAX_SPECIES),
+        ("is_ion", C.c_int32 * GD_MAX_SPECIES), ("sign", C.c_double * GD_MAX_SPECIES),
+        ("vth", C.c_double * GD_MAX_SPECIES), ("vth_e_coef", C.c_double),
+        ("power", (C.c_int32 * GD_MAX_SPECIES) * GD_MAX_REACTIONS),
+        ("net", (C.c_int32 * GD_MAX_SPECIES) * GD_MAX_REACTIONS),
+        ("energy_loss", C.c_double * GD_MAX_REACTIONS),
+        ("ref", (C.c_double * GD_MAX_SPECIES) * MAX_TAGS), ("gamma", C.c_double * MAX_TAGS),
+        ("we_secondary", C.c_double),
+        ("n_qp", C.c_int32), ("n_fqp", C.c_int32),
+        ("qp_x", C.c_double * MAX_QP), ("qp_y", C.c_double * MAX_QP), ("qp_w", C.c_double * MAX_QP),
+        ("fqp_t", C.c_double * MAX_FQP), ("fqp_w", C.c_double * MAX_FQP),
+    ]
+
+
 class MeshDesc(C.Structure):
     _fields_ = [("n_vertices", C.c_int32), ("n_cells", C.c_int32),
                 ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
@@ -83,6 +104,8 @@ _SIGNATURES = {
     "fedm_last_error": (C.c_char_p, []),
     "fedm_abi_version": (C.c_int, []),
     "fedm_ctx_create": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(ModelDesc), C.c_int, C.POINTER(_P)]),
+    "fedm_ctx_create_gd": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(GdDesc), C.c_int, C.POINTER(_P)]),
+    "fedm_gd_set_fields": (C.c_int, [_P, _D]),
     "fedm_ctx_destroy": (None, [_P]),
     "fedm_set_state": (C.c_int, [_P, _D, _D, _D]),
     "fedm_get_state": (C.c_int, [_P, _D]),

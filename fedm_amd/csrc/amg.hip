@@ -351,6 +351,8 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
         case 1: fs_apply_t<1>(c, amg, t, z, alpha); break;
         case 2: fs_apply_t<2>(c, amg, t, z, alpha); break;
         case 3: fs_apply_t<3>(c, amg, t, z, alpha); break;
+        case 4: fs_apply_t<4>(c, amg, t, z, alpha); break;
+        case 5: fs_apply_t<5>(c, amg, t, z, alpha); break;
     }
 }
 
@@ -360,6 +362,8 @@ void fieldsplit_setup(Ctx &c) {
         case 1: hipLaunchKernelGGL(species_block_inverse_kernel<1>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
         case 2: hipLaunchKernelGGL(species_block_inverse_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
         case 3: hipLaunchKernelGGL(species_block_inverse_kernel<3>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 4: hipLaunchKernelGGL(species_block_inverse_kernel<4>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 5: hipLaunchKernelGGL(species_block_inverse_kernel<5>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
     }
 }
 

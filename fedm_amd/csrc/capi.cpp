@@ -269,6 +269,9 @@ extern "C" {
 const char *fedm_last_error(void) { return g_error.c_str(); }
 int fedm_abi_version(void) { return 1; }
 
+static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *model,
+                           const fedm_gd_desc *gd, int device, fedm_ctx **out);
+
 int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, int device,
                     fedm_ctx **out) {
     if (!mesh || !model || !out) {
@@ -279,6 +282,39 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
         set_error("unsupported model descriptor (species/reaction/quadrature counts)");
         return -2;
     }
+    return ctx_create_impl(mesh, model, nullptr, device, out);
+}
+
+int fedm_ctx_create_gd(const fedm_mesh_desc *mesh, const fedm_gd_desc *gd, int device,
+                       fedm_ctx **out) {
+    if (!mesh || !gd || !out) {
+        set_error("null argument");
+        return -2;
+    }
+    if (gd->n_species < 2 || gd->n_species > FEDM_GD_MAX_SPECIES - 1 || gd->n_reactions < 0 ||
+        gd->n_reactions > FEDM_GD_MAX_REACTIONS || gd->n_qp < 1 || gd->n_qp > FEDM_MAX_QP ||
+        gd->n_fqp < 0 || gd->n_fqp > FEDM_MAX_FQP || gd->n_tags < 0 || gd->n_tags > FEDM_MAX_TAGS) {
+        set_error("unsupported LMEA model descriptor");
+        return -2;
+    }
+    return ctx_create_impl(mesh, nullptr, gd, device, out);
+}
+
+int fedm_gd_set_fields(fedm_ctx *h, const double *fields) {
+    Ctx &c = h->c;
+    if (c.model_kind != 1 || !fields) {
+        set_error("not an LMEA context");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipMemcpyAsync(c.d_gd_fields, fields, sizeof(double) * (size_t)c.gd_n_fields * c.nv,
+                                  hipMemcpyHostToDevice, c.stream));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *model,
+                           const fedm_gd_desc *gd, int device, fedm_ctx **out) {
     if (mesh->n_vertices < 3 || mesh->n_cells < 1) {
         set_error("empty mesh");
         return -2;
@@ -297,9 +333,18 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
     fedm_ctx *h = new fedm_ctx();
     Ctx &c = h->c;
     c.device = device;
-    c.model = *model;
-    c.ns = model->n_species;
-    c.poisson = model->poisson != 0;
+    const int n_tags_model = model ? model->n_tags : gd->n_tags;
+    if (model) {
+        c.model = *model;
+        c.ns = model->n_species;
+        c.poisson = model->poisson != 0;
+    } else {  // LMEA: energy + (n_species - 1) particle equations + potential
+        c.model_kind = 1;
+        c.gd = *gd;
+        c.ns = gd->n_species;
+        c.poisson = true;
+        c.assembly_kind = 0;
+    }
     c.neq = c.ns + (c.poisson ? 1 : 0);
     c.nv = mesh->n_vertices;
     c.nc = mesh->n_cells;
@@ -325,7 +370,7 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
         tags = zero_tags.data();
     }
     for (size_t i = 0; i < (size_t)3 * c.nc; ++i)
-        if (tags[i] < 0 || tags[i] > model->n_tags) {
+        if (tags[i] < 0 || tags[i] > n_tags_model) {
             set_error("facet tag out of range");
             return -2;
         }
@@ -367,7 +412,13 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
     }
     if (upload(c.d_cell_slots, c.pat.cell_slots.data(), c.pat.cell_slots.size())) return -1;
     if (upload(c.d_colour_cells, c.pat.colour_cells.data(), c.pat.colour_cells.size())) return -1;
-    if (upload(c.d_model, model, 1)) return -1;
+    if (model) {
+        if (upload(c.d_model, model, 1)) return -1;
+    } else {
+        if (upload(c.d_gd, gd, 1)) return -1;
+        c.gd_n_fields = FEDM_GD_N_FIELDS(gd->n_species, gd->n_reactions);
+        if (alloc_zero(c.d_gd_fields, (size_t)c.gd_n_fields * c.nv, c.stream)) return -1;
+    }
     if (upload(c.d_patch_cell_ptr, c.pat.patch_cell_ptr.data(), c.pat.patch_cell_ptr.size())) return -1;
     if (upload(c.d_patch_halo_ptr, c.pat.patch_halo_ptr.data(), c.pat.patch_halo_ptr.size())) return -1;
     if (upload(c.d_patch_halo, c.pat.patch_halo.data(), c.pat.patch_halo.size())) return -1;
@@ -377,7 +428,7 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
         // globally coloured kernel is the (deterministic, slower) alternative.
         const char *env = getenv("FEDM_ASSEMBLY");
         c.assembly_kind = (env && std::string(env) == "colour") ? 0 : 1;
-        if (!c.pat.patch_ok || patch_lds_bytes(c) > 160 * 1024) c.assembly_kind = 0;
+        if (!c.pat.patch_ok || patch_lds_bytes(c) > 160 * 1024 || c.model_kind == 1) c.assembly_kind = 0;
     }
     if (upload(c.d_slice_boff, c.pat.slice_boff.data(), c.pat.slice_boff.size())) return -1;
     if (upload(c.d_colidx, c.pat.colidx.data(), c.pat.colidx.size())) return -1;
@@ -395,7 +446,7 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
     if (alloc_zero(c.d_red, RED_K, c.stream)) return -1;
     FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_red, sizeof(double) * RED_K));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_stage, sizeof(double) * (size_t)c.np));
-    for (int s = 0; s < c.ns; ++s)
+    for (int s = 0; model && s < c.ns; ++s)
         if (model->ext_nodes[s] > 0)
             if (alloc_zero(c.d_ext[s], (size_t)c.nc * model->ext_nodes[s], c.stream)) return -1;
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
@@ -413,7 +464,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
                     c.d_dir_vals, c.d_u, c.d_uold, c.d_uold1, c.d_F, c.d_delta, c.d_w, c.d_rhs,
                     c.d_tmp, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
                     c.d_ext[3], c.d_patch_cell_ptr, c.d_patch_halo_ptr, c.d_patch_halo,
-                    c.d_patch_cells, c.d_bfacets};
+                    c.d_patch_cells, c.d_bfacets, c.d_gd, c.d_gd_fields};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c.amg) {
@@ -824,7 +875,7 @@ int fedm_profile_read(fedm_ctx *h, int kind, double *ms_total, int64_t *count) {
 
 int fedm_set_assembly(fedm_ctx *h, int kind) {
     Ctx &c = h->c;
-    if (kind == 1 && (!c.pat.patch_ok || patch_lds_bytes(c) > 160 * 1024)) {
+    if (kind == 1 && (!c.pat.patch_ok || patch_lds_bytes(c) > 160 * 1024 || c.model_kind == 1)) {
         set_error("LDS patch assembly unavailable for this mesh");
         return -2;
     }

@@ -77,6 +77,11 @@ struct Ctx {
     bool poisson = false;
     int64_t n = 0, np = 0;  // nv*neq, nvp*neq
     fedm_model_desc model{};
+    int model_kind = 0;  // 0: LFA family (fedm_model_desc), 1: LMEA family (fedm_gd_desc)
+    fedm_gd_desc gd{};
+    fedm_gd_desc *d_gd = nullptr;
+    double *d_gd_fields = nullptr;  // [n_fields][nv] nodal coefficient fields
+    int gd_n_fields = 0;
     Pattern pat;
     double dt = 1.0, dt_old = 1e30;
     // device mesh
@@ -121,6 +126,7 @@ constexpr int RED_K = 40;
 // ---- kernel launchers (kernels.hip) -----------------------------------------------------
 // mode: 0 = full model, 1 = Poisson row only (species rows become identity)
 void launch_assemble(Ctx &c, bool jacobian, int mode);
+void launch_assemble_gd(Ctx &c, bool jacobian, int mode);
 size_t patch_lds_bytes(const Ctx &c);
 void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks

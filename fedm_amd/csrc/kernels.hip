@@ -283,6 +283,12 @@ static void assemble_dispatch(Ctx &c, bool jacobian, int mode) {
 }
 
 void launch_assemble(Ctx &c, bool jacobian, int mode) {
+    if (c.model_kind == 1) {
+        prof_begin(c, jacobian ? 0 : 2);
+        launch_assemble_gd(c, jacobian, mode);
+        prof_end(c);
+        return;
+    }
     prof_begin(c, jacobian ? 0 : 2);  // the volume kernel only (all colours in variant 0)
     if (c.ns == 1 && !c.poisson) assemble_dispatch<1, false>(c, jacobian, mode);
     else if (c.ns == 1 && c.poisson) assemble_dispatch<1, true>(c, jacobian, mode);
@@ -449,6 +455,8 @@ void launch_block_inverse(Ctx &c) {
         case 2: hipLaunchKernelGGL(block_inverse_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
         case 3: hipLaunchKernelGGL(block_inverse_kernel<3>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
         case 4: hipLaunchKernelGGL(block_inverse_kernel<4>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 5: hipLaunchKernelGGL(block_inverse_kernel<5>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
+        case 6: hipLaunchKernelGGL(block_inverse_kernel<6>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
     }
 }
 
@@ -513,6 +521,8 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv) {
         case 2: hipLaunchKernelGGL(spmv_kernel<2>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
         case 3: hipLaunchKernelGGL(spmv_kernel<3>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
         case 4: hipLaunchKernelGGL(spmv_kernel<4>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 5: hipLaunchKernelGGL(spmv_kernel<5>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 6: hipLaunchKernelGGL(spmv_kernel<6>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
     }
 }
 
@@ -544,6 +554,8 @@ void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha) {
         case 2: hipLaunchKernelGGL(apply_dinv_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
         case 3: hipLaunchKernelGGL(apply_dinv_kernel<3>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
         case 4: hipLaunchKernelGGL(apply_dinv_kernel<4>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
+        case 5: hipLaunchKernelGGL(apply_dinv_kernel<5>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
+        case 6: hipLaunchKernelGGL(apply_dinv_kernel<6>, g, b, 0, c.stream, c.nvp, c.d_dinv, x, y, alpha); break;
     }
 }
 

@@ -106,6 +106,76 @@ class Model:
 
 
 @dataclass
+class GdModel:
+    """LMEA model family (examples/glow_discharge/fedm-gd.py): energy equation + particle
+    balances with nodal, semi-implicit coefficients + Poisson.  Species 0 is the gas."""
+    n_species: int
+    N0: float
+    eq_type: Sequence[str]
+    grad_diffusion: Sequence[bool]
+    is_ion: Sequence[bool]
+    sign: Sequence[float]
+    vth: Sequence[float]
+    electron_mass: float
+    power: Sequence[Sequence[int]]
+    net: Sequence[Sequence[int]]
+    energy_loss: Sequence[float]
+    ref: Sequence[Sequence[float]]             # [tag-1][species]
+    gamma: Sequence[float]                     # [tag-1]
+    we_secondary: float
+    quadrature_degree: int = 4
+    axisymmetric: bool = True
+    poisson: bool = True
+
+    @property
+    def n_eq(self):
+        return self.n_species + 1
+
+    @property
+    def n_reactions(self):
+        return len(self.power)
+
+    @property
+    def n_fields(self):
+        return 4 * self.n_species + 2 * self.n_reactions + 3
+
+    def to_c(self):
+        md = _lib.GdDesc()
+        ns, nr = self.n_species, self.n_reactions
+        if ns > _lib.GD_MAX_SPECIES - 1 or nr > _lib.GD_MAX_REACTIONS or len(self.ref) > _lib.MAX_TAGS:
+            raise ValueError("LMEA model too large for the device descriptor")
+        md.n_species, md.n_reactions, md.n_tags = ns, nr, len(self.ref)
+        md.axisymmetric, md.N0 = int(self.axisymmetric), float(self.N0)
+        md.charge_over_eps = elementary_charge / epsilon_0
+        for i in range(ns):
+            md.eq_type[i] = _lib.EQ_TYPES[self.eq_type[i]]
+            md.grad_diffusion[i] = int(bool(self.grad_diffusion[i]))
+            md.is_ion[i] = int(bool(self.is_ion[i]))
+            md.sign[i] = float(self.sign[i])
+            md.vth[i] = float(self.vth[i])
+        md.vth_e_coef = 16.0 * elementary_charge / (3.0 * np.pi * self.electron_mass)
+        for j in range(nr):
+            md.energy_loss[j] = float(self.energy_loss[j])
+            for i in range(ns):
+                md.power[j][i] = int(self.power[j][i])
+                md.net[j][i] = int(self.net[j][i])
+        for t in range(len(self.ref)):
+            md.gamma[t] = float(self.gamma[t])
+            for i in range(ns):
+                md.ref[t][i] = float(self.ref[t][i])
+        md.we_secondary = float(self.we_secondary)
+        xq, wq = quadrature.triangle(self.quadrature_degree)
+        md.n_qp = len(wq)
+        for q in range(len(wq)):
+            md.qp_x[q], md.qp_y[q], md.qp_w[q] = xq[q, 0], xq[q, 1], wq[q]
+        tq, wt = quadrature.interval(self.quadrature_degree)
+        md.n_fqp = len(wt)
+        for q in range(len(wt)):
+            md.fqp_t[q], md.fqp_w[q] = tq[q], wt[q]
+        return md
+
+
+@dataclass
 class NewtonReport:
     iterations: int
     converged: bool
@@ -184,7 +254,8 @@ class DeviceProblem:
         mesh.dirichlet_vals = _dp(self._dvals)
         mesh.n_owned_vertices = self.n_owned
         handle = C.c_void_p()
-        rc = self.lib.fedm_ctx_create(C.byref(mesh), C.byref(md), int(device), C.byref(handle))
+        create = self.lib.fedm_ctx_create_gd if isinstance(model, GdModel) else self.lib.fedm_ctx_create
+        rc = create(C.byref(mesh), C.byref(md), int(device), C.byref(handle))
         if rc != 0:
             raise RuntimeError(f"fedm_ctx_create failed ({rc}): {_lib.last_error()}")
         self._h = handle
@@ -245,6 +316,15 @@ class DeviceProblem:
         if v.size != self._ddofs.size:
             raise ValueError("wrong number of Dirichlet values")
         self._check(self.lib.fedm_set_dirichlet_values(self._h, _dp(v)), "fedm_set_dirichlet_values")
+
+    def set_gd_fields(self, fields):
+        """Nodal coefficient fields of the LMEA family, (n_fields, n_vertices) in the order
+        of FEDM_GD_N_FIELDS (include/fedm_hip.h), caller's vertex numbering."""
+        f = np.asarray(fields, dtype=np.float64)
+        if f.shape != (self.model.n_fields, self.nv):
+            raise ValueError(f"expected fields of shape {(self.model.n_fields, self.nv)}")
+        f = np.ascontiguousarray(f[:, self._order])
+        self._check(self.lib.fedm_gd_set_fields(self._h, _dp(f)), "fedm_gd_set_fields")
 
     def set_ext_source(self, species, nodal):
         v = np.ascontiguousarray(nodal, dtype=np.float64)

@@ -360,6 +360,8 @@ class PETScSNESSolver:
     def solve(self, problem, x=None):
         p = self.parameters
         dev = problem.device
+        if getattr(problem, "before_solve", None) is not None:
+            problem.before_solve()      # e.g. time-dependent Dirichlet values (functions.py:1042-1044)
         return dev.newton_solve(rtol=p["relative_tolerance"], max_it=p["maximum_iterations"],
                                 atol=p["absolute_tolerance"], stol=p["solution_tolerance"],
                                 ksp_restart=p["krylov_restart"],

@@ -114,6 +114,43 @@ typedef struct {
     double fnorm0, fnorm;        /* |F| before / after                                     */
 } fedm_newton_report;
 
+/* ---- LMEA model family (glow discharge, examples/glow_discharge/fedm-gd.py) --------------
+ * Components: 0 = ln(electron energy density), 1..n_species-1 = ln(number density) of the
+ * species with an equation (species 0, the background gas, has none), last = potential.
+ * Transport and rate coefficients are nodal P1 fields refreshed by the caller every step
+ * (Transport_/Rate_coefficient_interpolation, fedm/functions.py:531-750) and linearised in the
+ * mean electron energy on the device (semi_implicit_coefficients, :753-774). */
+#define FEDM_GD_MAX_SPECIES 6
+#define FEDM_GD_MAX_REACTIONS 16
+typedef struct {
+    int32_t n_species;                        /* including the background gas            */
+    int32_t n_reactions;
+    int32_t n_tags;
+    int32_t axisymmetric;
+    double N0;                                /* gas number density, exp_u[0] in Source_term */
+    double charge_over_eps;
+    int32_t eq_type[FEDM_GD_MAX_SPECIES];     /* per species (index 0 unused)            */
+    int32_t grad_diffusion[FEDM_GD_MAX_SPECIES];
+    int32_t is_ion[FEDM_GD_MAX_SPECIES];      /* contributes to Ion_flux, fedm-gd.py:351 */
+    double sign[FEDM_GD_MAX_SPECIES];
+    double vth[FEDM_GD_MAX_SPECIES];          /* heavy species thermal velocity          */
+    double vth_e_coef;                        /* 16 e / (3 pi m_e): vth_e = sqrt(coef * mean energy) */
+    int32_t power[FEDM_GD_MAX_REACTIONS][FEDM_GD_MAX_SPECIES];
+    int32_t net[FEDM_GD_MAX_REACTIONS][FEDM_GD_MAX_SPECIES];
+    double energy_loss[FEDM_GD_MAX_REACTIONS];
+    double ref[FEDM_MAX_TAGS][FEDM_GD_MAX_SPECIES];   /* reflection coefficients         */
+    double gamma[FEDM_MAX_TAGS];              /* secondary emission coefficient          */
+    double we_secondary;                      /* mean energy of secondary electrons [eV] */
+    int32_t n_qp, n_fqp;
+    double qp_x[FEDM_MAX_QP], qp_y[FEDM_MAX_QP], qp_w[FEDM_MAX_QP];
+    double fqp_t[FEDM_MAX_FQP], fqp_w[FEDM_MAX_FQP];
+} fedm_gd_desc;
+
+/* nodal fields of fedm_gd_set_fields, in this order, each [n_vertices]:
+ *   mu[n_species], D[n_species], mu_diff[n_species], D_diff[n_species],
+ *   k[n_reactions], k_diff[n_reactions], mean_energy_old, mean_energy, u_e_old           */
+#define FEDM_GD_N_FIELDS(ns, nr) (4 * (ns) + 2 * (nr) + 3)
+
 typedef struct fedm_ctx fedm_ctx;
 
 const char *fedm_last_error(void);
@@ -123,6 +160,9 @@ int fedm_abi_version(void);
  * Replaces FunctionSpace/derivative/Problem set-up, fedm-streamer.py:133-291. */
 int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, int device,
                     fedm_ctx **out);
+int fedm_ctx_create_gd(const fedm_mesh_desc *mesh, const fedm_gd_desc *model, int device,
+                       fedm_ctx **out);
+int fedm_gd_set_fields(fedm_ctx *ctx, const double *fields /* [n_fields][n_vertices] */);
 void fedm_ctx_destroy(fedm_ctx *ctx);
 
 /* u_new / u_old / u_old1 (N doubles each, any may be NULL to leave unchanged).

@@ -1,0 +1,78 @@
+"""Glow discharge (LMEA, 5 equations) on the device against the oracle and the reference's
+own goldens (tests/integrated_tests/glow_discharge/test_glow_discharge.py:48-62)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+DECK = ROOT / "decks" / "glow_discharge" / "file_input" / "4_particles"
+
+
+def test_gd_residual_and_jacobian_match_the_oracle():
+    from oracle import gd as ogd
+    from fedm_amd.cases import glow_discharge as gdc
+    case = gdc.Case(nx=10, ny=10)
+    o = ogd.GlowDischarge(DECK, 10, 10)
+    nv = o.mesh.nv
+    assert np.array_equal(o.mesh.cells, case.mesh.cells)
+    rng = np.random.default_rng(0)
+    me_old = 3.0 + rng.normal(0, 0.3, nv)
+    me = me_old + rng.normal(0, 0.05, nv)
+    U = case.U.copy()
+    U[:, 0] = np.log(me) + U[:, 3] + rng.normal(0, 0.05, nv)
+    U[:, 1:4] += rng.normal(0, 0.2, (nv, 3))
+    U[:, 4] = -100.0 * (1 - o.mesh.coords[:, 1] / 0.01) + rng.normal(0, 3.0, nv)
+    Uo = U + rng.normal(0, 0.02, U.shape)
+    Uo1 = U + rng.normal(0, 0.02, U.shape)
+    redE = o.reduced_field(U[:, 4])
+    assert np.allclose(case.project_reduced_field(U[:, 4]), redE, rtol=1e-12)
+    co = o.coefficients(me_old, redE)
+    t, dt, dt_old = 2e-12, 1.1e-12, 0.7e-12
+    dv = o.dirichlet_values(t)
+    F_cpu, J_cpu = o.residual_jacobian(U, Uo, Uo1, dt, dt_old, co, me_old, me, Uo[:, 3], dv)
+    # same nodal fields through the product pipeline
+    case.mean_energy_old.vector()[:] = me_old
+    case.mean_energy.vector()[:] = me
+    case.redE.vector()[:] = redE
+    from fedm_amd import functions as ff
+    ff.Transport_coefficient_interpolation("update", case.mu_dep, case.N0, case.Tgas, case.mu, case.mu_x,
+                                           case.mu_y, case.mean_energy_old, case.redE)
+    ff.Transport_coefficient_interpolation("update", case.D_dep, case.N0, case.Tgas, case.D, case.D_x,
+                                           case.D_y, case.mean_energy_old, case.redE, case.mu)
+    ff.Rate_coefficient_interpolation("update", case.k_dep, case.k, case.k_x, case.k_y,
+                                      case.mean_energy_old, case.redE, Te=0, Tgas=0)
+    for a, b in zip(case.mu + case.D + case.k, co["mu"] + co["D"] + co["k"]):
+        assert np.allclose(a.vector(), b, rtol=1e-14, atol=0)
+    case.U = Uo            # u_e_old field = old electron log density
+    case.upload_fields()
+    prob = case.prob
+    prob.set_state(U, Uo, Uo1)
+    prob.set_step(dt, dt_old)
+    prob.set_dirichlet_values(case.dirichlet_values(t))
+    F_gpu, _ = prob.residual()
+    scale = np.abs(F_cpu).reshape(-1, 5).max(axis=0)
+    assert (np.abs(F_gpu - F_cpu).reshape(-1, 5) / scale).max() < 1e-11
+    prob.jacobian()
+    J_gpu = prob.jacobian_csr()
+    D = abs(J_gpu - J_cpu)
+    rs = np.maximum(abs(J_cpu).max(axis=1).toarray().ravel(), 1e-300)
+    assert (sp.diags(1.0 / rs) @ D).max() < 1e-9
+
+
+def test_gd_golden_run(golden_dir):
+    from fedm_amd.cases import glow_discharge as gdc
+    gold = np.load(golden_dir / "gd_golden.npz")
+    ref_log = np.array(json.loads((golden_dir / "error_logs.json").read_text())["glow_discharge"])
+    out = gdc.Case().run()
+    log = np.array(out["log"])
+    assert log.shape == ref_log.shape
+    assert np.allclose(log, ref_log)                  # the reference's assertion (rtol 1e-5)
+    for key, comp in (("electrons", 3), ("Ar_plus", 2), ("Ar_star", 1)):
+        ref = gold[key + "_1"]
+        err = (out["snapshot"][:, comp] - ref) / ref
+        assert np.mean(np.abs(err)) < 1e-5 and np.sqrt(np.mean(err ** 2)) < 1e-5
+        assert np.max(np.abs(err)) < 1e-3
