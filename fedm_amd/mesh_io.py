@@ -1,0 +1,121 @@
+"""Mesh ingestion and result output in the reference's wire formats (cold path).
+
+* legacy DOLFIN XML meshes (``Mesh('mesh.xml')``, examples/streamer_discharge/fedm-streamer.py:116)
+* ASCII ``.vtu`` + ``.pvd`` as DOLFIN's ``File("x.pvd") << (function, t)`` writes them -- the
+  format the reference's tests read back (tests/integrated_tests/testing_utils.py:15-19)
+* ``file_output``: linear interpolation of the solution to the output times
+  (fedm/file_io.py:538-616)
+"""
+import xml.etree.ElementTree as ET
+from pathlib import Path
+
+import numpy as np
+
+from .mesh import Mesh
+
+
+def read_dolfin_xml(path):
+    """<dolfin><mesh celltype="triangle" dim="2"><vertices><vertex index x y/>...<cells><triangle index v0 v1 v2/>"""
+    root = ET.parse(path).getroot()
+    mesh = root.find("mesh") if root.tag != "mesh" else root
+    if mesh is None or mesh.get("celltype") != "triangle":
+        raise ValueError(f"{path}: not a DOLFIN XML triangle mesh")
+    verts = mesh.find("vertices")
+    cells = mesh.find("cells")
+    nv, nc = int(verts.get("size")), int(cells.get("size"))
+    coords = np.empty((nv, 2))
+    for v in verts.iter("vertex"):
+        coords[int(v.get("index"))] = (float(v.get("x")), float(v.get("y")))
+    tri = np.empty((nc, 3), dtype=np.int32)
+    for c in cells.iter("triangle"):
+        tri[int(c.get("index"))] = (int(c.get("v0")), int(c.get("v1")), int(c.get("v2")))
+    return Mesh(coords, tri)
+
+
+def write_dolfin_xml(mesh, path):
+    lines = ['<?xml version="1.0"?>', '<dolfin xmlns:dolfin="http://fenicsproject.org">',
+             '  <mesh celltype="triangle" dim="2">', f'    <vertices size="{mesh.num_vertices()}">']
+    lines += [f'      <vertex index="{i}" x="{x!r}" y="{y!r}" />' for i, (x, y) in enumerate(mesh.coords.tolist())]
+    lines += ['    </vertices>', f'    <cells size="{mesh.num_cells()}">']
+    lines += [f'      <triangle index="{i}" v0="{a}" v1="{b}" v2="{c}" />'
+              for i, (a, b, c) in enumerate(mesh.cells.tolist())]
+    lines += ['    </cells>', '  </mesh>', '</dolfin>']
+    Path(path).write_text("\n".join(lines) + "\n")
+
+
+class PVDFile:
+    """``File("dir/name.pvd")``: each ``write(values, name, t)`` adds ``name%06d.vtu``."""
+
+    def __init__(self, path, mesh):
+        self.path, self.mesh = Path(path), mesh
+        self.path.parent.mkdir(parents=True, exist_ok=True)
+        self.entries = []
+
+    def write(self, values, field_name, t):
+        idx = len(self.entries)
+        vtu = self.path.with_name(f"{self.path.stem}{idx:06d}.vtu")
+        write_vtu(vtu, self.mesh, np.asarray(values, dtype=np.float64), field_name)
+        self.entries.append((t, vtu.name))
+        body = "".join(f'<DataSet timestep="{tt!r}" part="0" file="{name}" />\n' for tt, name in self.entries)
+        self.path.write_text('<?xml version="1.0"?>\n<VTKFile type="Collection" version="0.1">\n<Collection>\n'
+                             + body + '</Collection>\n</VTKFile>\n')
+        return vtu
+
+
+def write_vtu(path, mesh, values, field_name):
+    nv, nc = mesh.num_vertices(), mesh.num_cells()
+    fmt = lambda a: " ".join(repr(float(x)) for x in a)
+    pts = "  ".join(f"{x!r} {y!r} 0" for x, y in mesh.coords.tolist())
+    conn = "  ".join(f"{a} {b} {c}" for a, b, c in mesh.cells.tolist())
+    offs = " ".join(str(3 * (i + 1)) for i in range(nc))
+    types = " ".join(["5"] * nc)
+    Path(path).write_text(
+        '<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid"  version="0.1"  >\n<UnstructuredGrid>\n'
+        f'<Piece  NumberOfPoints="{nv}" NumberOfCells="{nc}">\n<Points>\n'
+        f'<DataArray  type="Float64"  NumberOfComponents="3"  format="ascii">{pts}  </DataArray>\n</Points>\n'
+        f'<Cells>\n<DataArray  type="UInt32"  Name="connectivity"  format="ascii">{conn}  </DataArray>\n'
+        f'<DataArray  type="UInt32"  Name="offsets"  format="ascii">{offs} </DataArray>\n'
+        f'<DataArray  type="UInt8"  Name="types"  format="ascii">{types} </DataArray>\n</Cells>\n'
+        f'<PointData  Scalars="{field_name}"> \n'
+        f'<DataArray  type="Float64"  Name="{field_name}"  format="ascii">{fmt(values)}  </DataArray> \n'
+        '</PointData> \n</Piece>\n</UnstructuredGrid>\n</VTKFile>')
+
+
+def read_vtu(path, field_name):
+    """What tests/integrated_tests/testing_utils.py:15-19 does with vtk, for ASCII files."""
+    root = ET.parse(path).getroot()
+    for arr in root.iter("DataArray"):
+        if arr.get("Name") == field_name:
+            return np.array(arr.text.split(), dtype=np.float64)
+    raise KeyError(field_name)
+
+
+def file_output(t, t_old, t_out, step, t_out_list, step_list, file_type, output_file_list,
+                particle_name, u_old, u_old1, unit="s"):
+    """Linear interpolation of the solution to the output times, fedm/file_io.py:538-616: same
+    arguments (``u_old`` / ``u_old1`` are the lists of new / old nodal arrays, sic), same
+    stepping of ``t_out`` including the reference's stale-``step`` branch."""
+    units = {"ns": 1e9, "us": 1e6, "ms": 1e3, "s": 1.0}
+    if unit not in units:
+        raise ValueError(f"fedm.file_output: unit '{unit}' not valid. "
+                         f"Options are {', '.join(repr(u) for u in units)}.'")
+    scale = units[unit]
+    if t > max(t_out_list):
+        index = len(t_out_list) - 1
+    else:
+        index = next(x for x, val in enumerate(t_out_list) if val > t)
+    while t_out <= t:
+        for i in range(len(output_file_list)):
+            new, old = np.asarray(u_old[i]), np.asarray(u_old1[i])
+            temp = old + (t_out - t_old) * (new - old) / (t - t_old)
+            if file_type[i] == "pvd":
+                output_file_list[i].write(temp, particle_name[i], t_out * scale)
+            else:
+                raise ValueError(f"fedm.file_output: file type '{file_type}' not recognised. "
+                                 "Options are 'pvd' and 'xdmf'.")
+        if t_out >= 0.999 * t_out_list[index - 1] and t_out < 0.999 * t_out_list[index]:
+            step = step_list[index - 1]
+        elif t_out >= 0.999 * t_out_list[index]:
+            step = step_list[index]
+        t_out += step
+    return t_out, step

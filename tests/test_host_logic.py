@@ -286,3 +286,35 @@ def test_weak_form_argument_checks():
         assert ff.Boundary_flux("zero_flux", "reaction", "Heavy", 1, 0, 0, 0, 0, 0, 0, None) == 0.0
     assert ff.Boundary_flux("Neumann", "reaction", "Heavy", 1, 0, 0, 0, 0, 0, 0, None) == 0.0
     assert ff.Max(3.0, 5.0) == 5.0 and ff.Min(3.0, 5.0) == 3.0
+
+
+# ---- mesh ingestion / result output ---------------------------------------------------------------
+def test_dolfin_xml_and_vtu_round_trip(tmp_path, golden_dir):
+    from fedm_amd import mesh_io
+    from fedm_amd.mesh import RectangleMesh
+    m = RectangleMesh((0.0, 0.0), (2.5e-4, 5e-4), 40, 40)
+    mesh_io.write_dolfin_xml(m, tmp_path / "mesh.xml")
+    m2 = mesh_io.read_dolfin_xml(tmp_path / "mesh.xml")
+    assert np.array_equal(m2.cells, m.cells) and np.array_equal(m2.coords, m.coords)
+    gold = np.load(golden_dir / "tof_golden.npz")
+    f = mesh_io.PVDFile(tmp_path / "number density" / "electrons" / "electrons.pvd", m)
+    vtu = f.write(gold["n_e"], "f_52", 2.6e-9)
+    assert vtu.name == "electrons000000.vtu"
+    back = mesh_io.read_vtu(vtu, "f_52")
+    assert np.array_equal(back, gold["n_e"])            # repr() round-trips doubles exactly
+    assert "electrons000000.vtu" in (tmp_path / "number density" / "electrons" / "electrons.pvd").read_text()
+
+
+def test_file_output_interpolates_like_the_reference(tmp_path):
+    from fedm_amd import mesh_io
+    from fedm_amd.mesh import RectangleMesh
+    m = RectangleMesh((0, 0), (1, 1), 2, 2)
+    f = mesh_io.PVDFile(tmp_path / "a.pvd", m)
+    new, old = np.full(9, 3.0), np.full(9, 1.0)
+    t_out, step = mesh_io.file_output(1.6e-11, 0.6e-11, 1e-11, 1e-11, [1e-11, 1e-10], [1e-11, 1e-10],
+                                      ["pvd"], [f], ["x"], [new], [old], unit="us")
+    assert len(f.entries) == 1 and f.entries[0][0] == pytest.approx(1e-5)
+    assert np.allclose(mesh_io.read_vtu(tmp_path / "a000000.vtu", "x"), 1.0 + 0.4 * 2.0)
+    assert t_out == pytest.approx(2e-11) and step == 1e-11
+    with pytest.raises(ValueError, match="unit 'h' not valid"):
+        mesh_io.file_output(1, 0, 1, 1, [1], [1], ["pvd"], [f], ["x"], [new], [old], unit="h")
