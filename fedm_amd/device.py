@@ -444,6 +444,12 @@ class DeviceProblem:
         self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
         return self.multigrid_levels
 
+    def set_fieldsplit(self, weights=(0.8, 0.8, 0.8)):
+        """Richardson weights of the species-block sweeps; :func:`chebyshev_weights` gives the
+        optimal ones for a spectrum interval of Duu^-1 Juu."""
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self._check(self.lib.fedm_set_fieldsplit(self._h, int(w.size), _dp(w)), "fedm_set_fieldsplit")
+
     def clear_multigrid(self):
         self.lib.fedm_amg_clear(self._h)
 
@@ -509,3 +515,11 @@ def rccl_unique_id():
     if lib.fedm_comm_unique_id(buf) != 0:
         raise RuntimeError(f"fedm_comm_unique_id failed: {_lib.last_error()}")
     return buf.raw
+
+
+def chebyshev_weights(m, lam_min=0.5, lam_max=2.0):
+    """Richardson weights whose residual polynomial is the degree-m Chebyshev polynomial on
+    [lam_min, lam_max] (defaults: the diagonally scaled P1 mass matrix in 2-D)."""
+    theta, delta = 0.5 * (lam_max + lam_min), 0.5 * (lam_max - lam_min)
+    k = np.arange(1, m + 1)
+    return 1.0 / (theta + delta * np.cos((2 * k - 1) * np.pi / (2 * m)))

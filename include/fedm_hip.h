@@ -221,6 +221,9 @@ int fedm_jacobian_poisson_only(fedm_ctx *ctx);
 int fedm_amg_setup(fedm_ctx *ctx, int n_levels, const fedm_csr *A, const fedm_csr *P,
                    const fedm_csr *R, const double *coarse_inverse, int nu, double omega);
 int fedm_amg_clear(fedm_ctx *ctx);
+/* Richardson sweeps z += w_k Duu^-1 (r - Juu z) on the species block inside the field split;
+ * one weight per sweep (equal weights = damped block Jacobi, Chebyshev roots = polynomial) */
+int fedm_set_fieldsplit(fedm_ctx *ctx, int sweeps, const double *weights);
 /* host-side greedy aggregation on a strength graph (set-up helper, no GPU needed) */
 int fedm_amg_aggregate(int32_t n, const int64_t *indptr, const int32_t *indices,
                        const uint8_t *strong, int32_t *agg, int32_t *n_agg);
