@@ -64,6 +64,15 @@ class GdDesc(C.Structure):
     ]
 
 
+class GdFieldProg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("table", C.c_int32), ("arg", C.c_int32), ("src_row", C.c_int32),
+                ("scale", C.c_double)]
+
+
+GDP = {"keep": 0, "table": 1, "scaled_row": 2, "me_old": 3, "me": 4, "ue_old": 5}
+GDP_ARG = {"energy": 0, "redfield": 1}
+
+
 class MeshDesc(C.Structure):
     _fields_ = [("n_vertices", C.c_int32), ("n_cells", C.c_int32),
                 ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
@@ -106,6 +115,12 @@ _SIGNATURES = {
     "fedm_ctx_create": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(ModelDesc), C.c_int, C.POINTER(_P)]),
     "fedm_ctx_create_gd": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(GdDesc), C.c_int, C.POINTER(_P)]),
     "fedm_gd_set_fields": (C.c_int, [_P, _D]),
+    "fedm_gd_get_fields": (C.c_int, [_P, _D]),
+    "fedm_gd_prep_setup": (C.c_int, [_P, C.POINTER(Csr), C.c_int, C.POINTER(C.c_int32), _D, _D,
+                                     C.POINTER(GdFieldProg)]),
+    "fedm_gd_prep_step": (C.c_int, [_P]),
+    "fedm_gd_update_mean_energy": (C.c_int, [_P]),
+    "fedm_get_state_old": (C.c_int, [_P, _D]),
     "fedm_ctx_destroy": (None, [_P]),
     "fedm_set_state": (C.c_int, [_P, _D, _D, _D]),
     "fedm_get_state": (C.c_int, [_P, _D]),

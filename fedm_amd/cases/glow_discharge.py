@@ -29,7 +29,8 @@ class Case:
     """Set-up of fedm_gd.py:45-418 and one ``step()`` per pass of its time loop (:420-471)."""
 
     def __init__(self, nx=100, ny=100, file_input=DECK, device=0, T_final=1e-11,
-                 relative_tolerance=1e-4, maximum_iterations=20, quiet=True, error_file=None):
+                 relative_tolerance=1e-4, maximum_iterations=20, quiet=True, error_file=None,
+                 device_pipeline=True):
         import tempfile
         self.quiet = quiet
         model = "4_particles"
@@ -100,6 +101,10 @@ class Case:
         ff.Rate_coefficient_interpolation("initial", self.k_dep, self.k, self.k_x, self.k_y,
                                           self.mean_energy, self.redE, Te=0, Tgas=0)
         self.prob.setup_multigrid(nu=1)
+        self.device_pipeline = device_pipeline
+        if device_pipeline:
+            self.upload_fields()               # 'initial' values incl. the const rows
+            self._install_device_pipeline()
         # solver, time stepping (fedm_gd.py:104-133, 405-418)
         self.solver = ff.PETScSNESSolver()
         self.solver.parameters["relative_tolerance"] = relative_tolerance
@@ -151,6 +156,41 @@ class Case:
                           minlength=m.num_vertices())
         return self._mass.solve(rhs)
 
+    def _install_device_pipeline(self):
+        """The per-step refresh of fedm_gd.py:424-443 as field programs for the device."""
+        ns, nr, N0 = self.ns, self.nr, self.N0
+        tables, progs = [], []
+
+        def table(x, y):
+            tables.append((x, y))
+            return len(tables) - 1
+
+        arg = {"Umean": "energy", "E/N": "redfield"}
+        for dep, kx, ky in zip(self.mu_dep, self.mu_x, self.mu_y):                  # mu rows
+            progs.append(dict(kind="table", table=table(kx, ky), arg=arg[dep], scale=1.0 / N0)
+                         if dep in arg else dict(kind="keep"))
+        for i, (dep, kx, ky) in enumerate(zip(self.D_dep, self.D_x, self.D_y)):     # D rows
+            if dep in arg:
+                progs.append(dict(kind="table", table=table(kx, ky), arg=arg[dep], scale=1.0 / N0))
+            elif dep == "ESR":
+                progs.append(dict(kind="scaled_row", src_row=i, scale=kB * self.Tgas / elementary_charge))
+            else:
+                progs.append(dict(kind="keep"))
+        for i in range(ns):                                                          # mu_diff rows
+            progs.append(dict(kind="table", table=table(self.mu_x[i], self.mue_diff), arg="energy")
+                         if i == ns - 1 else dict(kind="keep"))
+        for i in range(ns):                                                          # D_diff rows
+            progs.append(dict(kind="table", table=table(self.D_x[i], self.De_diff), arg="energy")
+                         if i == ns - 1 else dict(kind="keep"))
+        for dep, kx, ky in zip(self.k_dep, self.k_x, self.k_y):                      # k rows
+            progs.append(dict(kind="table", table=table(kx, ky), arg=arg[dep]) if dep in arg
+                         else dict(kind="keep"))
+        for j, dep in enumerate(self.k_dep):                                         # k_diff rows
+            progs.append(dict(kind="table", table=table(self.k_x[j], self.k_diff[j]), arg="energy")
+                         if dep == "Umean" else dict(kind="keep"))
+        progs += [dict(kind="me_old"), dict(kind="me"), dict(kind="ue_old")]
+        self.prob.gd_prep_setup(tables, progs)
+
     def upload_fields(self):
         ns, nr, nv = self.ns, self.nr, self.mesh.num_vertices()
         me_old = self.mean_energy_old.vector()
@@ -170,6 +210,8 @@ class Case:
         prob, ns = self.prob, self.ns
         t_old = self.t
         prob.shift_state()                                           # :422-423
+        if self.device_pipeline:
+            return self._step_on_device(t_old)
         U_old = self.U
         self.mean_energy_old.assign(self.mean_energy)
         self.redE.vector()[:] = self.project_reduced_field(self.U[:, ns])
@@ -199,8 +241,37 @@ class Case:
         self.max_error[1] = self.max_error[0]
         return self.t
 
+    def _solve(self):
+        import contextlib, io, sys
+        with contextlib.redirect_stdout(io.StringIO() if self.quiet else sys.stdout):
+            self.t = ff.adaptive_solver(self.solver, self.problem, self.t, self.dt, self.dt_old,
+                                        self.u_new, self.u_old, None, None, self.assigner, self.error,
+                                        self.error_file, self.max_error, self.ttol, self.dt_min,
+                                        time_dependent_arguments=[self.Phi_powered], approximation="LMEA")
+        self.newton_iterations += self.prob.last_report.iterations
+        self.linear_iterations += self.prob.last_report.linear_iterations
+
+    def _step_on_device(self, t_old):
+        """Same step with the coefficient refresh and the mean-energy update on the device: no
+        state leaves the GPU unless an output time is crossed."""
+        prob = self.prob
+        prob.gd_prep_step()
+        self._solve()
+        prob.gd_update_mean_energy()
+        if self.snapshot is None and self.t_output <= self.t:
+            U_old, U = prob.get_state_old(), prob.get_state()
+            self.snapshot = U_old + (self.t_output - t_old) * (U - U_old) / (self.t - t_old)
+        self.dt_old.time_step = self.dt.time_step
+        self.dt.time_step = ff.adaptive_timestep(self.dt.time_step, self.max_error, self.ttol,
+                                                 self.dt_min, self.dt_max)
+        self.max_error[2] = self.max_error[1]
+        self.max_error[1] = self.max_error[0]
+        return self.t
+
     def run(self):
         while self.t < self.T_final:
             self.step()
+        if self.device_pipeline:
+            self.U = self.prob.get_state()
         return dict(log=[tuple(float(v) for v in line.split()) for line in open(self.error_file)],
                     snapshot=self.snapshot, U=self.U, t=self.t)

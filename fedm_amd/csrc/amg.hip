@@ -132,6 +132,11 @@ static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const
     }
 }
 
+void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double *b, double *y,
+               double omega, double *aux) {
+    ell_launch(c, A, mode, x, b, y, omega, aux);
+}
+
 __global__ void jacobi_first_kernel(int n, const double *__restrict__ dinv,
                                     const double *__restrict__ b, double *__restrict__ x, double omega) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -32,6 +32,9 @@ struct Amg {
     void release();
 };
 
+// y = A x (mode 0), b - A x (1), Jacobi sweep (2), y += A x (3), fused first sweep + residual (4)
+void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double *b, double *y,
+               double omega, double *aux = nullptr);
 void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha);  // z = alpha*Minv t
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z);

@@ -300,6 +300,58 @@ int fedm_ctx_create_gd(const fedm_mesh_desc *mesh, const fedm_gd_desc *gd, int d
     return ctx_create_impl(mesh, nullptr, gd, device, out);
 }
 
+int fedm_gd_prep_setup(fedm_ctx *h, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
+                       const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs) {
+    Ctx &c = h->c;
+    if (c.model_kind != 1 || !mass || !tab_ptr || !progs || n_tables < 0 || mass->n_rows != c.nv) {
+        set_error("bad LMEA field-refresh description");
+        return -2;
+    }
+    for (int r = 0; r < c.gd_n_fields; ++r)
+        if ((progs[r].kind == FEDM_GDP_TABLE && (progs[r].table < 0 || progs[r].table >= n_tables)) ||
+            (progs[r].kind == FEDM_GDP_SCALED_ROW && (progs[r].src_row < 0 || progs[r].src_row >= c.gd_n_fields))) {
+            set_error("field program refers to a missing table or row");
+            return -2;
+        }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    return gd_prep_setup(c, mass, n_tables, tab_ptr, tab_x, tab_y, progs);
+}
+
+int fedm_gd_prep_step(fedm_ctx *h) {
+    Ctx &c = h->c;
+    if (c.model_kind != 1 || !c.gd_prep) {
+        set_error("fedm_gd_prep_setup has not been called");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    const int rc = gd_prep_step(c);
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return rc;
+}
+
+int fedm_gd_update_mean_energy(fedm_ctx *h) {
+    Ctx &c = h->c;
+    if (c.model_kind != 1) {
+        set_error("not an LMEA context");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    gd_update_mean_energy(c);
+    return 0;
+}
+
+int fedm_gd_get_fields(fedm_ctx *h, double *out) {
+    Ctx &c = h->c;
+    if (c.model_kind != 1 || !out) {
+        set_error("not an LMEA context");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    FEDM_HIP_CHECK(hipMemcpy(out, c.d_gd_fields, sizeof(double) * (size_t)c.gd_n_fields * c.nv, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int fedm_gd_set_fields(fedm_ctx *h, const double *fields) {
     Ctx &c = h->c;
     if (c.model_kind != 1 || !fields) {
@@ -475,6 +527,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
         c.comm->release();
         delete c.comm;
     }
+    gd_prep_release(c);
     for (auto &e : c.prof.ev) hipEventDestroy(e);
     if (c.h_red) hipHostFree(c.h_red);
     if (c.h_stage) hipHostFree(c.h_stage);
@@ -508,6 +561,12 @@ int fedm_get_state(fedm_ctx *h, double *u_new) {
     Ctx &c = h->c;
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     return get_vec(c, u_new, c.d_u);
+}
+
+int fedm_get_state_old(fedm_ctx *h, double *u_old) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    return get_vec(c, u_old, c.d_uold);
 }
 
 int fedm_shift_state(fedm_ctx *h) {

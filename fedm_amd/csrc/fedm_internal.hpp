@@ -53,6 +53,7 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat);
 
 struct Amg;
 struct Comm;
+struct GdPrep;
 
 // Optional in-run kernel timing with HIP events on the library's stream (bench.py roofline).
 // kinds: 0 assembly F+J, 1 Jacobian SpMV, 2 assembly F only, 3 multigrid V-cycle
@@ -82,6 +83,7 @@ struct Ctx {
     fedm_gd_desc *d_gd = nullptr;
     double *d_gd_fields = nullptr;  // [n_fields][nv] nodal coefficient fields
     int gd_n_fields = 0;
+    GdPrep *gd_prep = nullptr;  // on-device per-step coefficient refresh (LMEA)
     Pattern pat;
     double dt = 1.0, dt_old = 1e30;
     // device mesh
@@ -129,6 +131,11 @@ constexpr int RED_K = 40;
 // mode: 0 = full model, 1 = Poisson row only (species rows become identity)
 void launch_assemble(Ctx &c, bool jacobian, int mode);
 void launch_assemble_gd(Ctx &c, bool jacobian, int mode);
+int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
+                  const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs);
+int gd_prep_step(Ctx &c);
+void gd_update_mean_energy(Ctx &c);
+void gd_prep_release(Ctx &c);
 size_t patch_lds_bytes(const Ctx &c);
 void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks

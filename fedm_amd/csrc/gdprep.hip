@@ -1,0 +1,252 @@
+// Per-step refresh of the LMEA coefficient fields on the device: reduced electric field by a
+// consistent P1 projection (Jacobi-CG on the mass matrix), table look-ups with np.interp's
+// semantics, derived rows, mean-energy bookkeeping.  Replaces the host code between two solves
+// of examples/glow_discharge/fedm-gd.py:424-443 and :452 (fedm/functions.py:531-750).
+#include "amg.hpp"
+#include "fedm_internal.hpp"
+
+namespace fedm {
+
+struct GdPrep {
+    EllMat M;
+    int n_tables = 0, n_rows = 0;
+    int *d_tab_ptr = nullptr;
+    double *d_tab_x = nullptr, *d_tab_y = nullptr;
+    fedm_gd_field_prog *d_progs = nullptr;
+    std::vector<fedm_gd_field_prog> progs;
+    double *d_redE = nullptr, *d_b = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
+    int nvp = 0;
+    void release() {
+        M.release();
+        for (void *p : {(void *)d_tab_ptr, (void *)d_tab_x, (void *)d_tab_y, (void *)d_progs, (void *)d_redE,
+                        (void *)d_b, (void *)d_r, (void *)d_p, (void *)d_q})
+            if (p) hipFree(p);
+    }
+};
+
+void gd_prep_release(Ctx &c) {
+    if (c.gd_prep) {
+        c.gd_prep->release();
+        delete c.gd_prep;
+        c.gd_prep = nullptr;
+    }
+}
+
+// b_v += f_c |detJ| / 6 with f_c = 1e21 |grad Phi| / N0 (cell-wise constant): colour by colour
+__global__ void redfield_rhs_kernel(int n_cells, const int *__restrict__ cell_list,
+                                    const int *__restrict__ cells, const double *__restrict__ coords,
+                                    const double *__restrict__ u, int neq, double N0,
+                                    double *__restrict__ b) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_cells) return;
+    const int c = cell_list[t];
+    int v[3];
+    double x[3][2], phi[3];
+    for (int a = 0; a < 3; ++a) {
+        v[a] = cells[3 * c + a];
+        x[a][0] = coords[2 * v[a]];
+        x[a][1] = coords[2 * v[a] + 1];
+        phi[a] = u[(size_t)v[a] * neq + (neq - 1)];
+    }
+    const double det = (x[1][0] - x[0][0]) * (x[2][1] - x[0][1]) - (x[1][1] - x[0][1]) * (x[2][0] - x[0][0]);
+    const double gx = (phi[0] * (x[1][1] - x[2][1]) + phi[1] * (x[2][1] - x[0][1]) + phi[2] * (x[0][1] - x[1][1])) / det;
+    const double gy = (phi[0] * (x[2][0] - x[1][0]) + phi[1] * (x[0][0] - x[2][0]) + phi[2] * (x[1][0] - x[0][0])) / det;
+    const double f = 1e21 * sqrt(gx * gx + gy * gy) / N0;
+    const double w = f * fabs(det) / 6.0;
+    for (int a = 0; a < 3; ++a) b[v[a]] += w;
+}
+
+// deterministic two-stage dot products on scalar vectors of length n
+__global__ __launch_bounds__(256) void sdot2_kernel(int n, const double *__restrict__ a,
+                                                    const double *__restrict__ b,
+                                                    const double *__restrict__ c2,
+                                                    const double *__restrict__ d,
+                                                    double *__restrict__ partials) {
+    __shared__ double sm[2][4];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        s0 += a[i] * b[i];
+        s1 += c2[i] * d[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sm[0][wave] = s0;
+        sm[1][wave] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        partials[(size_t)blockIdx.x * RED_K + threadIdx.x] =
+            sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3];
+}
+__global__ void sreduce_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) out[i] = s;
+}
+__global__ void saxpy2_kernel(int n, double a, const double *__restrict__ x, double *__restrict__ y,
+                              double b, const double *__restrict__ x2, double *__restrict__ y2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        y[i] += a * x[i];
+        y2[i] += b * x2[i];
+    }
+}
+__global__ void sxpby_kernel(int n, const double *__restrict__ dinv, const double *__restrict__ r,
+                             double beta, double *__restrict__ p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = dinv[i] * r[i] + beta * p[i];
+}
+__global__ void smul_kernel(int n, const double *__restrict__ dinv, const double *__restrict__ r,
+                            double *__restrict__ z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = dinv[i] * r[i];
+}
+
+// M x = b by Jacobi-preconditioned CG, rtol on |r|
+static int mass_solve(Ctx &c, GdPrep &g, const double *b, double *x, double rtol, int max_it) {
+    const int n = c.nv, np = g.nvp;
+    const dim3 gv((np + 255) / 256), bv(256);
+    int grid = (n + 255) / 256;
+    if (grid > RED_BLOCKS) grid = RED_BLOCKS;
+    auto dots = [&](const double *a, const double *bb, const double *cc, const double *dd) {
+        hipLaunchKernelGGL(sdot2_kernel, dim3(grid), dim3(256), 0, c.stream, n, a, bb, cc, dd, c.d_partials);
+        hipLaunchKernelGGL(sreduce_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, c.d_red);
+        read_red(c, 2);
+    };
+    hipMemsetAsync(x, 0, sizeof(double) * np, c.stream);
+    hipMemcpyAsync(g.d_r, b, sizeof(double) * np, hipMemcpyDeviceToDevice, c.stream);
+    hipLaunchKernelGGL(smul_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, g.d_p);  // p = z = Dinv r
+    dots(g.d_r, g.d_p, g.d_r, g.d_r);
+    double rz = c.h_red[0];
+    const double r0 = std::sqrt(c.h_red[1]);
+    if (r0 == 0.0) return 0;
+    for (int it = 0; it < max_it; ++it) {
+        ell_apply(c, g.M, 0, g.d_p, nullptr, g.d_q, 0.0);
+        dots(g.d_p, g.d_q, g.d_p, g.d_q);
+        const double alpha = rz / c.h_red[0];
+        hipLaunchKernelGGL(saxpy2_kernel, gv, bv, 0, c.stream, n, alpha, g.d_p, x, -alpha, g.d_q, g.d_r);
+        hipLaunchKernelGGL(smul_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, g.d_q);  // z in q
+        dots(g.d_r, g.d_q, g.d_r, g.d_r);
+        const double rz_new = c.h_red[0], rn = std::sqrt(c.h_red[1]);
+        if (!std::isfinite(rn)) return FEDM_DIVERGED_NAN;
+        if (rn <= rtol * r0) return 0;
+        const double beta = rz_new / rz;
+        rz = rz_new;
+        hipLaunchKernelGGL(sxpby_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, beta, g.d_p);
+    }
+    return FEDM_DIVERGED_LINEAR;
+}
+
+// np.interp(x, xp, fp): clamped ends, slope*(x - xp[j]) + fp[j] inside
+__device__ __forceinline__ double interp1(double x, const double *__restrict__ xp,
+                                          const double *__restrict__ fp, int n) {
+    if (x <= xp[0]) return fp[0];
+    if (x >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;  // xp[lo] <= x < xp[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid;
+        else hi = mid;
+    }
+    if (x == xp[lo]) return fp[lo];
+    const double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+    return slope * (x - xp[lo]) + fp[lo];
+}
+
+__global__ void gd_fields_kernel(int nv, int n_rows, const fedm_gd_field_prog *__restrict__ progs,
+                                 const int *__restrict__ tab_ptr, const double *__restrict__ tab_x,
+                                 const double *__restrict__ tab_y, const double *__restrict__ redE,
+                                 const double *__restrict__ uold, int neq, int row_me_old, int row_me,
+                                 double *__restrict__ fields) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    // mean_energy_old <- mean_energy first: the tables are evaluated at the old mean energy
+    const double me_old = fields[(size_t)row_me * nv + v];
+    fields[(size_t)row_me_old * nv + v] = me_old;
+    for (int r = 0; r < n_rows; ++r) {
+        const fedm_gd_field_prog p = progs[r];
+        if (p.kind == FEDM_GDP_TABLE) {
+            const double x = (p.arg == FEDM_GDP_ARG_ENERGY) ? me_old : redE[v];
+            const int t0 = tab_ptr[p.table], n = tab_ptr[p.table + 1] - t0;
+            fields[(size_t)r * nv + v] = interp1(x, tab_x + t0, tab_y + t0, n) * p.scale;
+        } else if (p.kind == FEDM_GDP_UE_OLD) {
+            fields[(size_t)r * nv + v] = uold[(size_t)v * neq + (neq - 2)];
+        }
+    }
+    for (int r = 0; r < n_rows; ++r) {  // rows derived from other rows (after the look-ups)
+        const fedm_gd_field_prog p = progs[r];
+        if (p.kind == FEDM_GDP_SCALED_ROW) fields[(size_t)r * nv + v] = p.scale * fields[(size_t)p.src_row * nv + v];
+    }
+}
+
+__global__ void gd_mean_energy_kernel(int nv, int neq, const double *__restrict__ u, int row_me,
+                                      double *__restrict__ fields) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nv) fields[(size_t)row_me * nv + v] = exp(u[(size_t)v * neq] - u[(size_t)v * neq + (neq - 2)]);
+}
+
+int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
+                  const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs) {
+    gd_prep_release(c);
+    GdPrep *g = new GdPrep();
+    if (g->M.from_csr(*mass, true)) {
+        set_error("mass matrix upload failed");
+        delete g;
+        return -1;
+    }
+    g->nvp = g->M.n_rows_p;
+    g->n_tables = n_tables;
+    g->n_rows = c.gd_n_fields;
+    g->progs.assign(progs, progs + g->n_rows);
+    const int ntab = tab_ptr[n_tables];
+    FEDM_HIP_CHECK(hipMalloc((void **)&g->d_tab_ptr, sizeof(int) * (n_tables + 1)));
+    FEDM_HIP_CHECK(hipMalloc((void **)&g->d_tab_x, sizeof(double) * std::max(ntab, 1)));
+    FEDM_HIP_CHECK(hipMalloc((void **)&g->d_tab_y, sizeof(double) * std::max(ntab, 1)));
+    FEDM_HIP_CHECK(hipMalloc((void **)&g->d_progs, sizeof(fedm_gd_field_prog) * g->n_rows));
+    FEDM_HIP_CHECK(hipMemcpy(g->d_tab_ptr, tab_ptr, sizeof(int) * (n_tables + 1), hipMemcpyHostToDevice));
+    FEDM_HIP_CHECK(hipMemcpy(g->d_tab_x, tab_x, sizeof(double) * ntab, hipMemcpyHostToDevice));
+    FEDM_HIP_CHECK(hipMemcpy(g->d_tab_y, tab_y, sizeof(double) * ntab, hipMemcpyHostToDevice));
+    FEDM_HIP_CHECK(hipMemcpy(g->d_progs, progs, sizeof(fedm_gd_field_prog) * g->n_rows, hipMemcpyHostToDevice));
+    for (double **p : {&g->d_redE, &g->d_b, &g->d_r, &g->d_p, &g->d_q}) {
+        FEDM_HIP_CHECK(hipMalloc((void **)p, sizeof(double) * g->nvp));
+        FEDM_HIP_CHECK(hipMemset(*p, 0, sizeof(double) * g->nvp));
+    }
+    c.gd_prep = g;
+    return 0;
+}
+
+int gd_prep_step(Ctx &c) {
+    GdPrep &g = *c.gd_prep;
+    const int ns = c.gd.n_species, nr = c.gd.n_reactions;
+    const int row_me_old = 4 * ns + 2 * nr, row_me = row_me_old + 1;
+    // reduced field of the current potential: project(1e21*sqrt(dot(-grad Phi, -grad Phi))/N0)
+    hipMemsetAsync(g.d_b, 0, sizeof(double) * g.nvp, c.stream);
+    const int ncol = (int)c.pat.colour_ptr.size() - 1;
+    for (int k = 0; k < ncol; ++k) {
+        const int n = c.pat.colour_ptr[k + 1] - c.pat.colour_ptr[k];
+        if (n == 0) continue;
+        hipLaunchKernelGGL(redfield_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, n,
+                           c.d_colour_cells + c.pat.colour_ptr[k], c.d_cells, c.d_coords, c.d_u, c.neq,
+                           c.gd.N0, g.d_b);
+    }
+    const int rc = mass_solve(c, g, g.d_b, g.d_redE, 1e-14, 500);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gd_fields_kernel, dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, c.nv, g.n_rows,
+                       g.d_progs, g.d_tab_ptr, g.d_tab_x, g.d_tab_y, g.d_redE, c.d_uold, c.neq, row_me_old,
+                       row_me, c.d_gd_fields);
+    return 0;
+}
+
+void gd_update_mean_energy(Ctx &c) {
+    const int row_me = 4 * c.gd.n_species + 2 * c.gd.n_reactions + 1;
+    hipLaunchKernelGGL(gd_mean_energy_kernel, dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, c.nv, c.neq,
+                       c.d_u, row_me, c.d_gd_fields);
+}
+
+}  // namespace fedm

@@ -326,6 +326,56 @@ class DeviceProblem:
         f = np.ascontiguousarray(f[:, self._order])
         self._check(self.lib.fedm_gd_set_fields(self._h, _dp(f)), "fedm_gd_set_fields")
 
+    def get_gd_fields(self):
+        out = np.empty((self.model.n_fields, self.nv))
+        self._check(self.lib.fedm_gd_get_fields(self._h, _dp(out)), "fedm_gd_get_fields")
+        return np.ascontiguousarray(out[:, self._inv])
+
+    def gd_prep_setup(self, tables, programs):
+        """Install the on-device per-step refresh of the LMEA coefficient fields.
+        ``tables``: list of (x, y) arrays; ``programs``: one dict per field row with keys
+        kind ('keep' | 'table' | 'scaled_row' | 'me_old' | 'me' | 'ue_old') and, as needed,
+        table, arg ('energy' | 'redfield'), scale, src_row."""
+        import scipy.sparse as sp
+        from . import amg
+        x = self._coords_dev[self._cells_dev]
+        d1, d2 = x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]
+        det = np.abs(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0])
+        vals = det[:, None, None] * ((np.ones((3, 3)) + np.eye(3)) / 24.0)[None]
+        c = self._cells_dev.astype(np.int64)
+        rows = np.broadcast_to(c[:, :, None], vals.shape).ravel()
+        cols = np.broadcast_to(c[:, None, :], vals.shape).ravel()
+        M = sp.coo_matrix((vals.ravel(), (rows, cols)), shape=(self.nv, self.nv)).tocsr()
+        keep = []
+        mass = amg._csr_struct(M, keep)
+        ptr = np.zeros(len(tables) + 1, dtype=np.int32)
+        ptr[1:] = np.cumsum([len(t[0]) for t in tables])
+        tx = np.ascontiguousarray(np.concatenate([np.asarray(t[0], float) for t in tables]) if tables else np.zeros(1))
+        ty = np.ascontiguousarray(np.concatenate([np.asarray(t[1], float) for t in tables]) if tables else np.zeros(1))
+        if len(programs) != self.model.n_fields:
+            raise ValueError("one program per field row")
+        progs = (_lib.GdFieldProg * len(programs))()
+        for r, p in enumerate(programs):
+            progs[r].kind = _lib.GDP[p["kind"]]
+            progs[r].table = int(p.get("table", 0))
+            progs[r].arg = _lib.GDP_ARG[p.get("arg", "energy")]
+            progs[r].src_row = int(p.get("src_row", 0))
+            progs[r].scale = float(p.get("scale", 1.0))
+        self._check(self.lib.fedm_gd_prep_setup(self._h, C.byref(mass), len(tables),
+                                                ptr.ctypes.data_as(C.POINTER(C.c_int32)), _dp(tx), _dp(ty),
+                                                progs), "fedm_gd_prep_setup")
+
+    def gd_prep_step(self):
+        self._check(self.lib.fedm_gd_prep_step(self._h), "fedm_gd_prep_step")
+
+    def gd_update_mean_energy(self):
+        self._check(self.lib.fedm_gd_update_mean_energy(self._h), "fedm_gd_update_mean_energy")
+
+    def get_state_old(self):
+        out = np.empty(self.n)
+        self._check(self.lib.fedm_get_state_old(self._h, _dp(out)), "fedm_get_state_old")
+        return self._back(out).reshape(self.nv, self.n_eq)
+
     def set_ext_source(self, species, nodal):
         v = np.ascontiguousarray(nodal, dtype=np.float64)
         self._check(self.lib.fedm_set_ext_source(self._h, int(species), _dp(v)), "fedm_set_ext_source")

@@ -114,6 +114,14 @@ typedef struct {
     double fnorm0, fnorm;        /* |F| before / after                                     */
 } fedm_newton_report;
 
+/* scalar CSR matrix handed across the boundary (multigrid operators, mass matrix) */
+typedef struct {
+    int32_t n_rows, n_cols;
+    const int64_t *indptr;
+    const int32_t *indices;
+    const double *values;
+} fedm_csr;
+
 /* ---- LMEA model family (glow discharge, examples/glow_discharge/fedm-gd.py) --------------
  * Components: 0 = ln(electron energy density), 1..n_species-1 = ln(number density) of the
  * species with an equation (species 0, the background gas, has none), last = potential.
@@ -151,6 +159,22 @@ typedef struct {
  *   k[n_reactions], k_diff[n_reactions], mean_energy_old, mean_energy, u_e_old           */
 #define FEDM_GD_N_FIELDS(ns, nr) (4 * (ns) + 2 * (nr) + 3)
 
+/* Per-step refresh of the LMEA coefficient fields on the device (what the script does on the
+ * host between solves, examples/glow_discharge/fedm-gd.py:424-443,452): one "program" per
+ * field row of fedm_gd_set_fields. */
+#define FEDM_GDP_KEEP 0      /* leave the row as uploaded ('const' dependence, set once)            */
+#define FEDM_GDP_TABLE 1     /* np.interp(arg, table) * scale      functions.py:627-630, 739-747    */
+#define FEDM_GDP_SCALED_ROW 2 /* scale * fields[src_row]           'ESR': kB*Tgas*mu/e, :633        */
+#define FEDM_GDP_ME_OLD 3    /* mean_energy_old <- mean_energy     fedm-gd.py:426-427               */
+#define FEDM_GDP_ME 4        /* mean_energy (updated after the solve, fedm-gd.py:452)               */
+#define FEDM_GDP_UE_OLD 5    /* ln n_e of the previous step (u_oldV[-1], fedm-gd.py:424)             */
+#define FEDM_GDP_ARG_ENERGY 0   /* mean_energy_old */
+#define FEDM_GDP_ARG_REDFIELD 1 /* reduced electric field project(1e21*|grad Phi|/N0), :432          */
+typedef struct {
+    int32_t kind, table, arg, src_row;
+    double scale;
+} fedm_gd_field_prog;
+
 typedef struct fedm_ctx fedm_ctx;
 
 const char *fedm_last_error(void);
@@ -163,12 +187,20 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
 int fedm_ctx_create_gd(const fedm_mesh_desc *mesh, const fedm_gd_desc *model, int device,
                        fedm_ctx **out);
 int fedm_gd_set_fields(fedm_ctx *ctx, const double *fields /* [n_fields][n_vertices] */);
+/* mass: consistent P1 mass matrix (Cartesian dx) for project(); tables: concatenated x/y with
+ * tab_ptr[n_tables+1]; progs: one per field row */
+int fedm_gd_prep_setup(fedm_ctx *ctx, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
+                       const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs);
+int fedm_gd_prep_step(fedm_ctx *ctx);            /* after fedm_shift_state, before the solve   */
+int fedm_gd_update_mean_energy(fedm_ctx *ctx);   /* mean_energy = exp(u_0 - u_e), :452         */
+int fedm_gd_get_fields(fedm_ctx *ctx, double *out /* [n_fields][n_vertices] */);
 void fedm_ctx_destroy(fedm_ctx *ctx);
 
 /* u_new / u_old / u_old1 (N doubles each, any may be NULL to leave unchanged).
  * Replaces Function.assign / rev_assigner.assign, fedm-streamer.py:282-283,306-307. */
 int fedm_set_state(fedm_ctx *ctx, const double *u_new, const double *u_old, const double *u_old1);
 int fedm_get_state(fedm_ctx *ctx, double *u_new);
+int fedm_get_state_old(fedm_ctx *ctx, double *u_old);
 /* u_old1 <- u_old; u_old <- u_new on the device (fedm-streamer.py:306-307) */
 int fedm_shift_state(fedm_ctx *ctx);
 /* u_new <- u_old (step rejection, fedm/functions.py:1103) */
@@ -202,12 +234,6 @@ int fedm_poisson_solve(fedm_ctx *ctx, double rtol, int max_it, int *iterations);
  * harness, tests/integrated_tests/streamer_discharge/fedm_streamer.py:32).  Here: GMRES with
  * point-block Jacobi on the species rows and, when a hierarchy has been installed, one
  * multigrid V-cycle on the (constant) potential block, combined block-triangularly. */
-typedef struct {
-    int32_t n_rows, n_cols;
-    const int64_t *indptr;
-    const int32_t *indices;
-    const double *values;
-} fedm_csr;
 
 /* scalar CSR of block component (cr, cc) of the assembled Jacobian (n_vertices rows) */
 int64_t fedm_block_nnz(fedm_ctx *ctx);

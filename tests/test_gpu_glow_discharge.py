@@ -15,7 +15,7 @@ DECK = ROOT / "decks" / "glow_discharge" / "file_input" / "4_particles"
 def test_gd_residual_and_jacobian_match_the_oracle():
     from oracle import gd as ogd
     from fedm_amd.cases import glow_discharge as gdc
-    case = gdc.Case(nx=10, ny=10)
+    case = gdc.Case(nx=10, ny=10, device_pipeline=False)
     o = ogd.GlowDischarge(DECK, 10, 10)
     nv = o.mesh.nv
     assert np.array_equal(o.mesh.cells, case.mesh.cells)
@@ -63,11 +63,29 @@ def test_gd_residual_and_jacobian_match_the_oracle():
     assert (sp.diags(1.0 / rs) @ D).max() < 1e-9
 
 
-def test_gd_golden_run(golden_dir):
+def test_gd_device_pipeline_matches_host_pipeline():
+    """fedm-gd.py:424-443,452 on the device (projection CG, np.interp look-ups, ESR, mean
+    energy) against the same steps with the façade's host functions."""
+    from fedm_amd.cases import glow_discharge as gdc
+    host = gdc.Case(nx=24, ny=24, device_pipeline=False, T_final=1.0)
+    dev = gdc.Case(nx=24, ny=24, device_pipeline=True, T_final=1.0)
+    for _ in range(4):
+        host.step()
+        dev.step()
+        fh, fd = host.prob.get_gd_fields(), dev.prob.get_gd_fields()
+        fh[-2] = host.mean_energy.vector()     # the host uploads this row before the next solve
+        scale = np.maximum(np.abs(fh).max(axis=1, keepdims=True), 1e-300)
+        assert (np.abs(fh - fd) / scale).max() < 1e-12
+    assert np.allclose(host.prob.get_state(), dev.prob.get_state(), rtol=1e-9, atol=1e-9)
+    assert np.allclose(np.loadtxt(host.error_file), np.loadtxt(dev.error_file), rtol=1e-7)
+
+
+@pytest.mark.parametrize("device_pipeline", [False, True])
+def test_gd_golden_run(golden_dir, device_pipeline):
     from fedm_amd.cases import glow_discharge as gdc
     gold = np.load(golden_dir / "gd_golden.npz")
     ref_log = np.array(json.loads((golden_dir / "error_logs.json").read_text())["glow_discharge"])
-    out = gdc.Case().run()
+    out = gdc.Case(device_pipeline=device_pipeline).run()
     log = np.array(out["log"])
     assert log.shape == ref_log.shape
     assert np.allclose(log, ref_log)                  # the reference's assertion (rtol 1e-5)
