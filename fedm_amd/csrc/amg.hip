@@ -5,21 +5,36 @@
 #include "amg.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace fedm {
 
 // ---- scalar sliced-ELL --------------------------------------------------------------------
-int EllMat::from_csr(const fedm_csr &m, bool want_dinv) {
+int EllMat::from_csr(const fedm_csr &m, bool want_dinv, int l2s) {
     n_rows = m.n_rows;
     n_cols = m.n_cols;
-    n_slices = (n_rows + SLICE - 1) / SLICE;
-    n_rows_p = n_slices * SLICE;
+    n_rows_p = ((n_rows + SLICE - 1) / SLICE) * SLICE;
+    if (const char *e = std::getenv("FEDM_ELL_SPLIT")) l2s = std::atoi(e);
+    if (l2s < 0) {
+        const double avg = n_rows ? (double)m.indptr[n_rows] / n_rows : 0.0;
+        l2s = 0;
+        while (l2s < 4 && avg / (1 << l2s) > 6.0 && ((int64_t)n_rows << l2s) < (int64_t)1 << 20) ++l2s;
+    }
+    log2_split = l2s;
+    const int split = 1 << l2s;
+    const int64_t n_lr = (int64_t)n_rows * split;  // lane-rows
+    n_slices = (int)((n_lr + SLICE - 1) / SLICE);
+    auto len_of = [&](int64_t lr) -> int {
+        const int r = (int)(lr >> l2s), k = (int)(lr & (split - 1));
+        const int len = (int)(m.indptr[r + 1] - m.indptr[r]);
+        return (len - k + split - 1) / split;
+    };
     std::vector<int> boff_h(n_slices + 1, 0);
     for (int s = 0; s < n_slices; ++s) {
         int w = 0;
         for (int l = 0; l < SLICE; ++l) {
-            const int r = s * SLICE + l;
-            if (r < n_rows) w = std::max(w, (int)(m.indptr[r + 1] - m.indptr[r]));
+            const int64_t lr = (int64_t)s * SLICE + l;
+            if (lr < n_lr) w = std::max(w, len_of(lr));
         }
         boff_h[s + 1] = boff_h[s] + w;
     }
@@ -29,10 +44,11 @@ int EllMat::from_csr(const fedm_csr &m, bool want_dinv) {
     std::vector<double> dinv_h(n_rows_p, 1.0);
     for (int s = 0; s < n_slices; ++s)
         for (int l = 0; l < SLICE; ++l) {
-            const int r = s * SLICE + l;
-            if (r >= n_rows) continue;
+            const int64_t lr = (int64_t)s * SLICE + l;
+            if (lr >= n_lr) continue;
+            const int r = (int)(lr >> l2s), k0 = (int)(lr & (split - 1));
             int j = 0;
-            for (int64_t k = m.indptr[r]; k < m.indptr[r + 1]; ++k, ++j) {
+            for (int64_t k = m.indptr[r] + k0; k < m.indptr[r + 1]; k += split, ++j) {
                 const size_t slot = (size_t)(boff_h[s] + j) * SLICE + l;
                 if (m.indices[k] < 0 || m.indices[k] >= n_cols) return -2;
                 col_h[slot] = m.indices[k];
@@ -66,7 +82,8 @@ void EllMat::release() {
 // MODE 4: first sweep from a zero guess fused with the residual:
 //         x1 = omega*dinv*b (written to `aux`),  y = b - A x1   (x is unused)
 template <int MODE>
-__global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *__restrict__ boff,
+__global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows, int log2_split,
+                                                       const int *__restrict__ boff,
                                                        const int *__restrict__ col,
                                                        const double *__restrict__ val,
                                                        const double *__restrict__ dinv,
@@ -108,8 +125,11 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, const int *
         const int cc = col[k];
         a0 += val[k] * (MODE == 4 ? omega * dinv[cc] * b[cc] : x[cc]);
     }
-    const double acc = (a0 + a1) + (a2 + a3);
-    const size_t r = (size_t)slice * SLICE + lane;
+    double acc = (a0 + a1) + (a2 + a3);
+    for (int off = (1 << log2_split) >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane & ((1 << log2_split) - 1)) return;
+    const size_t r = ((size_t)slice * SLICE + lane) >> log2_split;
+    if (r >= (size_t)n_rows) return;
     if (MODE == 0) y[r] = acc;
     if (MODE == 1) y[r] = b[r] - acc;
     if (MODE == 2) y[r] = x[r] + omega * dinv[r] * (b[r] - acc);
@@ -124,11 +144,11 @@ static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const
                        double *y, double omega, double *aux = nullptr) {
     const dim3 g((A.n_slices + 3) / 4), bl(256);
     switch (mode) {
-        case 0: hipLaunchKernelGGL(ell_spmv_kernel<0>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        case 1: hipLaunchKernelGGL(ell_spmv_kernel<1>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        case 2: hipLaunchKernelGGL(ell_spmv_kernel<2>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        case 3: hipLaunchKernelGGL(ell_spmv_kernel<3>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        default: hipLaunchKernelGGL(ell_spmv_kernel<4>, g, bl, 0, c.stream, A.n_slices, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 0: hipLaunchKernelGGL(ell_spmv_kernel<0>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 1: hipLaunchKernelGGL(ell_spmv_kernel<1>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 2: hipLaunchKernelGGL(ell_spmv_kernel<2>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 3: hipLaunchKernelGGL(ell_spmv_kernel<3>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        default: hipLaunchKernelGGL(ell_spmv_kernel<4>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
     }
 }
 
@@ -143,14 +163,22 @@ __global__ void jacobi_first_kernel(int n, const double *__restrict__ dinv,
     if (i < n) x[i] = omega * dinv[i] * b[i];
 }
 
-// y = Minv b for the dense coarsest operator: one wave per row
+// y = Minv b for the dense coarsest operator (rows padded to ld = 256 k): one wave per row,
+// 16-byte loads, two independent partial sums
 __global__ __launch_bounds__(256) void dense_gemv_kernel(int n, int ld, const double *__restrict__ M,
                                                          const double *__restrict__ b, double *__restrict__ y) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
-    double s = 0.0;
-    for (int j = lane; j < n; j += 64) s += M[(size_t)row * ld + j] * b[j];
+    const double2 *Mr = reinterpret_cast<const double2 *>(M + (size_t)row * ld);
+    double s0 = 0.0, s1 = 0.0;
+    for (int j2 = lane; j2 * 2 < n; j2 += 64) {
+        const double2 m = Mr[j2];
+        const int j = j2 * 2;
+        s0 += m.x * b[j];
+        if (j + 1 < n) s1 += m.y * b[j + 1];
+    }
+    double s = s0 + s1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) y[row] = s;
@@ -163,11 +191,23 @@ void Amg::vcycle(Ctx &c, int l) {
     Level &L = levels[l];
     if (l == (int)levels.size() - 1) {
         hipLaunchKernelGGL(dense_gemv_kernel, dim3((n_coarse + 3) / 4), dim3(256), 0, c.stream,
-                           n_coarse, n_coarse, coarse_inv, L.b, L.x);
+                           n_coarse, coarse_ld, coarse_inv, L.b, L.x);
         return;
     }
     const int np = L.A.n_rows_p;
     double *x = L.x2, *y = L.x;  // x: current iterate, y: the other buffer
+    if (!pre_smooth) {
+        // V(0,nu): x = 0, so the residual is b itself and the correction is P x_c
+        ell_launch(c, L.R, 0, L.b, nullptr, levels[l + 1].b, 0.0);
+        vcycle(c, l + 1);
+        if (nu % 2 == 0) std::swap(x, y);                        // nu swaps must end in L.x
+        ell_launch(c, L.P, 0, levels[l + 1].x, nullptr, x, 0.0);
+        for (int s = 0; s < nu; ++s) {
+            ell_launch(c, L.A, 2, x, L.b, y, omega);
+            std::swap(x, y);
+        }
+        return;
+    }
     if (nu == 1) {
         ell_launch(c, L.A, 4, nullptr, L.b, L.r, omega, x);    // x = w Dinv b;  r = b - A x
     } else {
@@ -227,11 +267,11 @@ void Amg::release() {
 }
 
 // ---- field split -----------------------------------------------------------------------------
-// z_u = Duu^-1 t_u per vertex; b0 = t_phi
+// z_u = omega * Duu^-1 (alpha t_u) per vertex; b0 = alpha t_phi
 template <int NS>
 __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
                                   const double *__restrict__ t, double *__restrict__ z,
-                                  double *__restrict__ b0, double alpha) {
+                                  double *__restrict__ b0, double alpha, double omega) {
     constexpr int NEQ = NS + 1;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nvp) return;
@@ -245,22 +285,26 @@ __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
         double acc = 0.0;
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx) acc += dp[(size_t)(r * NS + cidx) * SLICE] * tv[cidx];
-        z[(size_t)v * NEQ + r] = acc;
+        z[(size_t)v * NEQ + r] = omega * acc;
     }
+    z[(size_t)v * NEQ + NS] = 0.0;
     b0[v] = tv[NS];
 }
 
 // one more damped block-Jacobi sweep on the species block:
-//   z_out_u = z_in_u + omega * Duu^-1 (t_u - J_uu z_in_u)       (reads the NS x NS value planes)
+//   z_out_u = z_in_u + omega * Duu^-1 (t_u - J_uu z_in_u)
+// The sweeps and the coupling product stream the species columns of the Jacobian from an fp32
+// copy (species_planes_kernel): half the bytes of the fp64 planes, and a preconditioner does not
+// need more than single precision in its matrix (vectors and accumulation stay fp64).
 // Block Jacobi alone leaves a mass-matrix-like operator with eigenvalues in ~[0.5, 2]; a few
 // damped sweeps cut the outer GMRES iterations from 8 to 5 per Newton step.
 template <int NS>
 __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
-    const double *__restrict__ val, const double *__restrict__ dinv_uu,
+    const float *__restrict__ val32, const double *__restrict__ dinv_uu,
     const double *__restrict__ t, const double *__restrict__ zin, double *__restrict__ zout,
     double alpha, double omega) {
-    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    constexpr int NEQ = NS + 1, PL = NEQ * NS;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
@@ -272,11 +316,12 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
         double zj[NS];
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx) zj[cidx] = zin[(size_t)col * NEQ + cidx];
-        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+        const float *vp = val32 + (size_t)bc * PL * SLICE + lane;
 #pragma unroll
         for (int r = 0; r < NS; ++r)
 #pragma unroll
-            for (int cidx = 0; cidx < NS; ++cidx) acc[r] += vp[(size_t)(r * NEQ + cidx) * SLICE] * zj[cidx];
+            for (int cidx = 0; cidx < NS; ++cidx)
+                acc[r] += (double)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
     }
     const size_t v = (size_t)slice * SLICE + lane;
     const double *dp = dinv_uu + (size_t)slice * NS * NS * SLICE + lane;
@@ -290,25 +335,26 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
         for (int cidx = 0; cidx < NS; ++cidx) d += dp[(size_t)(r * NS + cidx) * SLICE] * res[cidx];
         zout[v * NEQ + r] = zin[v * NEQ + r] + omega * d;
     }
+    zout[v * NEQ + NS] = 0.0;  // full-line stores; the potential entry is set by fs_scatter_kernel
 }
 
 // b0 -= J_phi,u z_u   (reads only the n_species value planes of the potential row)
 template <int NS>
 __global__ __launch_bounds__(256) void fs_coupling_kernel(int n_slices, const int *__restrict__ boff,
                                                           const int *__restrict__ colidx,
-                                                          const double *__restrict__ val,
+                                                          const float *__restrict__ val32,
                                                           const double *__restrict__ z,
                                                           double *__restrict__ b0) {
-    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    constexpr int NEQ = NS + 1, PL = NEQ * NS;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
     double acc = 0.0;
     for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
         const int col = colidx[(size_t)bc * SLICE + lane];
-        const double *vp = val + ((size_t)bc * NEQ2 + NS * NEQ) * SLICE + lane;
+        const float *vp = val32 + ((size_t)bc * PL + NS * NS) * SLICE + lane;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc += vp[(size_t)s * SLICE] * z[(size_t)col * NEQ + s];
+        for (int s = 0; s < NS; ++s) acc += (double)vp[(size_t)s * SLICE] * z[(size_t)col * NEQ + s];
     }
     b0[(size_t)slice * SLICE + lane] -= acc;
 }
@@ -382,33 +428,37 @@ __global__ void species_block_inverse_kernel(int nvp, const double *__restrict__
         dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = I[e / NS][e % NS];
 }
 
-__global__ void gather_comp_scaled_kernel(int nvp, int neq, int comp, const double *__restrict__ t,
-                                         double *__restrict__ b0, double alpha) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < nvp) b0[v] = alpha * t[(size_t)v * neq + comp];
+// the species iterate ping-pongs between z and the scratch vector; it starts where it ends in z
+static double *fs_first_target(Ctx &c, double *z) {
+    const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
+    return (sweeps % 2 == 1) ? z : c.d_fs;
+}
+
+// stages after the first: remaining species sweeps, coupling, V-cycle on the potential block
+template <int NS>
+static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+    const dim3 gv((c.nvp + 255) / 256), bv(256);
+    const dim3 gs((c.pat.n_slices + 3) / 4);
+    const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
+    double *a = fs_first_target(c, z), *b = (a == z) ? c.d_fs : z;
+    for (int s = 1; s < sweeps; ++s) {
+        hipLaunchKernelGGL(fs_species_sweep_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
+                           c.d_slice_boff, c.d_colidx, c.d_val32, c.d_dinv, t, a, b, alpha, c.fs_w[s]);
+        std::swap(a, b);
+    }
+    hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
+                       c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
+    amg.run(c);
+    hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
 }
 
 template <int NS>
 static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
-    const dim3 gs((c.pat.n_slices + 3) / 4);
-    Amg::Level &L0 = amg.levels[0];
-    const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
-    const double omega = sweeps > 1 ? c.fs_w[0] : 1.0;
-    // the iterate ping-pongs between z and the scratch vector; start so that it ends in z
-    double *a = (sweeps % 2 == 1) ? z : c.d_fs, *b = (sweeps % 2 == 1) ? c.d_fs : z;
-    hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, a, L0.b, alpha * omega);
-    if (sweeps > 1)  // fs_species_kernel scaled b0 by omega as well: undo (b0 = alpha * t_phi)
-        hipLaunchKernelGGL(gather_comp_scaled_kernel, gv, bv, 0, c.stream, c.nvp, c.neq, c.neq - 1, t, L0.b, alpha);
-    for (int s = 1; s < sweeps; ++s) {
-        hipLaunchKernelGGL(fs_species_sweep_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
-                           c.d_slice_boff, c.d_colidx, c.d_val, c.d_dinv, t, a, b, alpha, c.fs_w[s]);
-        std::swap(a, b);
-    }
-    hipLaunchKernelGGL(fs_coupling_kernel<NS>, dim3((c.pat.n_slices + 3) / 4), dim3(256), 0, c.stream,
-                       c.pat.n_slices, c.d_slice_boff, c.d_colidx, c.d_val, z, L0.b);
-    amg.run(c);
-    hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
+    const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
+    hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
+                       amg.levels[0].b, alpha, omega);
+    fs_finish_t<NS>(c, amg, t, z, alpha);
 }
 
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
@@ -421,8 +471,54 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
     }
 }
 
+// z = Minv (J v): the SpMV's epilogue is the first stage (t = J v is kept for the sweeps)
+void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z) {
+    const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
+    prof_begin(c, 1);
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, omega);
+    prof_end(c);
+    switch (c.ns) {
+        case 1: fs_finish_t<1>(c, amg, t, z, 1.0); break;
+        case 2: fs_finish_t<2>(c, amg, t, z, 1.0); break;
+        case 3: fs_finish_t<3>(c, amg, t, z, 1.0); break;
+        case 4: fs_finish_t<4>(c, amg, t, z, 1.0); break;
+        case 5: fs_finish_t<5>(c, amg, t, z, 1.0); break;
+    }
+}
+
+// fp32 copy of the species columns of every block (all NEQ rows x NS columns)
+template <int NS>
+__global__ __launch_bounds__(256) void species_planes_kernel(size_t n_entries, const double *__restrict__ val,
+                                                             float *__restrict__ val32) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, PL = NEQ * NS;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // bc * 64 + lane
+    if (e >= n_entries) return;
+    const size_t bc = e >> 6, lane = e & 63;
+    const double *vp = val + bc * NEQ2 * SLICE + lane;
+    float *op = val32 + bc * PL * SLICE + lane;
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r)
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx)
+            op[(size_t)(r * NS + cidx) * SLICE] = (float)vp[(size_t)(r * NEQ + cidx) * SLICE];
+}
+
 void fieldsplit_setup(Ctx &c) {
     const dim3 g((c.nvp + 255) / 256), b(256);
+    const size_t n_entries = (size_t)c.pat.total_bc * SLICE;
+    if (!c.d_val32 && hipMalloc((void **)&c.d_val32, sizeof(float) * n_entries * c.neq * c.ns) != hipSuccess) {
+        set_error("hipMalloc of the fp32 species planes failed");
+        c.d_val32 = nullptr;
+        return;
+    }
+    const dim3 ge((unsigned)((n_entries + 255) / 256));
+    switch (c.ns) {
+        case 1: hipLaunchKernelGGL(species_planes_kernel<1>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
+        case 2: hipLaunchKernelGGL(species_planes_kernel<2>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
+        case 3: hipLaunchKernelGGL(species_planes_kernel<3>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
+        case 4: hipLaunchKernelGGL(species_planes_kernel<4>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
+        case 5: hipLaunchKernelGGL(species_planes_kernel<5>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
+    }
     switch (c.ns) {
         case 1: hipLaunchKernelGGL(species_block_inverse_kernel<1>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
         case 2: hipLaunchKernelGGL(species_block_inverse_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;

@@ -6,12 +6,16 @@
 
 namespace fedm {
 
-struct EllMat {  // scalar sliced-ELL, 64 rows per slice
-    int n_rows = 0, n_rows_p = 0, n_cols = 0, n_slices = 0;
+// Scalar sliced-ELL, 64 lanes per slice.  Long rows of small matrices (restrictions, coarse
+// operators) are split over `split` = 2^log2_split adjacent lanes (entry e of row r belongs to
+// lane-row r*split + e % split) and summed with lane shuffles: more waves, shorter dependent
+// gather chains -- the coarse levels are latency-bound, not bandwidth-bound.
+struct EllMat {
+    int n_rows = 0, n_rows_p = 0, n_cols = 0, n_slices = 0, log2_split = 0;
     int64_t total_bc = 0;
     int *boff = nullptr, *col = nullptr;
     double *val = nullptr, *dinv = nullptr;
-    int from_csr(const fedm_csr &m, bool want_dinv);
+    int from_csr(const fedm_csr &m, bool want_dinv, int log2_split = -1);  // -1: choose
     void release();
 };
 
@@ -21,9 +25,10 @@ struct Amg {
         double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
     };
     std::vector<Level> levels;
-    double *coarse_inv = nullptr;
-    int n_coarse = 0;
+    double *coarse_inv = nullptr;  // dense inverse of the coarsest operator, rows padded to ld
+    int n_coarse = 0, coarse_ld = 0;
     int nu = 2;
+    bool pre_smooth = true;  // false: V(0,nu) cycles (restrict the right-hand side directly)
     double omega = 0.67;
     hipGraphExec_t graph_exec = nullptr;
     void vcycle(Ctx &c, int level);  // levels[level].b -> levels[level].x (kernel launches)
@@ -37,6 +42,7 @@ void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double 
                double omega, double *aux = nullptr);
 void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha);  // z = alpha*Minv t
+void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z);  // z = Minv (J v)
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z);
 
 }  // namespace fedm

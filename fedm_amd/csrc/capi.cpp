@@ -36,6 +36,9 @@ void prof_collect(Ctx &c) {
 void prof_begin(Ctx &c, int kind) {
     Prof &p = c.prof;
     if (!p.on) return;
+    // events cost a few microseconds of stream time each: short, frequent kernels are sampled
+    p.recording = (p.seen[kind]++ % p.stride[kind]) == 0;
+    if (!p.recording) return;
     if (p.used + 2 > (int)p.ev.size()) prof_collect(c);
     p.kind[p.used / 2] = kind;
     hipEventRecord(p.ev[p.used], c.stream);
@@ -43,9 +46,10 @@ void prof_begin(Ctx &c, int kind) {
 
 void prof_end(Ctx &c) {
     Prof &p = c.prof;
-    if (!p.on) return;
+    if (!p.on || !p.recording) return;
     hipEventRecord(p.ev[p.used + 1], c.stream);
     p.used += 2;
+    p.recording = false;
 }
 
 template <class T>
@@ -93,10 +97,7 @@ static int ensure_krylov(Ctx &c, int restart) {
 static void apply_operator(Ctx &c, const double *v, double *w) {
     comm_halo(c, const_cast<double *>(v));  // ghost inputs from their owners (multi-GPU)
     if (c.amg && c.poisson) {
-        prof_begin(c, 1);
-        launch_spmv(c, v, c.d_tmp, false);
-        prof_end(c);
-        fieldsplit_apply(c, *c.amg, c.d_tmp, w, 1.0);
+        fieldsplit_apply_operator(c, *c.amg, v, c.d_tmp, w);
     } else {
         prof_begin(c, 1);
         launch_spmv(c, v, w, true);
@@ -174,7 +175,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             dotp[j + 1] = w;
             launch_dots(c, dotp.data(), w, j + 2, true);
             launch_cgs_update(c, j + 1, vp.data(), w);
-            read_red(c, RED_K);
+            wait_red(c);  // published by the finish kernel: the host works while the update runs
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = c.h_red[i];
             double hn2 = c.h_red[j + 1];
             const double ww = c.h_red[RED_K - 2];
@@ -496,7 +497,8 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (alloc_zero(*v, (size_t)c.np, c.stream)) return -1;
     if (alloc_zero(c.d_partials, (size_t)RED_BLOCKS * RED_K, c.stream)) return -1;
     if (alloc_zero(c.d_red, RED_K, c.stream)) return -1;
-    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_red, sizeof(double) * RED_K));
+    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_red, sizeof(double) * (RED_K + 1), hipHostMallocDefault));
+    std::memset(c.h_red, 0, sizeof(double) * (RED_K + 1));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_stage, sizeof(double) * (size_t)c.np));
     for (int s = 0; model && s < c.ns; ++s)
         if (model->ext_nodes[s] > 0)
@@ -530,6 +532,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     gd_prep_release(c);
     for (auto &e : c.prof.ev) hipEventDestroy(e);
     if (c.h_red) hipHostFree(c.h_red);
+    if (c.d_val32) hipFree(c.d_val32);
     if (c.h_stage) hipHostFree(c.h_stage);
     if (c.stream) hipStreamDestroy(c.stream);
     delete h;
@@ -923,6 +926,7 @@ int fedm_profile(fedm_ctx *h, int enable) {
         for (int k = 0; k < 8; ++k) {
             p.ms[k] = 0.0;
             p.cnt[k] = 0;
+            p.seen[k] = 0;
         }
     return 0;
 }
@@ -931,8 +935,11 @@ int fedm_profile_read(fedm_ctx *h, int kind, double *ms_total, int64_t *count) {
     Ctx &c = h->c;
     if (kind < 0 || kind >= 8) return -2;
     prof_collect(c);
-    if (ms_total) *ms_total = c.prof.ms[kind];
-    if (count) *count = c.prof.cnt[kind];
+    // kinds that are sampled (Prof::stride) report the sampled mean times the launches seen
+    const Prof &p = c.prof;
+    const double mean = p.cnt[kind] ? p.ms[kind] / (double)p.cnt[kind] : 0.0;
+    if (ms_total) *ms_total = mean * (double)p.seen[kind];
+    if (count) *count = p.seen[kind];
     return 0;
 }
 
@@ -1038,7 +1045,7 @@ int fedm_amg_clear(fedm_ctx *h) {
 int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr *P,
                    const fedm_csr *R, const double *coarse_inverse, int nu, double omega) {
     Ctx &c = h->c;
-    if (n_levels < 1 || !A || !coarse_inverse || (n_levels > 1 && (!P || !R)) || nu < 1) {
+    if (n_levels < 1 || !A || !coarse_inverse || (n_levels > 1 && (!P || !R)) || nu == 0) {
         set_error("bad multigrid description");
         return -2;
     }
@@ -1055,7 +1062,8 @@ int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr 
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     fedm_amg_clear(h);
     Amg *amg = new Amg();
-    amg->nu = nu;
+    amg->nu = nu < 0 ? -nu : nu;  // nu < 0 selects V(0,|nu|) cycles
+    amg->pre_smooth = nu > 0;
     amg->omega = omega;
     amg->levels.resize(n_levels);
     for (int l = 0; l < n_levels; ++l) {
@@ -1082,9 +1090,15 @@ int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr 
         }
     }
     amg->n_coarse = A[n_levels - 1].n_rows;
-    const size_t nc2 = (size_t)amg->n_coarse * amg->n_coarse;
-    FEDM_HIP_CHECK(hipMalloc((void **)&amg->coarse_inv, sizeof(double) * nc2));
-    FEDM_HIP_CHECK(hipMemcpy(amg->coarse_inv, coarse_inverse, sizeof(double) * nc2, hipMemcpyHostToDevice));
+    amg->coarse_ld = ((amg->n_coarse + 255) / 256) * 256;
+    {
+        std::vector<double> inv32((size_t)amg->n_coarse * amg->coarse_ld, 0.f);
+        for (int i = 0; i < amg->n_coarse; ++i)
+            for (int j = 0; j < amg->n_coarse; ++j)
+                inv32[(size_t)i * amg->coarse_ld + j] = coarse_inverse[(size_t)i * amg->n_coarse + j];
+        FEDM_HIP_CHECK(hipMalloc((void **)&amg->coarse_inv, sizeof(double) * inv32.size()));
+        FEDM_HIP_CHECK(hipMemcpy(amg->coarse_inv, inv32.data(), sizeof(double) * inv32.size(), hipMemcpyHostToDevice));
+    }
     c.amg = amg;
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     if (amg->capture(c) != 0) {

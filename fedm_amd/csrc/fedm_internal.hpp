@@ -59,6 +59,9 @@ struct GdPrep;
 // kinds: 0 assembly F+J, 1 Jacobian SpMV, 2 assembly F only, 3 multigrid V-cycle
 struct Prof {
     bool on = false;
+    bool recording = false;                        // between prof_begin and prof_end
+    int stride[8] = {1, 4, 1, 4, 1, 1, 1, 1};      // sample every n-th launch of a kind
+    long seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> ev;
     std::vector<int> kind;
     int used = 0;
@@ -106,6 +109,8 @@ struct Ctx {
     uint32_t *d_diag_slot = nullptr;
     double *d_val = nullptr;
     double *d_dinv = nullptr;  // sliced: [(slice*NEQ2 + e)*64 + lane]
+    float *d_val32 = nullptr;  // species columns of every block in fp32 for the field-split
+                               // sweeps: [(bc*NEQ*NS + r*NS + c)*64 + lane]
     // Dirichlet
     int n_dir = 0;
     int *d_dir_dofs = nullptr;
@@ -120,7 +125,9 @@ struct Ctx {
     // reductions
     double *d_partials = nullptr;  // [RED_BLOCKS][RED_K]
     double *d_red = nullptr;       // [RED_K]
-    double *h_red = nullptr;       // pinned
+    double *h_red = nullptr;       // pinned, host-mapped: [RED_K] values + sequence tag, written
+                                   // by the last kernel of a reduction and polled by the host
+    unsigned long long mail_seq = 0;
     double *h_stage = nullptr;     // pinned staging, np doubles
 };
 
@@ -140,6 +147,7 @@ size_t patch_lds_bytes(const Ctx &c);
 void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks
 void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv);
+void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
 void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y);
@@ -150,7 +158,8 @@ void launch_multi_axpy(Ctx &c, const double *coef_host, int k, const double *con
                        double *y, double sign);                             // y += sign*sum c_i x_i
 void launch_field_error(Ctx &c, int comp);  // d_red[0]=|new-old+eps|^2, d_red[1]=|old+eps|^2
 void launch_set_dirichlet_state(Ctx &c);    // u[dof] = g
-void read_red(Ctx &c, int k);               // d_red -> h_red, synchronises the stream
+void read_red(Ctx &c, int k);               // publish d_red[0..k) to h_red and wait for it
+void wait_red(Ctx &c);                      // wait for the publication launch_dots(finish) queued
 
 #define FEDM_HIP_CHECK(expr)                                                          \
     do {                                                                              \

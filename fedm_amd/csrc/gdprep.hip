@@ -195,7 +195,7 @@ int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab
                   const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs) {
     gd_prep_release(c);
     GdPrep *g = new GdPrep();
-    if (g->M.from_csr(*mass, true)) {
+    if (g->M.from_csr(*mass, true, 0)) {
         set_error("mass matrix upload failed");
         delete g;
         return -1;

@@ -1,6 +1,9 @@
 // HIP kernels (gfx950) of the FEDM hot path: coloured element assembly into the sliced
 // block-ELL Jacobian, Dirichlet rows, block-Jacobi inverse, SpMV and the vector kernels
 // that GMRES / Newton need.  All of it is fp64 and HBM-bound; no MFMA.
+#include <chrono>
+#include <cmath>
+
 #include "comm.hpp"
 #include "element.hpp"
 #include "fedm_internal.hpp"
@@ -465,14 +468,16 @@ void launch_block_inverse(Ctx &c) {
 // Matrix values and column indices stream in coalesced (lanes contiguous); x is gathered per
 // neighbour (n_eq contiguous doubles).  Optional fused block-Jacobi scaling y = Dinv (A x).
 // =============================================================================================
-template <int NEQ>
+template <int NEQ, bool FS>
 __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
                                                    const int *__restrict__ boff,
                                                    const int *__restrict__ colidx,
                                                    const double *__restrict__ val,
                                                    const double *__restrict__ x,
                                                    double *__restrict__ y,
-                                                   const double *__restrict__ dinv) {
+                                                   const double *__restrict__ dinv,
+                                                   double *__restrict__ fs_z, double *__restrict__ fs_b0,
+                                                   double fs_scale) {
     constexpr int NEQ2 = NEQ * NEQ;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -497,7 +502,23 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
 #pragma unroll
         for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
     }
-    if (dinv) {
+    if (FS) {
+        // first stage of the field-split preconditioner in the epilogue (amg.hip):
+        // t = A x is kept, z_u = fs_scale * Duu^-1 t_u starts the species sweeps, b0 = t_phi
+        constexpr int NS = NEQ - 1;
+        const double *dp = dinv + (size_t)slice * NS * NS * SLICE + lane;
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) y[vtx * NEQ + r] = acc[r];
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            double z = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NS; ++cc) z += dp[(size_t)(r * NS + cc) * SLICE] * acc[cc];
+            fs_z[vtx * NEQ + r] = fs_scale * z;
+        }
+        fs_z[vtx * NEQ + NS] = 0.0;  // whole lines are written; the V-cycle result lands here later
+        fs_b0[vtx] = acc[NS];
+    } else if (dinv) {
         const double *dp = dinv + (size_t)slice * NEQ2 * SLICE + lane;
 #pragma unroll
         for (int r = 0; r < NEQ; ++r) {
@@ -516,14 +537,35 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv) {
     const int n = c.pat.n_slices;
     const dim3 g((n + 3) / 4), b(256);
     const double *dinv = scale_dinv ? c.d_dinv : nullptr;
+#define FEDM_SPMV(NEQ)                                                                             \
+    hipLaunchKernelGGL((spmv_kernel<NEQ, false>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
+                       c.d_colidx, c.d_val, x, y, dinv, (double *)nullptr, (double *)nullptr, 0.0)
     switch (c.neq) {
-        case 1: hipLaunchKernelGGL(spmv_kernel<1>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 2: hipLaunchKernelGGL(spmv_kernel<2>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 3: hipLaunchKernelGGL(spmv_kernel<3>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 4: hipLaunchKernelGGL(spmv_kernel<4>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 5: hipLaunchKernelGGL(spmv_kernel<5>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
-        case 6: hipLaunchKernelGGL(spmv_kernel<6>, g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, c.d_val, x, y, dinv); break;
+        case 1: FEDM_SPMV(1); break;
+        case 2: FEDM_SPMV(2); break;
+        case 3: FEDM_SPMV(3); break;
+        case 4: FEDM_SPMV(4); break;
+        case 5: FEDM_SPMV(5); break;
+        case 6: FEDM_SPMV(6); break;
     }
+#undef FEDM_SPMV
+}
+
+// t = A x together with the first field-split stage (c.d_dinv holds the species-block inverses)
+void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale) {
+    const int n = c.pat.n_slices;
+    const dim3 g((n + 3) / 4), b(256);
+#define FEDM_SPMV(NEQ)                                                                            \
+    hipLaunchKernelGGL((spmv_kernel<NEQ, true>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
+                       c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale)
+    switch (c.neq) {
+        case 2: FEDM_SPMV(2); break;
+        case 3: FEDM_SPMV(3); break;
+        case 4: FEDM_SPMV(4); break;
+        case 5: FEDM_SPMV(5); break;
+        case 6: FEDM_SPMV(6); break;
+    }
+#undef FEDM_SPMV
 }
 
 // y = alpha * Dinv x
@@ -620,15 +662,36 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partials, int 
 // |w - sum h_i v_i|^2 = ww - sum h_i^2 (Pythagoras; V orthonormal).
 // out[k-1] <- that squared norm, out[RED_K-2] <- ww, out[RED_K-1] <- scale for the update
 // (1/norm, or 1 when cancellation is too strong to trust the formula -> host refines).
-__global__ void cgs_finish_kernel(int k, double *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double ww = out[k - 1];
-    double hh = 0.0;
-    for (int i = 0; i < k - 1; ++i) hh += out[i] * out[i];
-    const double hn2 = ww - hh;
-    out[RED_K - 2] = ww;
-    out[k - 1] = hn2;
-    out[RED_K - 1] = (hn2 > 1e-8 * ww && hn2 > 0.0) ? 1.0 / sqrt(hn2) : 1.0;
+// Results go to the host through a mailbox in host-mapped pinned memory: values, a system-scope
+// fence, then the sequence tag the host polls (wait_red) -- no copy kernel, no stream
+// synchronisation, and the host can queue the next iteration while this one finishes.
+__device__ __forceinline__ void publish(const double *__restrict__ red, int k, double *mail,
+                                        unsigned long long seq) {
+    for (int i = threadIdx.x; i < k; i += 64) mail[i] = red[i];
+    __threadfence_system();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + RED_K), seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(64) void publish_kernel(const double *__restrict__ red, int k, double *mail,
+                                                     unsigned long long seq) {
+    publish(red, k, mail, seq);
+}
+
+__global__ __launch_bounds__(64) void cgs_finish_kernel(int k, double *__restrict__ out, double *mail,
+                                                        unsigned long long seq) {
+    if (threadIdx.x == 0) {
+        const double ww = out[k - 1];
+        double hh = 0.0;
+        for (int i = 0; i < k - 1; ++i) hh += out[i] * out[i];
+        const double hn2 = ww - hh;
+        out[RED_K - 2] = ww;
+        out[k - 1] = hn2;
+        out[RED_K - 1] = (hn2 > 1e-8 * ww && hn2 > 0.0) ? 1.0 / sqrt(hn2) : 1.0;
+    }
+    __syncthreads();
+    publish(out, RED_K, mail, seq);
 }
 
 template <int K, bool FINAL>
@@ -674,7 +737,9 @@ void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool f
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
     comm_allreduce(c, c.d_red, k);
-    if (finish) hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red);
+    if (finish)
+        hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red, c.h_red,
+                           ++c.mail_seq);
 }
 
 // y = (y - sum_i d_red[i] xs[i]) * d_red[RED_K-1], coefficients stay on the device
@@ -722,9 +787,30 @@ void launch_norm2(Ctx &c, const double *x, int slot) {
     comm_allreduce(c, c.d_red + slot, 1);
 }
 
+void wait_red(Ctx &c) {
+    const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(c.h_red + RED_K);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == c.mail_seq) return;
+        __builtin_ia32_pause();
+        if ((spins & 0xffff) == 0xffff) {
+            // a faulted or lost queue never publishes: fall back to the runtime's own wait
+            const bool failed = hipStreamQuery(c.stream) != hipErrorNotReady &&
+                                __atomic_load_n(tag, __ATOMIC_ACQUIRE) != c.mail_seq;
+            const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120);
+            if (failed || late) {
+                hipStreamSynchronize(c.stream);
+                if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != c.mail_seq)
+                    for (int i = 0; i < RED_K; ++i) c.h_red[i] = std::nan("");
+                return;
+            }
+        }
+    }
+}
+
 void read_red(Ctx &c, int k) {
-    hipMemcpyAsync(c.h_red, c.d_red, sizeof(double) * k, hipMemcpyDeviceToHost, c.stream);
-    hipStreamSynchronize(c.stream);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_red, ++c.mail_seq);
+    wait_red(c);
 }
 
 // =============================================================================================

@@ -243,7 +243,8 @@ int fedm_block_csr(fedm_ctx *ctx, int cr, int cc, int64_t *indptr, int32_t *indi
 int fedm_jacobian_poisson_only(fedm_ctx *ctx);
 /* install a multigrid hierarchy for the potential block: n_levels operators A[l]
  * (A[0] = fine), n_levels-1 prolongators P[l] (rows of level l, cols of level l+1) and
- * their transposes R[l]; dense inverse of the coarsest operator; nu damped-Jacobi sweeps. */
+ * their transposes R[l]; dense inverse of the coarsest operator; V(nu,nu) cycles with damped
+ * Jacobi smoothing, nu < 0 selects V(0,|nu|) (no pre-smoothing). */
 int fedm_amg_setup(fedm_ctx *ctx, int n_levels, const fedm_csr *A, const fedm_csr *P,
                    const fedm_csr *R, const double *coarse_inverse, int nu, double omega);
 int fedm_amg_clear(fedm_ctx *ctx);
@@ -282,7 +283,8 @@ int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
  * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only.  ms per launch. */
 int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
 /* in-run kernel timing with HIP events on the library's stream.  kind: 0 = assembly F+J,
- * 1 = Jacobian SpMV, 2 = assembly F only, 3 = multigrid V-cycle (whole graph) */
+ * 1 = Jacobian SpMV, 2 = assembly F only, 3 = multigrid V-cycle (whole graph).  Kinds 1 and 3
+ * are sampled (every 4th launch carries events; totals are the sampled mean x launches). */
 int fedm_profile(fedm_ctx *ctx, int enable);
 int fedm_profile_read(fedm_ctx *ctx, int kind, double *ms_total, int64_t *count);
 /* assembly kernel: 0 = global graph colouring (bitwise reproducible), 1 = LDS patches
