@@ -39,9 +39,13 @@ def parse_args():
 def spmv_bytes(sz):
     """Algorithmic bytes of one SpMV in the sliced block-ELL layout:
     every structural block once (n_eq^2 values + one column index), x read once,
-    y written once, one slice offset per 64 vertices."""
+    y written once, one slice offset per 64 vertices; plus the field-split epilogue:
+    species-block inverse read, first species iterate (n_eq per vertex, whole lines) and the
+    potential right-hand side written."""
     neq, nnzb, nv = sz["n_eq"], sz["nnz_blocks"], sz["n_vertices"]
-    return nnzb * (neq * neq * 8 + 4) + nv * neq * 16 + (nv // 64 + 1) * 4
+    ns = neq - 1
+    return (nnzb * (neq * neq * 8 + 4) + nv * neq * 16 + (nv // 64 + 1) * 4
+            + nv * (ns * ns * 8 + neq * 8 + 8))
 
 
 def assembly_bytes(sz):
@@ -129,7 +133,7 @@ def main():
     for _ in range(args.warmup):
         runner.step()
 
-    runner.profile(True)          # HIP events around the hot kernels, on the library's stream
+    runner.profile(1)             # HIP events around the assembly kernel, on the library's stream
     barrier()
     t0 = time.perf_counter()
     n0 = (runner.newton_iterations, runner.linear_iterations)
@@ -137,7 +141,19 @@ def main():
         runner.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    n1 = (runner.newton_iterations, runner.linear_iterations)
     prof = runner.profile_read()
+    # Second, untimed pass for the kernels inside the Krylov iterations: timing them needs plain
+    # launches (HIP events cannot sit inside the replayed per-iteration graphs).
+    pass_steps = max(1, min(args.steps, 5))
+    runner.profile(2)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(pass_steps):
+        runner.step()
+    barrier()
+    elapsed2 = time.perf_counter() - t1
+    prof2 = runner.profile_read()
     runner.profile(False)
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -148,17 +164,20 @@ def main():
     sz = runner.sizes()
     # average launch duration of the hot kernels inside the timed region
     ms_asm = prof["assembly_FJ"][0] / max(prof["assembly_FJ"][1], 1)
-    ms_spmv = prof["spmv"][0] / max(prof["spmv"][1], 1)
+    ms_spmv = prof2["spmv"][0] / max(prof2["spmv"][1], 1)
     ms_res = prof["assembly_F"][0] / max(prof["assembly_F"][1], 1)
     b_spmv, b_asm = spmv_bytes(sz), assembly_bytes(sz)
     gbs_spmv = b_spmv / (ms_spmv * 1e-3) / 1e9
     gbs_asm = b_asm / (ms_asm * 1e-3) / 1e9
     share = {k: v[0] / (elapsed * 1e3) for k, v in prof.items()}
-    rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3> (Jacobian SpMV, sliced block-ELL)",
+    share2 = {k: v[0] / (elapsed2 * 1e3) for k, v in prof2.items()}
+    second_pass = (f"separate profiling pass of {pass_steps} steps right after the timed region, "
+                   f"kernels launched one by one ({1e3 * elapsed2 / pass_steps:.2f} ms/step)")
+    rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3,true> (Jacobian SpMV, sliced block-ELL, field-split epilogue)",
                "achieved": gbs_spmv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": gbs_spmv / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": b_spmv,
-               "ms_per_launch": ms_spmv, "launches": prof["spmv"][1],
-               "share_of_timed_region": share["spmv"]}
+               "ms_per_launch": ms_spmv, "launches": prof2["spmv"][1],
+               "share_of_profiling_pass": share2["spmv"], "measured": second_pass}
     rl_asm = {"bound": "hbm", "kernel": runner.assembly_kernel_name,
               "achieved": gbs_asm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": gbs_asm / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": b_asm,
@@ -167,7 +186,7 @@ def main():
     tr = pmc_traffic() if (world == 1 and n == 576) else {}
     rl_spmv["traffic"] = tr.get("spmv")
     rl_asm["traffic"] = next((v for k, v in tr.items() if "assemble_patch" in k), None)
-    dominant, other = (rl_asm, rl_spmv) if share["assembly_FJ"] >= share["spmv"] else (rl_spmv, rl_asm)
+    dominant, other = rl_asm, rl_spmv   # the assembly kernel is timed inside the timed region
 
     out = {
         "metric": "BDF2 DOF-updates/sec (streamer_discharge 2D axisym)",
@@ -185,13 +204,13 @@ def main():
                    "dofs_total": total_dofs, "vertices_per_gpu": sz["n_vertices"],
                    "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": "restart 30, rtol 1e-5, "
                    "field split: Chebyshev(4) block Jacobi on species + multigrid V(1,1) on the potential", "partition": runner.partition_name},
-        "newton_iterations_per_step": (runner.newton_iterations - n0[0]) / args.steps,
-        "gmres_iterations_per_step": (runner.linear_iterations - n0[1]) / args.steps,
+        "newton_iterations_per_step": (n1[0] - n0[0]) / args.steps,
+        "gmres_iterations_per_step": (n1[1] - n0[1]) / args.steps,
         "roofline": dominant,
         "roofline_other": other,
-        "vcycle": {"ms_per_cycle": prof["vcycle"][0] / max(prof["vcycle"][1], 1),
-                   "cycles": prof["vcycle"][1], "share_of_timed_region": share["vcycle"],
-                   "levels": runner.multigrid_levels},
+        "vcycle": {"ms_per_cycle": prof2["vcycle"][0] / max(prof2["vcycle"][1], 1),
+                   "cycles": prof2["vcycle"][1], "share_of_profiling_pass": share2["vcycle"],
+                   "levels": runner.multigrid_levels, "measured": second_pass},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_mesh, args.cpu_steps)

@@ -38,6 +38,18 @@ int EllMat::from_csr(const fedm_csr &m, bool want_dinv, int l2s) {
         }
         boff_h[s + 1] = boff_h[s] + w;
     }
+    // uniform width (no offset lookup in the kernels) when padding to the widest slice costs
+    // little: <= 25 % more entries, or a matrix so small that only latency matters
+    {
+        int wmax = 0;
+        for (int s = 0; s < n_slices; ++s) wmax = std::max(wmax, boff_h[s + 1] - boff_h[s]);
+        const int64_t uniform = (int64_t)wmax * n_slices;
+        width = 0;
+        if (uniform <= boff_h[n_slices] + boff_h[n_slices] / 4 || uniform * SLICE <= (int64_t)1 << 20) {
+            width = std::max(wmax, 1);
+            for (int s = 0; s <= n_slices; ++s) boff_h[s] = s * width;
+        }
+    }
     total_bc = boff_h[n_slices];
     std::vector<int> col_h((size_t)total_bc * SLICE, 0);
     std::vector<double> val_h((size_t)total_bc * SLICE, 0.0);
@@ -81,8 +93,12 @@ void EllMat::release() {
 // MODE 0: y = A x      1: y = b - A x      2: y = x + omega*dinv*(b - A x)     3: y += A x
 // MODE 4: first sweep from a zero guess fused with the residual:
 //         x1 = omega*dinv*b (written to `aux`),  y = b - A x1   (x is unused)
+// These kernels move little data; their duration is a chain of dependent memory round trips
+// (~1 us each).  So: no slice-offset lookup when the matrix has a uniform width (`width` > 0),
+// the row's own operands (b, dinv, x, y of the epilogue) are requested before the gather loop,
+// and four independent gather chains are in flight.
 template <int MODE>
-__global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows, int log2_split,
+__global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows, int log2_split, int width,
                                                        const int *__restrict__ boff,
                                                        const int *__restrict__ col,
                                                        const double *__restrict__ val,
@@ -94,9 +110,17 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
-    // four independent gather chains in flight: coarse levels have few waves and long rows,
-    // so the loop is latency-bound unless the loads of several entries overlap
-    const int b0 = boff[slice], b1 = boff[slice + 1];
+    const int b0 = width > 0 ? slice * width : boff[slice];
+    const int b1 = width > 0 ? b0 + width : boff[slice + 1];
+    const size_t r = ((size_t)slice * SLICE + lane) >> log2_split;
+    const bool writer = (lane & ((1 << log2_split) - 1)) == 0 && r < (size_t)n_rows;
+    double e_b = 0.0, e_d = 0.0, e_x = 0.0;  // epilogue operands of this row, loaded up front
+    if (writer) {
+        if (MODE == 1 || MODE == 2 || MODE == 4) e_b = b[r];
+        if (MODE == 2 || MODE == 4) e_d = dinv[r];
+        if (MODE == 2) e_x = x[r];
+        if (MODE == 3) e_x = y[r];
+    }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int bc = b0;
     for (; bc + 4 <= b1; bc += 4) {
@@ -127,29 +151,31 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
     }
     double acc = (a0 + a1) + (a2 + a3);
     for (int off = (1 << log2_split) >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane & ((1 << log2_split) - 1)) return;
-    const size_t r = ((size_t)slice * SLICE + lane) >> log2_split;
-    if (r >= (size_t)n_rows) return;
+    if (!writer) return;
     if (MODE == 0) y[r] = acc;
-    if (MODE == 1) y[r] = b[r] - acc;
-    if (MODE == 2) y[r] = x[r] + omega * dinv[r] * (b[r] - acc);
-    if (MODE == 3) y[r] += acc;
+    if (MODE == 1) y[r] = e_b - acc;
+    if (MODE == 2) y[r] = e_x + omega * e_d * (e_b - acc);
+    if (MODE == 3) y[r] = e_x + acc;
     if (MODE == 4) {
-        y[r] = b[r] - acc;
-        aux[r] = omega * dinv[r] * b[r];
+        y[r] = e_b - acc;
+        aux[r] = omega * e_d * e_b;
     }
 }
 
 static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const double *b,
                        double *y, double omega, double *aux = nullptr) {
     const dim3 g((A.n_slices + 3) / 4), bl(256);
+#define FEDM_ELL(M)                                                                                  \
+    hipLaunchKernelGGL(ell_spmv_kernel<M>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split,   \
+                       A.width, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux)
     switch (mode) {
-        case 0: hipLaunchKernelGGL(ell_spmv_kernel<0>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        case 1: hipLaunchKernelGGL(ell_spmv_kernel<1>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        case 2: hipLaunchKernelGGL(ell_spmv_kernel<2>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        case 3: hipLaunchKernelGGL(ell_spmv_kernel<3>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
-        default: hipLaunchKernelGGL(ell_spmv_kernel<4>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux); break;
+        case 0: FEDM_ELL(0); break;
+        case 1: FEDM_ELL(1); break;
+        case 2: FEDM_ELL(2); break;
+        case 3: FEDM_ELL(3); break;
+        default: FEDM_ELL(4); break;
     }
+#undef FEDM_ELL
 }
 
 void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double *b, double *y,
@@ -244,6 +270,10 @@ int Amg::capture(Ctx &c) {
 }
 
 void Amg::run(Ctx &c) {
+    if (c.capturing) {  // part of a whole-iteration graph: its kernels become nodes of that graph
+        vcycle(c, 0);
+        return;
+    }
     prof_begin(c, 3);
     if (graph_exec) hipGraphLaunch(graph_exec, c.stream);
     else vcycle(c, 0);
@@ -308,10 +338,22 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
+    // this row's own operands first: their latency hides behind the gather loop
+    const size_t v = (size_t)slice * SLICE + lane;
+    const double *dp = dinv_uu + (size_t)slice * NS * NS * SLICE + lane;
+    double tv[NS], zv[NS], dv[NS * NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        tv[r] = t[v * NEQ + r];
+        zv[r] = zin[v * NEQ + r];
+    }
+#pragma unroll
+    for (int e = 0; e < NS * NS; ++e) dv[e] = dp[(size_t)e * SLICE];
     double acc[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) acc[r] = 0.0;
-    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+    const int b0 = boff[slice], b1 = boff[slice + 1];
+    for (int bc = b0; bc < b1; ++bc) {
         const int col = colidx[(size_t)bc * SLICE + lane];
         double zj[NS];
 #pragma unroll
@@ -323,17 +365,15 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
             for (int cidx = 0; cidx < NS; ++cidx)
                 acc[r] += (double)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
     }
-    const size_t v = (size_t)slice * SLICE + lane;
-    const double *dp = dinv_uu + (size_t)slice * NS * NS * SLICE + lane;
     double res[NS];
 #pragma unroll
-    for (int r = 0; r < NS; ++r) res[r] = alpha * t[v * NEQ + r] - acc[r];
+    for (int r = 0; r < NS; ++r) res[r] = alpha * tv[r] - acc[r];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         double d = 0.0;
 #pragma unroll
-        for (int cidx = 0; cidx < NS; ++cidx) d += dp[(size_t)(r * NS + cidx) * SLICE] * res[cidx];
-        zout[v * NEQ + r] = zin[v * NEQ + r] + omega * d;
+        for (int cidx = 0; cidx < NS; ++cidx) d += dv[r * NS + cidx] * res[cidx];
+        zout[v * NEQ + r] = zv[r] + omega * d;
     }
     zout[v * NEQ + NS] = 0.0;  // full-line stores; the potential entry is set by fs_scatter_kernel
 }
@@ -349,14 +389,16 @@ __global__ __launch_bounds__(256) void fs_coupling_kernel(int n_slices, const in
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
+    const double own = b0[(size_t)slice * SLICE + lane];  // requested before the gather loop
     double acc = 0.0;
-    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+    const int bb0 = boff[slice], bb1 = boff[slice + 1];
+    for (int bc = bb0; bc < bb1; ++bc) {
         const int col = colidx[(size_t)bc * SLICE + lane];
         const float *vp = val32 + ((size_t)bc * PL + NS * NS) * SLICE + lane;
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc += (double)vp[(size_t)s * SLICE] * z[(size_t)col * NEQ + s];
     }
-    b0[(size_t)slice * SLICE + lane] -= acc;
+    b0[(size_t)slice * SLICE + lane] = own - acc;
 }
 
 template <int NS>
@@ -436,7 +478,7 @@ static double *fs_first_target(Ctx &c, double *z) {
 
 // stages after the first: remaining species sweeps, coupling, V-cycle on the potential block
 template <int NS>
-static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter = true) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     const dim3 gs((c.pat.n_slices + 3) / 4);
     const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
@@ -449,7 +491,7 @@ static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alp
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
                        c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
     amg.run(c);
-    hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
+    if (scatter) hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
 }
 
 template <int NS>
@@ -472,17 +514,17 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
 }
 
 // z = Minv (J v): the SpMV's epilogue is the first stage (t = J v is kept for the sweeps)
-void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z) {
+void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter) {
     const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
     prof_begin(c, 1);
     launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, omega);
     prof_end(c);
     switch (c.ns) {
-        case 1: fs_finish_t<1>(c, amg, t, z, 1.0); break;
-        case 2: fs_finish_t<2>(c, amg, t, z, 1.0); break;
-        case 3: fs_finish_t<3>(c, amg, t, z, 1.0); break;
-        case 4: fs_finish_t<4>(c, amg, t, z, 1.0); break;
-        case 5: fs_finish_t<5>(c, amg, t, z, 1.0); break;
+        case 1: fs_finish_t<1>(c, amg, t, z, 1.0, scatter); break;
+        case 2: fs_finish_t<2>(c, amg, t, z, 1.0, scatter); break;
+        case 3: fs_finish_t<3>(c, amg, t, z, 1.0, scatter); break;
+        case 4: fs_finish_t<4>(c, amg, t, z, 1.0, scatter); break;
+        case 5: fs_finish_t<5>(c, amg, t, z, 1.0, scatter); break;
     }
 }
 

@@ -12,6 +12,7 @@ namespace fedm {
 // gather chains -- the coarse levels are latency-bound, not bandwidth-bound.
 struct EllMat {
     int n_rows = 0, n_rows_p = 0, n_cols = 0, n_slices = 0, log2_split = 0;
+    int width = 0;  // > 0: every slice stores exactly `width` entries per lane (boff unused)
     int64_t total_bc = 0;
     int *boff = nullptr, *col = nullptr;
     double *val = nullptr, *dinv = nullptr;
@@ -42,7 +43,8 @@ void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double 
                double omega, double *aux = nullptr);
 void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha);  // z = alpha*Minv t
-void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z);  // z = Minv (J v)
+// z = Minv (J v); scatter = false leaves the potential component in amg.levels[0].x
+void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter);
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z);
 
 }  // namespace fedm

@@ -35,7 +35,8 @@ void prof_collect(Ctx &c) {
 
 void prof_begin(Ctx &c, int kind) {
     Prof &p = c.prof;
-    if (!p.on) return;
+    p.recording = false;
+    if (!p.on || c.capturing || ((kind == 1 || kind == 3) && !p.all_kinds)) return;
     // events cost a few microseconds of stream time each: short, frequent kernels are sampled
     p.recording = (p.seen[kind]++ % p.stride[kind]) == 0;
     if (!p.recording) return;
@@ -46,7 +47,7 @@ void prof_begin(Ctx &c, int kind) {
 
 void prof_end(Ctx &c) {
     Prof &p = c.prof;
-    if (!p.on || !p.recording) return;
+    if (!p.on || !p.recording || c.capturing) return;
     hipEventRecord(p.ev[p.used + 1], c.stream);
     p.used += 2;
     p.recording = false;
@@ -86,6 +87,7 @@ static int check_model(const fedm_model_desc &m) {
 
 static int ensure_krylov(Ctx &c, int restart) {
     if (restart + 1 <= c.krylov_cap) return 0;
+    iter_graphs_clear(c);  // they hold the old Krylov vectors' addresses
     if (c.d_V) hipFree(c.d_V);
     c.d_V = nullptr;
     FEDM_HIP_CHECK(hipMalloc((void **)&c.d_V, sizeof(double) * (size_t)c.np * (restart + 1)));
@@ -97,7 +99,7 @@ static int ensure_krylov(Ctx &c, int restart) {
 static void apply_operator(Ctx &c, const double *v, double *w) {
     comm_halo(c, const_cast<double *>(v));  // ghost inputs from their owners (multi-GPU)
     if (c.amg && c.poisson) {
-        fieldsplit_apply_operator(c, *c.amg, v, c.d_tmp, w);
+        fieldsplit_apply_operator(c, *c.amg, v, c.d_tmp, w, true);
     } else {
         prof_begin(c, 1);
         launch_spmv(c, v, w, true);
@@ -114,6 +116,54 @@ static void prepare_preconditioner_and_rhs(Ctx &c) {
         launch_block_inverse(c);
         launch_apply_dinv(c, c.d_F, c.d_rhs, -1.0);
     }
+}
+
+void iter_graphs_clear(Ctx &c) {
+    for (hipGraphExec_t g : c.iter_graph)
+        if (g) hipGraphExecDestroy(g);
+    c.iter_graph.clear();
+}
+
+// One Krylov step  w = Minv J v_j;  h = V^T w;  w <- (w - V h)/|.|  as a hipGraph, captured the
+// first time index j is reached: ~30 kernels replayed back to back with no launch gaps and one
+// host call.  All pointers are fixed for a given j; the mailbox tag is a device counter.
+static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w) {
+    if (!c.iter_graphs_ok || c.comm || !(c.amg && c.poisson) || (c.prof.on && c.prof.all_kinds)) return false;
+    if ((int)c.iter_graph.size() <= j) c.iter_graph.resize(j + 1, nullptr);
+    if (!c.iter_graph[j]) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            hipGetLastError();
+            c.iter_graphs_ok = false;
+            return false;
+        }
+        c.capturing = true;
+        std::vector<const double *> dotp(j + 2);
+        for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+        dotp[j + 1] = w;
+        // the V-cycle result is scattered into w by the reduction kernel itself
+        fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, false);
+        launch_dots_fused(c, dotp.data(), w, j + 2, c.amg->levels[0].x);
+        launch_cgs_update(c, j + 1, vp, w);
+        c.capturing = false;
+        hipGraphExec_t exec = nullptr;
+        const bool ok = hipStreamEndCapture(c.stream, &graph) == hipSuccess && graph &&
+                        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) {
+            hipGetLastError();
+            c.iter_graphs_ok = false;
+            return false;
+        }
+        c.iter_graph[j] = exec;
+    }
+    if (hipGraphLaunch(c.iter_graph[j], c.stream) != hipSuccess) {
+        hipGetLastError();
+        c.iter_graphs_ok = false;
+        return false;
+    }
+    ++c.mail_seq;
+    return true;
 }
 
 // ---- GMRES(m), left-preconditioned with the point-block Jacobi inverse ---------------------
@@ -167,14 +217,16 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         bool done = false;
         for (; j < m && its < max_it; ++j) {
             double *w = c.d_V + (size_t)(j + 1) * c.np;
-            apply_operator(c, vp[j], w);
-            // classical Gram-Schmidt with ONE reduction and ONE host sync per iteration:
+            // classical Gram-Schmidt with ONE reduction and ONE host wait per iteration:
             // h_i = v_i.w and ww = w.w together; |w - V h|^2 = ww - |h|^2 on the device;
             // the update and the normalisation read their coefficients from device memory.
-            for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
-            dotp[j + 1] = w;
-            launch_dots(c, dotp.data(), w, j + 2, true);
-            launch_cgs_update(c, j + 1, vp.data(), w);
+            if (!iter_graph_launch(c, j, vp.data(), w)) {
+                apply_operator(c, vp[j], w);
+                for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+                dotp[j + 1] = w;
+                launch_dots(c, dotp.data(), w, j + 2, true);
+                launch_cgs_update(c, j + 1, vp.data(), w);
+            }
             wait_red(c);  // published by the finish kernel: the host works while the update runs
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = c.h_red[i];
             double hn2 = c.h_red[j + 1];
@@ -499,6 +551,9 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
     if (alloc_zero(c.d_red, RED_K, c.stream)) return -1;
     FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_red, sizeof(double) * (RED_K + 1), hipHostMallocDefault));
     std::memset(c.h_red, 0, sizeof(double) * (RED_K + 1));
+    FEDM_HIP_CHECK(hipMalloc((void **)&c.d_mail_seq, sizeof(unsigned long long)));
+    FEDM_HIP_CHECK(hipMemset(c.d_mail_seq, 0, sizeof(unsigned long long)));
+
     FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_stage, sizeof(double) * (size_t)c.np));
     for (int s = 0; model && s < c.ns; ++s)
         if (model->ext_nodes[s] > 0)
@@ -531,6 +586,8 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     }
     gd_prep_release(c);
     for (auto &e : c.prof.ev) hipEventDestroy(e);
+    iter_graphs_clear(c);
+    if (c.d_mail_seq) hipFree(c.d_mail_seq);
     if (c.h_red) hipHostFree(c.h_red);
     if (c.d_val32) hipFree(c.d_val32);
     if (c.h_stage) hipHostFree(c.h_stage);
@@ -922,6 +979,7 @@ int fedm_profile(fedm_ctx *h, int enable) {
         for (auto &e : p.ev) FEDM_HIP_CHECK(hipEventCreate(&e));
     }
     p.on = enable != 0;
+    p.all_kinds = enable == 2;  // SpMV / V-cycle events need plain launches (no iteration graphs)
     if (enable)
         for (int k = 0; k < 8; ++k) {
             p.ms[k] = 0.0;
@@ -953,6 +1011,9 @@ int fedm_set_fieldsplit(fedm_ctx *h, int sweeps, const double *weights) {
             set_error("field-split weights must be positive");
             return -2;
         }
+    hipSetDevice(h->c.device);
+    hipStreamSynchronize(h->c.stream);
+    iter_graphs_clear(h->c);
     h->c.fs_sweeps = sweeps;
     for (int i = 0; i < sweeps; ++i) h->c.fs_w[i] = weights[i];
     return 0;
@@ -1035,6 +1096,7 @@ int fedm_amg_clear(fedm_ctx *h) {
     if (c.amg) {
         hipSetDevice(c.device);
         hipStreamSynchronize(c.stream);
+        iter_graphs_clear(c);
         c.amg->release();
         delete c.amg;
         c.amg = nullptr;

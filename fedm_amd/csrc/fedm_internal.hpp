@@ -59,6 +59,7 @@ struct GdPrep;
 // kinds: 0 assembly F+J, 1 Jacobian SpMV, 2 assembly F only, 3 multigrid V-cycle
 struct Prof {
     bool on = false;
+    bool all_kinds = false;                        // also time the kernels inside Krylov steps
     bool recording = false;                        // between prof_begin and prof_end
     int stride[8] = {1, 4, 1, 4, 1, 1, 1, 1};      // sample every n-th launch of a kind
     long seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -127,7 +128,13 @@ struct Ctx {
     double *d_red = nullptr;       // [RED_K]
     double *h_red = nullptr;       // pinned, host-mapped: [RED_K] values + sequence tag, written
                                    // by the last kernel of a reduction and polled by the host
-    unsigned long long mail_seq = 0;
+    unsigned long long mail_seq = 0;      // publications queued so far (host count)
+    unsigned long long *d_mail_seq = nullptr;  // same count on the device: replayed graphs cannot
+                                               // carry a fresh tag in their kernel arguments
+    // one captured hipGraph per Krylov index j: operator + preconditioner + orthogonalisation
+    std::vector<hipGraphExec_t> iter_graph;
+    bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
+    bool capturing = false;
     double *h_stage = nullptr;     // pinned staging, np doubles
 };
 
@@ -150,6 +157,7 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv);
 void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
+void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0);
 void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y);
 void launch_norm2(Ctx &c, const double *x, int slot);                       // d_red[slot] = x.x
 void launch_axpy(Ctx &c, double a, const double *x, double *y);             // y += a x
@@ -171,6 +179,7 @@ void wait_red(Ctx &c);                      // wait for the publication launch_d
     } while (0)
 
 void set_error(const std::string &msg);
+void iter_graphs_clear(Ctx &c);
 void prof_begin(Ctx &c, int kind);
 void prof_end(Ctx &c);
 void prof_collect(Ctx &c);

@@ -483,6 +483,14 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
     const int b0 = boff[slice], b1 = boff[slice + 1];
+    // epilogue operands (block inverse) requested before the gather loop
+    constexpr int ND = FS ? (NEQ - 1) * (NEQ - 1) : NEQ2;
+    double dv[ND > 0 ? ND : 1];
+    if (FS || dinv) {
+        const double *dp = dinv + (size_t)slice * ND * SLICE + lane;
+#pragma unroll
+        for (int e = 0; e < ND; ++e) dv[e] = dp[(size_t)e * SLICE];
+    }
     double acc[NEQ];
 #pragma unroll
     for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
@@ -506,25 +514,23 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
         // first stage of the field-split preconditioner in the epilogue (amg.hip):
         // t = A x is kept, z_u = fs_scale * Duu^-1 t_u starts the species sweeps, b0 = t_phi
         constexpr int NS = NEQ - 1;
-        const double *dp = dinv + (size_t)slice * NS * NS * SLICE + lane;
 #pragma unroll
         for (int r = 0; r < NEQ; ++r) y[vtx * NEQ + r] = acc[r];
 #pragma unroll
         for (int r = 0; r < NS; ++r) {
             double z = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < NS; ++cc) z += dp[(size_t)(r * NS + cc) * SLICE] * acc[cc];
+            for (int cc = 0; cc < NS; ++cc) z += dv[r * NS + cc] * acc[cc];
             fs_z[vtx * NEQ + r] = fs_scale * z;
         }
         fs_z[vtx * NEQ + NS] = 0.0;  // whole lines are written; the V-cycle result lands here later
         fs_b0[vtx] = acc[NS];
     } else if (dinv) {
-        const double *dp = dinv + (size_t)slice * NEQ2 * SLICE + lane;
 #pragma unroll
         for (int r = 0; r < NEQ; ++r) {
             double z = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < NEQ; ++cc) z += dp[(size_t)(r * NEQ + cc) * SLICE] * acc[cc];
+            for (int cc = 0; cc < NEQ; ++cc) z += dv[r * NEQ + cc] * acc[cc];
             y[vtx * NEQ + r] = z;
         }
     } else {
@@ -665,22 +671,26 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partials, int 
 // Results go to the host through a mailbox in host-mapped pinned memory: values, a system-scope
 // fence, then the sequence tag the host polls (wait_red) -- no copy kernel, no stream
 // synchronisation, and the host can queue the next iteration while this one finishes.
+// The tag is a launch counter kept in device memory (a replayed graph has fixed arguments).
 __device__ __forceinline__ void publish(const double *__restrict__ red, int k, double *mail,
-                                        unsigned long long seq) {
+                                        unsigned long long *seq) {
     for (int i = threadIdx.x; i < k; i += 64) mail[i] = red[i];
     __threadfence_system();
-    if (threadIdx.x == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + RED_K), seq, __ATOMIC_RELEASE,
+    if (threadIdx.x == 0) {
+        const unsigned long long tag = *seq + 1;
+        *seq = tag;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + RED_K), tag, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ __launch_bounds__(64) void publish_kernel(const double *__restrict__ red, int k, double *mail,
-                                                     unsigned long long seq) {
+                                                     unsigned long long *seq) {
     publish(red, k, mail, seq);
 }
 
 __global__ __launch_bounds__(64) void cgs_finish_kernel(int k, double *__restrict__ out, double *mail,
-                                                        unsigned long long seq) {
+                                                        unsigned long long *seq) {
     if (threadIdx.x == 0) {
         const double ww = out[k - 1];
         double hh = 0.0;
@@ -692,6 +702,88 @@ __global__ __launch_bounds__(64) void cgs_finish_kernel(int k, double *__restric
     }
     __syncthreads();
     publish(out, RED_K, mail, seq);
+}
+
+// Single-GPU Krylov step, two kernels instead of five:
+//  dots_scatter_kernel  finishes the preconditioner (the potential component of y is taken from
+//                       the V-cycle result x0 and stored into y: replaces fs_scatter_kernel) and
+//                       forms the per-block partial dot products like dots_kernel;
+//  reduce_finish_kernel reduces the partials of all k slots in the fixed order of
+//                       reduce_partials_kernel, applies the cgs_finish_kernel formulae and
+//                       publishes to the host mailbox.
+// Every kernel boundary costs ~4-5 us on this GPU, more than the work of these small kernels.
+// (A single kernel with a last-block-done ticket was tried: the agent-scope fences it needs
+// across the 8 XCDs' L2s cost 60 us.)
+template <int K>
+__global__ __launch_bounds__(256) void dots_scatter_kernel(PtrPack8 xs, double *__restrict__ y, size_t n,
+                                                           double *__restrict__ partials, int kbase,
+                                                           int self_index, const double *__restrict__ x0,
+                                                           int neq) {
+    double acc[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[i] = 0.0;
+    if (x0) {
+        // one vertex per thread: its potential component comes from x0 and is stored into y
+        const size_t nvert = n / (size_t)neq;
+        for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvert;
+             v += (size_t)gridDim.x * blockDim.x) {
+            const size_t base = v * neq;
+            const double phi = x0[v];
+            y[base + neq - 1] = phi;
+            for (int cidx = 0; cidx < neq; ++cidx) {
+                const double yv = (cidx == neq - 1) ? phi : y[base + cidx];
+#pragma unroll
+                for (int i = 0; i < K; ++i) acc[i] += (i == self_index ? yv : xs.p[i][base + cidx]) * yv;
+            }
+        }
+    } else {
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+             idx += (size_t)gridDim.x * blockDim.x) {
+            const double yv = y[idx];
+#pragma unroll
+            for (int i = 0; i < K; ++i) acc[i] += (i == self_index ? yv : xs.p[i][idx]) * yv;
+        }
+    }
+    block_reduce_store<K>(acc, partials, kbase);
+}
+
+__global__ __launch_bounds__(256) void reduce_finish_kernel(const double *__restrict__ partials, int nblocks,
+                                                            int k, double *__restrict__ out, double *mail,
+                                                            unsigned long long *seq) {
+    __shared__ double fin[RED_K];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < RED_K) fin[threadIdx.x] = 0.0;
+    __syncthreads();
+    for (int i = wave; i < k; i += 4) {
+        double sum = 0.0;
+        for (int b = lane; b < nblocks; b += 64) sum += partials[(size_t)b * RED_K + i];
+        sum = wave_sum(sum);
+        if (lane == 0) fin[i] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ww = fin[k - 1];
+        double hh = 0.0;
+        for (int i = 0; i < k - 1; ++i) hh += fin[i] * fin[i];
+        const double hn2 = ww - hh;
+        fin[RED_K - 2] = ww;
+        fin[k - 1] = hn2;
+        fin[RED_K - 1] = (hn2 > 1e-8 * ww && hn2 > 0.0) ? 1.0 / sqrt(hn2) : 1.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        for (int i = threadIdx.x; i < RED_K; i += 64) {
+            out[i] = fin[i];
+            mail[i] = fin[i];
+        }
+        __threadfence_system();
+        if (threadIdx.x == 0) {
+            const unsigned long long tag = *seq + 1;
+            *seq = tag;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + RED_K), tag, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <int K, bool FINAL>
@@ -737,9 +829,46 @@ void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool f
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
     comm_allreduce(c, c.d_red, k);
-    if (finish)
+    if (finish) {
         hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red, c.h_red,
-                           ++c.mail_seq);
+                           c.d_mail_seq);
+        if (!c.capturing) ++c.mail_seq;  // a captured launch counts when its graph is launched
+    }
+}
+
+// single-GPU Krylov step: dots (+ the scatter of the V-cycle result x0 into the potential
+// component of y), then reduction + finish + publication
+void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0) {
+    const int grid = red_grid(c);
+    int done = 0;
+    while (done < k) {
+        const int kk = (k - done) >= 8 ? 8 : (k - done);
+        PtrPack8 pk;
+        int self = -1;
+        for (int i = 0; i < 8; ++i) {
+            pk.p[i] = xs[done + (i < kk ? i : 0)];
+            if (i < kk && pk.p[i] == y) self = i;
+        }
+        const double *sc = (done == 0) ? x0 : nullptr;
+#define FEDM_DF(K)                                                                                     \
+    hipLaunchKernelGGL(dots_scatter_kernel<K>, dim3(grid), dim3(256), 0, c.stream, pk, y, (size_t)c.n_dot, \
+                       c.d_partials, done, self, sc, c.neq)
+        switch (kk) {
+            case 1: FEDM_DF(1); break;
+            case 2: FEDM_DF(2); break;
+            case 3: FEDM_DF(3); break;
+            case 4: FEDM_DF(4); break;
+            case 5: FEDM_DF(5); break;
+            case 6: FEDM_DF(6); break;
+            case 7: FEDM_DF(7); break;
+            default: FEDM_DF(8); break;
+        }
+#undef FEDM_DF
+        done += kk;
+    }
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, c.stream, c.d_partials, grid, k, c.d_red,
+                       c.h_red, c.d_mail_seq);
+    if (!c.capturing) ++c.mail_seq;
 }
 
 // y = (y - sum_i d_red[i] xs[i]) * d_red[RED_K-1], coefficients stay on the device
@@ -809,7 +938,8 @@ void wait_red(Ctx &c) {
 }
 
 void read_red(Ctx &c, int k) {
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_red, ++c.mail_seq);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_red, c.d_mail_seq);
+    ++c.mail_seq;
     wait_red(c);
 }
 

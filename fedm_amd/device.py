@@ -538,7 +538,10 @@ class DeviceProblem:
         return ms.value
 
     def profile(self, enable=True):
-        self._check(self.lib.fedm_profile(self._h, int(bool(enable))), "fedm_profile")
+        """True / 1: time the assembly kernels only (the solver is untouched).  2: also time the
+        Jacobian SpMV and the V-cycle -- GMRES then launches kernel by kernel instead of
+        replaying its per-iteration graphs, so use it for a separate profiling pass."""
+        self._check(self.lib.fedm_profile(self._h, int(enable)), "fedm_profile")
 
     def profile_read(self):
         """{kind: (total ms, launches)} of the kernels timed since profile(True)."""

@@ -284,7 +284,10 @@ int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
 int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
 /* in-run kernel timing with HIP events on the library's stream.  kind: 0 = assembly F+J,
  * 1 = Jacobian SpMV, 2 = assembly F only, 3 = multigrid V-cycle (whole graph).  Kinds 1 and 3
- * are sampled (every 4th launch carries events; totals are the sampled mean x launches). */
+ * are sampled (every 4th launch carries events; totals are the sampled mean x launches).
+ * enable = 1 times the assembly only and leaves the solver untouched; enable = 2 also times
+ * kinds 1 and 3, which makes GMRES launch its kernels one by one instead of replaying the
+ * captured per-iteration graphs (slower; use it for a separate profiling pass). */
 int fedm_profile(fedm_ctx *ctx, int enable);
 int fedm_profile_read(fedm_ctx *ctx, int kind, double *ms_total, int64_t *count);
 /* assembly kernel: 0 = global graph colouring (bitwise reproducible), 1 = LDS patches
