@@ -66,7 +66,12 @@ def pmc_traffic():
     out = {}
     for name, v in k.items():
         if "traffic_bytes_corrected" in v:
-            out["spmv" if name.startswith("fedm::spmv_kernel") else name] = v["traffic_bytes_corrected"]
+            out[name] = v["traffic_bytes_corrected"]
+    # the Krylov SpMV is the instantiation with the field-split epilogue (<n_eq, true>)
+    spmv = [n for n in out if "spmv_kernel" in n and "ell_" not in n]
+    fused = [n for n in spmv if "true>" in n]
+    if spmv:
+        out["spmv"] = out[(fused or spmv)[0]]
     return out
 
 
