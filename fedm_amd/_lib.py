@@ -105,7 +105,8 @@ class Csr(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
 EXCHANGE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_void_p)
 
-LIB_PATH = Path(__file__).resolve().parent / "libfedm_hip.so"
+# FEDM_HIP_LIB points at another build of the same C ABI (kernel experiments, system installs)
+LIB_PATH = Path(os.environ.get("FEDM_HIP_LIB") or Path(__file__).resolve().parent / "libfedm_hip.so")
 
 _P = C.c_void_p
 _D = C.POINTER(C.c_double)

@@ -8,8 +8,9 @@
 // The residual is written once on "value + spatial gradient" objects over a forward-mode
 // dual scalar; the element Jacobian is obtained column by column (one dual direction per
 // local dof), which is exact like UFL's `derivative` (fedm-gd.py:402) without a hand
-// derivation of the many cross terms.  One thread per cell, cells of one colour per launch
-// (conflict-free read-modify-write, bitwise reproducible).
+// derivation of the many cross terms.  Cells of one colour per launch (conflict-free
+// read-modify-write, bitwise reproducible); one thread per cell for the residual, one thread
+// per (cell, local dof) for the Jacobian -- a colour alone has too few cells to fill the chip.
 #include "fedm_internal.hpp"
 
 namespace fedm {
@@ -113,11 +114,14 @@ struct GdPoint {  // everything the integrands need at one point
     SG me;               // current mean-energy Function (thermal velocity of electrons)
 };
 
+// (the species count is NEQ - 1: loops over it unroll and the per-species arrays stay in registers)
 template <int NEQ>
-__device__ void gd_point(const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields,
-                         int nv, const GdCell &c, const Dual Uc[3][NEQ], const double phi[3],
-                         GdPoint &p, SG *k /* [n_reactions] or nullptr */) {
-    const int ns = md->n_species, nr = md->n_reactions;
+__device__ __forceinline__ void gd_point(const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields,
+                                         int nv, const GdCell &c, const Dual Uc[3][NEQ], const double phi[3],
+                                         GdPoint &p, SG &dme_out) {
+    constexpr int ns = NEQ - 1;
+    const int nr = md->n_reactions;
+#pragma unroll
     for (int i = 0; i < NEQ; ++i) p.u[i] = unknown_sg<NEQ>(Uc, i, c, phi);
     const int F_MU = 0, F_D = ns, F_MUD = 2 * ns, F_DD = 3 * ns, F_K = 4 * ns, F_KD = 4 * ns + nr,
               F_MEO = 4 * ns + 2 * nr, F_ME = F_MEO + 1, F_UEO = F_MEO + 2;
@@ -126,16 +130,29 @@ __device__ void gd_point(const fedm_gd_desc *__restrict__ md, const double *__re
     const SG ueo = nodal_sg(fields, nv, F_UEO, c, phi);
     p.Ex = -p.u[NEQ - 1].gx;
     p.Ey = -p.u[NEQ - 1].gy;
+#pragma unroll
     for (int i = 1; i < ns; ++i) p.n[i] = dexp(p.u[i].v);
     // mean energy of the new state, fedm-gd.py:215
     const SG dme = (sexp(p.u[0]) - sexp(p.u[ns - 1]) * meo) / sexp(ueo);
+#pragma unroll
     for (int i = 0; i < ns; ++i) {
         p.mu[i] = nodal_sg(fields, nv, F_MU + i, c, phi) + nodal_sg(fields, nv, F_MUD + i, c, phi) * dme;
         p.D[i] = nodal_sg(fields, nv, F_D + i, c, phi) + nodal_sg(fields, nv, F_DD + i, c, phi) * dme;
     }
-    if (k)
-        for (int j = 0; j < nr; ++j)
-            k[j] = nodal_sg(fields, nv, F_K + j, c, phi) + nodal_sg(fields, nv, F_KD + j, c, phi) * dme;
+    dme_out = dme;
+    (void)nr;
+    (void)F_K;
+    (void)F_KD;
+}
+
+// semi-implicit rate coefficient of reaction j at the point (value part only is used)
+__device__ __forceinline__ Dual gd_rate_coefficient(const double *__restrict__ fields, int nv, int ns, int nr,
+                                                    int j, const GdCell &c, const double phi[3], const SG &dme) {
+    const int F_K = 4 * ns, F_KD = 4 * ns + nr;
+    const double *fk = fields + (size_t)(F_K + j) * nv, *fd = fields + (size_t)(F_KD + j) * nv;
+    const double kv = fk[c.v[0]] * phi[0] + fk[c.v[1]] * phi[1] + fk[c.v[2]] * phi[2];
+    const double kd = fd[c.v[0]] * phi[0] + fd[c.v[1]] * phi[1] + fd[c.v[2]] * phi[2];
+    return mk(kv) + kd * dme.v;
 }
 
 // element residual R[a][comp] for the given (dual) nodal unknowns
@@ -145,7 +162,8 @@ __device__ void gd_element(const fedm_gd_desc *__restrict__ md, const double *__
                            const double Uo1[3][NEQ], double dt, double dt_old,
                            const int8_t tags[3], int mode, Dual R[3][NEQ]) {
     const double two_pi = 6.283185307179586476925286766559;
-    const int ns = md->n_species, nr = md->n_reactions, IPHI = NEQ - 1;
+    constexpr int ns = NEQ - 1, IPHI = NEQ - 1;
+    const int nr = md->n_reactions;
     const double tr = dt / dt_old, trp1 = 1.0 + tr, tr2p1 = 1.0 + 2.0 * tr;
     for (int a = 0; a < 3; ++a)
         for (int s = 0; s < NEQ; ++s) R[a][s] = mk(0.0);
@@ -156,29 +174,33 @@ __device__ void gd_element(const fedm_gd_desc *__restrict__ md, const double *__
         const double rq = c.rn[0] * phi[0] + c.rn[1] * phi[1] + c.rn[2] * phi[2];
         const double W = md->qp_w[q] * c.detJ * two_pi * rq;
         GdPoint p;
-        SG k[GR];
-        gd_point<NEQ>(md, fields, nv, c, Uc, phi, p, full ? k : nullptr);
+        SG dme;
+        gd_point<NEQ>(md, fields, nv, c, Uc, phi, p, dme);
         // Poisson row
         Dual rho = mk(0.0);
+#pragma unroll
         for (int i = 1; i < ns; ++i) rho = rho + (md->sign[i] * md->charge_over_eps) * p.n[i];
         for (int a = 0; a < 3; ++a)
             R[a][IPHI] = R[a][IPHI] + W * ((p.u[IPHI].gx * c.G[a][0] + p.u[IPHI].gy * c.G[a][1]) - rho * phi[a]);
         if (!full) continue;
         // reaction rates, Source_term / Energy_Source_term (functions.py:835-843, 901-912)
-        Dual f[GS], f_en = mk(0.0);
+        Dual f[ns], f_en = mk(0.0);
+#pragma unroll
         for (int i = 0; i < ns; ++i) f[i] = mk(0.0);
         for (int j = 0; j < nr; ++j) {
-            Dual rate = k[j].v;
+            Dual rate = gd_rate_coefficient(fields, nv, ns, nr, j, c, phi, dme);
+#pragma unroll
             for (int i = 0; i < ns; ++i)
                 for (int e = 0; e < md->power[j][i]; ++e) rate = (i == 0) ? rate * md->N0 : rate * p.n[i];
-            for (int i = 0; i < ns; ++i)
-                if (md->net[j][i]) f[i] = f[i] + (double)md->net[j][i] * rate;
+#pragma unroll
+            for (int i = 0; i < ns; ++i) f[i] = f[i] + (double)md->net[j][i] * rate;
             f_en = f_en - md->energy_loss[j] * rate;
         }
-        const int ie = ns - 1;  // electrons are the last species
+        constexpr int ie = ns - 1;  // electrons are the last species
         Dual gex, gey;
         gd_flux(md->sign[ie], p.u[ie], p.D[ie], p.mu[ie], p.Ex, p.Ey, md->grad_diffusion[ie] != 0, gex, gey);
         f_en = f_en - (gex * p.Ex + gey * p.Ey);  // Joule heating, fedm-gd.py:359
+#pragma unroll
         for (int comp = 0; comp < ns; ++comp) {
             // comp 0: energy equation with 5/3 of the electron coefficients (fedm-gd.py:354)
             const int sp = (comp == 0) ? ie : comp;
@@ -227,7 +249,7 @@ __device__ void gd_element(const fedm_gd_desc *__restrict__ md, const double *__
         const double nx = -c.G[i][0] / gi, ny = -c.G[i][1] / gi;
         const double ex = c.x[j][0] - c.x[kk][0], ey = c.x[j][1] - c.x[kk][1];
         const double L = sqrt(ex * ex + ey * ey);
-        const int ie = ns - 1;
+        constexpr int ie = ns - 1;
         for (int t = 0; t < md->n_fqp; ++t) {
             double phi[3] = {0.0, 0.0, 0.0};
             phi[j] = 1.0 - md->fqp_t[t];
@@ -235,9 +257,11 @@ __device__ void gd_element(const fedm_gd_desc *__restrict__ md, const double *__
             const double rq = c.rn[0] * phi[0] + c.rn[1] * phi[1] + c.rn[2] * phi[2];
             const double W = md->fqp_w[t] * L * two_pi * rq;
             GdPoint p;
-            gd_point<NEQ>(md, fields, nv, c, Uc, phi, p, nullptr);
+            SG dme;
+            gd_point<NEQ>(md, fields, nv, c, Uc, phi, p, dme);
             const Dual En = p.Ex * nx + p.Ey * ny;
             Dual ion = mk(0.0);  // Ion_flux = sum Max(Gamma_i . n, 0), fedm-gd.py:351
+#pragma unroll
             for (int s = 1; s < ns; ++s) {
                 if (!md->is_ion[s]) continue;
                 Dual gx, gy;
@@ -246,6 +270,7 @@ __device__ void gd_element(const fedm_gd_desc *__restrict__ md, const double *__
                 ion = ion + (gn + dabs(gn)) * 0.5;
             }
             const Dual vth_e = dsqrt(md->vth_e_coef * p.me.v);
+#pragma unroll
             for (int comp = 0; comp < ns; ++comp) {
                 const int sp = (comp == 0) ? ie : comp;
                 const double ref = md->ref[tag - 1][sp];
@@ -283,10 +308,12 @@ __global__ __launch_bounds__(128) void gd_assemble_kernel(
     const uint32_t *__restrict__ cell_slots, const double *__restrict__ u,
     const double *__restrict__ uold, const double *__restrict__ uold1, double dt, double dt_old,
     double *__restrict__ val, double *__restrict__ F, int jacobian, int mode) {
-    constexpr int NEQ2 = NEQ * NEQ;
+    constexpr int NEQ2 = NEQ * NEQ, NCOL = 3 * NEQ;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_cells) return;
-    const int cidx = cell_list[t];
+    const int ci = jacobian ? t / NCOL : t;       // cell within the colour
+    const int col = jacobian ? t - ci * NCOL : 0;  // local dof = element-matrix column
+    if (ci >= n_cells) return;
+    const int cidx = cell_list[ci];
     GdCell c;
     int8_t tags[3];
     Dual Uc[3][NEQ];
@@ -322,21 +349,22 @@ __global__ __launch_bounds__(128) void gd_assemble_kernel(
             for (int s = 0; s < NEQ; ++s) F[(size_t)c.v[a] * NEQ + s] += R[a][s].v;
         return;
     }
-    // one dual direction per local dof -> one column of the element Jacobian
-    for (int b = 0; b < 3; ++b)
-        for (int sc = 0; sc < NEQ; ++sc) {
-            if (mode == 1 && sc != NEQ - 1) continue;  // Poisson-only: potential columns
-            Uc[b][sc].d = 1.0;
-            gd_element<NEQ>(md, fields, nv, c, Uc, Uo, Uo1, dt, dt_old, tags, mode, R);
-            Uc[b][sc].d = 0.0;
-            for (int a = 0; a < 3; ++a) {
-                const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
-                double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
-                for (int sr = 0; sr < NEQ; ++sr) dst[(size_t)(sr * NEQ + sc) * SLICE] += R[a][sr].d;
-                if (b == 0 && sc == NEQ - 1)  // residual values once (any pass carries them)
-                    for (int sr = 0; sr < NEQ; ++sr) F[(size_t)c.v[a] * NEQ + sr] += R[a][sr].v;
-            }
-        }
+    // one dual direction per local dof -> one column of the element Jacobian per thread
+    const int b = col / NEQ, sc = col - b * NEQ;
+    const bool carries_residual = (b == 0 && sc == NEQ - 1);  // any pass has the values
+    if (mode == 1 && sc != NEQ - 1) return;  // Poisson-only: potential columns
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) Uc[bb][s].d = (bb == b && s == sc) ? 1.0 : 0.0;
+    gd_element<NEQ>(md, fields, nv, c, Uc, Uo, Uo1, dt, dt_old, tags, mode, R);
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
+        double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
+        for (int sr = 0; sr < NEQ; ++sr) dst[(size_t)(sr * NEQ + sc) * SLICE] += R[a][sr].d;
+        if (carries_residual)
+            for (int sr = 0; sr < NEQ; ++sr) F[(size_t)c.v[a] * NEQ + sr] += R[a][sr].v;
+    }
 }
 
 void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
@@ -347,7 +375,8 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
     for (int k = 0; k < ncol; ++k) {
         const int n = c.pat.colour_ptr[k + 1] - c.pat.colour_ptr[k];
         if (n == 0) continue;
-        const dim3 g((n + 127) / 128), b(128);
+        const size_t threads = jacobian ? (size_t)n * 3 * c.neq : (size_t)n;
+        const dim3 g((unsigned)((threads + 127) / 128)), b(128);
 #define FEDM_GD_LAUNCH(NEQ)                                                                        \
     hipLaunchKernelGGL((gd_assemble_kernel<NEQ>), g, b, 0, c.stream, c.d_gd, c.d_gd_fields, c.nv,   \
                        c.d_colour_cells + c.pat.colour_ptr[k], n, c.d_cells, c.d_coords, c.d_ftags, \
