@@ -118,7 +118,7 @@ class Stepper:
     """The script-level time loop of fedm-streamer.py:304-340 around one device problem."""
 
     partition_name = "single GPU"
-    assembly_kernel_name = "assemble_patch_kernel<2,true,1,true,192> (LDS patches, F+J)"
+    assembly_kernel_name = "assemble_patch_kernel<2,true,1,2,192> (LDS patches, F+J)"
 
     @property
     def multigrid_levels(self):

@@ -92,11 +92,25 @@ struct CellGeom {
 // CACHE: keep exp(u) and the BDF term at the (<= 3) quadrature points in registers and emit
 // the element tensors one equation row at a time, so that only one row's moments are live
 // (n_eq = 3: 22 instead of 60 doubles); without it every row pass re-evaluates exp(u).
-template <int NS, bool PO, int NR, bool CACHE>
+// CACHE = 2 additionally bakes FIAT's degree-2 triangle rule (the only 3-point rule the decks
+// produce) into the code: every model scalar read in the inner loops is a scalar-cache round trip
+// that the few resident waves cannot hide, and the constant weights fold into the arithmetic.
+template <int NS, bool PO, int NR, int CACHE>
 struct Element {
     static constexpr int NEQ = NS + (PO ? 1 : 0);
     static constexpr int IPHI = NEQ - 1;
     static constexpr int NQC = 3;
+    static constexpr bool CACHED = CACHE != 0, QSTD = CACHE == 2;
+
+    __device__ __forceinline__ static double qx(const fedm_model_desc *__restrict__ md, int q) {
+        return QSTD ? (q == 2 ? 2.0 / 3.0 : 1.0 / 6.0) : md->qp_x[q];
+    }
+    __device__ __forceinline__ static double qy(const fedm_model_desc *__restrict__ md, int q) {
+        return QSTD ? (q == 1 ? 2.0 / 3.0 : 1.0 / 6.0) : md->qp_y[q];
+    }
+    __device__ __forceinline__ static double qw(const fedm_model_desc *__restrict__ md, int q) {
+        return QSTD ? 1.0 / 6.0 : md->qp_w[q];
+    }
 
     // cell constants
     double G[3][2], detJ, rn[3];
@@ -108,6 +122,12 @@ struct Element {
     int nreac;
     // moments of the row being emitted
     double m2[NS][6], m1h[3], m1n[3], m0n, m1sp[3], m01;
+    // per cell: G_a.G_b (sym6 order) and d|E|/dPhi_b;  per row (row_prepare): the factors that
+    // every (a, b) entry shares, so that an entry costs two FMAs instead of a dozen:
+    //   J[s][s](a,b)   = m2 + DGm*gg(a,b) - velG[a]*m1n[b]
+    //   J[s][phi](a,b) = Kd*gg(a,b) - dE[b]*T[a]
+    double gg[6], dE[3];
+    double velG[3], T[3], DGm, Kd;
 
     __device__ __forceinline__ double dEm(int b) const {
         return -(E[0] * G[b][0] + E[1] * G[b][1]) * invEm;
@@ -144,6 +164,12 @@ struct Element {
                 Em = sqrt(E[0] * E[0] + E[1] * E[1]);
                 invEm = 1.0 / Em;
             }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            dE[a] = dEm(a);
+#pragma unroll
+            for (int b = a; b < 3; ++b) gg[sym6(a, b)] = GG(a, b);
         }
         const double lnE = log(Em);
         const double invEm_ = full && PO ? invEm : 1.0;
@@ -182,10 +208,10 @@ struct Element {
                 }
             }
         }
-        if (CACHE) {
+        if (CACHED) {
 #pragma unroll
             for (int q = 0; q < NQC; ++q) {
-                const double xq = md->qp_x[q], yq = md->qp_y[q];
+                const double xq = qx(md, q), yq = qy(md, q);
                 const double p0 = 1.0 - xq - yq;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -209,8 +235,8 @@ struct Element {
 #pragma unroll
             for (int k = 0; k < 6; ++k) m2[i][k] = 0.0;
         m0n = m01 = 0.0;
-        const int nq = md->n_qp;
-        if (CACHE) {
+        const int nq = QSTD ? 3 : md->n_qp;
+        if (CACHED) {
             // compile-time quadrature index: the cached values stay in registers
 #pragma unroll
             for (int q = 0; q < NQC; ++q) {
@@ -240,10 +266,10 @@ struct Element {
                                           const double *const ext[NS]) {
         const double two_pi = 6.283185307179586476925286766559;
         const bool phi_row = PO && row == IPHI;
-        const double xq = md->qp_x[q], yq = md->qp_y[q];
+        const double xq = qx(md, q), yq = qy(md, q);
         const double phi[3] = {1.0 - xq - yq, xq, yq};
         const double rq = rn[0] * phi[0] + rn[1] * phi[1] + rn[2] * phi[2];
-        const double W = md->qp_w[q] * detJ * two_pi * rq;
+        const double W = qw(md, q) * detJ * two_pi * rq;
         double g[NS], h = 0.0, sp = 0.0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) g[i] = 0.0;
@@ -307,44 +333,51 @@ struct Element {
         }
     }
 
-    // residual entry (a, row) -- after row_moments(row)
-    __device__ __forceinline__ double residual(int row, int a) const {
-        if (PO && row == IPHI) return (gradPhi[0] * G[a][0] + gradPhi[1] * G[a][1]) * m01 + m1h[a];
+    // shared factors of the row's entries -- after row_moments(row), before residual/block_row
+    __device__ __forceinline__ void row_prepare(const fedm_model_desc *__restrict__ md, int row) {
+        if (PO && row == IPHI) return;
         const int s = row < NS ? row : 0;
-        double r = m1h[a];
-        if (flux[s]) r -= (vel[s][0] * G[a][0] + vel[s][1] * G[a][1]) * m0n;
-        return r;
+        DGm = 0.0;
+        Kd = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            velG[a] = 0.0;
+            T[a] = m1sp[a];
+        }
+        if (!flux[s]) return;
+        DGm = Dv[s] * m0n;
+        const double zmud = fdrift[s] ? md->Z[s] * mud[s] : 0.0;
+        if (fdrift[s]) Kd = md->Z[s] * muv[s] * m0n;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            velG[a] = vel[s][0] * G[a][0] + vel[s][1] * G[a][1];
+            if (PO) {
+                const double Pa = gradu[s][0] * G[a][0] + gradu[s][1] * G[a][1];
+                const double Qa = E[0] * G[a][0] + E[1] * G[a][1];
+                T[a] += (zmud * Qa - Dd[s] * Pa) * m0n;
+            }
+        }
     }
 
-    // entries d R[a][row] / d U[b][0..NEQ) -- after row_moments(row)
-    __device__ __forceinline__ void block_row(const fedm_model_desc *__restrict__ md, int row, int a,
+    // residual entry (a, row)
+    __device__ __forceinline__ double residual(int row, int a) const {
+        if (PO && row == IPHI) return (gradPhi[0] * G[a][0] + gradPhi[1] * G[a][1]) * m01 + m1h[a];
+        return m1h[a] - velG[a] * m0n;
+    }
+
+    // entries d R[a][row] / d U[b][0..NEQ)
+    __device__ __forceinline__ void block_row(const fedm_model_desc *__restrict__, int row, int a,
                                               int b, double B[NEQ]) const {
         const int k = sym6(a, b);
 #pragma unroll
         for (int i = 0; i < NS; ++i) B[i] = m2[i][k];
         if (PO && row == IPHI) {
-            B[IPHI] = GG(a, b) * m01;
+            B[IPHI] = gg[k] * m01;
             return;
         }
         const int s = row < NS ? row : 0;
-        if (flux[s]) {
-            const double velGa = vel[s][0] * G[a][0] + vel[s][1] * G[a][1];
-            B[s] -= velGa * m1n[b] - Dv[s] * GG(a, b) * m0n;
-        }
-        if (PO) {
-            const double de = dEm(b);
-            double v = -de * m1sp[a];
-            if (flux[s]) {
-                double dv0 = -Dd[s] * de * gradu[s][0];
-                double dv1 = -Dd[s] * de * gradu[s][1];
-                if (fdrift[s]) {
-                    dv0 += md->Z[s] * (mud[s] * de * E[0] - muv[s] * G[b][0]);
-                    dv1 += md->Z[s] * (mud[s] * de * E[1] - muv[s] * G[b][1]);
-                }
-                v -= (dv0 * G[a][0] + dv1 * G[a][1]) * m0n;
-            }
-            B[IPHI] = v;
-        }
+        B[s] += DGm * gg[k] - velG[a] * m1n[b];
+        if (PO) B[IPHI] = Kd * gg[k] - dE[b] * T[a];
     }
 };
 

@@ -2,6 +2,7 @@
 // block-ELL Jacobian, Dirichlet rows, block-Jacobi inverse, SpMV and the vector kernels
 // that GMRES / Newton need.  All of it is fp64 and HBM-bound; no MFMA.
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 
 #include "comm.hpp"
@@ -16,7 +17,7 @@ namespace fedm {
 // and the summation order is fixed -> bitwise reproducible).
 // Problem.F / Problem.J, fedm/functions.py:188-202
 // =============================================================================================
-template <int NS, bool PO, int NR, bool CACHE>
+template <int NS, bool PO, int NR, int CACHE>
 __global__ __launch_bounds__(256) void assemble_colour_kernel(
     const fedm_model_desc *__restrict__ md, const int *__restrict__ cell_list, int n_cells,
     const int *__restrict__ cells, const double *__restrict__ coords,
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void assemble_colour_kernel(
     for (int row = 0; row < NEQ; ++row) {
         if (mode == 1 && PO && row != NEQ - 1) continue;  // Poisson-only: species rows are identity
         el.row_moments(md, row, Uc, Hc, sc, ext);
+            el.row_prepare(md, row);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             F[(size_t)v[a] * NEQ + row] += el.residual(row, a);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void assemble_colour_kernel(
     }
 }
 
-template <int NS, bool PO, int NR, bool CACHE>
+template <int NS, bool PO, int NR, int CACHE>
 static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     hipMemsetAsync(c.d_F, 0, sizeof(double) * c.np, c.stream);
@@ -107,7 +109,7 @@ static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
 
 // THREADS: workgroup size = the patch's cell count rounded up (192 for Z-ordered meshes: two
 // 3-wave workgroups per CU at 2 waves/SIMD keep 6 waves busy; 320 covers 1-D strips)
-template <int NS, bool PO, int NR, bool CACHE, int THREADS>
+template <int NS, bool PO, int NR, int CACHE, int THREADS>
 __global__ __launch_bounds__(THREADS) void assemble_patch_kernel(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(THREADS) void assemble_patch_kernel(
         for (int row = 0; row < NEQ; ++row) {
             if (mode == 1 && PO && row != NEQ - 1) continue;
             el.row_moments(md, row, Uc, Hc, sc, ext);
+            el.row_prepare(md, row);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int lane = pc.lv[a];
@@ -202,7 +205,7 @@ size_t patch_lds_bytes(const Ctx &c) {
                              2 * mv + (size_t)(neq + c.ns) * mv);
 }
 
-template <int NS, bool PO, int NR, bool CACHE>
+template <int NS, bool PO, int NR, int CACHE>
 static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     const StepCoef sc = step_coef(c.dt, c.dt_old);
@@ -267,7 +270,7 @@ static void launch_boundary(Ctx &c, bool jacobian) {
     }
 }
 
-template <int NS, bool PO, int NR, bool CACHE>
+template <int NS, bool PO, int NR, int CACHE>
 static void assemble_variant(Ctx &c, bool jacobian, int mode) {
     if (c.assembly_kind == 1) assemble_patch_t<NS, PO, NR, CACHE>(c, jacobian, mode);
     else assemble_colour_t<NS, PO, NR, CACHE>(c, jacobian, mode);
@@ -279,10 +282,17 @@ static void assemble_dispatch(Ctx &c, bool jacobian, int mode) {
     const bool few = c.model.n_reactions <= 1;
     // cache exp(u) at the quadrature points when the tensors are emitted in several row passes
     const bool cache = NEQ > 1 && c.model.n_qp <= 3;
-    if (few && cache) assemble_variant<NS, PO, 1, (NEQ > 1)>(c, jacobian, mode);
-    else if (few) assemble_variant<NS, PO, 1, false>(c, jacobian, mode);
-    else if (cache) assemble_variant<NS, PO, FEDM_MAX_REACTIONS, (NEQ > 1)>(c, jacobian, mode);
-    else assemble_variant<NS, PO, FEDM_MAX_REACTIONS, false>(c, jacobian, mode);
+    // FIAT's degree-2 rule (points (1/6,1/6), (1/6,2/3), (2/3,1/6), weights 1/6) as constants
+    const fedm_model_desc &m = c.model;
+    const double sixth = 1.0 / 6.0, two3 = 2.0 / 3.0;
+    const bool stdq = cache && m.n_qp == 3 && m.qp_x[0] == sixth && m.qp_x[1] == sixth && m.qp_x[2] == two3 &&
+                      m.qp_y[0] == sixth && m.qp_y[1] == two3 && m.qp_y[2] == sixth && m.qp_w[0] == sixth &&
+                      m.qp_w[1] == sixth && m.qp_w[2] == sixth;
+    if (few && stdq) assemble_variant<NS, PO, 1, (NEQ > 1) ? 2 : 0>(c, jacobian, mode);
+    else if (few && cache) assemble_variant<NS, PO, 1, (NEQ > 1) ? 1 : 0>(c, jacobian, mode);
+    else if (few) assemble_variant<NS, PO, 1, 0>(c, jacobian, mode);
+    else if (cache) assemble_variant<NS, PO, FEDM_MAX_REACTIONS, (NEQ > 1) ? 1 : 0>(c, jacobian, mode);
+    else assemble_variant<NS, PO, FEDM_MAX_REACTIONS, 0>(c, jacobian, mode);
 }
 
 void launch_assemble(Ctx &c, bool jacobian, int mode) {
