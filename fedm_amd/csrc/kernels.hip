@@ -107,10 +107,12 @@ static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
 // read-modify-write in HBM and no zero-fill pass.
 // =============================================================================================
 
+// The kernel sits at 237-255 VGPRs; amdgpu_waves_per_eu pins it to two waves per SIMD (one
+// wave per SIMD is 1.5x slower) should a compiler change push it over 256.
 // THREADS: workgroup size = the patch's cell count rounded up (192 for Z-ordered meshes: two
 // 3-wave workgroups per CU at 2 waves/SIMD keep 6 waves busy; 320 covers 1-D strips)
 template <int NS, bool PO, int NR, int CACHE, int THREADS>
-__global__ __launch_bounds__(THREADS) void assemble_patch_kernel(
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void assemble_patch_kernel(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
     const int *__restrict__ halo_ptr, const int *__restrict__ halo,
