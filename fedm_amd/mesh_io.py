@@ -90,6 +90,95 @@ def read_vtu(path, field_name):
     raise KeyError(field_name)
 
 
+class XDMFFile:
+    """``df.XDMFFile(path)`` as ``file_output`` uses it (fedm/file_io.py:597-604):
+    ``write_checkpoint(values, name, t, append=True)`` adds one snapshot of a P1 field to
+    ``<stem>.h5`` in DOLFIN's checkpoint layout -- ``/<name>/<name>_<k>/{vector, cell_dofs,
+    x_cell_dofs, cells, mesh/{geometry, topology}}``, the layout the reference's own tests read
+    (tests/integrated_tests/testing_utils.py:21-24) -- and rewrites the light ``.xdmf`` index.
+    The dof numbering is the vertex numbering (``cell_dofs`` = flattened topology)."""
+
+    def __init__(self, path, mesh):
+        self.path = Path(path)
+        self.mesh = mesh
+        self.h5path = self.path.with_suffix(".h5")
+        self.counts = {}
+        self.times = {}
+
+    def write_checkpoint(self, values, name, t, encoding=None, append=True):
+        from . import h5
+        values = np.asarray(values, dtype=np.float64).ravel()
+        if values.size != len(self.mesh.coords):
+            raise ValueError("write_checkpoint: one value per mesh vertex expected")
+        if not append or not self.h5path.exists():   # DOLFIN: append=False starts the file over
+            self.counts, self.times, mode = {}, {}, "w"
+        else:
+            mode = "a"
+        cells = np.asarray(self.mesh.cells, dtype=np.int64)
+        with h5.File(self.h5path, mode) as f:
+            if name not in self.counts:               # appending to a file of an earlier session
+                self.counts[name] = len(f.keys(f"/{name}")) if f"/{name}" in f else 0
+                self.times.setdefault(name, [float("nan")] * self.counts[name])
+            k = self.counts[name]
+            g = f"/{name}/{name}_{k}"
+            f.write(g + "/vector", values.reshape(-1, 1))
+            f.write(g + "/cell_dofs", cells.reshape(-1, 1))
+            f.write(g + "/x_cell_dofs", (3 * np.arange(len(cells) + 1, dtype=np.int64)).reshape(-1, 1))
+            f.write(g + "/cells", np.arange(len(cells), dtype=np.int64).reshape(-1, 1))
+            f.write(g + "/mesh/geometry", np.asarray(self.mesh.coords, dtype=np.float64))
+            f.write(g + "/mesh/topology", cells)
+        self.counts[name] = k + 1
+        self.times[name].append(float(t))
+        self._write_index()
+
+    def _write_index(self):
+        nv, nc = len(self.mesh.coords), len(self.mesh.cells)
+        out = ['<?xml version="1.0"?>', '<Xdmf Version="3.0"><Domain>']
+        for name, ts in self.times.items():
+            out.append(f'<Grid Name="{name}" GridType="Collection" CollectionType="Temporal">')
+            for k, t in enumerate(ts):
+                g = f"{self.h5path.name}:/{name}/{name}_{k}"
+                out += [f'<Grid Name="{name}_{k}" GridType="Uniform">',
+                        f'<Topology TopologyType="Triangle" NumberOfElements="{nc}" NodesPerElement="3">'
+                        f'<DataItem Dimensions="{nc} 3" NumberType="Int" Format="HDF">{g}/mesh/topology</DataItem></Topology>',
+                        f'<Geometry GeometryType="XY"><DataItem Dimensions="{nv} 2" Format="HDF">{g}/mesh/geometry</DataItem></Geometry>',
+                        f'<Time Value="{t!r}" />',
+                        f'<Attribute Name="{name}" AttributeType="Scalar" Center="Node">'
+                        f'<DataItem Dimensions="{nv} 1" Format="HDF">{g}/vector</DataItem></Attribute>',
+                        '</Grid>']
+            out.append('</Grid>')
+        out.append('</Domain></Xdmf>')
+        self.path.with_suffix(".xdmf").write_text("\n".join(out))
+
+
+def read_h5(path, key):
+    """tests/integrated_tests/testing_utils.py:21-24: the ``vector`` of every snapshot under
+    ``/<key>``, in file order."""
+    from . import h5
+    with h5.File(path, "r") as f:
+        return [f.read(f"/{key}/{sub}/vector") for sub in f.keys(f"/{key}")]
+
+
+def read_checkpoint(path, key):
+    """Snapshots of ``/<key>`` mapped from the file's dof numbering back to its own vertex
+    numbering (works for DOLFIN-written files too): ``(coords, cells, [nodal values, ...])``."""
+    from . import h5
+    with h5.File(path, "r") as f:
+        subs = f.keys(f"/{key}")
+        fields, coords, cells = [], None, None
+        for sub in subs:
+            g = f"/{key}/{sub}"
+            vec = f.read(g + "/vector")[:, 0]
+            topo = f.read(g + "/mesh/topology", np.int64)
+            cd = f.read(g + "/cell_dofs", np.int64)[:, 0].reshape(-1, 3)
+            coords = f.read(g + "/mesh/geometry")
+            nodal = np.empty(len(coords))
+            nodal[topo.ravel()] = vec[cd.ravel()]
+            fields.append(nodal)
+            cells = topo
+    return coords, cells, fields
+
+
 def file_output(t, t_old, t_out, step, t_out_list, step_list, file_type, output_file_list,
                 particle_name, u_old, u_old1, unit="s"):
     """Linear interpolation of the solution to the output times, fedm/file_io.py:538-616: same
@@ -110,6 +199,8 @@ def file_output(t, t_old, t_out, step, t_out_list, step_list, file_type, output_
             temp = old + (t_out - t_old) * (new - old) / (t - t_old)
             if file_type[i] == "pvd":
                 output_file_list[i].write(temp, particle_name[i], t_out * scale)
+            elif file_type[i] == "xdmf":
+                output_file_list[i].write_checkpoint(temp, particle_name[i], t_out * scale, None, True)
             else:
                 raise ValueError(f"fedm.file_output: file type '{file_type}' not recognised. "
                                  "Options are 'pvd' and 'xdmf'.")

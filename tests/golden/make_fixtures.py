@@ -155,9 +155,33 @@ def controller_and_sources():
     (OUT / "reference_values.json").write_text(json.dumps(out, indent=1, default=str))
 
 
+def h5_layout():
+    """Datasets of one snapshot group of DOLFIN's XDMF checkpoint (rank, i = integer / f = float)
+    as found in the glow-discharge golden -- what fedm_amd.mesh_io.XDMFFile has to write."""
+    sys.path.insert(0, str(OUT.parent.parent))
+    from fedm_amd import h5
+    f = IT / "glow_discharge/20220707_results/electrons.h5"
+    layout = {}
+    with h5.File(f) as hf:
+        assert hf.keys("/electrons")[:2] == ["electrons_0", "electrons_1"]
+        for ds, kind in (("vector", "f"), ("cell_dofs", "i"), ("x_cell_dofs", "i"), ("cells", "i"),
+                         ("mesh/geometry", "f"), ("mesh/topology", "i")):
+            arr = hf.read("/electrons/electrons_0/" + ds, np.int64 if kind == "i" else np.float64)
+            layout[ds] = [arr.ndim, kind]
+        assert sorted(hf.keys("/electrons/electrons_0")) == ["cell_dofs", "cells", "mesh", "vector", "x_cell_dofs"]
+    path = OUT / "reference_values.json"
+    out = json.loads(path.read_text())
+    out["h5_checkpoint_layout"] = layout
+    path.write_text(json.dumps(out, indent=1, default=str))
+
+
 if __name__ == "__main__":
+    if "--h5-layout-only" in sys.argv:
+        h5_layout()
+        sys.exit(0)
     tof_golden()
     gd_golden()
     error_logs()
     controller_and_sources()
+    h5_layout()
     print("fixtures written to", OUT)

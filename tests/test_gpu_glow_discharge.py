@@ -81,7 +81,8 @@ def test_gd_device_pipeline_matches_host_pipeline():
 
 
 @pytest.mark.parametrize("device_pipeline", [False, True])
-def test_gd_golden_run(golden_dir, device_pipeline):
+def test_gd_golden_run(golden_dir, device_pipeline, tmp_path):
+    from fedm_amd import mesh_io
     from fedm_amd.cases import glow_discharge as gdc
     gold = np.load(golden_dir / "gd_golden.npz")
     ref_log = np.array(json.loads((golden_dir / "error_logs.json").read_text())["glow_discharge"])
@@ -94,3 +95,12 @@ def test_gd_golden_run(golden_dir, device_pipeline):
         err = (out["snapshot"][:, comp] - ref) / ref
         assert np.mean(np.abs(err)) < 1e-5 and np.sqrt(np.mean(err ** 2)) < 1e-5
         assert np.max(np.abs(err)) < 1e-3
+        # the same check the way the reference's test does it: through the XDMF/HDF5 checkpoint
+        # (tests/integrated_tests/glow_discharge/test_glow_discharge.py, testing_utils.py:21-24)
+        from fedm_amd.mesh import Mesh
+        f = mesh_io.XDMFFile(tmp_path / f"{key}.xdmf", Mesh(gold["coords"], gold["cells"]))
+        f.write_checkpoint(np.zeros(len(ref)), key, 0.0)        # snapshot _0 (initial condition slot)
+        f.write_checkpoint(out["snapshot"][:, comp], key, 1e-11)
+        vec = mesh_io.read_h5(tmp_path / f"{key}.h5", key)[1][:, 0]
+        rel = (vec - ref) / ref
+        assert np.mean(np.abs(rel)) < 1e-5 and np.sqrt(np.mean(rel ** 2)) < 1e-5

@@ -318,3 +318,37 @@ def test_file_output_interpolates_like_the_reference(tmp_path):
     assert t_out == pytest.approx(2e-11) and step == 1e-11
     with pytest.raises(ValueError, match="unit 'h' not valid"):
         mesh_io.file_output(1, 0, 1, 1, [1], [1], ["pvd"], [f], ["x"], [new], [old], unit="h")
+
+
+def test_xdmf_checkpoint_layout_and_roundtrip(tmp_path, golden_dir):
+    """XDMFFile.write_checkpoint writes DOLFIN's checkpoint layout (the datasets, ranks and
+    dtypes recorded from the reference's glow-discharge goldens) and file_output drives it like
+    fedm/file_io.py:597-604; read_h5 / read_checkpoint read it back."""
+    import json
+    from fedm_amd import h5, mesh_io
+    from fedm_amd.mesh import RectangleMesh
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 2.0), 4, 6, "crossed")
+    f = mesh_io.XDMFFile(tmp_path / "electrons.xdmf", mesh)
+    u0 = np.sin(mesh.coords[:, 0]) + mesh.coords[:, 1]
+    u1 = u0 + 1.0
+    # two output times inside one step, as file_output interpolates them
+    t_out, step = mesh_io.file_output(1.0, 0.0, 0.25, 0.5, [0.0, 10.0], [0.5, 0.5], ["xdmf"], [f],
+                                      ["electrons"], [u1], [u0], unit="ns")
+    assert t_out == pytest.approx(1.25) and step == 0.5
+    vecs = mesh_io.read_h5(tmp_path / "electrons.h5", "electrons")
+    assert len(vecs) == 2 and vecs[0].shape == (mesh.num_vertices(), 1)
+    assert np.allclose(vecs[0][:, 0], u0 + 0.25) and np.allclose(vecs[1][:, 0], u0 + 0.75)
+    coords, cells, fields = mesh_io.read_checkpoint(tmp_path / "electrons.h5", "electrons")
+    assert np.array_equal(coords, mesh.coords) and np.array_equal(cells, mesh.cells)
+    assert np.allclose(fields[1], u0 + 0.75)
+    layout = json.loads((golden_dir / "reference_values.json").read_text())["h5_checkpoint_layout"]
+    with h5.File(tmp_path / "electrons.h5") as hf:
+        assert hf.keys("/electrons") == ["electrons_0", "electrons_1"]
+        for ds, (rank, kind) in layout.items():
+            arr = hf.read("/electrons/electrons_0/" + ds, np.int64 if kind == "i" else np.float64)
+            assert arr.ndim == rank, ds
+    xdmf = (tmp_path / "electrons.xdmf").read_text()
+    assert "electrons.h5:/electrons/electrons_1/vector" in xdmf and 'Value="750000000.0"' in xdmf
+    # append=False starts over
+    f.write_checkpoint(u0, "electrons", 0.0, None, False)
+    assert len(mesh_io.read_h5(tmp_path / "electrons.h5", "electrons")) == 1
