@@ -195,22 +195,28 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             hipMemcpyAsync(v0, c.d_rhs, sizeof(double) * c.np, hipMemcpyDeviceToDevice, c.stream);
             launch_axpy(c, -1.0, c.d_w, v0);
         }
-        launch_norm2(c, v0, 0);
-        read_red(c, 1);
-        double beta = std::sqrt(c.h_red[0]);
-        if (!std::isfinite(beta)) {
-            *its_out = its;
-            *rnorm_out = beta;
-            return FEDM_DIVERGED_NAN;
-        }
-        if (first) {
-            r0 = beta;
+        // First cycle: |rhs| is not waited for -- v0 is normalised on the device and the norm
+        // rides along with the first Krylov step's publication (slot RED_SPARE).
+        const bool deferred = first;
+        double beta = 0.0, tol = 0.0;
+        if (deferred) {
+            launch_norm2(c, v0, RED_SPARE);
+            launch_normalise_copy(c, RED_SPARE, v0, v0);
             first = false;
+        } else {
+            launch_norm2(c, v0, 0);
+            read_red(c, 1);
+            beta = std::sqrt(c.h_red[0]);
+            if (!std::isfinite(beta)) {
+                *its_out = its;
+                *rnorm_out = beta;
+                return FEDM_DIVERGED_NAN;
+            }
+            rnorm = beta;
+            tol = std::max(rtol * r0, atol);
+            if (beta <= tol || its >= max_it) break;
+            launch_scale_copy(c, 1.0 / beta, v0, v0);
         }
-        rnorm = beta;
-        const double tol = std::max(rtol * r0, atol);
-        if (beta <= tol || its >= max_it) break;
-        launch_scale_copy(c, 1.0 / beta, v0, v0);
         std::fill(gvec.begin(), gvec.end(), 0.0);
         gvec[0] = beta;
         int j = 0;
@@ -228,6 +234,18 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 launch_cgs_update(c, j + 1, vp.data(), w);
             }
             wait_red(c);  // published by the finish kernel: the host works while the update runs
+            if (deferred && j == 0) {
+                beta = std::sqrt(c.h_red[RED_SPARE]);
+                if (!std::isfinite(beta)) {
+                    *its_out = its;
+                    *rnorm_out = beta;
+                    return FEDM_DIVERGED_NAN;
+                }
+                r0 = rnorm = beta;
+                tol = std::max(rtol * r0, atol);
+                gvec[0] = beta;
+                if (beta <= tol) break;  // nothing to solve: delta stays 0 (j == 0: no update below)
+            }
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = c.h_red[i];
             double hn2 = c.h_red[j + 1];
             const double ww = c.h_red[RED_K - 2];
@@ -745,8 +763,12 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         // comes from the same pass (a J assembly is wasted only on the final check)
         eval_jacobian(c, 0);
         launch_norm2(c, c.d_F, 0);
-        read_red(c, 1);
+        read_red(c, 3);  // |F|, and |dx|, |x| of the previous update (slots 1, 2) in one wait
         fnorm = std::sqrt(c.h_red[0]);
+        if (it > 0) {
+            snorm = std::sqrt(c.h_red[1]);
+            xnorm = std::sqrt(c.h_red[2]);
+        }
         if (!std::isfinite(fnorm)) {
             rc = FEDM_DIVERGED_NAN;
             break;
@@ -773,11 +795,8 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         }
         launch_axpy(c, 1.0, c.d_delta, c.d_u);
         comm_halo(c, c.d_u);
-        launch_norm2(c, c.d_delta, 0);   // |dx| and |x| for the stol test, one sync
-        launch_norm2(c, c.d_u, 1);
-        read_red(c, 2);
-        snorm = std::sqrt(c.h_red[0]);
-        xnorm = std::sqrt(c.h_red[1]);
+        launch_norm2(c, c.d_delta, 1);   // |dx| and |x| for the stol test: read with the next |F|
+        launch_norm2(c, c.d_u, 2);
         ++it;
     }
     r.iterations = it;

@@ -140,6 +140,7 @@ struct Ctx {
 
 constexpr int RED_BLOCKS = 512;
 constexpr int RED_K = 40;
+constexpr int RED_SPARE = RED_K - 3;  // a norm that rides along with the next Krylov publication
 
 // ---- kernel launchers (kernels.hip) -----------------------------------------------------
 // mode: 0 = full model, 1 = Poisson row only (species rows become identity)
@@ -162,6 +163,7 @@ void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y);
 void launch_norm2(Ctx &c, const double *x, int slot);                       // d_red[slot] = x.x
 void launch_axpy(Ctx &c, double a, const double *x, double *y);             // y += a x
 void launch_scale_copy(Ctx &c, double a, const double *x, double *y);       // y = a x
+void launch_normalise_copy(Ctx &c, int slot, const double *x, double *y);   // y = x / sqrt(d_red[slot])
 void launch_multi_axpy(Ctx &c, const double *coef_host, int k, const double *const *xs,
                        double *y, double sign);                             // y += sign*sum c_i x_i
 void launch_field_error(Ctx &c, int comp);  // d_red[0]=|new-old+eps|^2, d_red[1]=|old+eps|^2

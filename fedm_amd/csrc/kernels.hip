@@ -229,7 +229,7 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
 // per facet colour (facets of a colour share no vertex), plain adds on top of the volume
 // assembly -> fixed summation order.
 // =============================================================================================
-template <int NS>
+template <int NS, bool ATOMIC>
 __global__ void boundary_kernel(const fedm_model_desc *__restrict__ md, int n_facets,
                                 const int *__restrict__ facets /* [n][3] = cell, local facet, tag */,
                                 const int *__restrict__ cells, const double *__restrict__ coords,
@@ -248,27 +248,43 @@ __global__ void boundary_kernel(const fedm_model_desc *__restrict__ md, int n_fa
         x[a][1] = coords[2 * v[a] + 1];
         for (int s = 0; s < NEQ; ++s) Uc[a][s] = u[(size_t)v[a] * NEQ + s];
     }
-    auto addR = [&](int a, int s, double value) { F[(size_t)v[a] * NEQ + s] += value; };
+    auto addR = [&](int a, int s, double value) {
+        double *p = &F[(size_t)v[a] * NEQ + s];
+        if (ATOMIC) unsafeAtomicAdd(p, value);
+        else *p += value;
+    };
     auto addJ = [&](int a, int b, int sr, int scol, double value) {
         const uint32_t slot = cell_slots[(size_t)c * 9 + a * 3 + b];
-        val[((size_t)(slot >> 6) * NEQ2 + sr * NEQ + scol) * SLICE + (slot & 63)] += value;
+        double *p = &val[((size_t)(slot >> 6) * NEQ2 + sr * NEQ + scol) * SLICE + (slot & 63)];
+        if (ATOMIC) unsafeAtomicAdd(p, value);
+        else *p += value;
     };
     boundary_facet<NS>(md, x, Uc, fi, tag, jacobian != 0, addR, addJ);
 }
 
+template <bool ATOMIC>
+static void launch_boundary_range(Ctx &c, bool jacobian, int f0, int n) {
+    const dim3 g((n + 127) / 128), b(128);
+    const int *fl = c.d_bfacets + 3 * f0;
+    switch (c.ns) {
+        case 1: hipLaunchKernelGGL((boundary_kernel<1, ATOMIC>), g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+        case 2: hipLaunchKernelGGL((boundary_kernel<2, ATOMIC>), g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+        case 3: hipLaunchKernelGGL((boundary_kernel<3, ATOMIC>), g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+    }
+}
+
 static void launch_boundary(Ctx &c, bool jacobian) {
     if (!c.poisson || c.n_bfacets == 0) return;
+    if (c.assembly_kind == 1) {
+        // the patch assembly already sums in a run-dependent order (LDS atomics): all facets in
+        // one launch with fp64 atomics instead of one launch per colour
+        launch_boundary_range<true>(c, jacobian, 0, c.n_bfacets);
+        return;
+    }
     const int ncol = (int)c.bfacet_colour_ptr.size() - 1;
     for (int k = 0; k < ncol; ++k) {
         const int f0 = c.bfacet_colour_ptr[k], n = c.bfacet_colour_ptr[k + 1] - f0;
-        if (n == 0) continue;
-        const dim3 g((n + 127) / 128), b(128);
-        const int *fl = c.d_bfacets + 3 * f0;
-        switch (c.ns) {
-            case 1: hipLaunchKernelGGL(boundary_kernel<1>, g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
-            case 2: hipLaunchKernelGGL(boundary_kernel<2>, g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
-            case 3: hipLaunchKernelGGL(boundary_kernel<3>, g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
-        }
+        if (n > 0) launch_boundary_range<false>(c, jacobian, f0, n);
     }
 }
 
@@ -764,7 +780,7 @@ __global__ __launch_bounds__(256) void reduce_finish_kernel(const double *__rest
                                                             unsigned long long *seq) {
     __shared__ double fin[RED_K];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x < RED_K) fin[threadIdx.x] = 0.0;
+    if (threadIdx.x < RED_K) fin[threadIdx.x] = (threadIdx.x == RED_SPARE) ? out[RED_SPARE] : 0.0;
     __syncthreads();
     for (int i = wave; i < k; i += 4) {
         double sum = 0.0;
@@ -976,6 +992,21 @@ static dim3 vec_grid(const Ctx &c) {
 void launch_axpy(Ctx &c, double a, const double *x, double *y) {
     hipLaunchKernelGGL(axpy_kernel, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, a, x, y);
 }
+// y = x / sqrt(d_red[slot]) (0 when that norm is 0 or not finite): normalisation without a host
+// round trip
+__global__ void normalise_copy_kernel(size_t n, const double *__restrict__ red, int slot,
+                                      const double *__restrict__ x, double *__restrict__ y) {
+    const double n2 = red[slot];
+    const double a = (n2 > 0.0 && n2 < 1.7e308) ? 1.0 / sqrt(n2) : 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i];
+}
+
+void launch_normalise_copy(Ctx &c, int slot, const double *x, double *y) {
+    hipLaunchKernelGGL(normalise_copy_kernel, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, c.d_red, slot,
+                       x, y);
+}
+
 void launch_scale_copy(Ctx &c, double a, const double *x, double *y) {
     hipLaunchKernelGGL(scale_copy_kernel, vec_grid(c), dim3(256), 0, c.stream, (size_t)c.np, a, x, y);
 }
