@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
                                                        const double *__restrict__ x,
                                                        const double *__restrict__ b,
                                                        double *__restrict__ y, double omega,
-                                                       double *__restrict__ aux) {
+                                                       double *__restrict__ aux, int ystride, int yoff) {
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
     if (!writer) return;
     if (MODE == 0) y[r] = acc;
     if (MODE == 1) y[r] = e_b - acc;
-    if (MODE == 2) y[r] = e_x + omega * e_d * (e_b - acc);
+    if (MODE == 2) y[r * ystride + yoff] = e_x + omega * e_d * (e_b - acc);  // strided: see Amg::out
     if (MODE == 3) y[r] = e_x + acc;
     if (MODE == 4) {
         y[r] = e_b - acc;
@@ -163,11 +163,11 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
 }
 
 static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const double *b,
-                       double *y, double omega, double *aux = nullptr) {
+                       double *y, double omega, double *aux = nullptr, int ystride = 1, int yoff = 0) {
     const dim3 g((A.n_slices + 3) / 4), bl(256);
 #define FEDM_ELL(M)                                                                                  \
     hipLaunchKernelGGL(ell_spmv_kernel<M>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split,   \
-                       A.width, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux)
+                       A.width, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux, ystride, yoff)
     switch (mode) {
         case 0: FEDM_ELL(0); break;
         case 1: FEDM_ELL(1); break;
@@ -249,6 +249,12 @@ void Amg::vcycle(Ctx &c, int l) {
     vcycle(c, l + 1);
     ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c
     for (int s = 0; s < nu; ++s) {
+        if (l == 0 && s == nu - 1 && out) {
+            // the cycle's result goes straight into the potential component of the caller's
+            // interleaved vector (no scatter kernel afterwards)
+            ell_launch(c, L.A, 2, x, L.b, out, omega, nullptr, out_stride, out_offset);
+            break;
+        }
         ell_launch(c, L.A, 2, x, L.b, y, omega);
         std::swap(x, y);
     }

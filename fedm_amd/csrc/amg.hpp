@@ -30,6 +30,10 @@ struct Amg {
     int n_coarse = 0, coarse_ld = 0;
     int nu = 2;
     bool pre_smooth = true;  // false: V(0,nu) cycles (restrict the right-hand side directly)
+    // when set (while a Krylov step is being captured): the last level-0 sweep writes
+    // out[r * out_stride + out_offset] instead of levels[0].x
+    double *out = nullptr;
+    int out_stride = 1, out_offset = 0;
     double omega = 0.67;
     hipGraphExec_t graph_exec = nullptr;
     void vcycle(Ctx &c, int level);  // levels[level].b -> levels[level].x (kernel launches)

@@ -141,9 +141,17 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
         std::vector<const double *> dotp(j + 2);
         for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
         dotp[j + 1] = w;
-        // the V-cycle result is scattered into w by the reduction kernel itself
+        // the V-cycle's last sweep writes the potential component of w itself (V(nu,nu) with
+        // more than one level); otherwise the reduction kernel scatters it
+        const bool direct = c.amg->pre_smooth && c.amg->levels.size() > 1;
+        if (direct) {
+            c.amg->out = w;
+            c.amg->out_stride = c.neq;
+            c.amg->out_offset = c.neq - 1;
+        }
         fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, false);
-        launch_dots_fused(c, dotp.data(), w, j + 2, c.amg->levels[0].x);
+        c.amg->out = nullptr;
+        launch_dots_fused(c, dotp.data(), w, j + 2, direct ? nullptr : c.amg->levels[0].x);
         launch_cgs_update(c, j + 1, vp, w);
         c.capturing = false;
         hipGraphExec_t exec = nullptr;
