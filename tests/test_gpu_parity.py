@@ -216,3 +216,9 @@ def test_krylov_graphs_match_plain_launches():
         prob.close()
     assert out["graphs"][0] == out["plain"][0]
     assert np.allclose(out["graphs"][1], out["plain"][1], rtol=1e-10, atol=1e-10)
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke() entry point (one small streamer solve checked against the oracle)."""
+    import __graft_entry__ as entry
+    entry.smoke()
