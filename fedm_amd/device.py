@@ -223,6 +223,10 @@ class DeviceProblem:
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.nv, self.nc = self.coords.shape[0], self.cells.shape[0]
+        if self.coords.ndim != 2 or self.coords.shape[1] != 2 or self.cells.ndim != 2 or self.cells.shape[1] != 3:
+            raise ValueError("DeviceProblem: coords must be (n_vertices, 2) and cells (n_cells, 3)")
+        if self.nc and (self.cells.min() < 0 or self.cells.max() >= self.nv):
+            raise ValueError("DeviceProblem: cell vertex index out of range")
         self.n_eq = model.n_eq
         self.n = self.nv * self.n_eq
         self._tags = None if facet_tags is None else np.ascontiguousarray(facet_tags, dtype=np.int8)

@@ -222,3 +222,53 @@ def test_graft_entry_smoke():
     """The driver's smoke() entry point (one small streamer solve checked against the oracle)."""
     import __graft_entry__ as entry
     entry.smoke()
+
+
+def test_numerical_failures_raise_and_adaptive_solver_recovers(tmp_path):
+    """Error behaviour of the boundary: positive return codes of the C ABI become
+    RuntimeError, which adaptive_solver's catch-all (fedm/functions.py:1080-1127) answers by
+    halving the step and repeating; a step whose error exceeds ttol is repeated with
+    dt * 0.5 * ttol / error (:1090-1101)."""
+    from fedm_amd.cases import streamer
+    msh = streamer.mesh(32, 4.0)
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    U, _ = streamer.initialise(prob)
+    # (1) Newton cannot converge in one iteration -> FEDM_DIVERGED_MAX_IT -> RuntimeError
+    prob.set_step(5e-12, 1e30)
+    with pytest.raises(RuntimeError, match="maximum"):
+        prob.newton_solve(rtol=1e-12, max_it=1)
+    # (2) NaN in the state -> FEDM_DIVERGED_NAN -> RuntimeError
+    bad = U.copy()
+    bad[5, 1] = np.nan
+    prob.set_state(bad, U, U)
+    with pytest.raises(RuntimeError, match="NaN"):
+        prob.newton_solve(rtol=1e-4, max_it=20)
+    # (3) the time loop recovers from both kinds of rejection
+    prob.set_state(U, U, U)
+    st = streamer.Stepper(prob, dt_init=4e-10, dt_max=4e-10, error_file=tmp_path / "relative error.log")
+    st.step()
+    rows = np.loadtxt(tmp_path / "relative error.log", ndmin=2)
+    assert st.dt_old.time_step < 4e-10                 # the accepted step is shorter than the first try
+    assert rows[-1, 0] < st.ttol                       # last logged attempt was accepted
+    assert len(rows) >= 2 or st.dt_old.time_step < 4e-10
+    assert np.all(np.isfinite(prob.get_state()))
+    prob.close()
+
+
+def test_bad_descriptors_are_hard_errors():
+    """Negative return codes (bad descriptor) raise with the library's message."""
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import DeviceProblem
+    msh = streamer.mesh(8, 1.0)
+    cells = msh.cells.copy()
+    cells[3, 1] = msh.coords.shape[0] + 7              # vertex index out of range
+    with pytest.raises(ValueError, match="out of range"):
+        DeviceProblem(msh.coords, cells, streamer.model())
+    # the C ABI checks on its own as well (a caller that binds the library directly)
+    from fedm_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    rc = lib.fedm_set_fieldsplit(prob._h, 0, None)
+    assert rc < 0 and b"sweeps" in lib.fedm_last_error()
+    prob.close()

@@ -352,3 +352,18 @@ def test_xdmf_checkpoint_layout_and_roundtrip(tmp_path, golden_dir):
     # append=False starts over
     f.write_checkpoint(u0, "electrons", 0.0, None, False)
     assert len(mesh_io.read_h5(tmp_path / "electrons.h5", "electrons")) == 1
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: without the HIP library the product refuses to load."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from fedm_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept (RuntimeError, OSError) as e:\n    print('REFUSED', e)\n") % str(root)
+    env = dict(os.environ, FEDM_HIP_LIB=str(tmp_path / "libfedm_hip_missing.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "REFUSED" in out.stdout and "not found" in out.stdout
