@@ -36,10 +36,21 @@ class Runner(streamer.Stepper):
                              dirichlet_dofs=ddofs, dirichlet_vals=dvals, device=local_rank,
                              n_owned=lm.n_owned)
         if transport == "rccl":
-            import torch
-            uid = [rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0, group=group)
-            prob.init_comm_rccl(lm, uid[0], rank, world)
+            # every rank must take the same branch: agree on the outcome of the RCCL set-up
+            ok = 1
+            try:
+                uid = [rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0, group=group)
+                prob.init_comm_rccl(lm, uid[0], rank, world)
+            except Exception as exc:                     # noqa: BLE001 - reported, then the fallback
+                ok = 0
+                print(f"[fedm_amd] rank {rank}: RCCL transport unavailable ({exc}); "
+                      f"falling back to host-staged exchanges", flush=True)
+            flags = [None] * world
+            dist.all_gather_object(flags, ok, group=group)
+            if not all(flags):
+                transport = "torch-gloo (RCCL set-up failed)"
+                prob.init_comm_torch(lm, dist.new_group(backend="gloo"))
         else:
             prob.init_comm_torch(lm, group)
         super().__init__(prob, **kw)

@@ -95,3 +95,38 @@ def test_rccl_transport_single_rank():
         prob.close()
     # not bitwise: the LDS-atomic assembly sums in a run-dependent order
     assert np.allclose(out[0], out[1], rtol=1e-9, atol=1e-9)
+
+
+def _worker_rccl(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from fedm_amd.cases import streamer_distributed
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        run = streamer_distributed.Runner(None, rank, world, 0, grading=2.0, transport="rccl",
+                                          n_per_gpu=N_PER_GPU)
+        run.initialise()
+        run.step()
+        q.put((rank, run.partition_name, run.linear_iterations))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_setup_failure_falls_back_on_every_rank():
+    """Two ranks on ONE device: the RCCL bootstrap between the processes works, then RCCL refuses
+    the duplicate GPU.  All ranks must agree on that and continue over the host-staged transport
+    (the scaling runs must not die on a transport problem)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rccl, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("RCCL set-up failed" in r[1] for r in res)
+    assert res[0][2] == res[1][2] > 0
