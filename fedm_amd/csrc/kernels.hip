@@ -107,6 +107,20 @@ static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
 // read-modify-write in HBM and no zero-fill pass.
 // =============================================================================================
 
+#ifdef FEDM_PHASE_TIMING
+__device__ unsigned long long g_phase[8];
+#define FEDM_T(k) if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase[k], now_ - t_prev_); t_prev_ = now_; }
+extern "C" void fedm_debug_phase(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    }
+}
+#else
+#define FEDM_T(k)
+#endif
+
 // The kernel sits at 237-255 VGPRs; amdgpu_waves_per_eu pins it to two waves per SIMD (one
 // wave per SIMD is 1.5x slower) should a compiler change push it over 256.
 // THREADS: workgroup size = the patch's cell count rounded up (192 for Z-ordered meshes: two
@@ -130,11 +144,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *Ul = vx + 2 * max_verts;            // [max_verts][NEQ]
     double *Hl = Ul + NEQ * max_verts;          // [max_verts][NS]
 
+#ifdef FEDM_PHASE_TIMING
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     const int S = blockIdx.x;
     const int b0 = boff[S], width = boff[S + 1] - b0;
     const int n_acc = jacobian ? width * NEQ2 * SLICE : 0;
     for (int k = threadIdx.x; k < n_acc; k += blockDim.x) acc[k] = 0.0;
     for (int k = threadIdx.x; k < SLICE * NEQ; k += blockDim.x) Fl[k] = 0.0;
+    FEDM_T(0)
     const int h0 = halo_ptr[S], n_local = SLICE + halo_ptr[S + 1] - h0;
     for (int i = threadIdx.x; i < n_local; i += blockDim.x) {
         const int g = (i < SLICE) ? S * SLICE + i : halo[h0 + i - SLICE];
@@ -148,7 +166,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 Hl[i * NS + s] = sc.c_old * uold[(size_t)g * NEQ + s] + sc.c_old1 * uold1[(size_t)g * NEQ + s];
         }
     }
+    FEDM_T(1)
     __syncthreads();
+    FEDM_T(2)
 
     const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
     for (int i = threadIdx.x; i < n_cells; i += blockDim.x) {
@@ -170,8 +190,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int s = 0; s < NS; ++s)
             ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)pc.cell * md->ext_nodes[s] : nullptr;
 
+        FEDM_T(3)
         Element<NS, PO, NR, CACHE> el;
         el.setup(md, x, Uc, Hc, sc, mode);
+        FEDM_T(4)
 #pragma unroll
         for (int row = 0; row < NEQ; ++row) {
             if (mode == 1 && PO && row != NEQ - 1) continue;
@@ -194,11 +216,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
     }
+    FEDM_T(5)
     __syncthreads();
+    FEDM_T(6)
     double *vdst = val + (size_t)b0 * NEQ2 * SLICE;
     for (int k = threadIdx.x; k < n_acc; k += blockDim.x) vdst[k] = acc[k];
     double *fdst = F + (size_t)S * SLICE * NEQ;
     for (int k = threadIdx.x; k < SLICE * NEQ; k += blockDim.x) fdst[k] = Fl[k];
+    FEDM_T(7)
 }
 
 size_t patch_lds_bytes(const Ctx &c) {

@@ -1,0 +1,20 @@
+"""Phase breakdown of the patch assembly kernel (needs a -DFEDM_PHASE_TIMING build: FEDM_HIP_LIB)."""
+import ctypes as C, sys
+sys.path.insert(0, '.')
+from fedm_amd.cases import streamer
+from fedm_amd import _lib
+msh = streamer.mesh(576, 4.0)
+prob = streamer.device_problem(msh.coords, msh.cells)
+streamer.initialise(prob, multigrid=False)
+prob.set_step(5e-12, 5e-12)
+lib = _lib.load()
+out = (C.c_ulonglong * 8)()
+lib.fedm_debug_phase(out, 1)
+n = 10
+for _ in range(n): prob.jacobian()
+lib.fedm_debug_phase(out, 1)
+names = ["zero LDS", "stage vertices (global loads)", "barrier 1", "cell record + LDS reads", "setup",
+         "rows: moments + emission + atomics", "barrier 2", "stream out"]
+tot = sum(out)
+for k, v in zip(names, out):
+    print(f"{k:38s} {100.0 * v / tot:5.1f} %   {v / n / 5203 / 100.0:7.2f} us per patch (100 MHz clock)")
