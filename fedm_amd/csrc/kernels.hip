@@ -137,7 +137,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int max_verts) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     constexpr int NEQ2 = NEQ * NEQ;
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *acc = lds;                          // [width][NEQ2][64]
     double *Fl = acc + acc_doubles;             // [64][NEQ]
     double *vx = Fl + SLICE * NEQ;              // [max_verts][2]
@@ -149,8 +149,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
     const int S = blockIdx.x;
     const int b0 = boff[S], width = boff[S + 1] - b0;
-    const int n_acc = jacobian ? width * NEQ2 * SLICE : 0;
-    for (int k = threadIdx.x; k < n_acc; k += blockDim.x) acc[k] = 0.0;
+    const int n_acc = jacobian ? width * NEQ2 * SLICE : 0;  // a multiple of 64: 16-byte LDS / HBM accesses
+    {
+        double2 *acc2 = reinterpret_cast<double2 *>(acc);
+        for (int k = threadIdx.x; k < n_acc / 2; k += blockDim.x) acc2[k] = make_double2(0.0, 0.0);
+    }
     for (int k = threadIdx.x; k < SLICE * NEQ; k += blockDim.x) Fl[k] = 0.0;
     FEDM_T(0)
     const int h0 = halo_ptr[S], n_local = SLICE + halo_ptr[S + 1] - h0;
@@ -219,8 +222,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
     FEDM_T(5)
     __syncthreads();
     FEDM_T(6)
-    double *vdst = val + (size_t)b0 * NEQ2 * SLICE;
-    for (int k = threadIdx.x; k < n_acc; k += blockDim.x) vdst[k] = acc[k];
+    {
+        double2 *vdst2 = reinterpret_cast<double2 *>(val + (size_t)b0 * NEQ2 * SLICE);
+        const double2 *acc2 = reinterpret_cast<const double2 *>(acc);
+        for (int k = threadIdx.x; k < n_acc / 2; k += blockDim.x) vdst2[k] = acc2[k];
+    }
     double *fdst = F + (size_t)S * SLICE * NEQ;
     for (int k = threadIdx.x; k < SLICE * NEQ; k += blockDim.x) fdst[k] = Fl[k];
     FEDM_T(7)
