@@ -119,6 +119,10 @@ def install(handle, levels, nu=2, omega=0.67):
     A = (_lib.Csr * n)(*[_csr_struct(a, keep) for a, _ in levels])
     P = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p, keep) for _, p in levels[:-1]])
     R = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p.T, keep) for _, p in levels[:-1]])
+    n_coarse = levels[-1][0].shape[0]
+    if n_coarse > 8192:   # a dense inverse of that size is the wrong tool (n^2 doubles on host and device)
+        raise RuntimeError(f"multigrid coarsening stalled at {n_coarse} rows (levels "
+                           f"{[a.shape[0] for a, _ in levels]}): adjust theta / max_coarse")
     coarse = np.ascontiguousarray(np.linalg.inv(levels[-1][0].toarray()))
     rc = lib.fedm_amg_setup(handle, n, A, P, R, coarse.ctypes.data_as(C.POINTER(C.c_double)),
                             int(nu), float(omega))
