@@ -127,9 +127,13 @@ void iter_graphs_clear(Ctx &c) {
 // One Krylov step  w = Minv J v_j;  h = V^T w;  w <- (w - V h)/|.|  as a hipGraph, captured the
 // first time index j is reached: ~30 kernels replayed back to back with no launch gaps and one
 // host call.  All pointers are fixed for a given j; the mailbox tag is a device counter.
+// Across GPUs the collectives stay outside the graph: halo exchange, then the graph up to the
+// local partial reductions, then the all-reduce, the finish/publish kernel and the update.
 static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w) {
-    if (!c.iter_graphs_ok || c.comm || !(c.amg && c.poisson) || (c.prof.on && c.prof.all_kinds)) return false;
+    if (!c.iter_graphs_ok || !(c.amg && c.poisson) || (c.prof.on && c.prof.all_kinds)) return false;
+    const bool multi = c.comm != nullptr;
     if ((int)c.iter_graph.size() <= j) c.iter_graph.resize(j + 1, nullptr);
+    if (multi) comm_halo(c, const_cast<double *>(vp[j]));  // ghost inputs from their owners
     if (!c.iter_graph[j]) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -151,8 +155,8 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
         }
         fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, false);
         c.amg->out = nullptr;
-        launch_dots_fused(c, dotp.data(), w, j + 2, direct ? nullptr : c.amg->levels[0].x);
-        launch_cgs_update(c, j + 1, vp, w);
+        launch_dots_fused(c, dotp.data(), w, j + 2, direct ? nullptr : c.amg->levels[0].x, !multi);
+        if (!multi) launch_cgs_update(c, j + 1, vp, w);
         c.capturing = false;
         hipGraphExec_t exec = nullptr;
         const bool ok = hipStreamEndCapture(c.stream, &graph) == hipSuccess && graph &&
@@ -168,9 +172,24 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
     if (hipGraphLaunch(c.iter_graph[j], c.stream) != hipSuccess) {
         hipGetLastError();
         c.iter_graphs_ok = false;
+        if (multi) {  // the halo exchange above has happened; finish this step with plain launches
+            std::vector<const double *> dotp(j + 2);
+            for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+            dotp[j + 1] = w;
+            fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, true);
+            launch_dots(c, dotp.data(), w, j + 2, true);
+            launch_cgs_update(c, j + 1, vp, w);
+            return true;
+        }
         return false;
     }
-    ++c.mail_seq;
+    if (multi) {
+        comm_allreduce(c, c.d_red, j + 2);
+        launch_cgs_finish(c, j + 2);
+        launch_cgs_update(c, j + 1, vp, w);
+    } else {
+        ++c.mail_seq;
+    }
     return true;
 }
 

@@ -158,7 +158,9 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv);
 void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
-void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0);
+void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0,
+                       bool finish = true);
+void launch_cgs_finish(Ctx &c, int k);  // finish formulae + publication on d_red[0..k)
 void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y);
 void launch_norm2(Ctx &c, const double *x, int slot);                       // d_red[slot] = x.x
 void launch_axpy(Ctx &c, double a, const double *x, double *y);             // y += a x

@@ -897,7 +897,13 @@ void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool f
 
 // single-GPU Krylov step: dots (+ the scatter of the V-cycle result x0 into the potential
 // component of y), then reduction + finish + publication
-void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0) {
+void launch_cgs_finish(Ctx &c, int k) {
+    hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red, c.h_red, c.d_mail_seq);
+    if (!c.capturing) ++c.mail_seq;
+}
+
+// finish = false (several GPUs): only the local sums, d_red[0..k), for the all-reduce that follows
+void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0, bool finish) {
     const int grid = red_grid(c);
     int done = 0;
     while (done < k) {
@@ -924,6 +930,10 @@ void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const 
         }
 #undef FEDM_DF
         done += kk;
+    }
+    if (!finish) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
+        return;
     }
     hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, c.stream, c.d_partials, grid, k, c.d_red,
                        c.h_red, c.d_mail_seq);
