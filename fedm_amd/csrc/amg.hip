@@ -534,6 +534,20 @@ void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, dou
     }
 }
 
+void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter,
+                                    int part, const int *slices, int n_slices) {
+    const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, omega, slices, n_slices);
+    if (part == 0) return;
+    switch (c.ns) {
+        case 1: fs_finish_t<1>(c, amg, t, z, 1.0, scatter); break;
+        case 2: fs_finish_t<2>(c, amg, t, z, 1.0, scatter); break;
+        case 3: fs_finish_t<3>(c, amg, t, z, 1.0, scatter); break;
+        case 4: fs_finish_t<4>(c, amg, t, z, 1.0, scatter); break;
+        case 5: fs_finish_t<5>(c, amg, t, z, 1.0, scatter); break;
+    }
+}
+
 // fp32 copy of the species columns of every block (all NEQ rows x NS columns)
 template <int NS>
 __global__ __launch_bounds__(256) void species_planes_kernel(size_t n_entries, const double *__restrict__ val,

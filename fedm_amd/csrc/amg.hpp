@@ -49,6 +49,10 @@ void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha);  // z = alpha*Minv t
 // z = Minv (J v); scatter = false leaves the potential component in amg.levels[0].x
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter);
+// the same in two parts for the halo overlap: part 0 = SpMV of `slices` only (interior rows),
+// part 1 = SpMV of `slices` (boundary rows) followed by the rest of the preconditioner
+void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter,
+                                    int part, const int *slices, int n_slices);
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z);
 
 }  // namespace fedm

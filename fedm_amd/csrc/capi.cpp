@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 
 #include "amg.hpp"
@@ -121,75 +122,117 @@ static void prepare_preconditioner_and_rhs(Ctx &c) {
 void iter_graphs_clear(Ctx &c) {
     for (hipGraphExec_t g : c.iter_graph)
         if (g) hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : c.iter_graph_interior)
+        if (g) hipGraphExecDestroy(g);
     c.iter_graph.clear();
+    c.iter_graph_interior.clear();
 }
 
 // One Krylov step  w = Minv J v_j;  h = V^T w;  w <- (w - V h)/|.|  as a hipGraph, captured the
 // first time index j is reached: ~30 kernels replayed back to back with no launch gaps and one
 // host call.  All pointers are fixed for a given j; the mailbox tag is a device counter.
-// Across GPUs the collectives stay outside the graph: halo exchange, then the graph up to the
-// local partial reductions, then the all-reduce, the finish/publish kernel and the update.
+// Across GPUs the collectives stay outside the graphs, and the halo exchange of v_j runs on the
+// communication stream while the compute stream already multiplies the interior matrix slices
+// (those without ghost columns):
+//   mark v_j complete -> graph I_j (interior SpMV)  ||  exchange  -> wait -> graph B_j (boundary
+//   SpMV, preconditioner, local partial sums) -> all-reduce -> finish/publish -> update.
+static bool capture_graph(Ctx &c, hipGraphExec_t *out, const std::function<void()> &body) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        hipGetLastError();
+        return false;
+    }
+    c.capturing = true;
+    body();
+    c.capturing = false;
+    hipGraphExec_t exec = nullptr;
+    const bool ok = hipStreamEndCapture(c.stream, &graph) == hipSuccess && graph &&
+                    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) hipGraphDestroy(graph);
+    if (!ok) {
+        hipGetLastError();
+        return false;
+    }
+    *out = exec;
+    return true;
+}
+
 static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w) {
     if (!c.iter_graphs_ok || !(c.amg && c.poisson) || (c.prof.on && c.prof.all_kinds)) return false;
     const bool multi = c.comm != nullptr;
-    if ((int)c.iter_graph.size() <= j) c.iter_graph.resize(j + 1, nullptr);
-    if (multi) comm_halo(c, const_cast<double *>(vp[j]));  // ghost inputs from their owners
+    if ((int)c.iter_graph.size() <= j) {
+        c.iter_graph.resize(j + 1, nullptr);
+        c.iter_graph_interior.resize(j + 1, nullptr);
+    }
     if (!c.iter_graph[j]) {
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-            hipGetLastError();
-            c.iter_graphs_ok = false;
-            return false;
-        }
-        c.capturing = true;
         std::vector<const double *> dotp(j + 2);
         for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
         dotp[j + 1] = w;
         // the V-cycle's last sweep writes the potential component of w itself (V(nu,nu) with
         // more than one level); otherwise the reduction kernel scatters it
         const bool direct = c.amg->pre_smooth && c.amg->levels.size() > 1;
-        if (direct) {
-            c.amg->out = w;
-            c.amg->out_stride = c.neq;
-            c.amg->out_offset = c.neq - 1;
+        const double *x0 = direct ? nullptr : c.amg->levels[0].x;
+        auto with_direct_output = [&](const std::function<void()> &f) {
+            if (direct) {
+                c.amg->out = w;
+                c.amg->out_stride = c.neq;
+                c.amg->out_offset = c.neq - 1;
+            }
+            f();
+            c.amg->out = nullptr;
+        };
+        bool ok = true;
+        if (!multi) {
+            ok = capture_graph(c, &c.iter_graph[j], [&] {
+                with_direct_output([&] { fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, false); });
+                launch_dots_fused(c, dotp.data(), w, j + 2, x0, true);
+                launch_cgs_update(c, j + 1, vp, w);
+            });
+        } else {
+            Comm &cm = *c.comm;
+            if (cm.n_interior)
+                ok = capture_graph(c, &c.iter_graph_interior[j], [&] {
+                    fieldsplit_apply_operator_part(c, *c.amg, vp[j], c.d_tmp, w, false, 0, cm.d_interior, cm.n_interior);
+                });
+            ok = ok && capture_graph(c, &c.iter_graph[j], [&] {
+                with_direct_output([&] {
+                    fieldsplit_apply_operator_part(c, *c.amg, vp[j], c.d_tmp, w, false, 1, cm.d_boundary, cm.n_boundary);
+                });
+                launch_dots_fused(c, dotp.data(), w, j + 2, x0, false);
+            });
         }
-        fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, false);
-        c.amg->out = nullptr;
-        launch_dots_fused(c, dotp.data(), w, j + 2, direct ? nullptr : c.amg->levels[0].x, !multi);
-        if (!multi) launch_cgs_update(c, j + 1, vp, w);
-        c.capturing = false;
-        hipGraphExec_t exec = nullptr;
-        const bool ok = hipStreamEndCapture(c.stream, &graph) == hipSuccess && graph &&
-                        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (graph) hipGraphDestroy(graph);
         if (!ok) {
+            c.iter_graphs_ok = false;
+            return false;
+        }
+    }
+    if (!multi) {
+        if (hipGraphLaunch(c.iter_graph[j], c.stream) != hipSuccess) {
             hipGetLastError();
             c.iter_graphs_ok = false;
             return false;
         }
-        c.iter_graph[j] = exec;
+        ++c.mail_seq;
+        return true;
     }
-    if (hipGraphLaunch(c.iter_graph[j], c.stream) != hipSuccess) {
+    comm_halo_begin(c);
+    bool ok = !c.iter_graph_interior[j] || hipGraphLaunch(c.iter_graph_interior[j], c.stream) == hipSuccess;
+    comm_halo_exchange(c, const_cast<double *>(vp[j]));
+    ok = ok && hipGraphLaunch(c.iter_graph[j], c.stream) == hipSuccess;
+    if (!ok) {  // the exchange has happened: redo the whole step with plain launches (same result)
         hipGetLastError();
         c.iter_graphs_ok = false;
-        if (multi) {  // the halo exchange above has happened; finish this step with plain launches
-            std::vector<const double *> dotp(j + 2);
-            for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
-            dotp[j + 1] = w;
-            fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, true);
-            launch_dots(c, dotp.data(), w, j + 2, true);
-            launch_cgs_update(c, j + 1, vp, w);
-            return true;
-        }
-        return false;
-    }
-    if (multi) {
-        comm_allreduce(c, c.d_red, j + 2);
-        launch_cgs_finish(c, j + 2);
+        std::vector<const double *> dotp(j + 2);
+        for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+        dotp[j + 1] = w;
+        fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, true);
+        launch_dots(c, dotp.data(), w, j + 2, true);
         launch_cgs_update(c, j + 1, vp, w);
-    } else {
-        ++c.mail_seq;
+        return true;
     }
+    comm_allreduce(c, c.d_red, j + 2);
+    launch_cgs_finish(c, j + 2);
+    launch_cgs_update(c, j + 1, vp, w);
     return true;
 }
 
@@ -957,6 +1000,8 @@ static int comm_common(Ctx &c, int n_nb, const int32_t *nb_rank, const int32_t *
         set_error("bad halo plan");
         return -2;
     }
+    hipStreamSynchronize(c.stream);
+    iter_graphs_clear(c);  // captured for the previous transport (or for none)
     if (c.comm) {
         c.comm->release();
         delete c.comm;

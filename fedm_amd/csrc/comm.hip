@@ -73,6 +73,14 @@ int comm_unique_id(void *out128) {
 void Comm::release() {
     if (nccl && g_nccl.CommDestroy) g_nccl.CommDestroy(nccl);
     nccl = nullptr;
+    if (d_interior) hipFree(d_interior);
+    if (d_boundary) hipFree(d_boundary);
+    if (ev_ready) hipEventDestroy(ev_ready);
+    if (ev_halo) hipEventDestroy(ev_halo);
+    if (stream) hipStreamDestroy(stream);
+    d_interior = d_boundary = nullptr;
+    ev_ready = ev_halo = nullptr;
+    stream = nullptr;
     if (d_send_idx) hipFree(d_send_idx);
     if (d_sendbuf) hipFree(d_sendbuf);
     if (h_send) hipHostFree(h_send);
@@ -109,6 +117,30 @@ int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const in
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_send, sizeof(double) * ns * c.neq));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_recv, sizeof(double) * ng * c.neq));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_red, sizeof(double) * RED_K));
+    // interior / boundary matrix slices: a slice is interior when none of its stored columns is
+    // a ghost vertex (padding entries point at the row itself)
+    std::vector<int> interior, boundary;
+    for (int sl = 0; sl < c.pat.n_slices; ++sl) {
+        bool ghost = false;
+        for (int bc = c.pat.slice_boff[sl]; bc < c.pat.slice_boff[sl + 1] && !ghost; ++bc)
+            for (int l = 0; l < SLICE; ++l)
+                if (c.pat.colidx[(size_t)bc * SLICE + l] >= c.n_owned) {
+                    ghost = true;
+                    break;
+                }
+        (ghost ? boundary : interior).push_back(sl);
+    }
+    cm.n_interior = (int)interior.size();
+    cm.n_boundary = (int)boundary.size();
+    FEDM_HIP_CHECK(hipMalloc((void **)&cm.d_interior, sizeof(int) * std::max<size_t>(interior.size(), 1)));
+    FEDM_HIP_CHECK(hipMalloc((void **)&cm.d_boundary, sizeof(int) * std::max<size_t>(boundary.size(), 1)));
+    if (cm.n_interior)
+        FEDM_HIP_CHECK(hipMemcpy(cm.d_interior, interior.data(), sizeof(int) * interior.size(), hipMemcpyHostToDevice));
+    if (cm.n_boundary)
+        FEDM_HIP_CHECK(hipMemcpy(cm.d_boundary, boundary.data(), sizeof(int) * boundary.size(), hipMemcpyHostToDevice));
+    FEDM_HIP_CHECK(hipStreamCreateWithFlags(&cm.stream, hipStreamNonBlocking));
+    FEDM_HIP_CHECK(hipEventCreateWithFlags(&cm.ev_ready, hipEventDisableTiming));
+    FEDM_HIP_CHECK(hipEventCreateWithFlags(&cm.ev_halo, hipEventDisableTiming));
     return 0;
 }
 
@@ -148,12 +180,10 @@ __global__ void halo_pack_kernel(int n_send, int neq, const int *__restrict__ id
     buf[t] = vec[(size_t)idx[i] * neq + s];
 }
 
-void comm_halo(Ctx &c, double *d_vec) {
-    Comm *cm = c.comm;
-    if (!cm || cm->kind == 0 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
+static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st) {
     const int w = c.neq;
     if (cm->n_send)
-        hipLaunchKernelGGL(halo_pack_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, c.stream,
+        hipLaunchKernelGGL(halo_pack_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, st,
                            cm->n_send, w, cm->d_send_idx, d_vec, cm->d_sendbuf);
     double *ghost = d_vec + (size_t)c.n_owned * w;
     if (cm->kind == 2) {
@@ -163,20 +193,41 @@ void comm_halo(Ctx &c, double *d_vec) {
             const int nr = cm->recv_ptr[k + 1] - cm->recv_ptr[k];
             if (ns)
                 g_nccl.Send(cm->d_sendbuf + (size_t)cm->send_ptr[k] * w, (size_t)ns * w, kNcclDouble,
-                            cm->nb_rank[k], cm->nccl, c.stream);
+                            cm->nb_rank[k], cm->nccl, st);
             if (nr)
                 g_nccl.Recv(ghost + (size_t)cm->recv_ptr[k] * w, (size_t)nr * w, kNcclDouble,
-                            cm->nb_rank[k], cm->nccl, c.stream);
+                            cm->nb_rank[k], cm->nccl, st);
         }
         g_nccl.GroupEnd();
         return;
     }
     if (cm->n_send)
-        hipMemcpyAsync(cm->h_send, cm->d_sendbuf, sizeof(double) * cm->n_send * w, hipMemcpyDeviceToHost, c.stream);
-    hipStreamSynchronize(c.stream);
+        hipMemcpyAsync(cm->h_send, cm->d_sendbuf, sizeof(double) * cm->n_send * w, hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
     cm->exchange_cb(cm->h_send, cm->h_recv, w, cm->user);
     if (cm->n_ghost)
-        hipMemcpyAsync(ghost, cm->h_recv, sizeof(double) * cm->n_ghost * w, hipMemcpyHostToDevice, c.stream);
+        hipMemcpyAsync(ghost, cm->h_recv, sizeof(double) * cm->n_ghost * w, hipMemcpyHostToDevice, st);
+}
+
+void comm_halo(Ctx &c, double *d_vec) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
+    halo_on_stream(c, cm, d_vec, c.stream);
+}
+
+void comm_halo_begin(Ctx &c) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0) return;
+    hipEventRecord(cm->ev_ready, c.stream);  // the vector (and the send buffer's last use) complete
+}
+
+void comm_halo_exchange(Ctx &c, double *d_vec) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0) return;
+    hipStreamWaitEvent(cm->stream, cm->ev_ready, 0);
+    if (cm->n_send || cm->n_ghost) halo_on_stream(c, cm, d_vec, cm->stream);
+    hipEventRecord(cm->ev_halo, cm->stream);
+    hipStreamWaitEvent(c.stream, cm->ev_halo, 0);  // what follows on the compute stream sees the ghosts
 }
 
 }  // namespace fedm

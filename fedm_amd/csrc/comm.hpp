@@ -26,6 +26,13 @@ struct Comm {
     fedm_exchange_fn exchange_cb = nullptr;
     void *user = nullptr;
     void *nccl = nullptr;  // ncclComm_t
+    // overlap of the halo exchange with the interior rows of the Krylov SpMV: the exchange runs
+    // on its own stream between two events; matrix slices are split into those that reference
+    // no ghost column (interior) and the rest (boundary)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+    int n_interior = 0, n_boundary = 0;
+    int *d_interior = nullptr, *d_boundary = nullptr;
     void release();
 };
 
@@ -35,5 +42,11 @@ int comm_init_rccl(Ctx &c, Comm &cm, const void *unique_id, int rank, int nranks
 int comm_unique_id(void *out128);
 void comm_allreduce(Ctx &c, double *d_buf, int n);  // sum over ranks, in place, stream-ordered
 void comm_halo(Ctx &c, double *d_vec);              // refresh ghost vertices of a block vector
+// The same exchange on the communication stream, overlapped with compute work: comm_halo_begin
+// marks the point of the compute stream at which the vector is complete; work queued on the
+// compute stream after it runs concurrently with comm_halo_exchange, which performs the exchange
+// on the communication stream and makes the compute stream wait for its end.
+void comm_halo_begin(Ctx &c);
+void comm_halo_exchange(Ctx &c, double *d_vec);
 
 }  // namespace fedm

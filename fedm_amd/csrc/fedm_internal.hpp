@@ -133,6 +133,7 @@ struct Ctx {
                                                // carry a fresh tag in their kernel arguments
     // one captured hipGraph per Krylov index j: operator + preconditioner + orthogonalisation
     std::vector<hipGraphExec_t> iter_graph;
+    std::vector<hipGraphExec_t> iter_graph_interior;  // several GPUs: the interior-rows SpMV of step j
     bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
     bool capturing = false;
     double *h_stage = nullptr;     // pinned staging, np doubles
@@ -155,7 +156,8 @@ size_t patch_lds_bytes(const Ctx &c);
 void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks
 void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv);
-void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale);
+void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale,
+                            const int *slice_list = nullptr, int n_list = 0);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
 void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0,

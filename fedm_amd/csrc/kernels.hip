@@ -536,11 +536,12 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
                                                    double *__restrict__ y,
                                                    const double *__restrict__ dinv,
                                                    double *__restrict__ fs_z, double *__restrict__ fs_b0,
-                                                   double fs_scale) {
+                                                   double fs_scale, const int *__restrict__ slice_list) {
     constexpr int NEQ2 = NEQ * NEQ;
-    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (slice >= n_slices) return;
+    if (wave_id >= n_slices) return;  // n_slices: number of slices this launch covers
+    const int slice = slice_list ? slice_list[wave_id] : wave_id;
     const int b0 = boff[slice], b1 = boff[slice + 1];
     // epilogue operands (block inverse) requested before the gather loop
     constexpr int ND = FS ? (NEQ - 1) * (NEQ - 1) : NEQ2;
@@ -604,7 +605,8 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv) {
     const double *dinv = scale_dinv ? c.d_dinv : nullptr;
 #define FEDM_SPMV(NEQ)                                                                             \
     hipLaunchKernelGGL((spmv_kernel<NEQ, false>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
-                       c.d_colidx, c.d_val, x, y, dinv, (double *)nullptr, (double *)nullptr, 0.0)
+                       c.d_colidx, c.d_val, x, y, dinv, (double *)nullptr, (double *)nullptr, 0.0,         \
+                       (const int *)nullptr)
     switch (c.neq) {
         case 1: FEDM_SPMV(1); break;
         case 2: FEDM_SPMV(2); break;
@@ -616,13 +618,16 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv) {
 #undef FEDM_SPMV
 }
 
-// t = A x together with the first field-split stage (c.d_dinv holds the species-block inverses)
-void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale) {
-    const int n = c.pat.n_slices;
+// t = A x together with the first field-split stage (c.d_dinv holds the species-block inverses);
+// slice_list != nullptr: only those n_list matrix slices (interior / boundary halves across GPUs)
+void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale,
+                            const int *slice_list, int n_list) {
+    const int n = slice_list ? n_list : c.pat.n_slices;
+    if (n == 0) return;
     const dim3 g((n + 3) / 4), b(256);
 #define FEDM_SPMV(NEQ)                                                                            \
     hipLaunchKernelGGL((spmv_kernel<NEQ, true>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
-                       c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale)
+                       c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale, slice_list)
     switch (c.neq) {
         case 2: FEDM_SPMV(2); break;
         case 3: FEDM_SPMV(3); break;
