@@ -215,9 +215,15 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
         ++c.mail_seq;
         return true;
     }
-    comm_halo_begin(c);
+    // FEDM_HALO_OVERLAP=0 keeps the exchange on the compute stream (diagnostics)
+    static const bool overlap = [] {
+        const char *e = std::getenv("FEDM_HALO_OVERLAP");
+        return !(e && e[0] == '0');
+    }();
+    if (overlap) comm_halo_begin(c);
+    else comm_halo(c, const_cast<double *>(vp[j]));
     bool ok = !c.iter_graph_interior[j] || hipGraphLaunch(c.iter_graph_interior[j], c.stream) == hipSuccess;
-    comm_halo_exchange(c, const_cast<double *>(vp[j]));
+    if (overlap) comm_halo_exchange(c, const_cast<double *>(vp[j]));
     ok = ok && hipGraphLaunch(c.iter_graph[j], c.stream) == hipSuccess;
     if (!ok) {  // the exchange has happened: redo the whole step with plain launches (same result)
         hipGetLastError();
