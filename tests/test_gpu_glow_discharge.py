@@ -104,3 +104,25 @@ def test_gd_golden_run(golden_dir, device_pipeline, tmp_path):
         vec = mesh_io.read_h5(tmp_path / f"{key}.h5", key)[1][:, 0]
         rel = (vec - ref) / ref
         assert np.mean(np.abs(rel)) < 1e-5 and np.sqrt(np.mean(rel ** 2)) < 1e-5
+
+
+def test_glow_discharge_example_writes_the_reference_outputs(tmp_path, golden_dir):
+    """examples/glow_discharge.py: deck -> device run -> `relative error.log` + XDMF/HDF5
+    checkpoints; the snapshot at 1e-11 s read back like the reference's test does agrees with
+    the golden fields."""
+    import importlib.util
+    from fedm_amd import mesh_io
+    root = golden_dir.parent.parent
+    spec = importlib.util.spec_from_file_location("gd_example", root / "examples" / "glow_discharge.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.main(output_dir=tmp_path)
+    gold = np.load(golden_dir / "gd_golden.npz")
+    ref_log = np.array(json.loads((golden_dir / "error_logs.json").read_text())["glow_discharge"])
+    assert np.allclose(np.loadtxt(tmp_path / "relative error.log"), ref_log)
+    for key in ("electrons", "Ar_plus", "Ar_star"):
+        vecs = mesh_io.read_h5(tmp_path / f"{key}.h5", key)
+        assert len(vecs) == 2                                  # _0 initial condition, _1 at 1e-11 s
+        assert np.allclose(vecs[0][:, 0], np.log(1e12), rtol=1e-14)
+        rel = (vecs[1][:, 0] - gold[key + "_1"]) / gold[key + "_1"]
+        assert np.mean(np.abs(rel)) < 1e-5 and np.sqrt(np.mean(rel ** 2)) < 1e-5 and np.max(np.abs(rel)) < 1e-3
