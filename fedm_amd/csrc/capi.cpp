@@ -837,7 +837,15 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     while (true) {
         // one fused F + J assembly per iteration: the residual norm that decides convergence
         // comes from the same pass (a J assembly is wasted only on the final check)
-        eval_jacobian(c, 0);
+        // The iteration at which the previous solve converged is expected to be the final check
+        // again: assemble the residual only there (a wrong guess costs one extra F+J assembly).
+        const bool residual_only = it > 0 && it == c.newton_its_hint;
+        if (residual_only) {
+            launch_assemble(c, false, 0);
+            launch_finalize(c, false, 0);
+        } else {
+            eval_jacobian(c, 0);
+        }
         launch_norm2(c, c.d_F, 0);
         read_red(c, 3);  // |F|, and |dx|, |x| of the previous update (slots 1, 2) in one wait
         fnorm = std::sqrt(c.h_red[0]);
@@ -860,6 +868,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             rc = FEDM_DIVERGED_MAX_IT;
             break;
         }
+        if (residual_only) eval_jacobian(c, 0);  // not converged after all: the Jacobian is needed
         prepare_preconditioner_and_rhs(c);
         int lits = 0;
         double lres = 0.0;
@@ -875,6 +884,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         launch_norm2(c, c.d_u, 2);
         ++it;
     }
+    if (rc == 0) c.newton_its_hint = it;
     r.iterations = it;
     r.linear_iterations = lin_total;
     r.fnorm0 = fnorm0;

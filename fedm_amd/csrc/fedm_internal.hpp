@@ -136,6 +136,7 @@ struct Ctx {
     std::vector<hipGraphExec_t> iter_graph_interior;  // several GPUs: the interior-rows SpMV of step j
     bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
     bool capturing = false;
+    int newton_its_hint = -1;     // Newton iterations of the previous converged solve
     double *h_stage = nullptr;     // pinned staging, np doubles
 };
 
