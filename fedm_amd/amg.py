@@ -111,21 +111,42 @@ def _csr_struct(M, keep):
                     values.ctypes.data_as(C.POINTER(C.c_double)))
 
 
-def install(handle, levels, nu=2, omega=0.67):
-    """Upload a hierarchy built by :func:`build_hierarchy` into a device context."""
-    lib = _lib.load()
+def _pack(levels, dense_coarse=True):
     keep = []
     n = len(levels)
     A = (_lib.Csr * n)(*[_csr_struct(a, keep) for a, _ in levels])
     P = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p, keep) for _, p in levels[:-1]])
     R = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p.T, keep) for _, p in levels[:-1]])
-    n_coarse = levels[-1][0].shape[0]
-    if n_coarse > 8192:   # a dense inverse of that size is the wrong tool (n^2 doubles on host and device)
-        raise RuntimeError(f"multigrid coarsening stalled at {n_coarse} rows (levels "
-                           f"{[a.shape[0] for a, _ in levels]}): adjust theta / max_coarse")
-    coarse = np.ascontiguousarray(np.linalg.inv(levels[-1][0].toarray()))
-    rc = lib.fedm_amg_setup(handle, n, A, P, R, coarse.ctypes.data_as(C.POINTER(C.c_double)),
-                            int(nu), float(omega))
+    coarse = None
+    if dense_coarse:
+        n_coarse = levels[-1][0].shape[0]
+        if n_coarse > 8192:   # a dense inverse of that size is the wrong tool (n^2 doubles on host and device)
+            raise RuntimeError(f"multigrid coarsening stalled at {n_coarse} rows (levels "
+                               f"{[a.shape[0] for a, _ in levels]}): adjust theta / max_coarse")
+        coarse = np.ascontiguousarray(np.linalg.inv(levels[-1][0].toarray()))
+        keep.append(coarse)
+    return n, A, P, R, coarse, keep
+
+
+def install(handle, levels, nu=2, omega=0.67, dense_coarse=True):
+    """Upload a hierarchy built by :func:`build_hierarchy` into a device context.
+    ``dense_coarse=False``: no inverse of the last level (a global hierarchy takes over there,
+    :func:`install_global`)."""
+    lib = _lib.load()
+    n, A, P, R, coarse, keep = _pack(levels, dense_coarse)
+    cptr = coarse.ctypes.data_as(C.POINTER(C.c_double)) if coarse is not None else None
+    rc = lib.fedm_amg_setup(handle, n, A, P, R, cptr, int(nu), float(omega))
     if rc != 0:
         raise RuntimeError(f"fedm_amg_setup failed ({rc}): {_lib.last_error()}")
+    return [a.shape[0] for a, _ in levels]
+
+
+def install_global(handle, levels, n_global, offset, nu=2, omega=0.67):
+    """Several GPUs: the replicated hierarchy below the rank-local finest level."""
+    lib = _lib.load()
+    n, A, P, R, coarse, keep = _pack(levels, True)
+    rc = lib.fedm_amg_set_global_hierarchy(handle, int(n_global), int(offset), n, A, P, R,
+                                           coarse.ctypes.data_as(C.POINTER(C.c_double)), int(nu), float(omega))
+    if rc != 0:
+        raise RuntimeError(f"fedm_amg_set_global_hierarchy failed ({rc}): {_lib.last_error()}")
     return [a.shape[0] for a, _ in levels]

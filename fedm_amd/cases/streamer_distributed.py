@@ -53,8 +53,27 @@ class Runner(streamer.Stepper):
                 prob.init_comm_torch(lm, dist.new_group(backend="gloo"))
         else:
             prob.init_comm_torch(lm, group)
+        self._group = group if transport != "torch-gloo (RCCL set-up failed)" else None
         super().__init__(prob, **kw)
+        self.world_size = world
         self.total_dofs = gmesh.num_vertices() * 3
         self.partition_name = (f"RCB vertex partition, {world} parts, global mesh {n}x{n}, "
                                f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices on rank {rank}, "
                                f"{len(lm.neighbours)} neighbours, transport {transport}")
+
+    def initialise(self):
+        """As Stepper.initialise, with the multigrid whose coarsest level spans all ranks."""
+        from ..device import chebyshev_weights
+        prob = self.prob
+        U = np.zeros((prob.nv, 3))
+        U[:, 0], U[:, 1] = streamer.initial_log_densities(prob.coords)
+        prob.set_state(U, U, U)
+        if self.world_size > 1:
+            prob.setup_multigrid_distributed(self.lm, self._group, **streamer.MULTIGRID)
+        else:
+            prob.setup_multigrid(**streamer.MULTIGRID)
+        prob.set_fieldsplit(chebyshev_weights(4))
+        its = prob.poisson_solve(rtol=1e-12)
+        U = prob.get_state()
+        prob.set_state(U, U, U)
+        return U, its

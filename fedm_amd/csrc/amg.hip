@@ -3,6 +3,7 @@
 // Every operator is a scalar sliced-ELL matrix (64 rows per slice, lanes contiguous), so the
 // V-cycle is a sequence of coalesced, HBM/L2-bound SpMV kernels with fused epilogues.
 #include "amg.hpp"
+#include "comm.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -210,22 +211,48 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(int n, int ld, const do
     if (lane == 0) y[row] = s;
 }
 
+// place the rank's coarsest right-hand side into the (zeroed) global coarse vector
+__global__ void coarse_place_kernel(int n_global, int offset, int n_local, const double *__restrict__ b,
+                                    double *__restrict__ gb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_global) return;
+    const int k = i - offset;
+    gb[i] = (k >= 0 && k < n_local) ? b[k] : 0.0;
+}
+
 // Buffers never swap on the host: with (nu-1) + nu Jacobi sweeps after the first one the
 // iterate ping-pongs an odd number of times, so it starts in x2 and always ends in x.  The
 // launch sequence is therefore static and is replayed as one hipGraph (Amg::run).
-void Amg::vcycle(Ctx &c, int l) {
+// phase 0: whole cycle.  Across GPUs everything below the finest level is global (Amg::global):
+// phase 1 is the down leg up to the rank's segment of the global right-hand side (d_gb), the
+// caller all-reduces d_gb, phase 2 is the replicated global cycle and the up leg.
+void Amg::vcycle(Ctx &c, int l, int phase) {
     Level &L = levels[l];
+    const bool down = phase != 2, up = phase != 1;
     if (l == (int)levels.size() - 1) {
-        hipLaunchKernelGGL(dense_gemv_kernel, dim3((n_coarse + 3) / 4), dim3(256), 0, c.stream,
-                           n_coarse, coarse_ld, coarse_inv, L.b, L.x);
+        if (global) {
+            if (down)
+                hipLaunchKernelGGL(coarse_place_kernel, dim3((n_global + 255) / 256), dim3(256), 0, c.stream,
+                                   n_global, g_offset, n_coarse, L.b, d_gb);
+            if (up) {
+                if (global->graph_exec && !c.capturing) hipGraphLaunch(global->graph_exec, c.stream);
+                else global->vcycle(c, 0, 0);
+                hipMemcpyAsync(L.x, global->levels[0].x + g_offset, sizeof(double) * n_coarse,
+                               hipMemcpyDeviceToDevice, c.stream);
+            }
+        } else if (up) {
+            hipLaunchKernelGGL(dense_gemv_kernel, dim3((n_coarse + 3) / 4), dim3(256), 0, c.stream,
+                               n_coarse, coarse_ld, coarse_inv, L.b, L.x);
+        }
         return;
     }
     const int np = L.A.n_rows_p;
     double *x = L.x2, *y = L.x;  // x: current iterate, y: the other buffer
     if (!pre_smooth) {
         // V(0,nu): x = 0, so the residual is b itself and the correction is P x_c
-        ell_launch(c, L.R, 0, L.b, nullptr, levels[l + 1].b, 0.0);
-        vcycle(c, l + 1);
+        if (down) ell_launch(c, L.R, 0, L.b, nullptr, levels[l + 1].b, 0.0);
+        vcycle(c, l + 1, phase);
+        if (!up) return;
         if (nu % 2 == 0) std::swap(x, y);                        // nu swaps must end in L.x
         ell_launch(c, L.P, 0, levels[l + 1].x, nullptr, x, 0.0);
         for (int s = 0; s < nu; ++s) {
@@ -234,21 +261,29 @@ void Amg::vcycle(Ctx &c, int l) {
         }
         return;
     }
+    // Global mode: the finest level is a truly distributed operator -- the ghost entries of the
+    // right-hand side (before the first sweep, whose neighbours' values are formed from b) and of
+    // the iterate (before the post-smoothing) come from their owners.
+    const bool exact0 = l == 0 && global && c.comm && !c.capturing;
+    if (exact0 && down) comm_halo_scalar(c, L.b);
     if (nu == 1) {
-        ell_launch(c, L.A, 4, nullptr, L.b, L.r, omega, x);    // x = w Dinv b;  r = b - A x
+        if (down) ell_launch(c, L.A, 4, nullptr, L.b, L.r, omega, x);    // x = w Dinv b;  r = b - A x
     } else {
-        hipLaunchKernelGGL(jacobi_first_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, np,
-                           L.A.dinv, L.b, x, omega);
+        if (down)
+            hipLaunchKernelGGL(jacobi_first_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, np,
+                               L.A.dinv, L.b, x, omega);
         for (int s = 1; s < nu; ++s) {
-            ell_launch(c, L.A, 2, x, L.b, y, omega);
+            if (down) ell_launch(c, L.A, 2, x, L.b, y, omega);
             std::swap(x, y);
         }
-        ell_launch(c, L.A, 1, x, L.b, L.r, 0.0);               // r = b - A x
+        if (down) ell_launch(c, L.A, 1, x, L.b, L.r, 0.0);               // r = b - A x
     }
-    ell_launch(c, L.R, 0, L.r, nullptr, levels[l + 1].b, 0.0);  // b_c = R r
-    vcycle(c, l + 1);
+    if (down) ell_launch(c, L.R, 0, L.r, nullptr, levels[l + 1].b, 0.0);  // b_c = R r
+    vcycle(c, l + 1, phase);
+    if (!up) return;
     ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c
     for (int s = 0; s < nu; ++s) {
+        if (exact0) comm_halo_scalar(c, x);
         if (l == 0 && s == nu - 1 && out) {
             // the cycle's result goes straight into the potential component of the caller's
             // interleaved vector (no scatter kernel afterwards)
@@ -267,8 +302,9 @@ int Amg::capture(Ctx &c) {
         graph_exec = nullptr;
     }
     hipGraph_t graph = nullptr;
+    if (global || !coarse_inv) return 0;  // the cycle contains an all-reduce: plain launches in Amg::run
     if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
-    vcycle(c, 0);
+    vcycle(c, 0, 0);
     if (hipStreamEndCapture(c.stream, &graph) != hipSuccess || !graph) return -1;
     const hipError_t e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
@@ -277,12 +313,19 @@ int Amg::capture(Ctx &c) {
 
 void Amg::run(Ctx &c) {
     if (c.capturing) {  // part of a whole-iteration graph: its kernels become nodes of that graph
-        vcycle(c, 0);
+        vcycle(c, 0, 0);
         return;
     }
     prof_begin(c, 3);
-    if (graph_exec) hipGraphLaunch(graph_exec, c.stream);
-    else vcycle(c, 0);
+    if (global) {
+        vcycle(c, 0, 1);
+        comm_allreduce(c, d_gb, n_global);
+        vcycle(c, 0, 2);
+    } else if (graph_exec) {
+        hipGraphLaunch(graph_exec, c.stream);
+    } else {
+        vcycle(c, 0, 0);
+    }
     prof_end(c);
 }
 
@@ -299,7 +342,13 @@ void Amg::release() {
     graph_exec = nullptr;
     if (coarse_inv) hipFree(coarse_inv);
     coarse_inv = nullptr;
-    n_coarse = 0;
+    if (global) {
+        global->release();
+        delete global;
+        global = nullptr;
+    }
+    d_gb = nullptr;
+    n_coarse = n_global = 0;
 }
 
 // ---- field split -----------------------------------------------------------------------------

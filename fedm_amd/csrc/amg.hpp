@@ -36,7 +36,17 @@ struct Amg {
     int out_stride = 1, out_offset = 0;
     double omega = 0.67;
     hipGraphExec_t graph_exec = nullptr;
-    void vcycle(Ctx &c, int level);  // levels[level].b -> levels[level].x (kernel launches)
+    // Across GPUs only the finest level is rank-local (smoothed as a distributed operator, with
+    // halo exchanges); below it the hierarchy is GLOBAL and replicated on every rank: the rank's
+    // level-1 right-hand side goes to its segment [g_offset, g_offset + n_coarse) of d_gb
+    // (= global->levels[0].b), d_gb is all-reduced, every rank runs the global cycle, and the
+    // rank takes its segment of the result.  Aggregates never cross rank boundaries; everything
+    // else is the single-GPU cycle.
+    int n_global = 0, g_offset = 0;
+    double *d_gb = nullptr;   // alias, owned by `global`
+    Amg *global = nullptr;
+    // levels[level].b -> levels[level].x; phase 0 whole cycle, 1 down leg, 2 coarse solve + up leg
+    void vcycle(Ctx &c, int level, int phase = 0);
     int capture(Ctx &c);             // record the V-cycle once as a hipGraph
     void run(Ctx &c);                // levels[0].b -> levels[0].x
     void release();

@@ -160,6 +160,7 @@ static bool capture_graph(Ctx &c, hipGraphExec_t *out, const std::function<void(
 static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w) {
     if (!c.iter_graphs_ok || !(c.amg && c.poisson) || (c.prof.on && c.prof.all_kinds)) return false;
     const bool multi = c.comm != nullptr;
+    if (multi && c.amg->global) return false;  // collectives inside the V-cycle: plain launches
     if ((int)c.iter_graph.size() <= j) {
         c.iter_graph.resize(j + 1, nullptr);
         c.iter_graph_interior.resize(j + 1, nullptr);
@@ -1211,15 +1212,15 @@ int fedm_amg_clear(fedm_ctx *h) {
     return 0;
 }
 
-int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr *P,
-                   const fedm_csr *R, const double *coarse_inverse, int nu, double omega) {
-    Ctx &c = h->c;
-    if (n_levels < 1 || !A || !coarse_inverse || (n_levels > 1 && (!P || !R)) || nu == 0) {
+// shared by the rank-local hierarchy and the replicated global one (several GPUs)
+static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, const fedm_csr *P,
+                     const fedm_csr *R, const double *coarse_inverse, int nu, double omega, Amg **out) {
+    if (n_levels < 1 || !A || (n_levels > 1 && (!P || !R)) || nu == 0) {
         set_error("bad multigrid description");
         return -2;
     }
-    if (A[0].n_rows != c.nv || A[0].n_cols != c.nv) {
-        set_error("finest multigrid operator must have n_vertices rows");
+    if (A[0].n_rows != n_first_rows || A[0].n_cols != n_first_rows) {
+        set_error("finest multigrid operator has the wrong size");
         return -2;
     }
     for (int l = 0; l + 1 < n_levels; ++l)
@@ -1228,13 +1229,16 @@ int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr 
             set_error("inconsistent multigrid level shapes");
             return -2;
         }
-    FEDM_HIP_CHECK(hipSetDevice(c.device));
-    fedm_amg_clear(h);
     Amg *amg = new Amg();
     amg->nu = nu < 0 ? -nu : nu;  // nu < 0 selects V(0,|nu|) cycles
     amg->pre_smooth = nu > 0;
     amg->omega = omega;
     amg->levels.resize(n_levels);
+    auto fail = [&](int rc) {
+        amg->release();
+        delete amg;
+        return rc;
+    };
     for (int l = 0; l < n_levels; ++l) {
         Amg::Level &L = amg->levels[l];
         int rc = 0;
@@ -1248,31 +1252,82 @@ int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr 
         }
         if (rc) {
             set_error("multigrid level upload failed (bad CSR or out of memory)");
-            amg->release();
-            delete amg;
-            return rc < -1 ? -2 : -1;
+            return fail(rc < -1 ? -2 : -1);
         }
         const size_t n = (size_t)L.A.n_rows_p;
-        for (double **p : {&L.x, &L.x2, &L.b, &L.r}) {
-            FEDM_HIP_CHECK(hipMalloc((void **)p, sizeof(double) * n));
-            FEDM_HIP_CHECK(hipMemset(*p, 0, sizeof(double) * n));
-        }
+        for (double **p : {&L.x, &L.x2, &L.b, &L.r})
+            if (hipMalloc((void **)p, sizeof(double) * n) != hipSuccess ||
+                hipMemset(*p, 0, sizeof(double) * n) != hipSuccess) {
+                set_error("out of device memory for the multigrid vectors");
+                return fail(-1);
+            }
     }
     amg->n_coarse = A[n_levels - 1].n_rows;
     amg->coarse_ld = ((amg->n_coarse + 255) / 256) * 256;
-    {
-        std::vector<double> inv32((size_t)amg->n_coarse * amg->coarse_ld, 0.f);
+    if (coarse_inverse) {  // nullptr: the coarsest problem will be handed to a global hierarchy
+        if (amg->n_coarse > 8192) {
+            set_error("dense coarsest multigrid level above 8192 unknowns");
+            return fail(-2);
+        }
+        std::vector<double> inv((size_t)amg->n_coarse * amg->coarse_ld, 0.0);
         for (int i = 0; i < amg->n_coarse; ++i)
             for (int j = 0; j < amg->n_coarse; ++j)
-                inv32[(size_t)i * amg->coarse_ld + j] = coarse_inverse[(size_t)i * amg->n_coarse + j];
-        FEDM_HIP_CHECK(hipMalloc((void **)&amg->coarse_inv, sizeof(double) * inv32.size()));
-        FEDM_HIP_CHECK(hipMemcpy(amg->coarse_inv, inv32.data(), sizeof(double) * inv32.size(), hipMemcpyHostToDevice));
+                inv[(size_t)i * amg->coarse_ld + j] = coarse_inverse[(size_t)i * amg->n_coarse + j];
+        if (hipMalloc((void **)&amg->coarse_inv, sizeof(double) * inv.size()) != hipSuccess ||
+            hipMemcpy(amg->coarse_inv, inv.data(), sizeof(double) * inv.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("out of device memory for the coarse inverse");
+            return fail(-1);
+        }
     }
+    *out = amg;
+    return 0;
+}
+
+int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr *P,
+                   const fedm_csr *R, const double *coarse_inverse, int nu, double omega) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    fedm_amg_clear(h);
+    Amg *amg = nullptr;
+    if (int rc = build_amg(c, c.nv, n_levels, A, P, R, coarse_inverse, nu, omega, &amg)) return rc;
     c.amg = amg;
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
-    if (amg->capture(c) != 0) {
+    if (coarse_inverse && amg->capture(c) != 0) {
         hipGetLastError();  // graph capture unavailable: fall back to plain launches
     }
+    return 0;
+}
+
+int fedm_amg_set_global_hierarchy(fedm_ctx *h, int n_global, int offset, int n_levels, const fedm_csr *A,
+                                  const fedm_csr *P, const fedm_csr *R, const double *coarse_inverse,
+                                  int nu, double omega) {
+    Ctx &c = h->c;
+    if (!c.amg || !coarse_inverse || offset < 0 || offset + c.amg->n_coarse > n_global) {
+        set_error("bad global hierarchy description (install the local hierarchy first)");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    iter_graphs_clear(c);
+    Amg &a = *c.amg;
+    if (a.global) {
+        a.global->release();
+        delete a.global;
+        a.global = nullptr;
+    }
+    if (a.graph_exec) {  // a captured cycle would solve the coarsest problem locally
+        hipGraphExecDestroy(a.graph_exec);
+        a.graph_exec = nullptr;
+    }
+    Amg *g = nullptr;
+    if (int rc = build_amg(c, n_global, n_levels, A, P, R, coarse_inverse, nu, omega, &g)) return rc;
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    if (g->capture(c) != 0) hipGetLastError();
+    a.global = g;
+    a.n_global = n_global;
+    a.g_offset = offset;
+    a.d_gb = g->levels[0].b;  // the global right-hand side IS the replicated hierarchy's input
+    if (c.comm && comm_reserve_reduction(c, n_global)) return -1;
     return 0;
 }
 

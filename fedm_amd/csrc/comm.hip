@@ -116,7 +116,8 @@ int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const in
     FEDM_HIP_CHECK(hipMalloc((void **)&cm.d_sendbuf, sizeof(double) * ns * c.neq));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_send, sizeof(double) * ns * c.neq));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_recv, sizeof(double) * ng * c.neq));
-    FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_red, sizeof(double) * RED_K));
+    FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_red, sizeof(double) * 16384));
+    cm.h_red_cap = 16384;
     // interior / boundary matrix slices: a slice is interior when none of its stored columns is
     // a ghost vertex (padding entries point at the row itself)
     std::vector<int> interior, boundary;
@@ -159,6 +160,16 @@ int comm_init_rccl(Ctx &c, Comm &cm, const void *unique_id, int rank, int nranks
     return 0;
 }
 
+int comm_reserve_reduction(Ctx &c, int n) {
+    Comm *cm = c.comm;
+    if (!cm || n <= cm->h_red_cap) return 0;
+    if (cm->h_red) hipHostFree(cm->h_red);
+    cm->h_red = nullptr;
+    FEDM_HIP_CHECK(hipHostMalloc((void **)&cm->h_red, sizeof(double) * n));
+    cm->h_red_cap = n;
+    return 0;
+}
+
 void comm_allreduce(Ctx &c, double *d_buf, int n) {
     Comm *cm = c.comm;
     if (!cm || cm->kind == 0) return;
@@ -180,8 +191,7 @@ __global__ void halo_pack_kernel(int n_send, int neq, const int *__restrict__ id
     buf[t] = vec[(size_t)idx[i] * neq + s];
 }
 
-static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st) {
-    const int w = c.neq;
+static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st, int w) {
     if (cm->n_send)
         hipLaunchKernelGGL(halo_pack_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, st,
                            cm->n_send, w, cm->d_send_idx, d_vec, cm->d_sendbuf);
@@ -212,7 +222,13 @@ static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st) {
 void comm_halo(Ctx &c, double *d_vec) {
     Comm *cm = c.comm;
     if (!cm || cm->kind == 0 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
-    halo_on_stream(c, cm, d_vec, c.stream);
+    halo_on_stream(c, cm, d_vec, c.stream, c.neq);
+}
+
+void comm_halo_scalar(Ctx &c, double *d_vec) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
+    halo_on_stream(c, cm, d_vec, c.stream, 1);
 }
 
 void comm_halo_begin(Ctx &c) {
@@ -225,7 +241,7 @@ void comm_halo_exchange(Ctx &c, double *d_vec) {
     Comm *cm = c.comm;
     if (!cm || cm->kind == 0) return;
     hipStreamWaitEvent(cm->stream, cm->ev_ready, 0);
-    if (cm->n_send || cm->n_ghost) halo_on_stream(c, cm, d_vec, cm->stream);
+    if (cm->n_send || cm->n_ghost) halo_on_stream(c, cm, d_vec, cm->stream, c.neq);
     hipEventRecord(cm->ev_halo, cm->stream);
     hipStreamWaitEvent(c.stream, cm->ev_halo, 0);  // what follows on the compute stream sees the ghosts
 }

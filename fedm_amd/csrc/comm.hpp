@@ -22,6 +22,7 @@ struct Comm {
     int *d_send_idx = nullptr;
     double *d_sendbuf = nullptr;
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;
+    int h_red_cap = 0;  // doubles (host-staged all-reduce)
     fedm_allreduce_fn allreduce_cb = nullptr;
     fedm_exchange_fn exchange_cb = nullptr;
     void *user = nullptr;
@@ -41,7 +42,9 @@ int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const in
 int comm_init_rccl(Ctx &c, Comm &cm, const void *unique_id, int rank, int nranks);
 int comm_unique_id(void *out128);
 void comm_allreduce(Ctx &c, double *d_buf, int n);  // sum over ranks, in place, stream-ordered
+int comm_reserve_reduction(Ctx &c, int n);          // host-staged transport: room for n doubles
 void comm_halo(Ctx &c, double *d_vec);              // refresh ghost vertices of a block vector
+void comm_halo_scalar(Ctx &c, double *d_vec);       // the same for one value per vertex
 // The same exchange on the communication stream, overlapped with compute work: comm_halo_begin
 // marks the point of the compute stream at which the vector is complete; work queued on the
 // compute stream after it runs concurrently with comm_halo_exchange, which performs the exchange

@@ -243,11 +243,21 @@ int fedm_block_csr(fedm_ctx *ctx, int cr, int cc, int64_t *indptr, int32_t *indi
 int fedm_jacobian_poisson_only(fedm_ctx *ctx);
 /* install a multigrid hierarchy for the potential block: n_levels operators A[l]
  * (A[0] = fine), n_levels-1 prolongators P[l] (rows of level l, cols of level l+1) and
- * their transposes R[l]; dense inverse of the coarsest operator; V(nu,nu) cycles with damped
+ * their transposes R[l]; dense inverse of the coarsest operator (NULL when
+ * fedm_amg_set_global_hierarchy takes over below the finest level); V(nu,nu) cycles with damped
  * Jacobi smoothing, nu < 0 selects V(0,|nu|) (no pre-smoothing). */
 int fedm_amg_setup(fedm_ctx *ctx, int n_levels, const fedm_csr *A, const fedm_csr *P,
                    const fedm_csr *R, const double *coarse_inverse, int nu, double omega);
 int fedm_amg_clear(fedm_ctx *ctx);
+/* several GPUs: the hierarchy installed with fedm_amg_setup holds the rank's finest level and its
+ * level-1 space only (coarse_inverse = NULL there).  The ranks' level-1 spaces are concatenated
+ * (n_global unknowns, this rank's start at `offset`) and everything below is ONE global
+ * hierarchy, replicated on every rank: A[0] is the Galerkin operator of the undecomposed
+ * potential block on that space.  A V-cycle exchanges the finest level's ghost values twice and
+ * all-reduces the level-1 right-hand side once. */
+int fedm_amg_set_global_hierarchy(fedm_ctx *ctx, int n_global, int offset, int n_levels,
+                                  const fedm_csr *A, const fedm_csr *P, const fedm_csr *R,
+                                  const double *coarse_inverse, int nu, double omega);
 /* Richardson sweeps z += w_k Duu^-1 (r - Juu z) on the species block inside the field split;
  * one weight per sweep (equal weights = damped block Jacobi, Chebyshev roots = polynomial) */
 int fedm_set_fieldsplit(fedm_ctx *ctx, int sweeps, const double *weights);
