@@ -240,9 +240,11 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
                 hipMemcpyAsync(L.x, global->levels[0].x + g_offset, sizeof(double) * n_coarse,
                                hipMemcpyDeviceToDevice, c.stream);
             }
-        } else if (up) {
+        } else if (up && coarse_inv) {
             hipLaunchKernelGGL(dense_gemv_kernel, dim3((n_coarse + 3) / 4), dim3(256), 0, c.stream,
                                n_coarse, coarse_ld, coarse_inv, L.b, L.x);
+        } else if (up) {  // neither a dense inverse nor a global hierarchy yet: no coarse correction
+            hipMemsetAsync(L.x, 0, sizeof(double) * n_coarse, c.stream);
         }
         return;
     }
