@@ -535,7 +535,8 @@ static double *fs_first_target(Ctx &c, double *z) {
 
 // stages after the first: remaining species sweeps, coupling, V-cycle on the potential block
 template <int NS>
-static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter = true) {
+static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter = true,
+                        bool with_cycle = true) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     const dim3 gs((c.pat.n_slices + 3) / 4);
     const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
@@ -547,6 +548,7 @@ static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alp
     }
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
                        c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
+    if (!with_cycle) return;  // the caller runs the V-cycle (collectives inside it) and scatters
     amg.run(c);
     if (scatter) hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
 }
@@ -590,12 +592,13 @@ void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t
     const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
     launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, omega, slices, n_slices);
     if (part == 0) return;
+    const bool cyc = part == 1;  // part 2: stop after the coupling product (amg.levels[0].b is ready)
     switch (c.ns) {
-        case 1: fs_finish_t<1>(c, amg, t, z, 1.0, scatter); break;
-        case 2: fs_finish_t<2>(c, amg, t, z, 1.0, scatter); break;
-        case 3: fs_finish_t<3>(c, amg, t, z, 1.0, scatter); break;
-        case 4: fs_finish_t<4>(c, amg, t, z, 1.0, scatter); break;
-        case 5: fs_finish_t<5>(c, amg, t, z, 1.0, scatter); break;
+        case 1: fs_finish_t<1>(c, amg, t, z, 1.0, scatter, cyc); break;
+        case 2: fs_finish_t<2>(c, amg, t, z, 1.0, scatter, cyc); break;
+        case 3: fs_finish_t<3>(c, amg, t, z, 1.0, scatter, cyc); break;
+        case 4: fs_finish_t<4>(c, amg, t, z, 1.0, scatter, cyc); break;
+        case 5: fs_finish_t<5>(c, amg, t, z, 1.0, scatter, cyc); break;
     }
 }
 

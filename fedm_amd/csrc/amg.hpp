@@ -60,7 +60,8 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
 // z = Minv (J v); scatter = false leaves the potential component in amg.levels[0].x
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter);
 // the same in two parts for the halo overlap: part 0 = SpMV of `slices` only (interior rows),
-// part 1 = SpMV of `slices` (boundary rows) followed by the rest of the preconditioner
+// part 1 = SpMV of `slices` (boundary rows) followed by the rest of the preconditioner,
+// part 2 = the same up to the potential block's right-hand side (the caller runs the V-cycle)
 void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter,
                                     int part, const int *slices, int n_slices);
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z);

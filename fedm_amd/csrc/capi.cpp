@@ -160,7 +160,6 @@ static bool capture_graph(Ctx &c, hipGraphExec_t *out, const std::function<void(
 static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w) {
     if (!c.iter_graphs_ok || !(c.amg && c.poisson) || (c.prof.on && c.prof.all_kinds)) return false;
     const bool multi = c.comm != nullptr;
-    if (multi && c.amg->global) return false;  // collectives inside the V-cycle: plain launches
     if ((int)c.iter_graph.size() <= j) {
         c.iter_graph.resize(j + 1, nullptr);
         c.iter_graph_interior.resize(j + 1, nullptr);
@@ -195,12 +194,17 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
                 ok = capture_graph(c, &c.iter_graph_interior[j], [&] {
                     fieldsplit_apply_operator_part(c, *c.amg, vp[j], c.d_tmp, w, false, 0, cm.d_interior, cm.n_interior);
                 });
-            ok = ok && capture_graph(c, &c.iter_graph[j], [&] {
-                with_direct_output([&] {
-                    fieldsplit_apply_operator_part(c, *c.amg, vp[j], c.d_tmp, w, false, 1, cm.d_boundary, cm.n_boundary);
+            if (c.amg->global)  // the V-cycle contains collectives: the graph ends at its right-hand side
+                ok = ok && capture_graph(c, &c.iter_graph[j], [&] {
+                    fieldsplit_apply_operator_part(c, *c.amg, vp[j], c.d_tmp, w, false, 2, cm.d_boundary, cm.n_boundary);
                 });
-                launch_dots_fused(c, dotp.data(), w, j + 2, x0, false);
-            });
+            else
+                ok = ok && capture_graph(c, &c.iter_graph[j], [&] {
+                    with_direct_output([&] {
+                        fieldsplit_apply_operator_part(c, *c.amg, vp[j], c.d_tmp, w, false, 1, cm.d_boundary, cm.n_boundary);
+                    });
+                    launch_dots_fused(c, dotp.data(), w, j + 2, x0, false);
+                });
         }
         if (!ok) {
             c.iter_graphs_ok = false;
@@ -236,6 +240,13 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
         launch_dots(c, dotp.data(), w, j + 2, true);
         launch_cgs_update(c, j + 1, vp, w);
         return true;
+    }
+    if (c.amg->global) {  // V-cycle with its collectives, then scatter + local partial sums
+        c.amg->run(c);
+        std::vector<const double *> dotp(j + 2);
+        for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+        dotp[j + 1] = w;
+        launch_dots_fused(c, dotp.data(), w, j + 2, c.amg->levels[0].x, false);
     }
     comm_allreduce(c, c.d_red, j + 2);
     launch_cgs_finish(c, j + 2);
