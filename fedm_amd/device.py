@@ -536,9 +536,7 @@ class DeviceProblem:
         diag_loc = K.diagonal()[self._inv]
         for k, blk in enumerate(from_neighbours(diag_loc)):
             diag_loc[n_own + lm.recv_ptr[k]:n_own + lm.recv_ptr[k + 1]] = blk
-        K = K.tolil()
-        K.setdiag(diag_loc[self._order])
-        K = K.tocsr()
+        K = (K + sp.diags(diag_loc[self._order] - K.diagonal())).tocsr()
         levels = amg.build_hierarchy(K, theta=theta, max_coarse=1, max_levels=2, fixed=fixed,
                                      coords=self._coords_dev)
         local_sizes = amg.install(self._h, levels, nu=nu, omega=omega, dense_coarse=False)
