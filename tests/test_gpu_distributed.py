@@ -130,3 +130,70 @@ def test_rccl_setup_failure_falls_back_on_every_rank():
         assert p.exitcode == 0
     assert all("RCCL set-up failed" in r[1] for r in res)
     assert res[0][2] == res[1][2] > 0
+
+
+def _worker_galerkin(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import numpy as np, scipy.sparse as sp
+    import torch.distributed as dist
+    from fedm_amd.cases import streamer_distributed
+    from fedm_amd import amg
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        run = streamer_distributed.Runner(None, rank, world, 0, grading=2.0, transport="torch", n_per_gpu=N_PER_GPU)
+        prob, lm = run.prob, run.lm
+        # monkeypatch: capture A1 and P0 inside setup
+        captured = {}
+        orig_build = amg.build_hierarchy
+        def spy(A, **kw):
+            lv = orig_build(A, **kw)
+            captured.setdefault("calls", []).append((A.copy(), lv))
+            return lv
+        amg.build_hierarchy = spy
+        run.initialise()
+        (K_dev, lv_local), (A1, lv_g) = captured["calls"]
+        P0 = sp.csr_matrix(lv_local[0][1])[prob._inv]          # local numbering
+        K_loc = sp.csr_matrix(K_dev)[prob._inv][:, prob._inv]
+        n_own = lm.n_owned
+        gid = lm.vertex_global
+        out = dict(rank=rank, gid_owned=gid[:n_own], gid_all=gid, K_rows=K_loc[:n_own].tocoo(), P_owned=P0[:n_own].tocoo(),
+                   A1=A1 if rank == 0 else None, n1=P0.shape[1])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, out)
+        if rank == 0:
+            nvg = max(int(g["gid_all"].max()) for g in gathered) + 1
+            offs = np.concatenate([[0], np.cumsum([g["n1"] for g in gathered])])
+            Kg = sp.lil_matrix((nvg, nvg)); Pg = sp.lil_matrix((nvg, offs[-1]))
+            Kr, Kc, Kv, Pr, Pc, Pv = [], [], [], [], [], []
+            for r, g in enumerate(gathered):
+                k = g["K_rows"]; Kr.append(g["gid_owned"][k.row]); Kc.append(g["gid_all"][k.col]); Kv.append(k.data)
+                p = g["P_owned"]; Pr.append(g["gid_owned"][p.row]); Pc.append(offs[r] + p.col); Pv.append(p.data)
+            Kg = sp.csr_matrix((np.concatenate(Kv), (np.concatenate(Kr), np.concatenate(Kc))), shape=(nvg, nvg))
+            Pg = sp.csr_matrix((np.concatenate(Pv), (np.concatenate(Pr), np.concatenate(Pc))), shape=(nvg, offs[-1]))
+            ref = (Pg.T @ Kg @ Pg).toarray()
+            got = gathered[0]["A1"].toarray()
+            q.put(("A1 max abs diff", float(np.abs(ref - got).max()), "scale", float(np.abs(ref).max()),
+                   "asym of ref", float(np.abs(ref - ref.T).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+
+def test_distributed_galerkin_operator_is_the_global_one():
+    """The level-1 operator of the multi-GPU multigrid is assembled from the ranks' block rows
+    (owned rows of K x prolongator rows fetched from the neighbours).  It must equal P^T K P of
+    the undecomposed block, formed here directly from the gathered pieces."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_galerkin, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    diff, scale, asym = res[1], res[3], res[5]
+    assert diff < 1e-13 * scale and asym < 1e-13 * scale
