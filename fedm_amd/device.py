@@ -498,7 +498,8 @@ class DeviceProblem:
         self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
         return self.multigrid_levels
 
-    def setup_multigrid_distributed(self, lm, group=None, theta=0.08, nu=1, omega=0.67, max_coarse=2000):
+    def setup_multigrid_distributed(self, lm, group=None, theta=0.08, nu=1, omega=0.67, max_coarse=2000,
+                                    local_coarsenings=1):
         """Several GPUs.  Only the finest level of the potential block's multigrid is rank-local:
         it is smoothed as a distributed operator (ghost values exchanged inside the V-cycle) and
         coarsened once, with aggregates that do not cross rank boundaries.  The Galerkin operator
@@ -537,10 +538,12 @@ class DeviceProblem:
         for k, blk in enumerate(from_neighbours(diag_loc)):
             diag_loc[n_own + lm.recv_ptr[k]:n_own + lm.recv_ptr[k + 1]] = blk
         K = (K + sp.diags(diag_loc[self._order] - K.diagonal())).tocsr()
-        levels = amg.build_hierarchy(K, theta=theta, max_coarse=1, max_levels=2, fixed=fixed,
-                                     coords=self._coords_dev)
+        levels = amg.build_hierarchy(K, theta=theta, max_coarse=1, max_levels=1 + local_coarsenings,
+                                     fixed=fixed, coords=self._coords_dev)
         local_sizes = amg.install(self._h, levels, nu=nu, omega=omega, dense_coarse=False)
-        P0 = sp.csr_matrix(levels[0][1])
+        P0 = sp.csr_matrix(levels[0][1])               # composite prolongator onto the last local level
+        for _, p in levels[1:-1]:
+            P0 = (P0 @ p).tocsr()
         n1 = P0.shape[1]
         sizes = [None] * world
         dist.all_gather_object(sizes, int(n1), group=group)
@@ -568,7 +571,7 @@ class DeviceProblem:
         coords1 = np.vstack([g[1] for g in gathered])
         levels_g = amg.build_hierarchy(A1, theta=theta, max_coarse=max_coarse, coords=coords1)
         global_sizes = amg.install_global(self._h, levels_g, n_g, int(offset[rank]), nu=nu, omega=omega)
-        self.multigrid_levels = [local_sizes[0], f"level 1: {n1} of {n_g} global"] + global_sizes[1:]
+        self.multigrid_levels = local_sizes[:-1] + [f"{n1} of {n_g} global"] + global_sizes[1:]
         return self.multigrid_levels
 
     def set_fieldsplit(self, weights=(0.8, 0.8, 0.8)):

@@ -4,6 +4,7 @@ import os, socket, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 N_GLOBAL = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+LOCAL_COARSENINGS = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 
 
 def worker(rank, world, port, q):
@@ -11,7 +12,8 @@ def worker(rank, world, port, q):
     sys.path.insert(0, str(ROOT))
     import numpy as np
     import torch.distributed as dist
-    from fedm_amd.cases import streamer_distributed
+    from fedm_amd.cases import streamer, streamer_distributed
+    streamer.MULTIGRID_DISTRIBUTED = dict(local_coarsenings=LOCAL_COARSENINGS)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         run = streamer_distributed.Runner(None, rank, world, 0, grading=4.0, transport="torch",
