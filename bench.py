@@ -33,6 +33,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=int, default=144)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    # rehearsal of the N > 1 path on a one-GPU box: all ranks on cuda:0, gloo process group (RCCL
+    # refuses two ranks on one device, so the library falls back to its host-staged transport)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true")
     return ap.parse_args()
 
 
@@ -126,6 +129,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -141,8 +146,11 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if distributed:
