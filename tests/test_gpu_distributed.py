@@ -197,3 +197,24 @@ def test_distributed_galerkin_operator_is_the_global_one():
         assert p.exitcode == 0
     diff, scale, asym = res[1], res[3], res[5]
     assert diff < 1e-13 * scale and asym < 1e-13 * scale
+
+
+def test_bench_multi_rank_path_end_to_end():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one JSON line from
+    rank 0), rehearsed with two ranks on this one GPU: gloo process group, RCCL set-up refused for
+    the duplicate device, host-staged transport."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--mesh", "64", "--rehearse-on-one-gpu",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak"
+    assert res["value"] > 0 and res["unit"] == "DOF-updates/s"
+    assert res["config"]["dofs_total"] > 2 * 64 * 64 * 3 * 0.9
+    assert {"roofline", "cpu_baseline", "ms_per_step", "metric"} <= set(res)
