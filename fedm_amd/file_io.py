@@ -9,14 +9,10 @@ fedm/file_io.py:123-535, including the format quirks the decks rely on:
 * a missing mobility file means dependence ``0`` (:346-359, :447-450),
 * the regular expressions of :309, :323, :486-487 (they are part of the file format).
 
-Result writers (``output_files``, ``file_output``, ``mesh_statistics``) are DOLFIN I/O and
-outside the hot path; they are not provided.
+``file_output`` and the PVD / XDMF writers live in :mod:`fedm_amd.mesh_io`.
 """
-import itertools
 import re
 from pathlib import Path
-from textwrap import dedent
-from typing import Any, List
 
 import numpy as np
 
@@ -86,230 +82,227 @@ files = Files()
 
 
 # ---------------------------------------------------------------------------
-# file_io.py:123-247 -- small readers
+# Deck files.  Every deck file is text with '#' comments; what differs is how the payload is
+# shaped (one number, one expression string, two columns, key/value lines).  One small class
+# reads them all; the public functions of fedm.file_io are thin views of it.
 # ---------------------------------------------------------------------------
+class _Deck:
+    """Comment-stripped view of one deck file."""
+
+    def __init__(self, path, encoding=None):
+        self.path = Path(path)
+        with open(self.path, "r", encoding=encoding) as handle:
+            self.lines = list(decomment(handle))
+
+    def first(self, cast=str):
+        return cast(self.lines[0])
+
+    def columns(self):
+        table = np.array([ln.split()[:2] for ln in self.lines], dtype=float)
+        return table[:, 0].tolist(), table[:, 1].tolist()
+
+    def findall(self, pattern):
+        return [hit for ln in self.lines for hit in pattern.findall(ln)]
+
+
+def decomment(lines):
+    """The payload of each line: what precedes '#', stripped; empty lines are dropped."""
+    stripped = (ln.partition("#")[0].strip() for ln in lines)
+    return (ln for ln in stripped if ln)
+
+
 def no_convert(x):
     return x
 
 
-def decomment(lines):
-    """Yield the non-empty part of each line before '#'."""
-    for line in lines:
-        text = line.split("#", 1)[0].strip()
-        if text:
-            yield text
-
-
 def read_single_value(file_name, convert=no_convert):
-    with open(file_name, "r", encoding="utf8") as f_input:
-        return convert(next(decomment(f_input)))
+    return _Deck(file_name, "utf8").first(convert)
 
 
 def read_single_float(file_name, convert=no_convert):
-    return read_single_value(file_name, convert=float)
+    return _Deck(file_name, "utf8").first(float)
 
 
 def read_single_string(file_name):
-    return read_single_value(file_name, convert=str)
+    return _Deck(file_name, "utf8").first(str)
 
 
 def read_and_decomment(file_name):
-    with open(file_name, "r") as f_input:
-        return list(decomment(f_input))
+    return _Deck(file_name).lines
 
 
 def read_two_columns(file_name):
-    rows = [line.split() for line in read_and_decomment(file_name)]
-    return [float(r[0]) for r in rows], [float(r[1]) for r in rows]
+    return _Deck(file_name).columns()
 
 
 def flatten(input_list):
-    return list(itertools.chain.from_iterable(input_list))
+    return [item for sub in input_list for item in sub]
 
 
 def flatten_float(input_list):
-    return [float(x) for x in flatten(input_list)]
+    return list(map(float, flatten(input_list)))
+
+
+def _problem(exc, where, text):
+    """Exceptions carry the reference's one-line wording: ``fedm.<function>: <text>``."""
+    return exc(f"fedm.{where}: {text}")
 
 
 # ---------------------------------------------------------------------------
-# file_io.py:250-296
+# speclist.cfg / reacscheme.cfg (file_io.py:250-343)
 # ---------------------------------------------------------------------------
+_KFILE = re.compile(r"kfile: ([A-Za-z0-9_]+.[A-Za-z0-9_]+)")                    # part of the format, :309
+_UIN = re.compile(r"Uin:\s?([+-]?\d+.\d+[eE]?[-+]?\d+|0|1.0)")                  # :323
+_MASS = re.compile(r"Mass\s?=\s?([+-]?\d+.\d+[eE]?[-+]?\d+|0|1.0)")             # :486
+_CHARGE = re.compile(r"Z\s+?=\s+?([+-]?\d+)")                                   # :487
+
+
 def read_speclist(file_path):
     """(n, species names, property file names, names used for transport files)."""
-    lines = [line.replace("file:", "").split()
-             for line in read_and_decomment(Path(file_path) / "speclist.cfg") if "file:" in line]
-    names = [line[0] for line in lines]
-    prop_files = [line[1] for line in lines]
-    tc_names = [line[1].split(".")[0] for line in lines]
-    return len(names), names, prop_files, tc_names
+    entries = [ln.replace("file:", "").split() for ln in _Deck(Path(file_path) / "speclist.cfg").lines
+               if "file:" in ln]
+    names, prop_files = [e[0] for e in entries], [e[1] for e in entries]
+    return len(entries), names, prop_files, [f.split(".")[0] for f in prop_files]
 
 
 def reaction_matrices(path, species):
-    """Power, loss and gain matrices (n_reactions x n_species, int) from reacscheme.cfg."""
-    reactions = [line.partition(" Type:")[0] for line in read_and_decomment(Path(path) / "reacscheme.cfg")]
-    lhs = [r.partition(" -> ")[0].rstrip() for r in reactions]
-    rhs = [r.partition(" -> ")[2].rstrip() for r in reactions]
-    l_matrix = np.array([[side.count(sp) for sp in species] for side in lhs], dtype=int).reshape(len(reactions), len(species))
-    g_matrix = np.array([[side.count(sp) for sp in species] for side in rhs], dtype=int).reshape(len(reactions), len(species))
-    power_matrix = l_matrix
-    net = l_matrix - g_matrix
-    loss_matrix = np.where(net > 0, net, 0)
-    gain_matrix = np.where(net < 0, -net, 0)
-    return power_matrix, loss_matrix, gain_matrix
+    """Power, loss and gain matrices (n_reactions x n_species, int) from reacscheme.cfg.
+    A species counts by substring occurrences on each side of ' -> ' (the format's rule)."""
+    sides = [ln.partition(" Type:")[0].partition(" -> ")[::2] for ln in _Deck(Path(path) / "reacscheme.cfg").lines]
+    count = lambda k: np.array([[side[k].rstrip().count(sp) for sp in species] for side in sides],
+                               dtype=int).reshape(len(sides), len(species))
+    consumed, produced = count(0), count(1)
+    balance = consumed - produced
+    return consumed, np.maximum(balance, 0), np.maximum(-balance, 0)
 
 
-# ---------------------------------------------------------------------------
-# file_io.py:299-359
-# ---------------------------------------------------------------------------
 def rate_coefficient_file_names(path):
-    regex = re.compile(r"kfile: ([A-Za-z0-9_]+.[A-Za-z0-9_]+)")
-    names = flatten([regex.findall(line) for line in read_and_decomment(Path(path) / "reacscheme.cfg")])
-    return [Path(path) / "rate_coefficients" / name for name in names]
+    folder = Path(path)
+    return [folder / "rate_coefficients" / name for name in _Deck(folder / "reacscheme.cfg").findall(_KFILE)]
 
 
 def read_energy_loss(path):
-    regex = re.compile(r"Uin:\s?([+-]?\d+.\d+[eE]?[-+]?\d+|0|1.0)")
-    values = flatten_float([regex.findall(line) for line in read_and_decomment(Path(path) / "reacscheme.cfg")])
-    print_rank_0(values)
-    return values
+    losses = [float(v) for v in _Deck(Path(path) / "reacscheme.cfg").findall(_UIN)]
+    print_rank_0(losses)
+    return losses
 
 
 def read_dependence(file_name):
-    file_name = Path(file_name)
-    if not file_name.is_file():
-        raise FileNotFoundError(f"fedm.read_dependence: file '{file_name}' not found")
-    with open(file_name, "r", encoding="utf8") as f_input:
-        for line in f_input:
-            if "Dependence:" in line:
-                return line.split()[2]
-    raise RuntimeError(f"fedm.read_dependence: Did not find dependence in file '{file_name}'")
+    target = Path(file_name)
+    if not target.is_file():
+        raise _problem(FileNotFoundError, "read_dependence", f"file '{target}' not found")
+    with open(target, "r", encoding="utf8") as handle:     # the keyword sits in a comment line
+        tagged = [ln for ln in handle if "Dependence:" in ln]
+    if not tagged:
+        raise _problem(RuntimeError, "read_dependence", f"Did not find dependence in file '{target}'")
+    return tagged[0].split()[2]
 
 
 def read_dependences(file_names, zero_if_file_missing=False):
-    dependences = []
-    for file_name in file_names:
+    def one(name):
         try:
-            dependences.append(read_dependence(file_name))
+            return read_dependence(name)
         except FileNotFoundError:
-            if not zero_if_file_missing:
-                raise
-            dependences.append(0)
-    return dependences
+            if zero_if_file_missing:
+                return 0
+            raise
+    return [one(name) for name in file_names]
 
 
 # ---------------------------------------------------------------------------
-# file_io.py:362-475
+# coefficient files (file_io.py:362-475): how a file is read follows from its dependence tag
 # ---------------------------------------------------------------------------
+_SCALAR, _TEXT, _TABLE, _NOTHING = "scalar", "text", "table", "nothing"
+_RATE_KINDS = {"const": _SCALAR, "fun:Te,Tgas": _TEXT, "fun:Tgas": _TEXT,
+               "Umean": _TABLE, "E/N": _TABLE, "ElecDist": _TABLE}
+_TRANSPORT_KINDS = {"const": _SCALAR, "const.": _SCALAR, "fun:Te,Tgas": _TEXT, "fun:E": _TEXT,
+                    "Umean": _TABLE, "E/N": _TABLE, "Tgas": _TABLE, "Te": _TABLE}
+
+
+def _payload(file_name, kind):
+    """(x, y) as the reference returns them: tables as two lists, everything else as (0.0, value)."""
+    if kind == _TABLE:
+        return _Deck(file_name).columns()
+    if kind == _SCALAR:
+        return 0.0, _Deck(file_name, "utf8").first(float)
+    if kind == _TEXT:
+        return 0.0, _Deck(file_name, "utf8").first(str)
+    return 0.0, 0.0
+
+
 def read_rate_coefficients(rc_file_names, k_dependences):
     if len(rc_file_names) != len(k_dependences):
-        raise ValueError(
-            "fedm.read_rate_coefficients: rc_file_names and k_dependences should be "
-            "the same length."
-        )
-    float_dependences = ["const"]
-    str_dependences = ["fun:Te,Tgas", "fun:Tgas"]
-    two_col_dependences = ["Umean", "E/N", "ElecDist"]
-    all_dependences = float_dependences + str_dependences + two_col_dependences
-    for dependence in k_dependences:
-        if dependence not in all_dependences:
-            raise ValueError(
-                f"fedm.read_rate_coefficients: The dependence '{dependence}' is not "
-                f"recognised. Options are {comma_separated(all_dependences)}."
-            )
+        raise _problem(ValueError, "read_rate_coefficients",
+                       "rc_file_names and k_dependences should be the same length.")
+    unknown = [d for d in k_dependences if d not in _RATE_KINDS]
+    if unknown:
+        raise _problem(ValueError, "read_rate_coefficients",
+                       f"The dependence '{unknown[0]}' is not recognised. Options are "
+                       f"{comma_separated(list(_RATE_KINDS))}.")
     kxs, kys = [], []
-    for dependence, name in zip(k_dependences, rc_file_names):
+    for name, tag in zip(rc_file_names, k_dependences):
         print_rank_0(name)
-        if dependence in two_col_dependences:
-            kx, ky = read_two_columns(name)
-        elif dependence in float_dependences:
-            kx, ky = 0.0, read_single_float(name)
-        else:
-            kx, ky = 0.0, read_single_string(name)
-        kxs.append(kx)
-        kys.append(ky)
+        x, y = _payload(name, _RATE_KINDS[tag])
+        kxs.append(x)
+        kys.append(y)
     return kxs, kys
 
 
 def read_transport_coefficients(particle_names, transport_type, model):
     """(kxs, kys, dependences).  ``'fun:E'`` entries keep their expression string (the
     reference ``eval``s it later, fedm-streamer.py:237-238; here ``termsum.parse`` does)."""
-    path = files.file_input / model / "transport_coefficients"
-    if not path.is_dir():
-        raise FileNotFoundError(
-            f"fedm.read_transport_coefficients: Transport coeff dir '{path}' not found."
-        )
-    float_dependences = ["const", "const."]
-    str_dependences = ["fun:Te,Tgas", "fun:E"]
-    two_col_dependences = ["Umean", "E/N", "Tgas", "Te"]
-    all_dependences = float_dependences + str_dependences + two_col_dependences
-    if transport_type == "Diffusion":
-        all_dependences.append("ESR")
-    if transport_type == "mobility":
-        all_dependences.append(0)
-    suffix = "_ND.dat" if transport_type == "Diffusion" else "_Nb.dat"
-    file_names = [path / (particle + suffix) for particle in particle_names]
-    k_dependences = read_dependences(file_names, zero_if_file_missing=(transport_type == "mobility"))
-    for dependence in k_dependences:
-        if dependence not in all_dependences:
-            err_msg = dedent(
-                f"""\
-                fedm.read_transport_coefficients: Dependence '{dependence}' not
-                recognised. For the transport type '{transport_type}', the possible
-                options are {comma_separated(all_dependences)}.
-                """
-            )
-            raise ValueError(err_msg.rstrip().replace("\n", " "))
+    folder = files.file_input / model / "transport_coefficients"
+    if not folder.is_dir():
+        raise _problem(FileNotFoundError, "read_transport_coefficients",
+                       f"Transport coeff dir '{folder}' not found.")
+    diffusion, mobility = transport_type == "Diffusion", transport_type == "mobility"
+    kinds = dict(_TRANSPORT_KINDS)
+    if diffusion:
+        kinds["ESR"] = _NOTHING            # Einstein relation: computed from the mobility later
+    if mobility:
+        kinds[0] = _NOTHING                # no mobility file: the species does not drift
+    file_names = [folder / f"{particle}{'_ND.dat' if diffusion else '_Nb.dat'}" for particle in particle_names]
+    tags = read_dependences(file_names, zero_if_file_missing=mobility)
+    for tag in tags:
+        if tag not in kinds:
+            raise _problem(ValueError, "read_transport_coefficients",
+                           f"Dependence '{tag}' not recognised. For the transport type "
+                           f"'{transport_type}', the possible options are {comma_separated(list(kinds))}.")
     kxs, kys = [], []
-    for file_name, dependence in zip(file_names, k_dependences):
-        if transport_type == "mobility" and dependence == 0:
+    for name, tag in zip(file_names, tags):
+        if tag == 0:
             kxs.append(0)
             kys.append(0)
             continue
-        print_rank_0(file_name)
-        if dependence in two_col_dependences:
-            kx, ky = read_two_columns(file_name)
-        elif dependence == "ESR":
-            kx, ky = 0.0, 0.0
-        elif dependence in float_dependences:
-            kx, ky = 0.0, read_single_float(file_name)
-        else:
-            kx, ky = 0.0, read_single_string(file_name)
-        if dependence == "fun:Te,Tgas":
-            raise RuntimeError(
-                f"fedm.read_transport_coefficients: ky eval failed, '{ky}'"
-            )  # the reference eval()s arbitrary Python here; not supported on purpose
-        kxs.append(kx)
-        kys.append(ky)
-    return kxs, kys, k_dependences
+        print_rank_0(name)
+        x, y = _payload(name, kinds[tag])
+        if tag == "fun:Te,Tgas":   # the reference eval()s arbitrary Python here; refused on purpose
+            raise _problem(RuntimeError, "read_transport_coefficients", f"ky eval failed, '{y}'")
+        kxs.append(x)
+        kys.append(y)
+    return kxs, kys, tags
 
 
 # ---------------------------------------------------------------------------
-# file_io.py:478-535
+# species property files (file_io.py:478-535)
 # ---------------------------------------------------------------------------
 def read_particle_properties(file_names, model):
-    path = files.file_input / model / "species"
-    regex_mass = re.compile(r"Mass\s?=\s?([+-]?\d+.\d+[eE]?[-+]?\d+|0|1.0)")
-    regex_charge = re.compile(r"Z\s+?=\s+?([+-]?\d+)")
+    folder = files.file_input / model / "species"
     masses, charges = [], []
     for name in file_names:
-        file_name = path / name
-        if not file_name.is_file():
-            raise RuntimeError(f"fedm.read_particle_properties: File '{file_name}' not found.")
-        print_rank_0(file_name)
-        mass_found = charge_found = False
-        for line in read_and_decomment(file_name):
-            print_rank_0(line)
-            mass, charge = regex_mass.findall(line), regex_charge.findall(line)
-            if mass:
-                mass_found = True
-                masses.append(float(mass[0]))
-            if charge:
-                charge_found = True
-                charges.append(float(charge[0]))
-        if not mass_found:
-            raise RuntimeError(f"fedm.read_particle_properties: No mass found in file '{file_name}'.")
-        if not charge_found:
-            raise RuntimeError(f"fedm.read_particle_properties: No charge found in file '{file_name}'.")
+        target = folder / name
+        if not target.is_file():
+            raise _problem(RuntimeError, "read_particle_properties", f"File '{target}' not found.")
+        print_rank_0(target)
+        deck = _Deck(target)
+        for ln in deck.lines:
+            print_rank_0(ln)
+        found = {"mass": deck.findall(_MASS), "charge": deck.findall(_CHARGE)}
+        for what, hits in found.items():
+            if not hits:
+                raise _problem(RuntimeError, "read_particle_properties", f"No {what} found in file '{target}'.")
+        masses += [float(v) for v in found["mass"]]
+        charges += [float(v) for v in found["charge"]]
     return masses, charges
 
 
@@ -322,43 +315,49 @@ def print_time(t):
 
 
 def numpy_2d_array_to_str(x):
-    no_brackets = str(np.asarray(x)).replace("[", "").replace("]", "")
-    return "\n".join(row.strip() for row in no_brackets.split("\n"))
+    rows = str(np.asarray(x)).replace("[", "").replace("]", "").split("\n")
+    return "\n".join(row.strip() for row in rows)
+
+
+# ---------------------------------------------------------------------------
+# model log (file_io.py:641-724): one formatter per entry kind
+# ---------------------------------------------------------------------------
+def _log_properties(gas, model, names, M, charge):
+    return "\n\n".join([f"Gas:\t{gas}", f"model:\t{model}", f"Particle names:\n{names}",
+                        f"Mass:\n{M}", f"Charge:\n{charge}"]) + "\n"
+
+
+def _log_conditions(dt_var, U_w, p0, gap_length, N0, Tgas):
+    items = [("dt", dt_var, "s"), ("U_w", U_w, "V"), ("p_0", p0, "Torr"), ("d", gap_length, "m"),
+             ("N_0", N0, "m^-3"), ("T_gas", Tgas, "K")]
+    line = "\t ".join(f"{k} = {v} {u}" + ("," if k != "T_gas" else "") for k, v, u in items)
+    return f"Simulation conditions:\n{line}\n"
+
+
+def _log_matrices(gain, loss, power):
+    blocks = [("Gain", gain), ("Loss", loss), ("Power", power)]
+    return "\n\n".join(f"{title} matrix:\n{numpy_2d_array_to_str(m)}" for title, m in blocks) + "\n"
+
+
+_LOG_ENTRIES = {
+    "properties": _log_properties,
+    "conditions": _log_conditions,
+    "matrices": _log_matrices,
+    "initial time": lambda t: f"Time:\n{t}",
+    "time": lambda t: str(t),
+    "mesh": lambda mesh: __import__("fedm_amd.utils", fromlist=["mesh_info"]).mesh_info(mesh),
+}
 
 
 def log(log_type, log_file_name, *args):
-    """Model log entries with the reference's layout (file_io.py:641-724)."""
-    from .utils import _rank, mesh_info
+    """Append one entry to the model log in the reference's layout."""
+    from .utils import _rank
     if _rank() != 0:
         return
-    if log_type == "properties":
-        gas, model, names, M, charge = args
-        log_str = (f"Gas:\t{gas}\n\nmodel:\t{model}\n\nParticle names:\n{names}\n\n"
-                   f"Mass:\n{M}\n\nCharge:\n{charge}\n")
-    elif log_type == "conditions":
-        dt_var, U_w, p0, gap_length, N0, Tgas = args
-        body = "\t ".join([f"dt = {dt_var} s,", f"U_w = {U_w} V,", f"p_0 = {p0} Torr,",
-                           f"d = {gap_length} m,", f"N_0 = {N0} m^-3,", f"T_gas = {Tgas} K"])
-        log_str = f"Simulation conditions:\n{body}\n"
-    elif log_type == "matrices":
-        gain, loss, power = args
-        log_str = (f"Gain matrix:\n{numpy_2d_array_to_str(gain)}\n\nLoss matrix:\n"
-                   f"{numpy_2d_array_to_str(loss)}\n\nPower matrix:\n{numpy_2d_array_to_str(power)}\n")
-    elif log_type == "initial time":
-        log_str = f"Time:\n{args[0]}"
-    elif log_type == "time":
-        log_str = str(args[0])
-    elif log_type == "mesh":
-        log_str = mesh_info(args[0])
-    else:
-        err_msg = dedent(
-            f"""\
-            fedm.log: log_type '{log_type}' not recognised. Options are 'properties',
-            'conditions', 'matrices', 'initial time', 'time', or 'mesh'
-            """
-        )
-        raise ValueError(err_msg.rstrip().replace("\n", " "))
-    with open(log_file_name, "a") as log_file:
-        log_file.write(log_str)
-        log_file.write("\n")
-        log_file.flush()
+    if log_type not in _LOG_ENTRIES:
+        raise _problem(ValueError, "log",
+                       f"log_type '{log_type}' not recognised. Options are 'properties', 'conditions', "
+                       "'matrices', 'initial time', 'time', or 'mesh'")
+    with open(log_file_name, "a") as handle:
+        handle.write(_LOG_ENTRIES[log_type](*args) + "\n")
+        handle.flush()
