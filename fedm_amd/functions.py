@@ -8,7 +8,6 @@ the GPU box.  The hot path -- ``Problem.F``, ``Problem.J`` and
 """
 import warnings
 from pathlib import Path
-from textwrap import dedent
 from typing import Any, List, Optional, Tuple
 
 import numpy as np
@@ -20,6 +19,15 @@ from .utils import comma_separated, print_rank_0
 DOLFIN_EPS = 3.0e-16
 
 
+def _must_be_one_of(where, what, value, allowed, quote=True):
+    """The reference's wording for a bad option: ``fedm.<where>: <what> '<value>' not recognised.
+    Must be one of a, b, c.``"""
+    if value not in allowed:
+        shown = f"'{value}'" if quote else f"{value}"
+        raise ValueError(f"fedm.{where}: {what} {shown} not recognised. Must be one of "
+                         f"{comma_separated(allowed)}.")
+
+
 # ---------------------------------------------------------------------------
 # fedm/functions.py:15-45
 # ---------------------------------------------------------------------------
@@ -27,15 +35,9 @@ def modify_approximation_vars(approximation_type, number_of_species, particle_sp
                               masses, charges):
     """LFA drops the first species; n_eq = n_species + 1.  Mutates the lists like the
     reference does."""
-    approximation_types = ["LFA", "LMEA"]
-    if approximation_type not in approximation_types:
-        err_msg = dedent(
-            f"""\
-            fedm.modify_approximation_vars: The approximation type {approximation_type}
-            is not recognised. Must be one of {comma_separated(approximation_types)}.
-            """
-        )
-        raise ValueError(err_msg.rstrip().replace("\n", " "))
+    if approximation_type not in ("LFA", "LMEA"):
+        raise ValueError(f"fedm.modify_approximation_vars: The approximation type {approximation_type} "
+                         f"is not recognised. Must be one of {comma_separated(['LFA', 'LMEA'])}.")
     if approximation_type == "LFA":
         number_of_species -= 1
         particle_species.pop(0)
@@ -61,15 +63,9 @@ def Function_definition(function_space, function_type, eq_number=1):
     functions = {"TrialFunction": forms.TrialFunction, "TestFunction": forms.TestFunction,
                  "Function": forms.Function}
     if function_type not in functions:
-        err_msg = dedent(
-            f"""\
-            fedm.Function_definition: Invalid function_type '{function_type}'.
-            Possible values are {comma_separated(functions)}.
-            """
-        )
-        raise ValueError(err_msg.rstrip().replace("\n", " "))
-    function = functions[function_type]
-    return [function(function_space) for _ in range(eq_number)]
+        raise ValueError(f"fedm.Function_definition: Invalid function_type '{function_type}'. "
+                         f"Possible values are {comma_separated(functions)}.")
+    return [functions[function_type](function_space) for _ in range(eq_number)]
 
 
 # ---------------------------------------------------------------------------
@@ -134,21 +130,14 @@ def weak_form_balance_equation(equation_type, dt, dt_old, dx, u, u_old, u_old1, 
                                r=0.5 / np.pi, D=None, log_representation=False):
     """Weak form of a particle balance equation, fedm/functions.py:240-368 (same positional
     arguments, same ValueErrors)."""
-    equation_types = ["reaction", "diffusion-reaction", "drift-diffusion-reaction"]
-    if equation_type not in equation_types:
-        err_msg = dedent(
-            f"""\
-            fedm.weak_form_balance_equation_log_representation: The equation type
-            {equation_type}' is not recognised. Must be one of
-            {comma_separated(equation_types)}.
-            """
-        )
-        raise ValueError(err_msg.rstrip().replace("\n", " "))
-    if equation_type == "diffusion-reaction" and D is None:
-        raise ValueError(
-            "fedm.weak_form_balance_equation_log_representation: When 'equation_type' "
-            "is diffusion-reaction, must also supply the diffusion coefficient 'D'."
-        )
+    me = "weak_form_balance_equation_log_representation"       # the name the reference reports
+    kinds = ["reaction", "diffusion-reaction", "drift-diffusion-reaction"]
+    if equation_type not in kinds:                              # (sic: unbalanced quote)
+        raise ValueError(f"fedm.{me}: The equation type {equation_type}' is not recognised. "
+                         f"Must be one of {comma_separated(kinds)}.")
+    if D is None and equation_type == "diffusion-reaction":
+        raise ValueError(f"fedm.{me}: When 'equation_type' is diffusion-reaction, must also supply "
+                         "the diffusion coefficient 'D'.")
     if not log_representation:
         raise NotImplementedError(
             "the device path implements the logarithmic representation "
@@ -170,37 +159,16 @@ def Boundary_flux(bc_type, equation_type, particle_type, sign, mu, E, normal, u,
                   ds_temp, r=0.5 / np.pi, vth=0.0, ref=1.0, Ion_flux=0.0):
     """Boundary terms, fedm/functions.py:404-528: same checks, warning and return
     convention (a form piece, or 0.0 when the condition contributes nothing)."""
-    bc_types = ["zero flux", "flux source", "Neumann"]
-    equation_types = ["reaction", "diffusion-reaction", "drift-diffusion-reaction"]
-    particle_types = ["Heavy", "electrons"]
     if "_" in bc_type:
         warnings.warn("fedm.BoundaryFlux: bc_type should have spaces, not underscores")
         bc_type = bc_type.replace("_", " ")
-    if bc_type not in bc_types:
-        err_msg = dedent(
-            f"""\
-            fedm.Boundary_flux: boundary condition type '{bc_type}' not recognised.
-            Must be one of {comma_separated(bc_types)}.
-            """
-        )
-        raise ValueError(err_msg.rstrip().replace("\n", " "))
-    if bc_type != "zero flux" and equation_type not in equation_types:
-        err_msg = dedent(
-            f"""\
-            fedm.Boundary_flux: equation type '{equation_type}' not recognised.
-            Must be one of {comma_separated(equation_types)}.
-            """
-        )
-        raise ValueError(err_msg.rstrip().replace("\n", " "))
-    if (bc_type == "flux source" and equation_type == "diffusion-reaction"
-            and particle_type not in particle_types):
-        err_msg = dedent(
-            f"""\
-            fedm.Boundary_flux: particle type '{particle_type}' not recognised.
-            Must be one of {comma_separated(particle_types)}.
-            """
-        )
-        raise ValueError(err_msg.rstrip())
+    _must_be_one_of("Boundary_flux", "boundary condition type", bc_type, ["zero flux", "flux source", "Neumann"])
+    if bc_type != "zero flux":
+        _must_be_one_of("Boundary_flux", "equation type", equation_type,
+                        ["reaction", "diffusion-reaction", "drift-diffusion-reaction"])
+    if (bc_type, equation_type) == ("flux source", "diffusion-reaction") and particle_type not in ("Heavy", "electrons"):
+        raise ValueError(f"fedm.Boundary_flux: particle type '{particle_type}' not recognised.\n"
+                         f"Must be one of {comma_separated(['Heavy', 'electrons'])}.")
     if bc_type == "flux source" and equation_type != "reaction":
         raise NotImplementedError(
             "'flux source' boundaries (glow-discharge model) are not on the device path yet")
@@ -380,27 +348,33 @@ def Min(a, b):
 # ---------------------------------------------------------------------------
 # fedm/functions.py:915-951 -- step-size controllers (host scalars)
 # ---------------------------------------------------------------------------
-def adaptive_timestep(dt, error, tol=1e-4, dt_min=1e-13, dt_max=1e-9):
-    dt *= (
-        (error[1] / error[0]) ** 0.075
-        * (tol / error[0]) ** 0.175
-        * (error[1] ** 2 / (error[0] * error[2])) ** 0.01
-    )
+def _within(dt, dt_min, dt_max):
     return max(min(dt, dt_max), dt_min)
+
+
+def adaptive_timestep(dt, error, tol=1e-4, dt_min=1e-13, dt_max=1e-9):
+    """PID step controller, fedm/functions.py:915-927; error = [e_n, e_{n-1}, e_{n-2}].  The
+    three factors are multiplied left to right and then applied to dt: the golden error logs
+    replay bit for bit only in that order."""
+    e0, e1, e2 = error[0], error[1], error[2]
+    proportional = (e1 / e0) ** 0.075
+    integral = (tol / e0) ** 0.175
+    derivative = (e1 ** 2 / (e0 * e2)) ** 0.01
+    return _within(dt * (proportional * integral * derivative), dt_min, dt_max)
 
 
 def adaptive_timestep_PI34(dt, error, tol=1e-4, dt_min=1e-13, dt_max=1e-9):
-    dt *= (0.8 * tol / error[0]) ** (0.3 / 3) * (0.8 * error[1] / error[0]) ** (0.4 / 3)
-    return max(min(dt, dt_max), dt_min)
+    """Soederlind's PI.3.4 controller, fedm/functions.py:930-937."""
+    e0, e1 = error[0], error[1]
+    growth = (0.8 * tol / e0) ** (0.3 / 3) * (0.8 * e1 / e0) ** (0.4 / 3)
+    return _within(dt * growth, dt_min, dt_max)
 
 
 def adaptive_timestep_H211b(dt, dt_old, error, tol=1e-4, dt_min=1e-13, dt_max=1e-9):
-    dt *= (
-        (0.8 * tol / error[0]) ** (1 / 12)
-        * (0.8 * tol / error[1]) ** (1 / 12)
-        * (dt / dt_old) ** (-1 / 4)
-    )
-    return max(min(dt, dt_max), dt_min)
+    """Soederlind's H211b digital filter, fedm/functions.py:940-951."""
+    e0, e1 = error[0], error[1]
+    growth = (0.8 * tol / e0) ** (1 / 12) * (0.8 * tol / e1) ** (1 / 12) * (dt / dt_old) ** (-1 / 4)
+    return _within(dt * growth, dt_min, dt_max)
 
 
 class ErrorGreaterThanTTOL(Exception):
@@ -413,154 +387,137 @@ class ErrorGreaterThanTTOL(Exception):
 def adaptive_solver(nonlinear_solver, problem, t, dt, dt_old, u_new, u_old, var_list_new,
                     var_list_old, assigner, error, error_file, max_error, ttol, dt_min,
                     time_dependent_arguments=None, approximation="LMEA"):
-    """One accepted time step with FEDM's accept/reject rule.
+    """One accepted time step with FEDM's accept/reject rule (same argument list; the reference
+    recurses after a rejection, this loops).
 
-    Same argument list as the reference.  ``dt``/``dt_old`` carry ``.time_step``;
-    ``u_new``/``u_old`` are the device-resident mixed states; the error norm of
-    functions.py:1062-1064 is a device reduction over one component."""
-    print_rank_0(
-        f"Attempting to solve the equation for t = {t} with dt = {dt.time_step}",
-        flush=True,
-    )
+    An attempt advances the time-dependent arguments, solves, measures the relative change of
+    one field (a device reduction, functions.py:1062-1064) and appends a row to the error log.
+    Rejected when that change reaches ``ttol`` (next attempt with dt * 0.5 * ttol / max_error) or
+    when anything raised (dt * 0.5); below ``dt_min`` the run ends with SystemExit.
+    ``dt``/``dt_old`` carry ``.time_step``; ``u_new``/``u_old`` are the device-resident states."""
     dev = problem.device
-    try:
-        t += dt.time_step
-        if time_dependent_arguments is not None:
-            for arg in time_dependent_arguments:
-                arg.t = t
-        dev.set_step(dt.time_step, dt_old.time_step)
-        nonlinear_solver.solve(problem, u_new.vector())
-        assigner.assign(var_list_new, u_new)
-        if approximation == "LMEA" or approximation == "LFA":
-            idx = 0 if approximation == "LMEA" else dev.n_eq - 2
-            error[0] = dev.field_error(idx)
-        else:
-            error[0] = dev.state_error()
-        with open(error_file, "a") as f_err:
-            f_err.write(f"{error[0]:<23}  {dt_old.time_step:<23}  {dt.time_step:<23}\n")
-            f_err.flush()
-        max_error[0] = max(error)
-        if error[0] >= ttol:
-            raise ErrorGreaterThanTTOL
-    except Exception as exc:
-        t -= dt.time_step
-        if isinstance(exc, ErrorGreaterThanTTOL):
-            dt.time_step *= 0.5 * ttol / max_error[0]
-            print_rank_0(
-                "Residual is greater than the prescribed tolerance. Reducing "
-                "time-step size and repeating calculation."
-            )
-        else:
-            dt.time_step *= 0.5
-            print_rank_0(
-                "An exception was raised while solving. Reducing time-step size "
-                "and repeating calculation."
-            )
-        if dt.time_step < dt_min:
-            raise SystemExit("Minimum time-step size reached, program is terminating.")
-        u_new.assign(u_old)
-        assigner.assign(var_list_new, u_new)
-        t = adaptive_solver(nonlinear_solver, problem, t, dt, dt_old, u_new, u_old,
-                            var_list_new, var_list_old, assigner, error, error_file,
-                            max_error, ttol, dt_min, time_dependent_arguments, approximation)
-    return t
+    watched = {"LMEA": 0, "LFA": dev.n_eq - 2}
+    while True:
+        print_rank_0(f"Attempting to solve the equation for t = {t} with dt = {dt.time_step}", flush=True)
+        step = dt.time_step
+        try:
+            for arg in (time_dependent_arguments or ()):
+                arg.t = t + step
+            dev.set_step(step, dt_old.time_step)
+            nonlinear_solver.solve(problem, u_new.vector())
+            assigner.assign(var_list_new, u_new)
+            error[0] = dev.field_error(watched[approximation]) if approximation in watched else dev.state_error()
+            with open(error_file, "a") as rows:
+                rows.write(f"{error[0]:<23}  {dt_old.time_step:<23}  {step:<23}\n")
+                rows.flush()
+            max_error[0] = max(error)
+            if error[0] >= ttol:
+                raise ErrorGreaterThanTTOL
+            return t + step
+        except Exception as problem_found:     # the reference catches everything here as well
+            t = (t + step) - step              # it advances t first and steps back: same rounding
+            if isinstance(problem_found, ErrorGreaterThanTTOL):
+                dt.time_step *= 0.5 * ttol / max_error[0]
+                print_rank_0("Residual is greater than the prescribed tolerance. Reducing "
+                             "time-step size and repeating calculation.")
+            else:
+                dt.time_step *= 0.5
+                print_rank_0("An exception was raised while solving. Reducing time-step size "
+                             "and repeating calculation.")
+            if dt.time_step < dt_min:
+                raise SystemExit("Minimum time-step size reached, program is terminating.")
+            u_new.assign(u_old)
+            assigner.assign(var_list_new, u_new)
 
 
 # ---------------------------------------------------------------------------
 # fedm/functions.py:531-750 -- coefficient table look-ups (nodal arrays)
 # ---------------------------------------------------------------------------
+def _choice(where, what, value, allowed):
+    if value not in allowed:
+        raise ValueError(f"fedm.{where}: {what} '{value}' not recognised. Must be one of "
+                         f"{comma_separated(allowed)}.")
+
+
+def _equal_lengths(where, message, reference, *others):
+    if any(len(o) != len(reference) for o in others):
+        raise ValueError(f"fedm.{where}: {message} must be the same length.")
+
+
+# How a nodal coefficient field follows from its dependence tag.  Each rule gets the table
+# (kx, ky) and a context with the nodal mean energy, reduced field, gas temperature and, for the
+# Einstein relation, the mobility field; ``None`` means "leave the field as it is".
+def _transport_rules(status, N0, Tgas, energy, redfield):
+    table = lambda arg: (lambda kx, ky, mu: np.interp(arg(), kx, ky) / N0)
+    return {
+        0: None,
+        "const": (lambda kx, ky, mu: ky / N0) if status == "initial" else None,
+        "Umean": table(lambda: energy.vector()[:]),
+        "E/N": table(lambda: redfield.vector()[:]),
+        "Tgas": table(lambda: Tgas),
+        "ESR": lambda kx, ky, mu: kB * Tgas * mu.vector()[:] / elementary_charge,
+    }
+
+
+def _rate_rules(status, energy, redfield):
+    table = lambda arg: (lambda kx, ky: np.interp(arg(), kx, ky))
+    return {
+        0: None,
+        "const": (lambda kx, ky: ky) if status == "initial" else None,
+        "Umean": table(lambda: energy.vector()[:]),
+        "E/N": table(lambda: redfield.vector()[:]),
+        "Te": table(lambda: 2 * energy.vector()[:] / (3 * kB_eV)),
+        "fun:Te,Tgas": None,          # accepted and ignored, as in the reference (functions.py:730)
+        "fun:Tgas": None,
+    }
+
+
 def Transport_coefficient_interpolation(status, dependences, N0, Tgas, k_coeffs, kxs, kys,
                                         energy, redfield, mus=None):
-    possible_statuses = ["initial", "update"]
-    possible_dependences = [0, "const", "Umean", "E/N", "ESR", "Tgas"]
-    if status not in possible_statuses:
-        err_msg = dedent(
-            f"""\
-            fedm.Transport_coefficient_interpolation: status '{status}' not recognised.
-            Must be one of {comma_separated(possible_statuses)}.
-            """
-        )
-        raise ValueError(err_msg.rstrip().replace("\n", " "))
-    for dependence in dependences:
-        if dependence not in possible_dependences:
-            err_msg = dedent(
-                f"""\
-                fedm.Transport_coefficient_interpolation: dependence '{dependence}' not
-                recognised. Must be one of {comma_separated(possible_dependences)}.
-                """
-            )
-            raise ValueError(err_msg.rstrip().replace("\n", " "))
+    """fedm/functions.py:531-639: refresh the nodal transport coefficients (``np.interp`` with
+    clamped ends, divided by N0; Einstein relation for 'ESR')."""
+    me = "Transport_coefficient_interpolation"
+    rules = _transport_rules(status, N0, Tgas, energy, redfield)
+    _choice(me, "status", status, ["initial", "update"])
+    for tag in dependences:
+        _choice(me, "dependence", tag, [0, "const", "Umean", "E/N", "ESR", "Tgas"])
     if mus is None:
         if "ESR" in dependences:
-            raise ValueError(
-                "fedm.Transport_coefficient_interpolation: Must provide mus "
-                "(mobilities) when using ESR dependence."
-            )
+            raise ValueError(f"fedm.{me}: Must provide mus (mobilities) when using ESR dependence.")
         mus = [None] * len(k_coeffs)
-    if not all([len(x) == len(k_coeffs) for x in [dependences, kxs, kys, mus]]):
-        raise ValueError(
-            "fedm.Transport_coefficient_interpolation: The lists 'dependences', 'kxs', "
-            "'kys', 'k_coeffs', and (optionally) 'mus' must be the same length."
-        )
-    for k_coeff, dependence, kx, ky, mu in zip(k_coeffs, dependences, kxs, kys, mus):
-        if dependence == "const" and status == "initial":
-            k_coeff.vector()[:] = ky / N0
-        elif dependence == "Umean":
-            k_coeff.vector()[:] = np.interp(energy.vector()[:], kx, ky) / N0
-        elif dependence == "E/N":
-            k_coeff.vector()[:] = np.interp(redfield.vector()[:], kx, ky) / N0
-        elif dependence == "ESR":
-            k_coeff.vector()[:] = kB * Tgas * mu.vector()[:] / elementary_charge
-        elif dependence == "Tgas":
-            k_coeff.vector()[:] = np.interp(Tgas, kx, ky) / N0
+    _equal_lengths(me, "The lists 'dependences', 'kxs', 'kys', 'k_coeffs', and (optionally) 'mus'",
+                   k_coeffs, dependences, kxs, kys, mus)
+    for field, tag, kx, ky, mu in zip(k_coeffs, dependences, kxs, kys, mus):
+        rule = rules[tag]
+        if rule is not None:
+            field.vector()[:] = rule(kx, ky, mu)
 
 
 def Rate_coefficient_interpolation(status, dependences, k_coeffs, kxs, kys, energy, redfield,
                                    Te=300.0, Tgas=300.0):
-    possible_statuses = ["initial", "update"]
-    possible_dependences = [0, "const", "Umean", "E/N", "Te", "fun:Te,Tgas", "fun:Tgas"]
-    if status not in possible_statuses:
-        raise ValueError(
-            f"fedm.Rate_coefficient_interpolation: status '{status}' not recognised. "
-            f"Must be one of {comma_separated(possible_statuses)}."
-        )
-    for dependence in dependences:
-        if dependence not in possible_dependences:
-            raise ValueError(
-                f"fedm.Rate_coefficient_interpolation: dependence '{dependence}' not "
-                f"recognised. Must be one of {comma_separated(possible_dependences)}."
-            )
-    if not all([len(x) == len(k_coeffs) for x in [dependences, kxs, kys]]):
-        raise ValueError(
-            "fedm.Rate_coefficient_interpolation: The lists 'dependences', 'kxs', "
-            "'kys', and 'k_coeffs' must be the same length."
-        )
-    for k_coeff, dependence, kx, ky in zip(k_coeffs, dependences, kxs, kys):
-        if dependence == "const" and status == "initial":
-            k_coeff.vector()[:] = ky
-        elif dependence == "Te":
-            k_coeff.vector()[:] = np.interp(2 * energy.vector()[:] / (3 * kB_eV), kx, ky)
-        elif dependence == "Umean":
-            k_coeff.vector()[:] = np.interp(energy.vector()[:], kx, ky)
-        elif dependence == "E/N":
-            k_coeff.vector()[:] = np.interp(redfield.vector()[:], kx, ky)
-        # 'fun:...' is unreachable in the reference as well (functions.py:730)
+    """fedm/functions.py:642-750: the same for the rate coefficients (no N0 scaling; 'Te' looks
+    the table up at 2/3 of the mean energy in kelvin-equivalent electron volts)."""
+    me = "Rate_coefficient_interpolation"
+    rules = _rate_rules(status, energy, redfield)
+    _choice(me, "status", status, ["initial", "update"])
+    for tag in dependences:
+        _choice(me, "dependence", tag, [0, "const", "Umean", "E/N", "Te", "fun:Te,Tgas", "fun:Tgas"])
+    _equal_lengths(me, "The lists 'dependences', 'kxs', 'kys', and 'k_coeffs'", k_coeffs, dependences, kxs, kys)
+    for field, tag, kx, ky in zip(k_coeffs, dependences, kxs, kys):
+        rule = rules[tag]
+        if rule is not None:
+            field.vector()[:] = rule(kx, ky)
 
 
 def semi_implicit_coefficients(dependences, mean_energy_new, mean_energy_old, coefficients,
                                coefficient_diffs):
-    if not all([len(x) == len(dependences) for x in [coefficients, coefficient_diffs]]):
-        raise ValueError(
-            "fedm.semi_implicit_coefficients: The lists 'dependences', 'coefficients', "
-            "and 'coefficient_diffs' must be the same length."
-        )
-    si_coefficients = []
-    for coeff, diff, dep in zip(coefficients, coefficient_diffs, dependences):
-        if dep == "Umean":
-            si_coefficients.append(coeff + diff * (mean_energy_new - mean_energy_old))
-        else:
-            si_coefficients.append(coeff)
-    return si_coefficients
+    """fedm/functions.py:753-774: c + c' (mean_energy_new - mean_energy_old) for the entries that
+    depend on the mean energy, c otherwise."""
+    _equal_lengths("semi_implicit_coefficients", "The lists 'dependences', 'coefficients', and 'coefficient_diffs'",
+                   dependences, coefficients, coefficient_diffs)
+    shift = mean_energy_new - mean_energy_old
+    return [c + dc * shift if tag == "Umean" else c
+            for c, dc, tag in zip(coefficients, coefficient_diffs, dependences)]
 
 
 # ---------------------------------------------------------------------------
@@ -571,49 +528,52 @@ def _exp(x):
     return forms.exp(x)
 
 
+def _reaction_rates(p_matrix, densities, k_coeffs):
+    """rate_j = k_j * prod_i n_i^P_ji, multiplying in species order (symbolic or numeric n_i)."""
+    rates = []
+    for powers, k in zip(np.asarray(p_matrix), k_coeffs):
+        product = 1.0
+        for n_i, p in zip(densities, powers):
+            product = product * n_i ** int(p)
+        rates.append(product * k)
+    return rates
+
+
 def Source_term(coupling, approx, p_matrix, l_matrix, g_matrix, k_coeffs, N0, u):
-    couplings = ["coupled", "uncoupled"]
-    approximations = ["LFA", "LMEA"]
-    if coupling not in couplings:
+    """fedm/functions.py:777-843: f_i = sum_j (G - L)_ji rate_j.  The background gas (density N0)
+    is species 0 of the matrices; which entries of ``u`` are particle species depends on the
+    coupling (the last one is the potential when coupled) and the approximation (the first one
+    is the energy in LMEA)."""
+    if coupling not in ("coupled", "uncoupled"):
         raise ValueError("fedm.Source_term: coupling must be 'coupled' or 'uncoupled'.")
-    if approx not in approximations:
+    if approx not in ("LFA", "LMEA"):
         raise ValueError("fedm.Source_term: approx must be 'LFA' or 'LMEA'.")
-    start = 0 if coupling == "coupled" and approx == "LFA" else 1
-    end = len(u) - 1 if coupling == "coupled" else len(u)
-    exp_u = [N0] + [_exp(u[i]) for i in range(start, end)]
-    p_matrix = np.asarray(p_matrix)
-    rate = []
-    for j in range(p_matrix.shape[0]):
-        temp = 1.0
-        for i in range(p_matrix.shape[1]):
-            temp = temp * exp_u[i] ** int(p_matrix[j, i])
-        rate.append(temp * k_coeffs[j])
-    gl = np.asarray(g_matrix) - np.asarray(l_matrix)
-    f_temp = []
-    for i in range(gl.shape[1]):
-        acc = 0.0
-        for j in range(gl.shape[0]):
-            acc = acc + rate[j] * int(gl[j, i])
-        f_temp.append(acc)
-    return f_temp
+    first = 0 if (coupling, approx) == ("coupled", "LFA") else 1
+    last = len(u) - (1 if coupling == "coupled" else 0)
+    rates = _reaction_rates(p_matrix, [N0] + [_exp(u[i]) for i in range(first, last)], k_coeffs)
+    net = (np.asarray(g_matrix) - np.asarray(l_matrix)).astype(int)
+    sources = []
+    for column in net.T:
+        total = 0.0
+        for rate, nu in zip(rates, column):
+            total = total + rate * int(nu)
+        sources.append(total)
+    return sources
 
 
 def Energy_Source_term(coupling, p_matrix, l_matrix, g_matrix, k_coeffs, u_loss, mean_energy,
                        N0, n, Ei=0):
-    neq = len(n) - 1 if coupling == "coupled" else len(n)
-    exp_u = [N0] + [_exp(n[i]) for i in range(1, neq)]
-    p_matrix = np.asarray(p_matrix)
+    """fedm/functions.py:845-912: -sum_j rate_j * loss_j, where the two sentinel loss values of
+    the decks stand for (Ei - mean energy) and the mean energy itself."""
+    last = len(n) - (1 if coupling == "coupled" else 0)
+    rates = _reaction_rates(p_matrix, [N0] + [_exp(n[i]) for i in range(1, last)], k_coeffs)
     total = 0.0
-    for idx, loss in enumerate(u_loss):
-        temp = 1.0
-        for i in range(p_matrix.shape[1]):
-            temp = temp * exp_u[i] ** int(p_matrix[idx, i])
-        rate = -temp * k_coeffs[idx]
-        if loss > 7e77 and loss < 8e77:
-            rate = rate * (Ei - mean_energy)
-        elif loss > 9e99 and loss < 1e100:
-            rate = rate * mean_energy
+    for rate, loss in zip(rates, u_loss):
+        if 7e77 < loss < 8e77:
+            factor = Ei - mean_energy
+        elif 9e99 < loss < 1e100:
+            factor = mean_energy
         else:
-            rate = rate * loss
-        total = total + rate
+            factor = loss
+        total = total + (-rate) * factor
     return total
