@@ -43,6 +43,33 @@ def _z_order(xy):
     return locality_order(xy)
 
 
+def tentative_prolongator(A, theta, free, xy=None):
+    """One aggregation step: the piecewise-constant prolongator T (n x n_aggregates, zero rows
+    for the fixed vertices) and the aggregates' centroids (or None).  Returns None when the
+    coarsening stalls.  With coordinates the nodes are visited in a lexicographic sweep and the
+    aggregates are numbered along a Z-curve of their centroids."""
+    n = A.shape[0]
+    idx = np.nonzero(free)[0]
+    if xy is not None:                   # lexicographic sweep: by y, then x
+        idx = idx[np.lexsort((xy[idx, 0], xy[idx, 1]))]
+    Af = A[idx][:, idx].tocsr()
+    agg_f, nagg = aggregate(Af, theta)
+    if nagg >= 0.8 * idx.size:
+        return None
+    xy_next = None
+    if xy is not None:
+        cnt = np.bincount(agg_f, minlength=nagg).astype(np.float64)
+        cxy = np.stack([np.bincount(agg_f, weights=xy[idx, d], minlength=nagg) / cnt
+                        for d in range(2)], axis=1)
+        order = _z_order(cxy)            # new -> old aggregate id
+        relabel = np.empty(nagg, dtype=np.int64)
+        relabel[order] = np.arange(nagg)
+        agg_f = relabel[agg_f]
+        xy_next = cxy[order]
+    T = sp.csr_matrix((np.ones(idx.size), (idx, agg_f)), shape=(n, nagg))
+    return T, xy_next
+
+
 def build_hierarchy(A, theta=0.08, omega=4.0 / 3.0, max_coarse=600, max_levels=12,
                     fixed=None, coords=None, max_sparse_levels=None):
     """Levels [(A_l, P_l)] of a smoothed-aggregation hierarchy; the last A is coarsest.
@@ -61,24 +88,10 @@ def build_hierarchy(A, theta=0.08, omega=4.0 / 3.0, max_coarse=600, max_levels=1
     free = np.ones(A.shape[0], dtype=bool) if fixed is None else ~np.asarray(fixed, dtype=bool)
     xy = None if coords is None else np.asarray(coords, dtype=np.float64)
     while A.shape[0] > max_coarse and len(levels) < max_levels - 1:
-        n = A.shape[0]
-        idx = np.nonzero(free)[0]
-        if xy is not None:                   # lexicographic sweep: by y, then x
-            idx = idx[np.lexsort((xy[idx, 0], xy[idx, 1]))]
-        Af = A[idx][:, idx].tocsr()
-        agg_f, nagg = aggregate(Af, theta)
-        if nagg >= 0.8 * idx.size:          # coarsening stalled
+        step = tentative_prolongator(A, theta, free, xy)
+        if step is None:                    # coarsening stalled
             break
-        if xy is not None:
-            cnt = np.bincount(agg_f, minlength=nagg).astype(np.float64)
-            cxy = np.stack([np.bincount(agg_f, weights=xy[idx, d], minlength=nagg) / cnt
-                            for d in range(2)], axis=1)
-            order = _z_order(cxy)            # new -> old aggregate id
-            relabel = np.empty(nagg, dtype=np.int64)
-            relabel[order] = np.arange(nagg)
-            agg_f = relabel[agg_f]
-            xy_next = cxy[order]
-        T = sp.csr_matrix((np.ones(idx.size), (idx, agg_f)), shape=(n, nagg))
+        T, xy_next = step
         d = A.diagonal()
         DinvA = sp.diags(1.0 / d) @ A
         rho = np.abs(DinvA).sum(axis=1).max()          # Gershgorin bound on rho(D^-1 A)

@@ -93,7 +93,6 @@ def device_problem(coords, cells, device=0, **model_kw):
 
 
 MULTIGRID = dict(nu=1)      # V(1,1): as effective as V(2,2) here at 75 % of the cost
-MULTIGRID_DISTRIBUTED = dict(local_coarsenings=1)   # extra arguments of setup_multigrid_distributed
 
 
 def initialise(prob, multigrid=True):

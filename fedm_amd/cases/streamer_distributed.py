@@ -69,8 +69,7 @@ class Runner(streamer.Stepper):
         U[:, 0], U[:, 1] = streamer.initial_log_densities(prob.coords)
         prob.set_state(U, U, U)
         if self.world_size > 1:
-            prob.setup_multigrid_distributed(self.lm, self._group, **streamer.MULTIGRID,
-                                             **streamer.MULTIGRID_DISTRIBUTED)
+            prob.setup_multigrid_distributed(self.lm, self._group, **streamer.MULTIGRID)
         else:
             prob.setup_multigrid(**streamer.MULTIGRID)
         prob.set_fieldsplit(chebyshev_weights(4))

@@ -499,15 +499,23 @@ class DeviceProblem:
         return self.multigrid_levels
 
     def setup_multigrid_distributed(self, lm, group=None, theta=0.08, nu=1, omega=0.67, max_coarse=2000,
-                                    local_coarsenings=1):
-        """Several GPUs.  Only the finest level of the potential block's multigrid is rank-local:
-        it is smoothed as a distributed operator (ghost values exchanged inside the V-cycle) and
-        coarsened once, with aggregates that do not cross rank boundaries.  The Galerkin operator
-        of the UNDECOMPOSED block on the union of the ranks' level-1 spaces is assembled from the
-        ranks' block rows (owned rows of K reach into ghost columns, whose prolongator rows come
-        from the neighbours), and the hierarchy below it is built and replicated on every rank.
+                                    prolongator_damping=4.0 / 3.0):
+        """Several GPUs.  The potential block's multigrid is ONE global smoothed-aggregation
+        hierarchy whose finest level is distributed and whose coarser levels are replicated:
+
+        * aggregates are formed rank by rank (they never cross a partition boundary);
+        * the prolongator is smoothed with the undecomposed operator: an owned vertex next to the
+          boundary also interpolates from the neighbour's aggregates (the aggregate ids of the
+          ghost vertices come from their owners), so constants are reproduced across ranks;
+        * the level-1 operator is the sum of the ranks' contributions P_r^T K_r P (owned rows of K
+          reach into ghost columns, whose prolongator rows come from the neighbours); every rank
+          builds the hierarchy below it from the same matrix;
+        * on the device the finest level is smoothed as a distributed operator (ghost values
+          exchanged inside the V-cycle); its restriction writes straight into the global level-1
+          vector, which is all-reduced once per cycle.
+
         With rank-local hierarchies (block Jacobi over ranks) GMRES needs 3x (2 ranks) to 4.5x
-        (4 ranks) the single-GPU iterations; the exchanges at set-up go through the process group."""
+        (4 ranks) the single-GPU iterations.  The exchanges at set-up go through the process group."""
         import scipy.sparse as sp
         import torch.distributed as dist
         from . import amg
@@ -515,63 +523,71 @@ class DeviceProblem:
             raise ValueError("the model has no potential equation")
         self._check(self.lib.fedm_jacobian_poisson_only(self._h), "fedm_jacobian_poisson_only")
         ip = self.n_eq - 1
-        K = sp.csr_matrix(self.block_csr(ip, ip))      # device numbering
-        fixed = np.zeros(self.nv, dtype=bool)
-        d = self._ddofs[self._ddofs % self.n_eq == ip] // self.n_eq
-        fixed[d] = True
-        fixed[self.n_owned:] = True
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        n_own = lm.n_owned
+        n_own, nv = lm.n_owned, self.nv
+        to_dev, to_loc = self._inv, self._order            # local -> device index and back
 
         def from_neighbours(per_vertex):
-            """Values of this rank's ghost vertices from their owners; per_vertex is indexed in
-            the partition's local numbering (rows: vertices)."""
+            """Values of this rank's ghost vertices from their owners (list per neighbour);
+            per_vertex is indexed by the partition's local vertex number."""
             send = {int(q): per_vertex[lm.send_idx[lm.send_ptr[k]:lm.send_ptr[k + 1]]]
                     for k, q in enumerate(lm.neighbours)}
             got = [None] * world
             dist.all_gather_object(got, send, group=group)
             return [got[int(q)][rank] for q in lm.neighbours]
 
-        # ghost rows of the finest operator get their owners' diagonal entries (their Jacobi
-        # sweeps are discarded, but the first sweep forms neighbours' values from dinv * b)
-        diag_loc = K.diagonal()[self._inv]
-        for k, blk in enumerate(from_neighbours(diag_loc)):
-            diag_loc[n_own + lm.recv_ptr[k]:n_own + lm.recv_ptr[k + 1]] = blk
-        K = (K + sp.diags(diag_loc[self._order] - K.diagonal())).tocsr()
-        levels = amg.build_hierarchy(K, theta=theta, max_coarse=1, max_levels=1 + local_coarsenings,
-                                     fixed=fixed, coords=self._coords_dev)
-        local_sizes = amg.install(self._h, levels, nu=nu, omega=omega, dense_coarse=False)
-        P0 = sp.csr_matrix(levels[0][1])               # composite prolongator onto the last local level
-        for _, p in levels[1:-1]:
-            P0 = (P0 @ p).tocsr()
-        n1 = P0.shape[1]
-        sizes = [None] * world
-        dist.all_gather_object(sizes, int(n1), group=group)
-        offset = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        def gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj, group=group)
+            return out
+
+        # everything below in the partition's local numbering (owned vertices first)
+        K = sp.csr_matrix(self.block_csr(ip, ip))[to_dev][:, to_dev]
+        fixed = np.zeros(nv, dtype=bool)
+        fixed[to_loc[self._ddofs[self._ddofs % self.n_eq == ip] // self.n_eq]] = True
+        fixed[n_own:] = True
+        diag = K.diagonal()
+        for k, blk in enumerate(from_neighbours(diag)):     # ghost rows: their owners' diagonal
+            diag[n_own + lm.recv_ptr[k]:n_own + lm.recv_ptr[k + 1]] = blk
+        K = (K + sp.diags(diag - K.diagonal())).tocsr()
+        step = amg.tentative_prolongator(K, theta, ~fixed, self.coords)
+        if step is None:
+            raise RuntimeError("multigrid coarsening of the finest level stalled")
+        T, cxy = step                                        # n_local x n1 (ghost / fixed rows empty)
+        n1 = T.shape[1]
+        offset = np.concatenate([[0], np.cumsum(gather(int(n1)))]).astype(np.int64)
         n_g = int(offset[-1])
-        P_loc = P0[self._inv]                          # rows in the partition's local numbering
-        K_loc = K[self._inv][:, self._inv]
-        Po = P_loc[:n_own].tocoo()
-        rows, cols, vals = [Po.row], [Po.col + offset[rank]], [Po.data]
-        for k, blk in enumerate(from_neighbours(P_loc)):
-            blk = sp.coo_matrix(blk)
-            rows.append(n_own + lm.recv_ptr[k] + blk.row)
-            cols.append(offset[int(lm.neighbours[k])] + blk.col)
-            vals.append(blk.data)
-        P_ext = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
-                              shape=(self.nv, n_g))
-        A_rows = (P_loc[:n_own].T @ (K_loc[:n_own] @ P_ext)).tocsr()      # n1 x n_g block row
-        absP = abs(P_loc[:n_own])
-        cnt = np.maximum(np.asarray(absP.sum(axis=0)).ravel(), 1e-300)
-        cxy = np.stack([np.asarray(absP.T @ self.coords[:n_own, dd]).ravel() / cnt for dd in range(2)], axis=1)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (A_rows, cxy), group=group)
-        A1 = sp.vstack([g[0] for g in gathered]).tocsr()
-        A1 = (0.5 * (A1 + A1.T)).tocsr()               # symmetric up to rounding already
-        coords1 = np.vstack([g[1] for g in gathered])
+        # tentative prolongator with global columns, ghost rows filled from their owners
+        agg = np.full(nv, -1, dtype=np.int64)
+        Tc = T.tocoo()
+        agg[Tc.row] = Tc.col + offset[rank]
+        for k, blk in enumerate(from_neighbours(agg)):
+            agg[n_own + lm.recv_ptr[k]:n_own + lm.recv_ptr[k + 1]] = blk
+        has = agg >= 0
+        T_ext = sp.csr_matrix((np.ones(int(has.sum())), (np.nonzero(has)[0], agg[has])), shape=(nv, n_g))
+        # smoothed prolongator rows of the owned vertices: (I - w/rho D^-1 K) T with the whole K row
+        DinvK = sp.diags(1.0 / diag[:n_own]) @ K[:n_own]
+        rho = max(gather(float(np.abs(DinvK).sum(axis=1).max())))
+        free_own = sp.diags((~fixed[:n_own]).astype(np.float64))
+        P_own = (free_own @ (T_ext[:n_own] - (prolongator_damping / rho) * (DinvK @ T_ext))).tocsr()
+        P_own.eliminate_zeros()
+        # ... and of the ghost vertices, from their owners, for the Galerkin product
+        P_ext = sp.vstack([P_own] + [sp.csr_matrix(blk) for blk in from_neighbours(P_own)]).tocsr() \
+            if lm.n_ghost else P_own
+        contribution = (P_own.T @ (K[:n_own] @ P_ext)).tocsr()            # n_g x n_g, sparse
+        pieces = gather((contribution, cxy))
+        A1 = pieces[0][0]
+        for piece, _ in pieces[1:]:
+            A1 = A1 + piece
+        A1 = (0.5 * (A1 + A1.T)).tocsr()
+        coords1 = np.vstack([c for _, c in pieces])
+        # device: finest level (device numbering) with the global level-1 space as its coarse space
+        P_dev = sp.vstack([P_own, sp.csr_matrix((nv - n_own, n_g))]).tocsr()[to_loc]
+        K_dev = K[to_loc][:, to_loc]
+        local_sizes = amg.install(self._h, [(K_dev, P_dev), (A1, None)], nu=nu, omega=omega, dense_coarse=False)
         levels_g = amg.build_hierarchy(A1, theta=theta, max_coarse=max_coarse, coords=coords1)
-        global_sizes = amg.install_global(self._h, levels_g, n_g, int(offset[rank]), nu=nu, omega=omega)
-        self.multigrid_levels = local_sizes[:-1] + [f"{n1} of {n_g} global"] + global_sizes[1:]
+        global_sizes = amg.install_global(self._h, levels_g, n_g, 0, nu=nu, omega=omega)
+        self.multigrid_levels = [local_sizes[0], f"{n1} of {n_g} global"] + global_sizes[1:]
         return self.multigrid_levels
 
     def set_fieldsplit(self, weights=(0.8, 0.8, 0.8)):

@@ -135,55 +135,57 @@ def test_rccl_setup_failure_falls_back_on_every_rank():
 def _worker_galerkin(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, str(ROOT))
-    import numpy as np, scipy.sparse as sp
+    import scipy.sparse as sp
     import torch.distributed as dist
-    from fedm_amd.cases import streamer_distributed
     from fedm_amd import amg
+    from fedm_amd.cases import streamer_distributed
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run = streamer_distributed.Runner(None, rank, world, 0, grading=2.0, transport="torch", n_per_gpu=N_PER_GPU)
+        run = streamer_distributed.Runner(None, rank, world, 0, grading=2.0, transport="torch",
+                                          n_per_gpu=N_PER_GPU)
         prob, lm = run.prob, run.lm
-        # monkeypatch: capture A1 and P0 inside setup
-        captured = {}
-        orig_build = amg.build_hierarchy
-        def spy(A, **kw):
-            lv = orig_build(A, **kw)
-            captured.setdefault("calls", []).append((A.copy(), lv))
-            return lv
-        amg.build_hierarchy = spy
+        seen = {}
+        original = amg.install
+
+        def spy(handle, levels, **kw):                 # the finest level as it goes to the device
+            seen["levels"] = levels
+            return original(handle, levels, **kw)
+        amg.install = spy
         run.initialise()
-        (K_dev, lv_local), (A1, lv_g) = captured["calls"]
-        P0 = sp.csr_matrix(lv_local[0][1])[prob._inv]          # local numbering
-        K_loc = sp.csr_matrix(K_dev)[prob._inv][:, prob._inv]
-        n_own = lm.n_owned
-        gid = lm.vertex_global
-        out = dict(rank=rank, gid_owned=gid[:n_own], gid_all=gid, K_rows=K_loc[:n_own].tocoo(), P_owned=P0[:n_own].tocoo(),
-                   A1=A1 if rank == 0 else None, n1=P0.shape[1])
+        (K_dev, P_dev), (A1, _) = seen["levels"]
+        n_own, gid = lm.n_owned, lm.vertex_global
+        K_rows = sp.csr_matrix(K_dev)[prob._inv][:, prob._inv][:n_own].tocoo()     # local numbering
+        P_rows = sp.csr_matrix(P_dev)[prob._inv][:n_own].tocoo()                    # global columns
         gathered = [None] * world
-        dist.all_gather_object(gathered, out)
+        dist.all_gather_object(gathered, dict(gid=gid, n_own=n_own, K=K_rows, P=P_rows, A1=A1 if rank == 0 else None))
         if rank == 0:
-            nvg = max(int(g["gid_all"].max()) for g in gathered) + 1
-            offs = np.concatenate([[0], np.cumsum([g["n1"] for g in gathered])])
-            Kg = sp.lil_matrix((nvg, nvg)); Pg = sp.lil_matrix((nvg, offs[-1]))
-            Kr, Kc, Kv, Pr, Pc, Pv = [], [], [], [], [], []
-            for r, g in enumerate(gathered):
-                k = g["K_rows"]; Kr.append(g["gid_owned"][k.row]); Kc.append(g["gid_all"][k.col]); Kv.append(k.data)
-                p = g["P_owned"]; Pr.append(g["gid_owned"][p.row]); Pc.append(offs[r] + p.col); Pv.append(p.data)
-            Kg = sp.csr_matrix((np.concatenate(Kv), (np.concatenate(Kr), np.concatenate(Kc))), shape=(nvg, nvg))
-            Pg = sp.csr_matrix((np.concatenate(Pv), (np.concatenate(Pr), np.concatenate(Pc))), shape=(nvg, offs[-1]))
+            nvg = max(int(g["gid"].max()) for g in gathered) + 1
+            n_g = A1.shape[0]
+            kr, kc, kv, pr, pc, pv = [], [], [], [], [], []
+            for g in gathered:
+                own = g["gid"][:g["n_own"]]
+                kr.append(own[g["K"].row]); kc.append(g["gid"][g["K"].col]); kv.append(g["K"].data)
+                pr.append(own[g["P"].row]); pc.append(g["P"].col); pv.append(g["P"].data)
+            Kg = sp.csr_matrix((np.concatenate(kv), (np.concatenate(kr), np.concatenate(kc))), shape=(nvg, nvg))
+            Pg = sp.csr_matrix((np.concatenate(pv), (np.concatenate(pr), np.concatenate(pc))), shape=(nvg, n_g))
             ref = (Pg.T @ Kg @ Pg).toarray()
-            got = gathered[0]["A1"].toarray()
-            q.put(("A1 max abs diff", float(np.abs(ref - got).max()), "scale", float(np.abs(ref).max()),
-                   "asym of ref", float(np.abs(ref - ref.T).max())))
+            ones = np.asarray(Pg.sum(axis=1)).ravel()
+            offdiag = np.asarray(abs(Kg).sum(axis=1)).ravel() - abs(Kg.diagonal())
+            dirichlet = (offdiag == 0.0).astype(np.float64)                 # identity rows
+            away = (dirichlet == 0.0) & (np.asarray(abs(Kg) @ dirichlet).ravel() == 0.0)
+            q.put(("A1 max abs diff", float(np.abs(ref - A1.toarray()).max()), "scale", float(np.abs(ref).max()),
+                   "asym of ref", float(np.abs(ref - ref.T).max()),
+                   "row sums of P off 1", float(np.abs(ones[away] - 1.0).max())))
     finally:
         dist.destroy_process_group()
 
 
-
 def test_distributed_galerkin_operator_is_the_global_one():
-    """The level-1 operator of the multi-GPU multigrid is assembled from the ranks' block rows
-    (owned rows of K x prolongator rows fetched from the neighbours).  It must equal P^T K P of
-    the undecomposed block, formed here directly from the gathered pieces."""
+    """The level-1 operator of the multi-GPU multigrid is the sum of the ranks' contributions
+    (owned rows of K x prolongator rows, the ghost vertices' rows fetched from the neighbours).
+    It must equal P^T K P of the undecomposed block, formed here directly from the gathered
+    pieces, and the prolongator -- smoothed with the undecomposed operator -- must reproduce
+    constants across the partition boundary."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -195,8 +197,9 @@ def test_distributed_galerkin_operator_is_the_global_one():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    diff, scale, asym = res[1], res[3], res[5]
+    diff, scale, asym, rowsum = res[1], res[3], res[5], res[7]
     assert diff < 1e-13 * scale and asym < 1e-13 * scale
+    assert rowsum < 1e-12
 
 
 def test_bench_multi_rank_path_end_to_end():

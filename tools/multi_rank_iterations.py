@@ -13,7 +13,6 @@ def worker(rank, world, port, q):
     import numpy as np
     import torch.distributed as dist
     from fedm_amd.cases import streamer, streamer_distributed
-    streamer.MULTIGRID_DISTRIBUTED = dict(local_coarsenings=LOCAL_COARSENINGS)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         run = streamer_distributed.Runner(None, rank, world, 0, grading=4.0, transport="torch",
@@ -32,7 +31,7 @@ def worker(rank, world, port, q):
 if __name__ == "__main__":
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    for world in (1, 2, 4):
+    for world in [int(w) for w in (sys.argv[3].split(",") if len(sys.argv) > 3 else "1,2,4".split(","))]:
         q = ctx.Queue()
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
