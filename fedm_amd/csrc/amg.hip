@@ -378,34 +378,32 @@ __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
     b0[v] = tv[NS];
 }
 
-// one more damped block-Jacobi sweep on the species block:
-//   z_out_u = z_in_u + omega * Duu^-1 (t_u - J_uu z_in_u)
-// The sweeps and the coupling product stream the species columns of the Jacobian from an fp32
-// copy (species_planes_kernel): half the bytes of the fp64 planes, and a preconditioner does not
-// need more than single precision in its matrix (vectors and accumulation stay fp64).
+// one more damped block-Jacobi sweep on the species block, with g = Duu^-1 (alpha t_u) from the
+// first stage and S = Duu^-1 J_uu:
+//   z_out_u = zs z_in_u + omega * (g_u - S (zs z_in_u))
+// (zs = the first stage's weight in the first sweep, whose z_in is g itself; 1 afterwards).
+// S is streamed from a half-precision copy (species_planes_kernel): scaled by the block diagonal
+// its entries are O(1), and a preconditioner's matrix needs no more than that -- a quarter of the
+// fp64 bytes, and neither t nor Duu^-1 is read again.  Vectors and accumulation stay fp64.
 // Block Jacobi alone leaves a mass-matrix-like operator with eigenvalues in ~[0.5, 2]; a few
 // damped sweeps cut the outer GMRES iterations from 8 to 5 per Newton step.
 template <int NS>
 __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
-    const float *__restrict__ val32, const double *__restrict__ dinv_uu,
-    const double *__restrict__ t, const double *__restrict__ zin, double *__restrict__ zout,
-    double alpha, double omega) {
-    constexpr int NEQ = NS + 1, PL = NEQ * NS;
+    const _Float16 *__restrict__ s16, const double *__restrict__ g, const double *__restrict__ zin,
+    double *__restrict__ zout, double zs, double omega) {
+    constexpr int NEQ = NS + 1, PL = NS * NS;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
     // this row's own operands first: their latency hides behind the gather loop
     const size_t v = (size_t)slice * SLICE + lane;
-    const double *dp = dinv_uu + (size_t)slice * NS * NS * SLICE + lane;
-    double tv[NS], zv[NS], dv[NS * NS];
+    double gv[NS], zv[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
-        tv[r] = t[v * NEQ + r];
+        gv[r] = g[v * NEQ + r];
         zv[r] = zin[v * NEQ + r];
     }
-#pragma unroll
-    for (int e = 0; e < NS * NS; ++e) dv[e] = dp[(size_t)e * SLICE];
     double acc[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) acc[r] = 0.0;
@@ -415,23 +413,15 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
         double zj[NS];
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx) zj[cidx] = zin[(size_t)col * NEQ + cidx];
-        const float *vp = val32 + (size_t)bc * PL * SLICE + lane;
+        const _Float16 *vp = s16 + (size_t)bc * PL * SLICE + lane;
 #pragma unroll
         for (int r = 0; r < NS; ++r)
 #pragma unroll
             for (int cidx = 0; cidx < NS; ++cidx)
-                acc[r] += (double)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
+                acc[r] += (double)(float)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
     }
-    double res[NS];
 #pragma unroll
-    for (int r = 0; r < NS; ++r) res[r] = alpha * tv[r] - acc[r];
-#pragma unroll
-    for (int r = 0; r < NS; ++r) {
-        double d = 0.0;
-#pragma unroll
-        for (int cidx = 0; cidx < NS; ++cidx) d += dv[r * NS + cidx] * res[cidx];
-        zout[v * NEQ + r] = zv[r] + omega * d;
-    }
+    for (int r = 0; r < NS; ++r) zout[v * NEQ + r] = zs * zv[r] + omega * (gv[r] - zs * acc[r]);
     zout[v * NEQ + NS] = 0.0;  // full-line stores; the potential entry is set by fs_scatter_kernel
 }
 
@@ -442,7 +432,7 @@ __global__ __launch_bounds__(256) void fs_coupling_kernel(int n_slices, const in
                                                           const float *__restrict__ val32,
                                                           const double *__restrict__ z,
                                                           double *__restrict__ b0) {
-    constexpr int NEQ = NS + 1, PL = NEQ * NS;
+    constexpr int NEQ = NS + 1;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
@@ -451,7 +441,7 @@ __global__ __launch_bounds__(256) void fs_coupling_kernel(int n_slices, const in
     const int bb0 = boff[slice], bb1 = boff[slice + 1];
     for (int bc = bb0; bc < bb1; ++bc) {
         const int col = colidx[(size_t)bc * SLICE + lane];
-        const float *vp = val32 + ((size_t)bc * PL + NS * NS) * SLICE + lane;
+        const float *vp = val32 + (size_t)bc * NS * SLICE + lane;
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc += (double)vp[(size_t)s * SLICE] * z[(size_t)col * NEQ + s];
     }
@@ -527,24 +517,25 @@ __global__ void species_block_inverse_kernel(int nvp, const double *__restrict__
         dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = I[e / NS][e % NS];
 }
 
-// the species iterate ping-pongs between z and the scratch vector; it starts where it ends in z
-static double *fs_first_target(Ctx &c, double *z) {
-    const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
-    return (sweeps % 2 == 1) ? z : c.d_fs;
-}
+// With sweeps, the first stage leaves g = Duu^-1 (alpha t_u) (weight 1) in its own vector, which
+// every sweep reads; the iterate then ping-pongs between z and the scratch vector so that the last
+// sweep writes z.  Without sweeps the first stage writes z itself.
+static double *fs_first_target(Ctx &c, double *z) { return c.fs_sweeps > 1 ? c.d_fs_g : z; }
+static double fs_first_weight(Ctx &c) { return 1.0; }
 
 // stages after the first: remaining species sweeps, coupling, V-cycle on the potential block
 template <int NS>
-static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter = true,
-                        bool with_cycle = true) {
+static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool with_cycle = true) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     const dim3 gs((c.pat.n_slices + 3) / 4);
-    const int sweeps = c.fs_sweeps < 1 ? 1 : c.fs_sweeps;
-    double *a = fs_first_target(c, z), *b = (a == z) ? c.d_fs : z;
-    for (int s = 1; s < sweeps; ++s) {
+    const int n_sweeps = (c.fs_sweeps < 1 ? 1 : c.fs_sweeps) - 1;
+    const double *in = c.d_fs_g;
+    for (int s = 1; s <= n_sweeps; ++s) {
+        double *out = ((n_sweeps - s) % 2 == 0) ? z : c.d_fs;
         hipLaunchKernelGGL(fs_species_sweep_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
-                           c.d_slice_boff, c.d_colidx, c.d_val32, c.d_dinv, t, a, b, alpha, c.fs_w[s]);
-        std::swap(a, b);
+                           c.d_slice_boff, c.d_colidx, c.d_s16, c.d_fs_g, in, out, s == 1 ? c.fs_w[0] : 1.0,
+                           c.fs_w[s]);
+        in = out;
     }
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
                        c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
@@ -556,10 +547,9 @@ static void fs_finish_t(Ctx &c, Amg &amg, const double *t, double *z, double alp
 template <int NS>
 static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
-    const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
     hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
-                       amg.levels[0].b, alpha, omega);
-    fs_finish_t<NS>(c, amg, t, z, alpha);
+                       amg.levels[0].b, alpha, fs_first_weight(c));
+    fs_finish_t<NS>(c, amg, z);
 }
 
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
@@ -574,66 +564,81 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
 
 // z = Minv (J v): the SpMV's epilogue is the first stage (t = J v is kept for the sweeps)
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter) {
-    const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
     prof_begin(c, 1);
-    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, omega);
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, fs_first_weight(c));
     prof_end(c);
     switch (c.ns) {
-        case 1: fs_finish_t<1>(c, amg, t, z, 1.0, scatter); break;
-        case 2: fs_finish_t<2>(c, amg, t, z, 1.0, scatter); break;
-        case 3: fs_finish_t<3>(c, amg, t, z, 1.0, scatter); break;
-        case 4: fs_finish_t<4>(c, amg, t, z, 1.0, scatter); break;
-        case 5: fs_finish_t<5>(c, amg, t, z, 1.0, scatter); break;
+        case 1: fs_finish_t<1>(c, amg, z, scatter); break;
+        case 2: fs_finish_t<2>(c, amg, z, scatter); break;
+        case 3: fs_finish_t<3>(c, amg, z, scatter); break;
+        case 4: fs_finish_t<4>(c, amg, z, scatter); break;
+        case 5: fs_finish_t<5>(c, amg, z, scatter); break;
     }
 }
 
 void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter,
                                     int part, const int *slices, int n_slices) {
-    const double omega = c.fs_sweeps > 1 ? c.fs_w[0] : 1.0;
-    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, omega, slices, n_slices);
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, fs_first_weight(c), slices, n_slices);
     if (part == 0) return;
     const bool cyc = part == 1;  // part 2: stop after the coupling product (amg.levels[0].b is ready)
     switch (c.ns) {
-        case 1: fs_finish_t<1>(c, amg, t, z, 1.0, scatter, cyc); break;
-        case 2: fs_finish_t<2>(c, amg, t, z, 1.0, scatter, cyc); break;
-        case 3: fs_finish_t<3>(c, amg, t, z, 1.0, scatter, cyc); break;
-        case 4: fs_finish_t<4>(c, amg, t, z, 1.0, scatter, cyc); break;
-        case 5: fs_finish_t<5>(c, amg, t, z, 1.0, scatter, cyc); break;
+        case 1: fs_finish_t<1>(c, amg, z, scatter, cyc); break;
+        case 2: fs_finish_t<2>(c, amg, z, scatter, cyc); break;
+        case 3: fs_finish_t<3>(c, amg, z, scatter, cyc); break;
+        case 4: fs_finish_t<4>(c, amg, z, scatter, cyc); break;
+        case 5: fs_finish_t<5>(c, amg, z, scatter, cyc); break;
     }
 }
 
-// fp32 copy of the species columns of every block (all NEQ rows x NS columns)
+// Copies of the species columns of every block for the preconditioner: the species rows scaled
+// by the row's inverse diagonal block, S = Duu^-1 J_uu, in half precision (the sweeps), and the
+// potential row J_phi,u in single precision (the coupling product).  One wave per slice.
 template <int NS>
-__global__ __launch_bounds__(256) void species_planes_kernel(size_t n_entries, const double *__restrict__ val,
-                                                             float *__restrict__ val32) {
-    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, PL = NEQ * NS;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // bc * 64 + lane
-    if (e >= n_entries) return;
-    const size_t bc = e >> 6, lane = e & 63;
-    const double *vp = val + bc * NEQ2 * SLICE + lane;
-    float *op = val32 + bc * PL * SLICE + lane;
+__global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const int *__restrict__ boff,
+                                                             const double *__restrict__ val,
+                                                             const double *__restrict__ dinv_uu,
+                                                             _Float16 *__restrict__ s16, float *__restrict__ val32) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slice >= n_slices) return;
+    double d[NS * NS];
 #pragma unroll
-    for (int r = 0; r < NEQ; ++r)
+    for (int e = 0; e < NS * NS; ++e) d[e] = dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane];
+    const int b0 = boff[slice], b1 = boff[slice + 1];
+    for (int bc = b0; bc < b1; ++bc) {
+        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+        double J[NS][NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx) J[r][cidx] = vp[(size_t)(r * NEQ + cidx) * SLICE];
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < NS; ++m) acc += d[r * NS + m] * J[m][cidx];
+                // (out-of-range entries saturate: only the preconditioner's quality is at stake)
+                const float f = fminf(fmaxf((float)acc, -65504.f), 65504.f);
+                s16[((size_t)bc * NS * NS + r * NS + cidx) * SLICE + lane] = (_Float16)f;
+            }
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx)
-            op[(size_t)(r * NS + cidx) * SLICE] = (float)vp[(size_t)(r * NEQ + cidx) * SLICE];
+            val32[((size_t)bc * NS + cidx) * SLICE + lane] = (float)vp[(size_t)(NS * NEQ + cidx) * SLICE];
+    }
 }
 
 void fieldsplit_setup(Ctx &c) {
     const dim3 g((c.nvp + 255) / 256), b(256);
     const size_t n_entries = (size_t)c.pat.total_bc * SLICE;
-    if (!c.d_val32 && hipMalloc((void **)&c.d_val32, sizeof(float) * n_entries * c.neq * c.ns) != hipSuccess) {
-        set_error("hipMalloc of the fp32 species planes failed");
+    if (!c.d_val32 && (hipMalloc((void **)&c.d_val32, sizeof(float) * n_entries * c.ns) != hipSuccess ||
+                       hipMalloc((void **)&c.d_s16, sizeof(_Float16) * n_entries * c.ns * c.ns) != hipSuccess)) {
+        set_error("hipMalloc of the preconditioner's species planes failed");
+        if (c.d_val32) hipFree(c.d_val32);
         c.d_val32 = nullptr;
         return;
-    }
-    const dim3 ge((unsigned)((n_entries + 255) / 256));
-    switch (c.ns) {
-        case 1: hipLaunchKernelGGL(species_planes_kernel<1>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
-        case 2: hipLaunchKernelGGL(species_planes_kernel<2>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
-        case 3: hipLaunchKernelGGL(species_planes_kernel<3>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
-        case 4: hipLaunchKernelGGL(species_planes_kernel<4>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
-        case 5: hipLaunchKernelGGL(species_planes_kernel<5>, ge, b, 0, c.stream, n_entries, c.d_val, c.d_val32); break;
     }
     switch (c.ns) {
         case 1: hipLaunchKernelGGL(species_block_inverse_kernel<1>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
@@ -642,6 +647,18 @@ void fieldsplit_setup(Ctx &c) {
         case 4: hipLaunchKernelGGL(species_block_inverse_kernel<4>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
         case 5: hipLaunchKernelGGL(species_block_inverse_kernel<5>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
     }
+    const dim3 gs((c.pat.n_slices + 3) / 4);
+#define FEDM_PLANES(NS_)                                                                                   \
+    hipLaunchKernelGGL(species_planes_kernel<NS_>, gs, b, 0, c.stream, c.pat.n_slices, c.d_slice_boff, c.d_val, \
+                       c.d_dinv, c.d_s16, c.d_val32)
+    switch (c.ns) {
+        case 1: FEDM_PLANES(1); break;
+        case 2: FEDM_PLANES(2); break;
+        case 3: FEDM_PLANES(3); break;
+        case 4: FEDM_PLANES(4); break;
+        case 5: FEDM_PLANES(5); break;
+    }
+#undef FEDM_PLANES
 }
 
 // z = [0, V-cycle(t_phi)] : preconditioner of the Poisson-only CG (species rows are identity

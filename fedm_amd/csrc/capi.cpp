@@ -650,7 +650,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
     const size_t nval = (size_t)c.pat.total_bc * SLICE * c.neq * c.neq;
     if (alloc_zero(c.d_val, nval, c.stream)) return -1;
     if (alloc_zero(c.d_dinv, (size_t)c.nvp * c.neq * c.neq, c.stream)) return -1;
-    double **vecs[] = {&c.d_u, &c.d_uold, &c.d_uold1, &c.d_F, &c.d_delta, &c.d_w, &c.d_rhs, &c.d_tmp, &c.d_fs};
+    double **vecs[] = {&c.d_u, &c.d_uold, &c.d_uold1, &c.d_F, &c.d_delta, &c.d_w, &c.d_rhs, &c.d_tmp, &c.d_fs, &c.d_fs_g};
     for (auto v : vecs)
         if (alloc_zero(*v, (size_t)c.np, c.stream)) return -1;
     if (alloc_zero(c.d_partials, (size_t)RED_BLOCKS * RED_K, c.stream)) return -1;
@@ -677,7 +677,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     void *ptrs[] = {c.d_coords, c.d_cells, c.d_ftags, c.d_cell_slots, c.d_colour_cells, c.d_model,
                     c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.d_val, c.d_dinv, c.d_dir_dofs,
                     c.d_dir_vals, c.d_u, c.d_uold, c.d_uold1, c.d_F, c.d_delta, c.d_w, c.d_rhs,
-                    c.d_tmp, c.d_fs, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
+                    c.d_tmp, c.d_fs, c.d_fs_g, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
                     c.d_ext[3], c.d_patch_cell_ptr, c.d_patch_halo_ptr, c.d_patch_halo,
                     c.d_patch_cells, c.d_bfacets, c.d_gd, c.d_gd_fields};
     for (void *p : ptrs)
@@ -696,6 +696,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (c.d_mail_seq) hipFree(c.d_mail_seq);
     if (c.h_red) hipHostFree(c.h_red);
     if (c.d_val32) hipFree(c.d_val32);
+    if (c.d_s16) hipFree(c.d_s16);
     if (c.h_stage) hipHostFree(c.h_stage);
     if (c.stream) hipStreamDestroy(c.stream);
     delete h;

@@ -110,15 +110,16 @@ struct Ctx {
     uint32_t *d_diag_slot = nullptr;
     double *d_val = nullptr;
     double *d_dinv = nullptr;  // sliced: [(slice*NEQ2 + e)*64 + lane]
-    float *d_val32 = nullptr;  // species columns of every block in fp32 for the field-split
-                               // sweeps: [(bc*NEQ*NS + r*NS + c)*64 + lane]
+    // copies for the field-split preconditioner (species_planes_kernel):
+    float *d_val32 = nullptr;   // potential row's species columns J_phi,u in fp32: [(bc*NS + c)*64 + lane]
+    _Float16 *d_s16 = nullptr;  // Duu^-1 J_uu in fp16: [(bc*NS*NS + r*NS + c)*64 + lane]
     // Dirichlet
     int n_dir = 0;
     int *d_dir_dofs = nullptr;
     double *d_dir_vals = nullptr;
     // vectors (np doubles each)
     double *d_u = nullptr, *d_uold = nullptr, *d_uold1 = nullptr, *d_F = nullptr;
-    double *d_delta = nullptr, *d_w = nullptr, *d_rhs = nullptr, *d_tmp = nullptr, *d_fs = nullptr;
+    double *d_delta = nullptr, *d_w = nullptr, *d_rhs = nullptr, *d_tmp = nullptr, *d_fs = nullptr, *d_fs_g = nullptr;
     int fs_sweeps = 1;       // Richardson sweeps with block-Jacobi scaling on the species block
     double fs_w[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};  // 1 sweep = block Jacobi
     double *d_V = nullptr;  // (restart+1) Krylov vectors
