@@ -545,20 +545,20 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
 }
 
 template <int NS>
-static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
                        amg.levels[0].b, alpha, fs_first_weight(c));
-    fs_finish_t<NS>(c, amg, z);
+    fs_finish_t<NS>(c, amg, z, scatter);
 }
 
-void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter) {
     switch (c.ns) {
-        case 1: fs_apply_t<1>(c, amg, t, z, alpha); break;
-        case 2: fs_apply_t<2>(c, amg, t, z, alpha); break;
-        case 3: fs_apply_t<3>(c, amg, t, z, alpha); break;
-        case 4: fs_apply_t<4>(c, amg, t, z, alpha); break;
-        case 5: fs_apply_t<5>(c, amg, t, z, alpha); break;
+        case 1: fs_apply_t<1>(c, amg, t, z, alpha, scatter); break;
+        case 2: fs_apply_t<2>(c, amg, t, z, alpha, scatter); break;
+        case 3: fs_apply_t<3>(c, amg, t, z, alpha, scatter); break;
+        case 4: fs_apply_t<4>(c, amg, t, z, alpha, scatter); break;
+        case 5: fs_apply_t<5>(c, amg, t, z, alpha, scatter); break;
     }
 }
 

@@ -124,6 +124,10 @@ struct Ctx {
     double fs_w[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};  // 1 sweep = block Jacobi
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
+    // Flexible GMRES with the field split on the right (single GPU): z_j = Minv v_j is kept, so the
+    // update is Z y and no preconditioner application is spent on the right-hand side.
+    double *d_Z = nullptr;
+    bool right_precond = true;
     // reductions
     double *d_partials = nullptr;  // [RED_BLOCKS][RED_K]
     double *d_red = nullptr;       // [RED_K]

@@ -626,6 +626,11 @@ class DeviceProblem:
         code = {"colour": 0, "patch": 1}[kind]
         self._check(self.lib.fedm_set_assembly(self._h, code), "fedm_set_assembly")
 
+    def set_preconditioner_side(self, side):
+        """'right' (default on one GPU: flexible GMRES, true residual norm) or 'left'."""
+        code = {"left": 0, "right": 1}[side]
+        self._check(self.lib.fedm_set_preconditioner_side(self._h, code), "fedm_set_preconditioner_side")
+
     # -- measurement ----------------------------------------------------------
     def time_kernel(self, kind, repeats=20):
         ms = C.c_double()
