@@ -545,20 +545,31 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
 }
 
 template <int NS>
-static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter) {
+static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter, bool with_cycle) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
                        amg.levels[0].b, alpha, fs_first_weight(c));
-    fs_finish_t<NS>(c, amg, z, scatter);
+    fs_finish_t<NS>(c, amg, z, scatter, with_cycle);
 }
 
-void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter) {
+void fieldsplit_scatter(Ctx &c, Amg &amg, double *z) {
+    const dim3 gv((c.nvp + 255) / 256), bv(256);
     switch (c.ns) {
-        case 1: fs_apply_t<1>(c, amg, t, z, alpha, scatter); break;
-        case 2: fs_apply_t<2>(c, amg, t, z, alpha, scatter); break;
-        case 3: fs_apply_t<3>(c, amg, t, z, alpha, scatter); break;
-        case 4: fs_apply_t<4>(c, amg, t, z, alpha, scatter); break;
-        case 5: fs_apply_t<5>(c, amg, t, z, alpha, scatter); break;
+        case 1: hipLaunchKernelGGL(fs_scatter_kernel<1>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z); break;
+        case 2: hipLaunchKernelGGL(fs_scatter_kernel<2>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z); break;
+        case 3: hipLaunchKernelGGL(fs_scatter_kernel<3>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z); break;
+        case 4: hipLaunchKernelGGL(fs_scatter_kernel<4>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z); break;
+        case 5: hipLaunchKernelGGL(fs_scatter_kernel<5>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z); break;
+    }
+}
+
+void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter, bool with_cycle) {
+    switch (c.ns) {
+        case 1: fs_apply_t<1>(c, amg, t, z, alpha, scatter, with_cycle); break;
+        case 2: fs_apply_t<2>(c, amg, t, z, alpha, scatter, with_cycle); break;
+        case 3: fs_apply_t<3>(c, amg, t, z, alpha, scatter, with_cycle); break;
+        case 4: fs_apply_t<4>(c, amg, t, z, alpha, scatter, with_cycle); break;
+        case 5: fs_apply_t<5>(c, amg, t, z, alpha, scatter, with_cycle); break;
     }
 }
 

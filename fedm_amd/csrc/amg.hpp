@@ -56,8 +56,11 @@ struct Amg {
 void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double *b, double *y,
                double omega, double *aux = nullptr);
 void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
-void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha,
-                      bool scatter = true);  // z = alpha*Minv t (scatter = false: Amg::out places the potential)
+// z = alpha*Minv t.  scatter = false: Amg::out places the potential; with_cycle = false: stop
+// after the coupling product (the caller runs the V-cycle, whose right-hand side is ready)
+void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter = true,
+                      bool with_cycle = true);
+void fieldsplit_scatter(Ctx &c, Amg &amg, double *z);  // potential component of z <- the V-cycle's result
 // z = Minv (J v); scatter = false leaves the potential component in amg.levels[0].x
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter);
 // the same in two parts for the halo overlap: part 0 = SpMV of `slices` only (interior rows),

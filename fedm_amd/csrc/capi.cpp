@@ -111,8 +111,8 @@ static void apply_operator(Ctx &c, const double *v, double *w) {
     }
 }
 
-// the field split sits on the right of the operator (flexible GMRES) on one GPU
-static bool right_preconditioned(const Ctx &c) { return c.right_precond && c.amg && c.poisson && !c.comm; }
+// the field split sits on the right of the operator (flexible GMRES)
+static bool right_preconditioned(const Ctx &c) { return c.right_precond && c.amg && c.poisson; }
 
 // rhs = -Minv F (preconditioner on the left) or -F (on the right), after the Jacobian has been assembled
 static void prepare_preconditioner_and_rhs(Ctx &c) {
@@ -133,8 +133,11 @@ void iter_graphs_clear(Ctx &c) {
         if (g) hipGraphExecDestroy(g);
     for (hipGraphExec_t g : c.iter_graph_interior)
         if (g) hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : c.iter_graph_pre)
+        if (g) hipGraphExecDestroy(g);
     c.iter_graph.clear();
     c.iter_graph_interior.clear();
+    c.iter_graph_pre.clear();
 }
 
 // One Krylov step  w = Minv J v_j;  h = V^T w;  w <- (w - V h)/|.|  as a hipGraph, captured the
@@ -191,22 +194,7 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
             c.amg->out = nullptr;
         };
         bool ok = true;
-        if (right_preconditioned(c)) {
-            // z_j = Minv v_j (kept),  w = J z_j
-            double *z = c.d_Z + (size_t)j * c.np;
-            ok = capture_graph(c, &c.iter_graph[j], [&] {
-                if (direct) {
-                    c.amg->out = z;
-                    c.amg->out_stride = c.neq;
-                    c.amg->out_offset = c.neq - 1;
-                }
-                fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct);
-                c.amg->out = nullptr;
-                launch_spmv(c, z, w, false);
-                launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, true);
-                launch_cgs_update(c, j + 1, vp, w);
-            });
-        } else if (!multi) {
+        if (!multi) {
             ok = capture_graph(c, &c.iter_graph[j], [&] {
                 with_direct_output([&] { fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, false); });
                 launch_dots_fused(c, dotp.data(), w, j + 2, x0, true);
@@ -278,6 +266,123 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
     return true;
 }
 
+// The same step with the field split on the right:  z_j = Minv v_j (kept),  w = J z_j,  h = V^T w,
+// w <- (w - V h)/|.|.  One GPU: one graph.  Several GPUs: it is z_j whose ghost entries the
+// product needs --
+//   graph P_j (first stage, sweeps, coupling[, V-cycle]) [-> V-cycle with its collectives] ->
+//   mark z_j complete -> graph I_j (interior rows of J z_j)  ||  exchange of z_j -> wait ->
+//   graph B_j (boundary rows, local partial sums) -> all-reduce -> finish/publish -> update.
+// The Krylov vectors keep zero ghost entries (ghost rows of the product are zero), so Minv sees
+// the same inputs as on the left.
+static void right_step_plain(Ctx &c, int j, const double *const *vp, double *z, double *w) {
+    fieldsplit_apply(c, *c.amg, vp[j], z, 1.0);
+    comm_halo(c, z);
+    prof_begin(c, 1);
+    launch_spmv(c, z, w, false);
+    prof_end(c);
+    std::vector<const double *> dotp(j + 2);
+    for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+    dotp[j + 1] = w;
+    launch_dots(c, dotp.data(), w, j + 2, true);
+    launch_cgs_update(c, j + 1, vp, w);
+}
+
+static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, double *z, double *w) {
+    if (!c.iter_graphs_ok || (c.prof.on && c.prof.all_kinds)) return false;
+    const bool multi = c.comm != nullptr;
+    if ((int)c.iter_graph.size() <= j) {
+        c.iter_graph.resize(j + 1, nullptr);
+        c.iter_graph_interior.resize(j + 1, nullptr);
+        c.iter_graph_pre.resize(j + 1, nullptr);
+    }
+    // the V-cycle's last sweep writes the potential component of z itself (V(nu,nu) with more
+    // than one level); otherwise a scatter kernel does
+    const bool direct = c.amg->pre_smooth && c.amg->levels.size() > 1;
+    auto with_direct_output = [&](const std::function<void()> &f) {
+        if (direct) {
+            c.amg->out = z;
+            c.amg->out_stride = c.neq;
+            c.amg->out_offset = c.neq - 1;
+        }
+        f();
+        c.amg->out = nullptr;
+    };
+    if (!c.iter_graph[j]) {
+        std::vector<const double *> dotp(j + 2);
+        for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+        dotp[j + 1] = w;
+        bool ok = true;
+        if (!multi) {
+            ok = capture_graph(c, &c.iter_graph[j], [&] {
+                with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct); });
+                launch_spmv(c, z, w, false);
+                launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, true);
+                launch_cgs_update(c, j + 1, vp, w);
+            });
+        } else {
+            Comm &cm = *c.comm;
+            const bool cycle_inside = !c.amg->global;  // no collectives in the V-cycle
+            ok = capture_graph(c, &c.iter_graph_pre[j], [&] {
+                with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct, cycle_inside); });
+            });
+            if (cm.n_interior)
+                ok = ok && capture_graph(c, &c.iter_graph_interior[j], [&] {
+                    launch_spmv(c, z, w, false, cm.d_interior, cm.n_interior);
+                });
+            ok = ok && capture_graph(c, &c.iter_graph[j], [&] {
+                launch_spmv(c, z, w, false, cm.d_boundary, cm.n_boundary);
+                launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, false);
+            });
+        }
+        if (!ok) {
+            c.iter_graphs_ok = false;
+            return false;
+        }
+    }
+    if (!multi) {
+        if (hipGraphLaunch(c.iter_graph[j], c.stream) != hipSuccess) {
+            hipGetLastError();
+            c.iter_graphs_ok = false;
+            return false;
+        }
+        ++c.mail_seq;
+        return true;
+    }
+    if (hipGraphLaunch(c.iter_graph_pre[j], c.stream) != hipSuccess) {
+        hipGetLastError();
+        c.iter_graphs_ok = false;
+        return false;  // nothing has been communicated yet: the caller repeats the step plainly
+    }
+    if (c.amg->global) {  // V-cycle with its collectives
+        with_direct_output([&] { c.amg->run(c); });
+        if (!direct) fieldsplit_scatter(c, *c.amg, z);
+    }
+    static const bool overlap = [] {
+        const char *e = std::getenv("FEDM_HALO_OVERLAP");
+        return !(e && e[0] == '0');
+    }();
+    if (overlap) comm_halo_begin(c);
+    else comm_halo(c, z);
+    bool ok = !c.iter_graph_interior[j] || hipGraphLaunch(c.iter_graph_interior[j], c.stream) == hipSuccess;
+    if (overlap) comm_halo_exchange(c, z);
+    ok = ok && hipGraphLaunch(c.iter_graph[j], c.stream) == hipSuccess;
+    if (!ok) {  // z_j is complete on every rank: redo the product with plain launches (same result)
+        hipGetLastError();
+        c.iter_graphs_ok = false;
+        std::vector<const double *> dotp(j + 2);
+        for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+        dotp[j + 1] = w;
+        launch_spmv(c, z, w, false);
+        launch_dots(c, dotp.data(), w, j + 2, true);
+        launch_cgs_update(c, j + 1, vp, w);
+        return true;
+    }
+    comm_allreduce(c, c.d_red, j + 2);
+    launch_cgs_finish(c, j + 2);
+    launch_cgs_update(c, j + 1, vp, w);
+    return true;
+}
+
 // ---- GMRES(m) ---------------------------------------------------------------------------------
 // Preconditioner on the left (point-block Jacobi; field split across GPUs): solves
 // Minv J delta = Minv rhs (rhs in c.d_rhs, already scaled), convergence on the preconditioned
@@ -299,7 +404,8 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
     for (int i = 0; i < m; ++i) zp[i] = c.d_Z + (size_t)i * c.np;
     const bool right = right_preconditioned(c);
     // the (unpreconditioned) operator of the right-preconditioned variant
-    auto plain_operator = [&](const double *v, double *w) {
+    auto plain_operator = [&](double *v, double *w) {
+        comm_halo(c, v);  // ghost inputs from their owners (multi-GPU)
         prof_begin(c, 1);
         launch_spmv(c, v, w, false);
         prof_end(c);
@@ -350,14 +456,11 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             // classical Gram-Schmidt with ONE reduction and ONE host wait per iteration:
             // h_i = v_i.w and ww = w.w together; |w - V h|^2 = ww - |h|^2 on the device;
             // the update and the normalisation read their coefficients from device memory.
-            if (!iter_graph_launch(c, j, vp.data(), w)) {
-                if (right) {
-                    double *z = c.d_Z + (size_t)j * c.np;
-                    fieldsplit_apply(c, *c.amg, vp[j], z, 1.0);
-                    plain_operator(z, w);
-                } else {
-                    apply_operator(c, vp[j], w);
-                }
+            if (right) {
+                double *z = c.d_Z + (size_t)j * c.np;
+                if (!iter_graph_launch_right(c, j, vp.data(), z, w)) right_step_plain(c, j, vp.data(), z, w);
+            } else if (!iter_graph_launch(c, j, vp.data(), w)) {
+                apply_operator(c, vp[j], w);
                 for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
                 dotp[j + 1] = w;
                 launch_dots(c, dotp.data(), w, j + 2, true);

@@ -124,8 +124,8 @@ struct Ctx {
     double fs_w[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};  // 1 sweep = block Jacobi
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
-    // Flexible GMRES with the field split on the right (single GPU): z_j = Minv v_j is kept, so the
-    // update is Z y and no preconditioner application is spent on the right-hand side.
+    // Flexible GMRES with the field split on the right: z_j = Minv v_j is kept, so the update is
+    // Z y and no preconditioner application is spent on the right-hand side.
     double *d_Z = nullptr;
     bool right_precond = true;
     // reductions
@@ -139,6 +139,7 @@ struct Ctx {
     // one captured hipGraph per Krylov index j: operator + preconditioner + orthogonalisation
     std::vector<hipGraphExec_t> iter_graph;
     std::vector<hipGraphExec_t> iter_graph_interior;  // several GPUs: the interior-rows SpMV of step j
+    std::vector<hipGraphExec_t> iter_graph_pre;       // several GPUs, field split on the right: z_j = Minv v_j
     bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
     bool capturing = false;
     int newton_its_hint = -1;     // Newton iterations of the previous converged solve
@@ -161,7 +162,8 @@ void gd_prep_release(Ctx &c);
 size_t patch_lds_bytes(const Ctx &c);
 void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks
-void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv);
+void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int *slice_list = nullptr,
+                 int n_list = 0);
 void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale,
                             const int *slice_list = nullptr, int n_list = 0);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);

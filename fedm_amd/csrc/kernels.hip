@@ -599,14 +599,16 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
     }
 }
 
-void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv) {
-    const int n = c.pat.n_slices;
+// slice_list != nullptr: only those n_list matrix slices (interior / boundary halves across GPUs)
+void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int *slice_list, int n_list) {
+    const int n = slice_list ? n_list : c.pat.n_slices;
+    if (n == 0) return;
     const dim3 g((n + 3) / 4), b(256);
     const double *dinv = scale_dinv ? c.d_dinv : nullptr;
 #define FEDM_SPMV(NEQ)                                                                             \
     hipLaunchKernelGGL((spmv_kernel<NEQ, false>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
                        c.d_colidx, c.d_val, x, y, dinv, (double *)nullptr, (double *)nullptr, 0.0,         \
-                       (const int *)nullptr)
+                       slice_list)
     switch (c.neq) {
         case 1: FEDM_SPMV(1); break;
         case 2: FEDM_SPMV(2); break;
