@@ -248,6 +248,12 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
         }
         return;
     }
+    if (L.composite) {
+        if (down) ell_launch(c, L.C, 0, L.b, nullptr, levels[l + 1].b, 0.0);   // b_c = R (b - A w Dinv b)
+        vcycle(c, l + 1, phase);
+        if (up) ell_launch(c, L.GQ, 0, L.b, nullptr, L.x, 0.0);                // [b ; x_c] -> x
+        return;
+    }
     const int np = L.A.n_rows_p;
     double *x = L.x2, *y = L.x;  // x: current iterate, y: the other buffer
     if (!pre_smooth) {
@@ -336,6 +342,9 @@ void Amg::release() {
         L.A.release();
         L.P.release();
         L.R.release();
+        L.C.release();
+        L.GQ.release();
+        if (L.x_is_alias) L.x = nullptr;
         for (double *p : {L.x, L.x2, L.b, L.r})
             if (p) hipFree(p);
     }

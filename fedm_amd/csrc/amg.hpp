@@ -24,6 +24,16 @@ struct Amg {
     struct Level {
         EllMat A, P, R;
         double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
+        // Composite level (V(1,1), levels whose kernels are bound by launch latency, not bytes):
+        // with x = w Dinv b after the first sweep the whole leg down is one product
+        //   b_c = C b,            C  = R (I - w A Dinv),
+        // and prolongation + second sweep is one product on the concatenated vector [b ; x_c]
+        //   x   = G b + Q x_c,    G  = w Dinv (2 I - w A Dinv),   Q = (I - w Dinv A) P
+        // (built on the host at set-up, capi.cpp).  Two kernels per level instead of four.  b holds
+        // n_rows_p + (rows of the next level) entries and the next level's x is its tail.
+        EllMat C, GQ;
+        bool composite = false;
+        bool x_is_alias = false;   // x points into the previous level's b
     };
     std::vector<Level> levels;
     double *coarse_inv = nullptr;  // dense inverse of the coarsest operator, rows padded to ld

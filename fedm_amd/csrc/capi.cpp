@@ -565,6 +565,92 @@ static void eval_jacobian(Ctx &c, int mode) {
     launch_finalize(c, true, mode);
 }
 
+// ---- host-side sparse algebra for the composite multigrid levels (amg.hpp) ------------------
+namespace {
+struct HostCsr {
+    int n_rows = 0, n_cols = 0;
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> indices;
+    std::vector<double> values;
+    fedm_csr view() const { return fedm_csr{n_rows, n_cols, indptr.data(), indices.data(), values.data()}; }
+};
+
+// alpha * A * diag(dc) * B  (dc may be null), rows merged with a dense accumulator, columns sorted
+HostCsr csr_product(const fedm_csr &A, const double *dc, const fedm_csr &B, double alpha) {
+    HostCsr out;
+    out.n_rows = A.n_rows;
+    out.n_cols = B.n_cols;
+    out.indptr.assign((size_t)A.n_rows + 1, 0);
+    std::vector<double> acc((size_t)B.n_cols, 0.0);
+    std::vector<char> seen((size_t)B.n_cols, 0);
+    std::vector<int32_t> cols;
+    for (int i = 0; i < A.n_rows; ++i) {
+        cols.clear();
+        for (int64_t k = A.indptr[i]; k < A.indptr[i + 1]; ++k) {
+            const int j = A.indices[k];
+            const double a = alpha * A.values[k] * (dc ? dc[j] : 1.0);
+            for (int64_t q = B.indptr[j]; q < B.indptr[j + 1]; ++q) {
+                const int cidx = B.indices[q];
+                if (!seen[cidx]) {
+                    seen[cidx] = 1;
+                    cols.push_back(cidx);
+                }
+                acc[cidx] += a * B.values[q];
+            }
+        }
+        std::sort(cols.begin(), cols.end());
+        for (int32_t cidx : cols) {
+            out.indices.push_back(cidx);
+            out.values.push_back(acc[cidx]);
+            acc[cidx] = 0.0;
+            seen[cidx] = 0;
+        }
+        out.indptr[i + 1] = (int64_t)out.indices.size();
+    }
+    return out;
+}
+
+// diag(dl) * (alpha * A + beta * B) with B's columns shifted by `shift` into a matrix of n_cols
+// columns (A and B may overlap in pattern when shift == 0); dl may be null
+HostCsr csr_combine(const fedm_csr &A, double alpha, const fedm_csr &B, double beta, int shift, int n_cols,
+                    const double *dl) {
+    HostCsr out;
+    out.n_rows = A.n_rows;
+    out.n_cols = n_cols;
+    out.indptr.assign((size_t)A.n_rows + 1, 0);
+    std::vector<std::pair<int32_t, double>> row;
+    for (int i = 0; i < A.n_rows; ++i) {
+        row.clear();
+        const double s = dl ? dl[i] : 1.0;
+        for (int64_t k = A.indptr[i]; k < A.indptr[i + 1]; ++k) row.emplace_back(A.indices[k], s * alpha * A.values[k]);
+        for (int64_t k = B.indptr[i]; k < B.indptr[i + 1]; ++k)
+            row.emplace_back(B.indices[k] + shift, s * beta * B.values[k]);
+        std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (size_t k = 0; k < row.size(); ++k) {
+            if (!out.indices.empty() && (int64_t)out.indices.size() > out.indptr[i] && out.indices.back() == row[k].first)
+                out.values.back() += row[k].second;
+            else {
+                out.indices.push_back(row[k].first);
+                out.values.push_back(row[k].second);
+            }
+        }
+        out.indptr[i + 1] = (int64_t)out.indices.size();
+    }
+    return out;
+}
+
+HostCsr csr_identity(int n) {
+    HostCsr out;
+    out.n_rows = out.n_cols = n;
+    out.indptr.resize((size_t)n + 1);
+    out.indices.resize(n);
+    out.values.assign(n, 1.0);
+    for (int i = 0; i <= n; ++i) out.indptr[i] = i;
+    for (int i = 0; i < n; ++i) out.indices[i] = i;
+    return out;
+}
+}  // namespace
+
 }  // namespace fedm
 
 using namespace fedm;
@@ -785,6 +871,15 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         // globally coloured kernel is the (deterministic, slower) alternative.
         const char *env = getenv("FEDM_ASSEMBLY");
         c.assembly_kind = (env && std::string(env) == "colour") ? 0 : 1;
+        // Side of the field split: right for the LFA systems (3 instead of 5.25 Krylov steps per
+        // Newton iteration on the streamer case); left for LMEA, whose rows (energy balance next to
+        // densities) are scaled so differently that the true residual norm is the harder target
+        // (glow discharge, 402k DOFs: 70 against 100 steps per time step).  FEDM_PRECOND_SIDE or
+        // fedm_set_preconditioner_side override.
+        c.right_precond = c.model_kind == 0;
+        const char *side = getenv("FEDM_PRECOND_SIDE");
+        if (side && std::string(side) == "left") c.right_precond = false;
+        if (side && std::string(side) == "right") c.right_precond = true;
         if (!c.pat.patch_ok || patch_lds_bytes(c) > 160 * 1024 || c.model_kind == 1) c.assembly_kind = 0;
     }
     if (upload(c.d_slice_boff, c.pat.slice_boff.data(), c.pat.slice_boff.size())) return -1;
@@ -1387,7 +1482,8 @@ int fedm_amg_clear(fedm_ctx *h) {
 
 // shared by the rank-local hierarchy and the replicated global one (several GPUs)
 static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, const fedm_csr *P,
-                     const fedm_csr *R, const double *coarse_inverse, int nu, double omega, Amg **out) {
+                     const fedm_csr *R, const double *coarse_inverse, int nu, double omega, Amg **out,
+                     int composite_from) {
     if (n_levels < 1 || !A || (n_levels > 1 && (!P || !R)) || nu == 0) {
         set_error("bad multigrid description");
         return -2;
@@ -1415,7 +1511,31 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
     for (int l = 0; l < n_levels; ++l) {
         Amg::Level &L = amg->levels[l];
         int rc = 0;
-        if (l + 1 < n_levels) {
+        const char *composite_env = std::getenv("FEDM_AMG_COMPOSITE");  // "0": four kernels per level everywhere
+        const bool composite_ok = !(composite_env && composite_env[0] == '0');
+        L.composite = composite_ok && l + 1 < n_levels && l >= composite_from && nu == 1;
+        if (L.composite) {
+            const int n = A[l].n_rows, np = ((n + SLICE - 1) / SLICE) * SLICE;
+            std::vector<double> wd((size_t)n, omega);  // w / A_ii (EllMat::from_csr's rule for dinv)
+            for (int i = 0; i < n; ++i)
+                for (int64_t k = A[l].indptr[i]; k < A[l].indptr[i + 1]; ++k)
+                    if (A[l].indices[k] == i && A[l].values[k] != 0.0) wd[i] = omega / A[l].values[k];
+            const HostCsr I = csr_identity(n);
+            const fedm_csr Iv = I.view();
+            const HostCsr M1 = csr_product(A[l], wd.data(), Iv, 1.0);                         // w A Dinv
+            const HostCsr T = csr_combine(Iv, 1.0, M1.view(), -1.0, 0, n, nullptr);            // I - w A Dinv
+            const HostCsr Cm = csr_product(R[l], nullptr, T.view(), 1.0);                      // R (I - w A Dinv)
+            const HostCsr G = csr_combine(Iv, 2.0, M1.view(), -1.0, 0, n, wd.data());          // w Dinv (2I - w A Dinv)
+            HostCsr WAP = csr_product(A[l], nullptr, P[l], 1.0);                               // w Dinv A P
+            for (int i = 0; i < n; ++i)
+                for (int64_t k = WAP.indptr[i]; k < WAP.indptr[i + 1]; ++k) WAP.values[k] *= wd[i];
+            const HostCsr Q = csr_combine(P[l], 1.0, WAP.view(), -1.0, 0, P[l].n_cols, nullptr);  // (I - w Dinv A) P
+            const HostCsr GQ = csr_combine(G.view(), 1.0, Q.view(), 1.0, np, np + P[l].n_cols, nullptr);
+            rc |= L.C.from_csr(Cm.view(), false);
+            rc |= L.GQ.from_csr(GQ.view(), false);
+            L.A.n_rows = n;
+            L.A.n_rows_p = np;
+        } else if (l + 1 < n_levels) {
             rc |= L.A.from_csr(A[l], true);
             rc |= L.P.from_csr(P[l], false);
             rc |= L.R.from_csr(R[l], false);
@@ -1428,12 +1548,18 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
             return fail(rc < -1 ? -2 : -1);
         }
         const size_t n = (size_t)L.A.n_rows_p;
-        for (double **p : {&L.x, &L.x2, &L.b, &L.r})
-            if (hipMalloc((void **)p, sizeof(double) * n) != hipSuccess ||
-                hipMemset(*p, 0, sizeof(double) * n) != hipSuccess) {
+        const size_t n_next = L.composite ? (size_t)(((A[l + 1].n_rows + SLICE - 1) / SLICE) * SLICE) : 0;
+        L.x_is_alias = l > 0 && amg->levels[l - 1].composite;
+        if (L.x_is_alias) L.x = amg->levels[l - 1].b + amg->levels[l - 1].A.n_rows_p;
+        for (double **p : {&L.x, &L.x2, &L.b, &L.r}) {
+            if (p == &L.x && L.x_is_alias) continue;
+            const size_t len = n + (p == &L.b ? n_next : 0);
+            if (hipMalloc((void **)p, sizeof(double) * len) != hipSuccess ||
+                hipMemset(*p, 0, sizeof(double) * len) != hipSuccess) {
                 set_error("out of device memory for the multigrid vectors");
                 return fail(-1);
             }
+        }
     }
     amg->n_coarse = A[n_levels - 1].n_rows;
     amg->coarse_ld = ((amg->n_coarse + 255) / 256) * 256;
@@ -1462,7 +1588,7 @@ int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr 
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     fedm_amg_clear(h);
     Amg *amg = nullptr;
-    if (int rc = build_amg(c, c.nv, n_levels, A, P, R, coarse_inverse, nu, omega, &amg)) return rc;
+    if (int rc = build_amg(c, c.nv, n_levels, A, P, R, coarse_inverse, nu, omega, &amg, 1)) return rc;
     c.amg = amg;
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     if (coarse_inverse && amg->capture(c) != 0) {
@@ -1493,7 +1619,7 @@ int fedm_amg_set_global_hierarchy(fedm_ctx *h, int n_global, int offset, int n_l
         a.graph_exec = nullptr;
     }
     Amg *g = nullptr;
-    if (int rc = build_amg(c, n_global, n_levels, A, P, R, coarse_inverse, nu, omega, &g)) return rc;
+    if (int rc = build_amg(c, n_global, n_levels, A, P, R, coarse_inverse, nu, omega, &g, 0)) return rc;
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     if (g->capture(c) != 0) hipGetLastError();
     a.global = g;

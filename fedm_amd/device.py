@@ -627,7 +627,8 @@ class DeviceProblem:
         self._check(self.lib.fedm_set_assembly(self._h, code), "fedm_set_assembly")
 
     def set_preconditioner_side(self, side):
-        """'right' (default on one GPU: flexible GMRES, true residual norm) or 'left'."""
+        """'right' (flexible GMRES, true residual norm; default for LFA models) or 'left'
+        (preconditioned residual norm; default for LMEA models)."""
         code = {"left": 0, "right": 1}[side]
         self._check(self.lib.fedm_set_preconditioner_side(self._h, code), "fedm_set_preconditioner_side")
 

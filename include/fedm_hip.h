@@ -303,9 +303,10 @@ int fedm_profile_read(fedm_ctx *ctx, int kind, double *ms_total, int64_t *count)
 /* assembly kernel: 0 = global graph colouring (bitwise reproducible), 1 = LDS patches
  * (default; each matrix value written once, LDS fp64 atomics) */
 int fedm_set_assembly(fedm_ctx *ctx, int kind);
-/* side of the field-split preconditioner in the Newton linear solves on one GPU: 1 = right
- * (default; flexible GMRES, convergence on the true residual norm), 0 = left (as across GPUs,
- * convergence on the preconditioned residual norm).  Both solve J delta = -F to ksp_rtol. */
+/* side of the field-split preconditioner in the Newton linear solves: 1 = right (flexible GMRES,
+ * convergence on the true residual norm; default for LFA models), 0 = left (convergence on the
+ * preconditioned residual norm; default for LMEA models).  Both solve J delta = -F to ksp_rtol.
+ * Environment: FEDM_PRECOND_SIDE=left|right sets the default of new contexts. */
 int fedm_set_preconditioner_side(fedm_ctx *ctx, int right);
 /* sizes the roofline model needs */
 int fedm_sizes(fedm_ctx *ctx, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq,

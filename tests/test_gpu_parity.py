@@ -218,6 +218,27 @@ def test_krylov_graphs_match_plain_launches():
     assert np.allclose(out["graphs"][1], out["plain"][1], rtol=1e-10, atol=1e-10)
 
 
+def test_composite_multigrid_levels_are_the_same_cycle(monkeypatch):
+    """Below the finest level the V(1,1) cycle runs two precomputed products per level
+    (b_c = R(I - wA Dinv) b and x = G b + Q x_c) instead of sweep, restriction, prolongation, sweep.
+    The same linear operator: the Poisson CG and the time steps must not notice."""
+    from fedm_amd.cases import streamer
+    msh = streamer.mesh(128, 4.0)
+    out = {}
+    for composite in ("0", "1"):
+        monkeypatch.setenv("FEDM_AMG_COMPOSITE", composite)
+        prob = streamer.device_problem(msh.coords, msh.cells)
+        st = streamer.Stepper(prob)
+        _, its = st.initialise()
+        assert len(prob.multigrid_levels) >= 3          # at least one composite level
+        for _ in range(2):
+            st.step()
+        out[composite] = (its, st.linear_iterations, prob.get_state())
+        prob.close()
+    assert out["0"][0] == out["1"][0] and out["0"][1] == out["1"][1]
+    assert np.allclose(out["0"][2], out["1"][2], rtol=1e-9, atol=1e-9)
+
+
 def test_preconditioner_side_left_and_right_agree():
     """The Newton systems are solved by flexible GMRES with the field split on the right (true
     residual norm) or, selectable, on the left (preconditioned residual norm).  Both solve
