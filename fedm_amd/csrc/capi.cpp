@@ -117,8 +117,7 @@ static bool right_preconditioned(const Ctx &c) { return c.right_precond && c.amg
 // rhs = -Minv F (preconditioner on the left) or -F (on the right), after the Jacobian has been assembled
 static void prepare_preconditioner_and_rhs(Ctx &c) {
     if (right_preconditioned(c)) {
-        fieldsplit_setup(c);
-        launch_scale_copy(c, -1.0, c.d_F, c.d_rhs);
+        fieldsplit_setup(c);  // the right-hand side is -F itself: gmres reads c.d_F
     } else if (c.amg && c.poisson) {
         fieldsplit_setup(c);
         fieldsplit_apply(c, *c.amg, c.d_F, c.d_rhs, -1.0);
@@ -391,7 +390,8 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
 // solve, and the norm tested is that of the true residual.  delta starts at 0; classical
 // Gram-Schmidt (PETSc's KSPGMRES default).
 static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int *its_out,
-                 double *rnorm_out) {
+                 double *rnorm_out, const double *bvec, double bscale, double bnorm_known, double *u_update,
+                 bool *u_updated) {
     if (restart < 1 || restart > RED_K - 10) {
         set_error("GMRES restart must be between 1 and 30");
         return -2;
@@ -410,8 +410,18 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         launch_spmv(c, v, w, false);
         prof_end(c);
     };
-    hipMemsetAsync(c.d_delta, 0, sizeof(double) * c.np, c.stream);
-    int its = 0;
+    // The system is  J delta = bscale * bvec  (bvec = c.d_rhs, already preconditioned, on the left;
+    // bvec = F, bscale = -1 on the right, where |bvec| is the |F| the Newton loop has just read:
+    // bnorm_known >= 0).  u_update != nullptr: when the solve converges within its first cycle the
+    // Newton update u += delta and the norms |delta|^2, |u|^2 (slots 1, 2) are formed by the kernel
+    // that forms delta (*u_updated = true); c.d_delta is zeroed only if a generic update needs it.
+    bool delta_zeroed = false;
+    auto zero_delta = [&] {
+        if (!delta_zeroed) hipMemsetAsync(c.d_delta, 0, sizeof(double) * c.np, c.stream);
+        delta_zeroed = true;
+    };
+    if (u_updated) *u_updated = false;
+    int its = 0, cycle = 0;
     double r0 = -1.0, rnorm = 0.0;
     bool first = true;
     while (true) {
@@ -422,16 +432,26 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         if (!first) {
             if (right) plain_operator(c.d_delta, c.d_w);
             else apply_operator(c, c.d_delta, c.d_w);
-            launch_scale_copy(c, 1.0, c.d_rhs, v0);
+            launch_scale_copy(c, bscale, bvec, v0);
             launch_axpy(c, -1.0, c.d_w, v0);
         }
         // First cycle: |rhs| is not waited for -- v0 is normalised on the device and the norm
         // rides along with the first Krylov step's publication (slot RED_SPARE).
-        const bool deferred = first;
+        const bool deferred = first && bnorm_known < 0.0;
         double beta = 0.0, tol = 0.0;
-        if (deferred) {
-            launch_norm2(c, c.d_rhs, RED_SPARE);
-            launch_normalise_copy(c, RED_SPARE, c.d_rhs, v0);  // v0 = rhs / |rhs|
+        if (first && !deferred) {
+            beta = bnorm_known;
+            r0 = rnorm = beta;
+            tol = std::max(rtol * r0, atol);
+            first = false;
+            if (beta <= tol) {  // nothing to solve
+                zero_delta();
+                break;
+            }
+            launch_scale_copy(c, bscale / beta, bvec, v0);
+        } else if (deferred) {
+            launch_norm2(c, bvec, RED_SPARE);
+            launch_normalise_copy(c, RED_SPARE, bvec, v0);  // v0 = b / |b|  (bscale is 1 on this path)
             first = false;
         } else {
             launch_norm2(c, v0, 0);
@@ -477,7 +497,10 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 r0 = rnorm = beta;
                 tol = std::max(rtol * r0, atol);
                 gvec[0] = beta;
-                if (beta <= tol) break;  // nothing to solve: delta stays 0 (j == 0: no update below)
+                if (beta <= tol) {  // nothing to solve: delta = 0 (j == 0: no update below)
+                    zero_delta();
+                    break;
+                }
             }
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = c.h_red[i];
             double hn2 = c.h_red[j + 1];
@@ -532,7 +555,16 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             for (int l = i + 1; l < k; ++l) s -= H[(size_t)i * m + l] * yv[l];
             yv[i] = s / H[(size_t)i * m + i];
         }
-        if (k > 0) launch_multi_axpy(c, yv.data(), k, right ? zp.data() : vp.data(), c.d_delta, 1.0);
+        if (k > 0) {
+            if (u_update && done && cycle == 0 && k <= 8) {
+                launch_newton_update(c, yv.data(), k, right ? zp.data() : vp.data(), u_update, c.d_delta);
+                *u_updated = true;
+            } else {
+                zero_delta();
+                launch_multi_axpy(c, yv.data(), k, right ? zp.data() : vp.data(), c.d_delta, 1.0);
+            }
+        }
+        ++cycle;
         if (done || its >= max_it) {
             if (!done) {  // recompute the true (preconditioned, on the left) residual for the report
                 if (right) plain_operator(c.d_delta, c.d_w);
@@ -1127,16 +1159,22 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         prepare_preconditioner_and_rhs(c);
         int lits = 0;
         double lres = 0.0;
-        const int lrc = gmres(c, o->ksp_restart, o->ksp_rtol, o->ksp_atol, o->ksp_max_it, &lits, &lres);
+        const bool right = right_preconditioned(c);
+        bool updated = false;
+        const int lrc = gmres(c, o->ksp_restart, o->ksp_rtol, o->ksp_atol, o->ksp_max_it, &lits, &lres,
+                              right ? c.d_F : c.d_rhs, right ? -1.0 : 1.0, right ? fnorm : -1.0, c.d_u, &updated);
         lin_total += lits;
         if (lrc != 0) {
             rc = lrc < 0 ? lrc : (lrc == FEDM_DIVERGED_NAN ? FEDM_DIVERGED_NAN : FEDM_DIVERGED_LINEAR);
             break;
         }
-        launch_axpy(c, 1.0, c.d_delta, c.d_u);
+        // |dx| and |x| for the stol test (slots 1, 2) are read with the next |F|
+        if (!updated) {
+            launch_axpy(c, 1.0, c.d_delta, c.d_u);
+            launch_norm2(c, c.d_delta, 1);
+            launch_norm2(c, c.d_u, 2);
+        }
         comm_halo(c, c.d_u);
-        launch_norm2(c, c.d_delta, 1);   // |dx| and |x| for the stol test: read with the next |F|
-        launch_norm2(c, c.d_u, 2);
         ++it;
     }
     if (rc == 0) c.newton_its_hint = it;

@@ -172,6 +172,9 @@ void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const 
                        bool finish = true);
 void launch_cgs_finish(Ctx &c, int k);  // finish formulae + publication on d_red[0..k)
 void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y);
+// u += delta = sum_i coef_i zs[i] (k <= 8), d_red[1] = |delta|^2, d_red[2] = |u|^2 (owned entries)
+void launch_newton_update(Ctx &c, const double *coef_host, int k, const double *const *zs, double *u,
+                          double *delta);
 void launch_norm2(Ctx &c, const double *x, int slot);                       // d_red[slot] = x.x
 void launch_axpy(Ctx &c, double a, const double *x, double *y);             // y += a x
 void launch_scale_copy(Ctx &c, double a, const double *x, double *y);       // y = a x

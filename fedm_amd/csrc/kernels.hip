@@ -1097,6 +1097,65 @@ void launch_multi_axpy(Ctx &c, const double *coef_host, int k, const double *con
     }
 }
 
+// Newton update in one pass: delta = sum_i c_i z_i, u += delta, and the per-block partial sums of
+// |delta|^2 and |u|^2 over the owned entries (slots 1, 2 of the reduction buffer) -- instead of a
+// memset, a multi-axpy, an axpy and two norm kernels.
+template <int K>
+__global__ __launch_bounds__(256) void newton_update_kernel(size_t n, size_t n_dot, CoefPack8 cf, PtrPack8 zs,
+                                                            double *__restrict__ u, double *__restrict__ delta,
+                                                            double *__restrict__ partials) {
+    double acc[2] = {0.0, 0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) d += cf.c[k] * zs.p[k][i];
+        const double un = u[i] + d;
+        u[i] = un;
+        delta[i] = d;
+        if (i < n_dot) {
+            acc[0] += d * d;
+            acc[1] += un * un;
+        }
+    }
+    block_reduce_store<2>(acc, partials, 1);
+}
+
+__global__ void reduce_partials_range_kernel(const double *__restrict__ partials, int nblocks, int k0,
+                                             double *__restrict__ out) {
+    const int i = k0 + blockIdx.x;  // one wave per output; fixed summation order
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[i] = s;
+}
+
+void launch_newton_update(Ctx &c, const double *coef_host, int k, const double *const *zs, double *u,
+                          double *delta) {
+    const int grid = red_grid(c);
+    PtrPack8 pk;
+    CoefPack8 cf;
+    for (int i = 0; i < 8; ++i) {
+        pk.p[i] = zs[i < k ? i : 0];
+        cf.c[i] = i < k ? coef_host[i] : 0.0;
+    }
+#define FEDM_NU(K)                                                                                         \
+    hipLaunchKernelGGL(newton_update_kernel<K>, dim3(grid), dim3(256), 0, c.stream, (size_t)c.np, (size_t)c.n_dot, \
+                       cf, pk, u, delta, c.d_partials)
+    switch (k) {
+        case 1: FEDM_NU(1); break;
+        case 2: FEDM_NU(2); break;
+        case 3: FEDM_NU(3); break;
+        case 4: FEDM_NU(4); break;
+        case 5: FEDM_NU(5); break;
+        case 6: FEDM_NU(6); break;
+        case 7: FEDM_NU(7); break;
+        default: FEDM_NU(8); break;
+    }
+#undef FEDM_NU
+    hipLaunchKernelGGL(reduce_partials_range_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, 1, c.d_red);
+    comm_allreduce(c, c.d_red + 1, 2);
+}
+
 // |new - old + eps|^2 and |old + eps|^2 over one component (fedm/functions.py:1062-1064)
 __global__ __launch_bounds__(256) void field_error_kernel(int nv, int neq, int comp,
                                                           const double *__restrict__ u,
