@@ -102,11 +102,13 @@ def initialise(prob, multigrid=True):
     prob.set_state(U, U, U)
     if multigrid:
         prob.setup_multigrid(**MULTIGRID)
-        # species block ~ diagonally scaled P1 mass matrix (spectrum in [0.5, 2]): a degree-4
-        # Chebyshev polynomial in Duu^-1 Juu instead of plain block Jacobi: 24 -> 15 GMRES
-        # iterations per step
+        # species block ~ diagonally scaled P1 mass matrix (spectrum in [0.5, 2]): a Chebyshev
+        # polynomial in Duu^-1 Juu instead of plain block Jacobi.  Degree 6 makes a Newton system
+        # cost 2 Krylov steps early in the run (degree 4: 3, block Jacobi: 5); later the potential
+        # block limits the convergence (9 steps whatever the degree) and degree 4 is cheaper:
+        # the library switches on the iteration count (tools/fs_sweeps.py)
         from ..device import chebyshev_weights
-        prob.set_fieldsplit(chebyshev_weights(4))
+        prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(4))
     its = prob.poisson_solve(rtol=1e-12)
     U = prob.get_state()
     prob.set_state(U, U, U)

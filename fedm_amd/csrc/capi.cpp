@@ -1178,6 +1178,19 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         ++it;
     }
     if (rc == 0) c.newton_its_hint = it;
+    if (c.fs_alt_sweeps > 0 && it > 0) {
+        // same counts on every rank, so every rank takes the same decision
+        const double per_solve = (double)lin_total / it;
+        const bool to_alt = !c.fs_alt_active && per_solve >= c.fs_switch_above;
+        const bool to_main = c.fs_alt_active && per_solve <= c.fs_back_below;
+        if (to_alt || to_main) {
+            hipStreamSynchronize(c.stream);
+            iter_graphs_clear(c);  // the captured steps contain the other number of sweeps
+            c.fs_alt_active = to_alt;
+            c.fs_sweeps = to_alt ? c.fs_alt_sweeps : c.fs_main_sweeps;
+            for (int i = 0; i < c.fs_sweeps; ++i) c.fs_w[i] = to_alt ? c.fs_alt_w[i] : c.fs_main_w[i];
+        }
+    }
     r.iterations = it;
     r.linear_iterations = lin_total;
     r.fnorm0 = fnorm0;
@@ -1414,8 +1427,38 @@ int fedm_set_fieldsplit(fedm_ctx *h, int sweeps, const double *weights) {
     hipSetDevice(h->c.device);
     hipStreamSynchronize(h->c.stream);
     iter_graphs_clear(h->c);
-    h->c.fs_sweeps = sweeps;
-    for (int i = 0; i < sweeps; ++i) h->c.fs_w[i] = weights[i];
+    Ctx &c = h->c;
+    c.fs_sweeps = c.fs_main_sweeps = sweeps;
+    for (int i = 0; i < sweeps; ++i) c.fs_w[i] = c.fs_main_w[i] = weights[i];
+    c.fs_alt_sweeps = 0;
+    c.fs_alt_active = false;
+    return 0;
+}
+
+int fedm_set_fieldsplit_alternative(fedm_ctx *h, int alt_sweeps, const double *alt_weights,
+                                    double switch_above, double back_below) {
+    Ctx &c = h->c;
+    if (alt_sweeps < 0 || alt_sweeps > 16 || (alt_sweeps > 0 && !alt_weights) || !(back_below < switch_above)) {
+        set_error("alternative field-split sweeps must be 0..16 with one weight each, back_below < switch_above");
+        return -2;
+    }
+    for (int i = 0; i < alt_sweeps; ++i)
+        if (!(alt_weights[i] > 0.0 && alt_weights[i] < 4.0)) {
+            set_error("field-split weights must be positive");
+            return -2;
+        }
+    if (c.fs_alt_active) {  // back to the main set first
+        hipSetDevice(c.device);
+        hipStreamSynchronize(c.stream);
+        iter_graphs_clear(c);
+        c.fs_sweeps = c.fs_main_sweeps;
+        for (int i = 0; i < c.fs_main_sweeps; ++i) c.fs_w[i] = c.fs_main_w[i];
+        c.fs_alt_active = false;
+    }
+    c.fs_alt_sweeps = alt_sweeps;
+    for (int i = 0; i < alt_sweeps; ++i) c.fs_alt_w[i] = alt_weights[i];
+    c.fs_switch_above = switch_above;
+    c.fs_back_below = back_below;
     return 0;
 }
 

@@ -122,6 +122,11 @@ struct Ctx {
     double *d_delta = nullptr, *d_w = nullptr, *d_rhs = nullptr, *d_tmp = nullptr, *d_fs = nullptr, *d_fs_g = nullptr;
     int fs_sweeps = 1;       // Richardson sweeps with block-Jacobi scaling on the species block
     double fs_w[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};  // 1 sweep = block Jacobi
+    // the two sets of fedm_set_fieldsplit / fedm_set_fieldsplit_alternative; fs_w is the active one
+    int fs_main_sweeps = 1, fs_alt_sweeps = 0;
+    double fs_main_w[16] = {1}, fs_alt_w[16] = {1};
+    bool fs_alt_active = false;
+    double fs_switch_above = 5.0, fs_back_below = 3.5;
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
     // Flexible GMRES with the field split on the right: z_j = Minv v_j is kept, so the update is

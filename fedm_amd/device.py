@@ -590,11 +590,18 @@ class DeviceProblem:
         self.multigrid_levels = [local_sizes[0], f"{n1} of {n_g} global"] + global_sizes[1:]
         return self.multigrid_levels
 
-    def set_fieldsplit(self, weights=(0.8, 0.8, 0.8)):
+    def set_fieldsplit(self, weights=(0.8, 0.8, 0.8), hard_weights=None, switch_above=5.0, back_below=3.5):
         """Richardson weights of the species-block sweeps; :func:`chebyshev_weights` gives the
-        optimal ones for a spectrum interval of Duu^-1 Juu."""
+        optimal ones for a spectrum interval of Duu^-1 Juu.  `hard_weights`: a cheaper set used
+        while Newton solves need >= `switch_above` Krylov steps per Newton iteration (until one
+        needs <= `back_below` again)."""
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self._check(self.lib.fedm_set_fieldsplit(self._h, int(w.size), _dp(w)), "fedm_set_fieldsplit")
+        if hard_weights is not None:
+            a = np.ascontiguousarray(hard_weights, dtype=np.float64)
+            self._check(self.lib.fedm_set_fieldsplit_alternative(self._h, int(a.size), _dp(a),
+                                                                 float(switch_above), float(back_below)),
+                        "fedm_set_fieldsplit_alternative")
 
     def clear_multigrid(self):
         self.lib.fedm_amg_clear(self._h)

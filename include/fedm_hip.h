@@ -261,6 +261,13 @@ int fedm_amg_set_global_hierarchy(fedm_ctx *ctx, int n_global, int offset, int n
 /* Richardson sweeps z += w_k Duu^-1 (r - Juu z) on the species block inside the field split;
  * one weight per sweep (equal weights = damped block Jacobi, Chebyshev roots = polynomial) */
 int fedm_set_fieldsplit(fedm_ctx *ctx, int sweeps, const double *weights);
+/* A second, cheaper set of sweeps for hard systems: after a Newton solve that needed at least
+ * `switch_above` Krylov steps per Newton iteration the field split uses the alternative set, after
+ * one that needed at most `back_below` the set of fedm_set_fieldsplit again (which also resets this).
+ * A long polynomial pays while it saves whole Krylov steps; once the potential block limits the
+ * convergence it only costs.  alt_sweeps = 0 switches the rule off. */
+int fedm_set_fieldsplit_alternative(fedm_ctx *ctx, int alt_sweeps, const double *alt_weights,
+                                    double switch_above, double back_below);
 /* host-side greedy aggregation on a strength graph (set-up helper, no GPU needed) */
 int fedm_amg_aggregate(int32_t n, const int64_t *indptr, const int32_t *indices,
                        const uint8_t *strong, int32_t *agg, int32_t *n_agg);
