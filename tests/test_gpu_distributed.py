@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, restart=30):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
@@ -32,6 +32,7 @@ def _worker(rank, world, port, q):
         run = streamer_distributed.Runner(None, rank, world, 0, grading=2.0, transport="torch",
                                           n_per_gpu=N_PER_GPU, **TOL)
         run.solver.parameters["krylov_relative_tolerance"] = 1e-11
+        run.solver.parameters["krylov_restart"] = restart
         run.initialise()
         for _ in range(STEPS):
             run.step()
@@ -41,13 +42,16 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_gpu():
+@pytest.mark.parametrize("restart", [30, 3])
+def test_two_ranks_match_single_gpu(restart):
+    """restart = 3 makes every linear solve run through several GMRES cycles: the restarted
+    residual rhs - J delta (halo exchange of delta, plain product) and the accumulated update."""
     import torch.multiprocessing as mp
     from fedm_amd.cases import streamer
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, restart)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
