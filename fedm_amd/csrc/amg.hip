@@ -463,23 +463,13 @@ __global__ void fs_scatter_kernel(int nvp, const double *__restrict__ x0, double
     if (v < nvp) z[(size_t)v * (NS + 1) + NS] = x0[v];
 }
 
-// inverse of the leading NS x NS (species) part of every diagonal block
+// inverse of the leading NS x NS (species) part of a diagonal block (Gauss-Jordan, partial pivoting)
 template <int NS>
-__global__ void species_block_inverse_kernel(int nvp, const double *__restrict__ val,
-                                             const uint32_t *__restrict__ diag_slot,
-                                             double *__restrict__ dinv_uu) {
-    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
-    const int vtx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (vtx >= nvp) return;
-    const uint32_t ds = diag_slot[vtx];
-    double A[NS][NS], I[NS][NS];
+__device__ __forceinline__ void invert_species_block(double (&A)[NS][NS], double (&I)[NS][NS]) {
 #pragma unroll
     for (int r = 0; r < NS; ++r)
 #pragma unroll
-        for (int cidx = 0; cidx < NS; ++cidx) {
-            A[r][cidx] = val[((size_t)(ds >> 6) * NEQ2 + r * NEQ + cidx) * SLICE + (ds & 63)];
-            I[r][cidx] = (r == cidx) ? 1.0 : 0.0;
-        }
+        for (int cidx = 0; cidx < NS; ++cidx) I[r][cidx] = (r == cidx) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         int piv = k;
@@ -520,10 +510,6 @@ __global__ void species_block_inverse_kernel(int nvp, const double *__restrict__
             }
         }
     }
-    const int slice = vtx >> 6, lane = vtx & 63;
-#pragma unroll
-    for (int e = 0; e < NS * NS; ++e)
-        dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = I[e / NS][e % NS];
 }
 
 // With sweeps, the first stage leaves g = Duu^-1 (alpha t_u) (weight 1) in its own vector, which
@@ -610,21 +596,35 @@ void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t
     }
 }
 
-// Copies of the species columns of every block for the preconditioner: the species rows scaled
-// by the row's inverse diagonal block, S = Duu^-1 J_uu, in half precision (the sweeps), and the
-// potential row J_phi,u in single precision (the coupling product).  One wave per slice.
+// Set-up of the field split after a Jacobian assembly, one wave per slice: the inverse of the
+// species part of every diagonal block (D_uu^-1, kept in c.d_dinv for the first stage), and the
+// copies of the species columns the preconditioner streams: the species rows scaled by it,
+// S = Duu^-1 J_uu, in half precision (the sweeps), and the potential row J_phi,u in single
+// precision (the coupling product).
 template <int NS>
 __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const int *__restrict__ boff,
                                                              const double *__restrict__ val,
-                                                             const double *__restrict__ dinv_uu,
+                                                             const uint32_t *__restrict__ diag_slot,
+                                                             double *__restrict__ dinv_uu,
                                                              _Float16 *__restrict__ s16, float *__restrict__ val32) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
-    double d[NS * NS];
+    double d[NS][NS];
+    {
+        const uint32_t ds = diag_slot[(size_t)slice * SLICE + lane];
+        double A[NS][NS];
 #pragma unroll
-    for (int e = 0; e < NS * NS; ++e) d[e] = dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane];
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx)
+                A[r][cidx] = val[((size_t)(ds >> 6) * NEQ2 + r * NEQ + cidx) * SLICE + (ds & 63)];
+        invert_species_block<NS>(A, d);
+#pragma unroll
+        for (int e = 0; e < NS * NS; ++e)
+            dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = d[e / NS][e % NS];
+    }
     const int b0 = boff[slice], b1 = boff[slice + 1];
     for (int bc = b0; bc < b1; ++bc) {
         const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
             for (int cidx = 0; cidx < NS; ++cidx) {
                 double acc = 0.0;
 #pragma unroll
-                for (int m = 0; m < NS; ++m) acc += d[r * NS + m] * J[m][cidx];
+                for (int m = 0; m < NS; ++m) acc += d[r][m] * J[m][cidx];
                 // (out-of-range entries saturate: only the preconditioner's quality is at stake)
                 const float f = fminf(fmaxf((float)acc, -65504.f), 65504.f);
                 s16[((size_t)bc * NS * NS + r * NS + cidx) * SLICE + lane] = (_Float16)f;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
 }
 
 void fieldsplit_setup(Ctx &c) {
-    const dim3 g((c.nvp + 255) / 256), b(256);
+    const dim3 b(256);
     const size_t n_entries = (size_t)c.pat.total_bc * SLICE;
     if (!c.d_val32 && (hipMalloc((void **)&c.d_val32, sizeof(float) * n_entries * c.ns) != hipSuccess ||
                        hipMalloc((void **)&c.d_s16, sizeof(_Float16) * n_entries * c.ns * c.ns) != hipSuccess)) {
@@ -660,17 +660,10 @@ void fieldsplit_setup(Ctx &c) {
         c.d_val32 = nullptr;
         return;
     }
-    switch (c.ns) {
-        case 1: hipLaunchKernelGGL(species_block_inverse_kernel<1>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
-        case 2: hipLaunchKernelGGL(species_block_inverse_kernel<2>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
-        case 3: hipLaunchKernelGGL(species_block_inverse_kernel<3>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
-        case 4: hipLaunchKernelGGL(species_block_inverse_kernel<4>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
-        case 5: hipLaunchKernelGGL(species_block_inverse_kernel<5>, g, b, 0, c.stream, c.nvp, c.d_val, c.d_diag_slot, c.d_dinv); break;
-    }
     const dim3 gs((c.pat.n_slices + 3) / 4);
 #define FEDM_PLANES(NS_)                                                                                   \
     hipLaunchKernelGGL(species_planes_kernel<NS_>, gs, b, 0, c.stream, c.pat.n_slices, c.d_slice_boff, c.d_val, \
-                       c.d_dinv, c.d_s16, c.d_val32)
+                       c.d_diag_slot, c.d_dinv, c.d_s16, c.d_val32)
     switch (c.ns) {
         case 1: FEDM_PLANES(1); break;
         case 2: FEDM_PLANES(2); break;

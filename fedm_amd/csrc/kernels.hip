@@ -378,19 +378,38 @@ __device__ __forceinline__ void identity_row(double *val, const int *boff, const
     // they are only ever produced for j >= row_len where the first match already got the 1.
 }
 
+// Dirichlet rows (F = u - value, unit row) and, in the same launch when no species is frozen, the
+// identity rows of the vertices [n_owned, nvp) (ghosts and padding): one kernel boundary less per
+// assembly.  n_id = 0: Dirichlet rows only.
 __global__ void dirichlet_kernel(int n_dir, const int *__restrict__ dofs,
                                  const double *__restrict__ vals, const double *__restrict__ u,
                                  double *__restrict__ F, double *__restrict__ val,
                                  const int *__restrict__ boff, const int *__restrict__ colidx,
-                                 const uint32_t *__restrict__ diag_slot, int neq, int jacobian) {
+                                 const uint32_t *__restrict__ diag_slot, int neq, int jacobian,
+                                 int id_first, int n_id) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_dir) return;
+    const int neq2 = neq * neq;
+    if (t >= n_dir) {
+        if (t - n_dir >= n_id) return;
+        const int vtx = id_first + (t - n_dir);
+        const int slice = vtx >> 6, lane = vtx & 63;
+        for (int cr = 0; cr < neq; ++cr) {
+            F[(size_t)vtx * neq + cr] = 0.0;
+            if (!jacobian) continue;
+            for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc)
+                for (int cc = 0; cc < neq; ++cc)
+                    val[((size_t)bc * neq2 + cr * neq + cc) * SLICE + lane] = 0.0;
+            const uint32_t ds = diag_slot[vtx];
+            val[((size_t)(ds >> 6) * neq2 + cr * neq + cr) * SLICE + (ds & 63)] = 1.0;
+        }
+        return;
+    }
     const int dof = dofs[t];
+    const int vtx = dof / neq, cr = dof % neq;
+    if (n_id > 0 && vtx >= id_first) return;  // a ghost's row: identity with F = 0, written above
     F[dof] = u[dof] - vals[t];
     if (!jacobian) return;
-    const int vtx = dof / neq, cr = dof % neq;
     const int slice = vtx >> 6, lane = vtx & 63;
-    const int neq2 = neq * neq;
     for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc)
         for (int cc = 0; cc < neq; ++cc)
             val[((size_t)bc * neq2 + cr * neq + cc) * SLICE + lane] = 0.0;
@@ -422,14 +441,18 @@ __global__ void identity_rows_kernel(int nv, int nvp, int neq, int ns_frozen,
 
 void launch_finalize(Ctx &c, bool jacobian, int mode) {
     const int ns_frozen = (mode == 1) ? c.ns : 0;
-    if (c.nvp > c.n_owned || ns_frozen > 0)  // padding + ghost vertices, frozen species
+    int n_id = c.nvp - c.n_owned;  // padding + ghost vertices
+    if (ns_frozen > 0) {           // frozen species: every vertex has identity rows
         hipLaunchKernelGGL(identity_rows_kernel, dim3((c.nvp + 255) / 256), dim3(256), 0, c.stream,
                            c.n_owned, c.nvp, c.neq, ns_frozen, c.d_F, c.d_val, c.d_slice_boff,
                            c.d_diag_slot, jacobian ? 1 : 0);
-    if (c.n_dir > 0)
-        hipLaunchKernelGGL(dirichlet_kernel, dim3((c.n_dir + 255) / 256), dim3(256), 0, c.stream,
+        n_id = 0;
+    }
+    // (Dirichlet dofs of ghost vertices are left to the identity branch: the row sets are disjoint)
+    if (c.n_dir + n_id > 0)
+        hipLaunchKernelGGL(dirichlet_kernel, dim3((c.n_dir + n_id + 255) / 256), dim3(256), 0, c.stream,
                            c.n_dir, c.d_dir_dofs, c.d_dir_vals, c.d_u, c.d_F, c.d_val,
-                           c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.neq, jacobian ? 1 : 0);
+                           c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.neq, jacobian ? 1 : 0, c.n_owned, n_id);
 }
 
 __global__ void set_dirichlet_state_kernel(int n_dir, const int *__restrict__ dofs,
