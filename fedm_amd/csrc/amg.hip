@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
     const bool writer = (lane & ((1 << log2_split) - 1)) == 0 && r < (size_t)n_rows;
     double e_b = 0.0, e_d = 0.0, e_x = 0.0;  // epilogue operands of this row, loaded up front
     if (writer) {
-        if (MODE == 1 || MODE == 2 || MODE == 4) e_b = b[r];
-        if (MODE == 2 || MODE == 4) e_d = dinv[r];
+        if (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5) e_b = b[r];
+        if (MODE == 2 || MODE == 4 || MODE == 5) e_d = dinv[r];
         if (MODE == 2) e_x = x[r];
         if (MODE == 3) e_x = y[r];
     }
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
     if (MODE == 1) y[r] = e_b - acc;
     if (MODE == 2) y[r * ystride + yoff] = e_x + omega * e_d * (e_b - acc);  // strided: see Amg::out
     if (MODE == 3) y[r] = e_x + acc;
+    if (MODE == 5) y[r] = omega * e_d * e_b + acc;
     if (MODE == 4) {
         y[r] = e_b - acc;
         aux[r] = omega * e_d * e_b;
@@ -164,16 +165,19 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
 }
 
 static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const double *b,
-                       double *y, double omega, double *aux = nullptr, int ystride = 1, int yoff = 0) {
+                       double *y, double omega, double *aux = nullptr, int ystride = 1, int yoff = 0,
+                       const double *dinv = nullptr /* default: the matrix's own */) {
     const dim3 g((A.n_slices + 3) / 4), bl(256);
+    if (!dinv) dinv = A.dinv;
 #define FEDM_ELL(M)                                                                                  \
     hipLaunchKernelGGL(ell_spmv_kernel<M>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split,   \
-                       A.width, A.boff, A.col, A.val, A.dinv, x, b, y, omega, aux, ystride, yoff)
+                       A.width, A.boff, A.col, A.val, dinv, x, b, y, omega, aux, ystride, yoff)
     switch (mode) {
         case 0: FEDM_ELL(0); break;
         case 1: FEDM_ELL(1); break;
         case 2: FEDM_ELL(2); break;
         case 3: FEDM_ELL(3); break;
+        case 5: FEDM_ELL(5); break;
         default: FEDM_ELL(4); break;
     }
 #undef FEDM_ELL
@@ -274,7 +278,10 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
     // the iterate (before the post-smoothing) come from their owners.
     const bool exact0 = l == 0 && global && c.comm && !c.capturing;
     if (exact0 && down) comm_halo_scalar(c, L.b);
-    if (nu == 1) {
+    const bool dc = L.down_composite && nu == 1;
+    if (dc) {
+        if (down) ell_launch(c, L.C, 0, L.b, nullptr, levels[l + 1].b, 0.0);  // b_c = R (b - A w Dinv b)
+    } else if (nu == 1) {
         if (down) ell_launch(c, L.A, 4, nullptr, L.b, L.r, omega, x);    // x = w Dinv b;  r = b - A x
     } else {
         if (down)
@@ -286,10 +293,11 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
         }
         if (down) ell_launch(c, L.A, 1, x, L.b, L.r, 0.0);               // r = b - A x
     }
-    if (down) ell_launch(c, L.R, 0, L.r, nullptr, levels[l + 1].b, 0.0);  // b_c = R r
+    if (down && !dc) ell_launch(c, L.R, 0, L.r, nullptr, levels[l + 1].b, 0.0);  // b_c = R r
     vcycle(c, l + 1, phase);
     if (!up) return;
-    ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c
+    if (dc) ell_launch(c, L.P, 5, levels[l + 1].x, L.b, x, omega, nullptr, 1, 0, L.A.dinv);  // x = w Dinv b + P x_c
+    else ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c
     for (int s = 0; s < nu; ++s) {
         if (exact0) comm_halo_scalar(c, x);
         if (l == 0 && s == nu - 1 && out) {
@@ -516,7 +524,6 @@ __device__ __forceinline__ void invert_species_block(double (&A)[NS][NS], double
 // every sweep reads; the iterate then ping-pongs between z and the scratch vector so that the last
 // sweep writes z.  Without sweeps the first stage writes z itself.
 static double *fs_first_target(Ctx &c, double *z) { return c.fs_sweeps > 1 ? c.d_fs_g : z; }
-static double fs_first_weight(Ctx &c) { return 1.0; }
 
 // stages after the first: remaining species sweeps, coupling, V-cycle on the potential block
 template <int NS>
@@ -543,7 +550,7 @@ template <int NS>
 static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter, bool with_cycle) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
-                       amg.levels[0].b, alpha, fs_first_weight(c));
+                       amg.levels[0].b, alpha, 1.0);
     fs_finish_t<NS>(c, amg, z, scatter, with_cycle);
 }
 
@@ -571,7 +578,7 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
 // z = Minv (J v): the SpMV's epilogue is the first stage (t = J v is kept for the sweeps)
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter) {
     prof_begin(c, 1);
-    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, fs_first_weight(c));
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, 1.0);
     prof_end(c);
     switch (c.ns) {
         case 1: fs_finish_t<1>(c, amg, z, scatter); break;
@@ -584,7 +591,7 @@ void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, dou
 
 void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter,
                                     int part, const int *slices, int n_slices) {
-    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, fs_first_weight(c), slices, n_slices);
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, 1.0, slices, n_slices);
     if (part == 0) return;
     const bool cyc = part == 1;  // part 2: stop after the coupling product (amg.levels[0].b is ready)
     switch (c.ns) {

@@ -33,6 +33,10 @@ struct Amg {
         // n_rows_p + (rows of the next level) entries and the next level's x is its tail.
         EllMat C, GQ;
         bool composite = false;
+        // finest level of a single-GPU hierarchy: only the leg down is composite (b_c = C b, 30 MB
+        // instead of the 55 MB of first sweep + residual + restriction); the leg up keeps
+        // prolongation and sweep, the prolongation kernel forming x = w Dinv b + P x_c itself
+        bool down_composite = false;
         bool x_is_alias = false;   // x points into the previous level's b
     };
     std::vector<Level> levels;
@@ -62,7 +66,8 @@ struct Amg {
     void release();
 };
 
-// y = A x (mode 0), b - A x (1), Jacobi sweep (2), y += A x (3), fused first sweep + residual (4)
+// y = A x (mode 0), b - A x (1), Jacobi sweep (2), y += A x (3), fused first sweep + residual (4),
+// y = w Dinv b + A x (5)
 void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double *b, double *y,
                double omega, double *aux = nullptr);
 void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv

@@ -569,7 +569,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             if (!done) {  // recompute the true (preconditioned, on the left) residual for the report
                 if (right) plain_operator(c.d_delta, c.d_w);
                 else apply_operator(c, c.d_delta, c.d_w);
-                launch_axpy(c, -1.0, c.d_rhs, c.d_w);
+                launch_axpy(c, -bscale, bvec, c.d_w);
                 launch_norm2(c, c.d_w, 0);
                 read_red(c, 1);
                 rnorm = std::sqrt(c.h_red[0]);
@@ -1619,7 +1619,23 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
         } else if (l + 1 < n_levels) {
             rc |= L.A.from_csr(A[l], true);
             rc |= L.P.from_csr(P[l], false);
-            rc |= L.R.from_csr(R[l], false);
+            // single-GPU hierarchy (its coarsest level is solved here): the finest level's leg down
+            // as one product; across GPUs that level is a distributed operator with halo exchanges
+            L.down_composite = composite_ok && l == 0 && composite_from == 1 && coarse_inverse && nu == 1;
+            if (L.down_composite) {
+                const int n = A[l].n_rows;
+                std::vector<double> wd((size_t)n, omega);
+                for (int i = 0; i < n; ++i)
+                    for (int64_t k = A[l].indptr[i]; k < A[l].indptr[i + 1]; ++k)
+                        if (A[l].indices[k] == i && A[l].values[k] != 0.0) wd[i] = omega / A[l].values[k];
+                const HostCsr I = csr_identity(n);
+                const HostCsr M1 = csr_product(A[l], wd.data(), I.view(), 1.0);
+                const HostCsr T = csr_combine(I.view(), 1.0, M1.view(), -1.0, 0, n, nullptr);
+                const HostCsr Cm = csr_product(R[l], nullptr, T.view(), 1.0);
+                rc |= L.C.from_csr(Cm.view(), false);
+            } else {
+                rc |= L.R.from_csr(R[l], false);
+            }
         } else {
             L.A.n_rows = A[l].n_rows;
             L.A.n_rows_p = ((A[l].n_rows + SLICE - 1) / SLICE) * SLICE;
