@@ -164,7 +164,7 @@ int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab
 int gd_prep_step(Ctx &c);
 void gd_update_mean_energy(Ctx &c);
 void gd_prep_release(Ctx &c);
-size_t patch_lds_bytes(const Ctx &c);
+size_t patch_lds_bytes(const Ctx &c, bool jacobian = true);
 void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + padding rows
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks
 void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int *slice_list = nullptr,

@@ -125,16 +125,20 @@ extern "C" void fedm_debug_phase(unsigned long long *out, int reset) {
 // wave per SIMD is 1.5x slower) should a compiler change push it over 256.
 // THREADS: workgroup size = the patch's cell count rounded up (192 for Z-ordered meshes: two
 // 3-wave workgroups per CU at 2 waves/SIMD keep 6 waves busy; 320 covers 1-D strips)
-template <int NS, bool PO, int NR, int CACHE, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void assemble_patch_kernel(
+// JAC = false is the residual-only assembly (final Newton check): without the Jacobian code it
+// needs about half the registers and no accumulators, so it is compiled as a kernel of its own
+// that the compiler may run at a higher occupancy.
+template <int NS, bool PO, int NR, int CACHE, int THREADS, bool JAC>
+__device__ __forceinline__ void assemble_patch_body(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
     const int *__restrict__ halo_ptr, const int *__restrict__ halo,
     const double *__restrict__ coords, const double *__restrict__ u,
     const double *__restrict__ uold, const double *__restrict__ uold1, StepCoef sc,
     const double *ext0, const double *ext1, const double *ext2, const double *ext3,
-    double *__restrict__ val, double *__restrict__ F, int jacobian, int mode, int acc_doubles,
+    double *__restrict__ val, double *__restrict__ F, int mode, int acc_doubles,
     int max_verts) {
+    constexpr bool jacobian = JAC;
     constexpr int NEQ = NS + (PO ? 1 : 0);
     constexpr int NEQ2 = NEQ * NEQ;
     extern __shared__ __align__(16) double lds[];
@@ -232,26 +236,56 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
     FEDM_T(7)
 }
 
-size_t patch_lds_bytes(const Ctx &c) {
+#define FEDM_PATCH_PARAMS                                                                          \
+    const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,                  \
+        const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,                    \
+        const int *__restrict__ halo_ptr, const int *__restrict__ halo,                            \
+        const double *__restrict__ coords, const double *__restrict__ u,                           \
+        const double *__restrict__ uold, const double *__restrict__ uold1, StepCoef sc,            \
+        const double *ext0, const double *ext1, const double *ext2, const double *ext3,            \
+        double *__restrict__ val, double *__restrict__ F, int mode, int acc_doubles, int max_verts
+#define FEDM_PATCH_ARGS                                                                            \
+    md, nv, boff, cell_ptr, pcells, halo_ptr, halo, coords, u, uold, uold1, sc, ext0, ext1, ext2,  \
+        ext3, val, F, mode, acc_doubles, max_verts
+
+template <int NS, bool PO, int NR, int CACHE, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void assemble_patch_kernel(
+    FEDM_PATCH_PARAMS) {
+    assemble_patch_body<NS, PO, NR, CACHE, THREADS, true>(FEDM_PATCH_ARGS);
+}
+
+template <int NS, bool PO, int NR, int CACHE, int THREADS>
+__global__ __launch_bounds__(THREADS) void residual_patch_kernel(FEDM_PATCH_PARAMS) {
+    assemble_patch_body<NS, PO, NR, CACHE, THREADS, false>(FEDM_PATCH_ARGS);
+}
+#undef FEDM_PATCH_PARAMS
+#undef FEDM_PATCH_ARGS
+
+size_t patch_lds_bytes(const Ctx &c, bool jacobian) {
     const int neq = c.neq, mv = c.pat.max_patch_verts;
-    return sizeof(double) * ((size_t)c.pat.max_patch_width * neq * neq * SLICE + SLICE * neq +
-                             2 * mv + (size_t)(neq + c.ns) * mv);
+    const size_t acc = jacobian ? (size_t)c.pat.max_patch_width * neq * neq * SLICE : 0;
+    return sizeof(double) * (acc + SLICE * neq + 2 * mv + (size_t)(neq + c.ns) * mv);
 }
 
 template <int NS, bool PO, int NR, int CACHE>
 static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     const StepCoef sc = step_coef(c.dt, c.dt_old);
-    const int acc_doubles = c.pat.max_patch_width * NEQ * NEQ * SLICE;
-#define FEDM_PATCH_LAUNCH(T)                                                                      \
-    hipLaunchKernelGGL((assemble_patch_kernel<NS, PO, NR, CACHE, T>), dim3(c.pat.n_slices), dim3(T), \
-                       patch_lds_bytes(c), c.stream, c.d_model, c.nv, c.d_slice_boff,               \
-                       c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr, c.d_patch_halo,     \
-                       c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],          \
-                       c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, jacobian ? 1 : 0, mode, acc_doubles, \
+    const int acc_doubles = jacobian ? c.pat.max_patch_width * NEQ * NEQ * SLICE : 0;
+#define FEDM_PATCH_LAUNCH(KERNEL, T)                                                              \
+    hipLaunchKernelGGL((KERNEL<NS, PO, NR, CACHE, T>), dim3(c.pat.n_slices), dim3(T),              \
+                       patch_lds_bytes(c, jacobian), c.stream, c.d_model, c.nv, c.d_slice_boff,    \
+                       c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr, c.d_patch_halo,    \
+                       c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],         \
+                       c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_doubles,                  \
                        c.pat.max_patch_verts)
-    if (c.pat.max_patch_cells <= 192) FEDM_PATCH_LAUNCH(192);
-    else FEDM_PATCH_LAUNCH(320);
+    if (jacobian) {
+        if (c.pat.max_patch_cells <= 192) FEDM_PATCH_LAUNCH(assemble_patch_kernel, 192);
+        else FEDM_PATCH_LAUNCH(assemble_patch_kernel, 320);
+    } else {
+        if (c.pat.max_patch_cells <= 192) FEDM_PATCH_LAUNCH(residual_patch_kernel, 192);
+        else FEDM_PATCH_LAUNCH(residual_patch_kernel, 320);
+    }
 #undef FEDM_PATCH_LAUNCH
 }
 
