@@ -909,6 +909,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         // (glow discharge, 402k DOFs: 70 against 100 steps per time step).  FEDM_PRECOND_SIDE or
         // fedm_set_preconditioner_side override.
         c.right_precond = c.model_kind == 0;
+        if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] != '0';
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;
         if (side && std::string(side) == "right") c.right_precond = true;

@@ -82,6 +82,7 @@ struct Ctx {
     bool poisson = false;
     int64_t n = 0, np = 0;  // nv*neq, nvp*neq
     fedm_model_desc model{};
+    bool assembly_lean = true;  // F + J patches through element_lean.hpp where it applies
     int model_kind = 0;  // 0: LFA family (fedm_model_desc), 1: LMEA family (fedm_gd_desc)
     fedm_gd_desc gd{};
     fedm_gd_desc *d_gd = nullptr;

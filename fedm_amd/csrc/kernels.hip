@@ -7,6 +7,7 @@
 
 #include "comm.hpp"
 #include "element.hpp"
+#include "element_lean.hpp"
 #include "fedm_internal.hpp"
 
 namespace fedm {
@@ -128,7 +129,7 @@ extern "C" void fedm_debug_phase(unsigned long long *out, int reset) {
 // JAC = false is the residual-only assembly (final Newton check): without the Jacobian code it
 // needs about half the registers and no accumulators, so it is compiled as a kernel of its own
 // that the compiler may run at a higher occupancy.
-template <int NS, bool PO, int NR, int CACHE, int THREADS, bool JAC>
+template <int NS, bool PO, int NR, int CACHE, int THREADS, bool JAC, bool LEAN = false>
 __device__ __forceinline__ void assemble_patch_body(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
@@ -180,6 +181,11 @@ __device__ __forceinline__ void assemble_patch_body(
     const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
     for (int i = threadIdx.x; i < n_cells; i += blockDim.x) {
         const PatchCell pc = pcells[c0 + i];
+        if constexpr (LEAN) {  // one row's state at a time (element_lean.hpp)
+            double *nql = Hl + NS * max_verts;  // [3 * NS][THREADS] after the staging arrays
+            lean_cell<NS, NR>(md, pc, vx, Ul, Hl, sc, acc, Fl, nql + threadIdx.x, THREADS);
+            continue;
+        }
         double x[3][2], Uc[3][NEQ], Hc[3][NS];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -258,6 +264,13 @@ template <int NS, bool PO, int NR, int CACHE, int THREADS>
 __global__ __launch_bounds__(THREADS) void residual_patch_kernel(FEDM_PATCH_PARAMS) {
     assemble_patch_body<NS, PO, NR, CACHE, THREADS, false>(FEDM_PATCH_ARGS);
 }
+
+// F + J with the lean cell routine: three workgroups per CU
+template <int NS, int NR, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void assemble_lean_kernel(
+    FEDM_PATCH_PARAMS) {
+    assemble_patch_body<NS, true, NR, 2, THREADS, true, true>(FEDM_PATCH_ARGS);
+}
 #undef FEDM_PATCH_PARAMS
 #undef FEDM_PATCH_ARGS
 
@@ -279,6 +292,19 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
                        c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],         \
                        c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_doubles,                  \
                        c.pat.max_patch_verts)
+    if constexpr (PO && CACHE == 2 && NS >= 1) {
+        bool ext = false;
+        for (int s_ = 0; s_ < NS; ++s_) ext = ext || c.model.ext_nodes[s_] > 0;
+        if (jacobian && mode == 0 && !ext && c.assembly_lean && c.pat.max_patch_cells <= 192) {
+            hipLaunchKernelGGL((assemble_lean_kernel<NS, NR, 192>), dim3(c.pat.n_slices), dim3(192),
+                               patch_lds_bytes(c, true) + sizeof(double) * 3 * NS * 192, c.stream, c.d_model,
+                               c.nv, c.d_slice_boff, c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr,
+                               c.d_patch_halo, c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0],
+                               c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_doubles,
+                               c.pat.max_patch_verts);
+            return;
+        }
+    }
     if (jacobian) {
         if (c.pat.max_patch_cells <= 192) FEDM_PATCH_LAUNCH(assemble_patch_kernel, 192);
         else FEDM_PATCH_LAUNCH(assemble_patch_kernel, 320);
