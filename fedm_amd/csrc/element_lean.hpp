@@ -18,6 +18,61 @@ __device__ __forceinline__ double pick(const double (&v)[NS], int s) {
     return r;
 }
 
+template <int NS>
+__device__ __forceinline__ void poisson_row(const fedm_model_desc *__restrict__ md, const double (&G)[3][2],
+                                            const double (&W)[3], const double (&E)[2], const int (&lv)[3],
+                                            int wj0, int wj1, int wj2, const double *__restrict__ nql,
+                                            int nq_stride, double *__restrict__ acc, double *__restrict__ Fl) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, IPHI = NS;
+
+        double m2[NS][6], m1h[3] = {0.0, 0.0, 0.0}, m01 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m2[i][k] = 0.0;
+        const double coe = md->charge_over_eps;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double h = 0.0, g[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double cz = md->Z[i] * nql[(q * NS + i) * nq_stride] * coe;
+                h -= cz;
+                g[i] = -cz;
+            }
+            const double Wq = W[q];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double pa = Wq * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
+                m1h[a] += pa * h;
+#pragma unroll
+                for (int b = a; b < 3; ++b) {
+                    const double pp = pa * (b == q ? 2.0 / 3.0 : 1.0 / 6.0);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) m2[i][sym6(a, b)] += pp * g[i];
+                }
+            }
+            m01 += Wq;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int lane = lv[a];
+            if (lane >= SLICE) continue;
+            unsafeAtomicAdd(&Fl[lane * NEQ + IPHI], m1h[a] - (E[0] * G[a][0] + E[1] * G[a][1]) * m01);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int k = sym6(a, b);
+                const double ggk = G[a][0] * G[b][0] + G[a][1] * G[b][1];
+                const int e = a * 3 + b;
+                const int jab = ((e < 4 ? wj0 : e < 8 ? wj1 : wj2) >> (8 * (e & 3))) & 255;
+                double *dst = acc + ((size_t)jab * NEQ2 + IPHI * NEQ) * SLICE + lane;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) unsafeAtomicAdd(&dst[i * SLICE], m2[i][k]);
+                unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
+            }
+        }
+    }
+
 // one cell of a patch: residual and Jacobian rows of the vertices this patch owns (local id < 64)
 // accumulated into Fl [64][NEQ] and acc [bc][NEQ2][64] with LDS atomics
 template <int NS, int NR>
@@ -37,76 +92,81 @@ __device__ __forceinline__ void lean_cell(const fedm_model_desc *__restrict__ md
     int wj2 = pc.j[8];
     const int l0 = wl & 255, l1 = (wl >> 8) & 255, l2 = (wl >> 16) & 255;
     int lv[3] = {l0, l1, l2};
-    // geometry
-    double G[3][2], W[3];
-    {
-        double x[3][2];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            x[a][0] = vx[2 * lv[a]];
-            x[a][1] = vx[2 * lv[a] + 1];
-        }
-        CellGeom cg;
-        cg.init(x, md->axisymmetric);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            G[a][0] = cg.G[a][0];
-            G[a][1] = cg.G[a][1];
-        }
-        // quadrature weights times 2 pi r: points (1/6,1/6), (2/3,1/6), (1/6,2/3) -> the basis
-        // function values at point q are 2/3 for vertex q and 1/6 for the other two
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double rq = 0.0;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) rq += cg.rn[a] * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
-            W[q] = (1.0 / 6.0) * cg.detJ * two_pi * rq;
-        }
-    }
-    // field
-    double gradPhi[2] = {0.0, 0.0};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double p = Ul[lv[a] * NEQ + IPHI];
-        gradPhi[0] += p * G[a][0];
-        gradPhi[1] += p * G[a][1];
-    }
-    double E[2] = {-gradPhi[0], -gradPhi[1]};
-    const double Em = sqrt(E[0] * E[0] + E[1] * E[1]);
-    double invEm = 1.0 / Em;
-    const double lnE = log(Em);
-    // rate coefficients and exp(u) at the quadrature points (all species: the sources couple them)
-    const int nreac = md->n_reactions;
-    double kv[NR], kd[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        kv[j] = kd[j] = 0.0;
-        if (j < nreac) termsum_eval(md->k[j], Em, invEm, lnE, kv[j], kd[j]);
-    }
     // exp(u) of every species at the three points: parked in a per-thread LDS column (6 doubles
     // that would otherwise be live across every row)
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const double u0 = Ul[l0 * NEQ + i], u1 = Ul[l1 * NEQ + i], u2 = Ul[l2 * NEQ + i];
         const double sum6 = (u0 + u1 + u2) * (1.0 / 6.0);
+        // (one exp at a time: six interleaved ones cost 100 registers)
+        __builtin_amdgcn_sched_barrier(0);
         nql[(0 * NS + i) * nq_stride] = exp(sum6 + 0.5 * u0);
+        __builtin_amdgcn_sched_barrier(0);
         nql[(1 * NS + i) * nq_stride] = exp(sum6 + 0.5 * u1);
+        __builtin_amdgcn_sched_barrier(0);
         nql[(2 * NS + i) * nq_stride] = exp(sum6 + 0.5 * u2);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- species rows -----------------------------------------------------------------------
+    // ---- one equation row per pass; nothing but the packed indices lives across passes: the
+    // geometry, the field and the rate coefficients are recomputed from the LDS staging area
+    // (a few dozen instructions) instead of occupying registers through every row ---------------
 #pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
-        // The geometry, the field and the weights pass through an empty asm in every pass (same
-        // registers, no instruction): the row-independent products below (G_a.G_b, E.G_a, W_q/6)
-        // are then not loop invariants, which keeps the compiler from hoisting two dozen of them
-        // out of the loop -- and from spilling them to make room for the row.
-#pragma unroll
-        for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(G[a][0]), "+v"(G[a][1]), "+v"(W[a]));
-        asm volatile("" : "+v"(E[0]), "+v"(E[1]), "+v"(invEm));
+    for (int row = 0; row < NEQ; ++row) {
         asm volatile("" : "+v"(wl), "+v"(wj0), "+v"(wj1), "+v"(wj2));
 #pragma unroll
         for (int a = 0; a < 3; ++a) lv[a] = (wl >> (8 * a)) & 255;
+        // geometry
+        double G[3][2], W[3];
+        {
+            double x[3][2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                x[a][0] = vx[2 * lv[a]];
+                x[a][1] = vx[2 * lv[a] + 1];
+            }
+            CellGeom cg;
+            cg.init(x, md->axisymmetric);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                G[a][0] = cg.G[a][0];
+                G[a][1] = cg.G[a][1];
+            }
+            // quadrature weights times 2 pi r: points (1/6,1/6), (2/3,1/6), (1/6,2/3) -> the basis
+            // function values at point q are 2/3 for vertex q and 1/6 for the other two
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                double rq = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) rq += cg.rn[a] * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
+                W[q] = (1.0 / 6.0) * cg.detJ * two_pi * rq;
+            }
+        }
+        // field
+        double gradPhi[2] = {0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double p = Ul[lv[a] * NEQ + IPHI];
+            gradPhi[0] += p * G[a][0];
+            gradPhi[1] += p * G[a][1];
+        }
+        double E[2] = {-gradPhi[0], -gradPhi[1]};
+        const double Em = sqrt(E[0] * E[0] + E[1] * E[1]);
+        double invEm = 1.0 / Em;
+        const double lnE = log(Em);
+        if (row == NS) {
+            poisson_row<NS>(md, G, W, E, lv, wj0, wj1, wj2, nql, nq_stride, acc, Fl);
+            continue;
+        }
+        const int s = row;
+        // rate coefficients (the sources couple the species)
+        const int nreac = md->n_reactions;
+        double kv[NR], kd[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            kv[j] = kd[j] = 0.0;
+            if (j < nreac) termsum_eval(md->k[j], Em, invEm, lnE, kv[j], kd[j]);
+        }
         double Us[3], Hs[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -230,55 +290,6 @@ __device__ __forceinline__ void lean_cell(const fedm_model_desc *__restrict__ md
         }
     }
 
-    // ---- Poisson row -------------------------------------------------------------------------
-    {
-        double m2[NS][6], m1h[3] = {0.0, 0.0, 0.0}, m01 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) m2[i][k] = 0.0;
-        const double coe = md->charge_over_eps;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double h = 0.0, g[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const double cz = md->Z[i] * nql[(q * NS + i) * nq_stride] * coe;
-                h -= cz;
-                g[i] = -cz;
-            }
-            const double Wq = W[q];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double pa = Wq * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
-                m1h[a] += pa * h;
-#pragma unroll
-                for (int b = a; b < 3; ++b) {
-                    const double pp = pa * (b == q ? 2.0 / 3.0 : 1.0 / 6.0);
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) m2[i][sym6(a, b)] += pp * g[i];
-                }
-            }
-            m01 += Wq;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int lane = lv[a];
-            if (lane >= SLICE) continue;
-            unsafeAtomicAdd(&Fl[lane * NEQ + IPHI], m1h[a] - (E[0] * G[a][0] + E[1] * G[a][1]) * m01);
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int k = sym6(a, b);
-                const double ggk = G[a][0] * G[b][0] + G[a][1] * G[b][1];
-                const int e = a * 3 + b;
-                const int jab = ((e < 4 ? wj0 : e < 8 ? wj1 : wj2) >> (8 * (e & 3))) & 255;
-                double *dst = acc + ((size_t)jab * NEQ2 + IPHI * NEQ) * SLICE + lane;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) unsafeAtomicAdd(&dst[i * SLICE], m2[i][k]);
-                unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
-            }
-        }
-    }
 }
 
 }  // namespace fedm

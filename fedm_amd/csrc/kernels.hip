@@ -267,7 +267,7 @@ __global__ __launch_bounds__(THREADS) void residual_patch_kernel(FEDM_PATCH_PARA
 
 // F + J with the lean cell routine: three workgroups per CU
 template <int NS, int NR, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void assemble_lean_kernel(
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void assemble_lean_kernel(
     FEDM_PATCH_PARAMS) {
     assemble_patch_body<NS, true, NR, 2, THREADS, true, true>(FEDM_PATCH_ARGS);
 }
