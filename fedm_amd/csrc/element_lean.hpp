@@ -23,8 +23,7 @@ __device__ __forceinline__ void poisson_row(const fedm_model_desc *__restrict__ 
                                             const double (&W)[3], const double (&E)[2], const int (&lv)[3],
                                             int wj0, int wj1, int wj2, const double *__restrict__ nql,
                                             int nq_stride, double *__restrict__ acc, double *__restrict__ Fl) {
-    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, IPHI = NS;
-
+    constexpr int NEQ = NS + 1, IPHI = NS;
         double m2[NS][6], m1h[3] = {0.0, 0.0, 0.0}, m01 = 0.0;
 #pragma unroll
         for (int i = 0; i < NS; ++i)
@@ -65,7 +64,7 @@ __device__ __forceinline__ void poisson_row(const fedm_model_desc *__restrict__ 
                 const double ggk = G[a][0] * G[b][0] + G[a][1] * G[b][1];
                 const int e = a * 3 + b;
                 const int jab = ((e < 4 ? wj0 : e < 8 ? wj1 : wj2) >> (8 * (e & 3))) & 255;
-                double *dst = acc + ((size_t)jab * NEQ2 + IPHI * NEQ) * SLICE + lane;
+                double *dst = acc + (size_t)jab * NEQ * SLICE + lane;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) unsafeAtomicAdd(&dst[i * SLICE], m2[i][k]);
                 unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
@@ -73,27 +72,24 @@ __device__ __forceinline__ void poisson_row(const fedm_model_desc *__restrict__ 
         }
     }
 
-// one cell of a patch: residual and Jacobian rows of the vertices this patch owns (local id < 64)
-// accumulated into Fl [64][NEQ] and acc [bc][NEQ2][64] with LDS atomics
-template <int NS, int NR>
-__device__ __forceinline__ void lean_cell(const fedm_model_desc *__restrict__ md, const PatchCell &pc,
-                                          const double *__restrict__ vx, const double *__restrict__ Ul,
-                                          const double *__restrict__ Hl, const StepCoef sc,
-                                          double *__restrict__ acc, double *__restrict__ Fl,
-                                          double *__restrict__ nql /* [3*NS][threads] + this thread */,
-                                          int nq_stride) {
-    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, IPHI = NS;
-    const double two_pi = 6.283185307179586476925286766559;
-    // local vertex ids and block columns as packed words: unpacked where they are used, so that the
-    // LDS addresses derived from them are row-local values, not two dozen loop invariants
-    int wl = pc.lv[0] | (pc.lv[1] << 8) | (pc.lv[2] << 16);
-    int wj0 = pc.j[0] | (pc.j[1] << 8) | (pc.j[2] << 16) | (pc.j[3] << 24);
-    int wj1 = pc.j[4] | (pc.j[5] << 8) | (pc.j[6] << 16) | (pc.j[7] << 24);
-    int wj2 = pc.j[8];
-    const int l0 = wl & 255, l1 = (wl >> 8) & 255, l2 = (wl >> 16) & 255;
-    int lv[3] = {l0, l1, l2};
-    // exp(u) of every species at the three points: parked in a per-thread LDS column (6 doubles
-    // that would otherwise be live across every row)
+// The packed indices of a cell (local vertex ids, block columns) are all that a thread keeps in
+// registers between equation rows.
+struct LeanCell {
+    int wl, wj0, wj1, wj2;
+};
+
+// once per cell: pack the indices; exp(u) of every species at the three quadrature points goes to
+// a per-thread LDS column (6 doubles that would otherwise be live across every row)
+template <int NS>
+__device__ __forceinline__ LeanCell lean_prologue(const PatchCell &pc, const double *__restrict__ Ul,
+                                                  double *__restrict__ nql, int nq_stride) {
+    constexpr int NEQ = NS + 1;
+    LeanCell lc;
+    lc.wl = pc.lv[0] | (pc.lv[1] << 8) | (pc.lv[2] << 16);
+    lc.wj0 = pc.j[0] | (pc.j[1] << 8) | (pc.j[2] << 16) | (pc.j[3] << 24);
+    lc.wj1 = pc.j[4] | (pc.j[5] << 8) | (pc.j[6] << 16) | (pc.j[7] << 24);
+    lc.wj2 = pc.j[8];
+    const int l0 = pc.lv[0], l1 = pc.lv[1], l2 = pc.lv[2];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const double u0 = Ul[l0 * NEQ + i], u1 = Ul[l1 * NEQ + i], u2 = Ul[l2 * NEQ + i];
@@ -107,13 +103,25 @@ __device__ __forceinline__ void lean_cell(const fedm_model_desc *__restrict__ md
         nql[(2 * NS + i) * nq_stride] = exp(sum6 + 0.5 * u2);
         __builtin_amdgcn_sched_barrier(0);
     }
+    return lc;
+}
 
-    // ---- one equation row per pass; nothing but the packed indices lives across passes: the
-    // geometry, the field and the rate coefficients are recomputed from the LDS staging area
-    // (a few dozen instructions) instead of occupying registers through every row ---------------
-#pragma unroll 1
-    for (int row = 0; row < NEQ; ++row) {
-        asm volatile("" : "+v"(wl), "+v"(wj0), "+v"(wj1), "+v"(wj2));
+// One equation row of one cell: residual and Jacobian entries of the row's vertices that this
+// patch owns (local id < 64), accumulated with LDS atomics into Fl [64][NEQ] and into the ROW's
+// accumulators acc [block column][NEQ][64].  Everything but the packed indices is recomputed
+// from the LDS staging area (geometry, field: a few dozen instructions), so nothing else
+// occupies registers from one row to the next.
+template <int NS, int NR>
+__device__ __forceinline__ void lean_row(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
+                                         const double *__restrict__ vx, const double *__restrict__ Ul,
+                                         const double *__restrict__ Hl, const StepCoef sc,
+                                         double *__restrict__ acc, double *__restrict__ Fl,
+                                         const double *__restrict__ nql, int nq_stride) {
+    constexpr int NEQ = NS + 1, IPHI = NS;
+    const double two_pi = 6.283185307179586476925286766559;
+    const int wl = lc.wl, wj0 = lc.wj0, wj1 = lc.wj1, wj2 = lc.wj2;
+    int lv[3];
+    {
 #pragma unroll
         for (int a = 0; a < 3; ++a) lv[a] = (wl >> (8 * a)) & 255;
         // geometry
@@ -156,7 +164,7 @@ __device__ __forceinline__ void lean_cell(const fedm_model_desc *__restrict__ md
         const double lnE = log(Em);
         if (row == NS) {
             poisson_row<NS>(md, G, W, E, lv, wj0, wj1, wj2, nql, nq_stride, acc, Fl);
-            continue;
+            return;
         }
         const int s = row;
         // rate coefficients (the sources couple the species)
@@ -281,7 +289,7 @@ __device__ __forceinline__ void lean_cell(const fedm_model_desc *__restrict__ md
                 const double dEb = -(E[0] * G[b][0] + E[1] * G[b][1]) * invEm;
                 const int e = a * 3 + b;
                 const int jab = ((e < 4 ? wj0 : e < 8 ? wj1 : wj2) >> (8 * (e & 3))) & 255;
-                double *dst = acc + ((size_t)jab * NEQ2 + s * NEQ) * SLICE + lane;
+                double *dst = acc + (size_t)jab * NEQ * SLICE + lane;
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
                     unsafeAtomicAdd(&dst[i * SLICE], m2[i][k] + ((i == s) ? DGm * ggk - velG[a] * m1n[b] : 0.0));

@@ -129,7 +129,7 @@ extern "C" void fedm_debug_phase(unsigned long long *out, int reset) {
 // JAC = false is the residual-only assembly (final Newton check): without the Jacobian code it
 // needs about half the registers and no accumulators, so it is compiled as a kernel of its own
 // that the compiler may run at a higher occupancy.
-template <int NS, bool PO, int NR, int CACHE, int THREADS, bool JAC, bool LEAN = false>
+template <int NS, bool PO, int NR, int CACHE, int THREADS, bool JAC>
 __device__ __forceinline__ void assemble_patch_body(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
@@ -181,11 +181,6 @@ __device__ __forceinline__ void assemble_patch_body(
     const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
     for (int i = threadIdx.x; i < n_cells; i += blockDim.x) {
         const PatchCell pc = pcells[c0 + i];
-        if constexpr (LEAN) {  // one row's state at a time (element_lean.hpp)
-            double *nql = Hl + NS * max_verts;  // [3 * NS][THREADS] after the staging arrays
-            lean_cell<NS, NR>(md, pc, vx, Ul, Hl, sc, acc, Fl, nql + threadIdx.x, THREADS);
-            continue;
-        }
         double x[3][2], Uc[3][NEQ], Hc[3][NS];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -265,11 +260,71 @@ __global__ __launch_bounds__(THREADS) void residual_patch_kernel(FEDM_PATCH_PARA
     assemble_patch_body<NS, PO, NR, CACHE, THREADS, false>(FEDM_PATCH_ARGS);
 }
 
-// F + J with the lean cell routine: three workgroups per CU
+// workgroup barrier that orders LDS accesses only: global stores issued before it stay in flight
+__device__ __forceinline__ void lds_only_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// F + J one equation row at a time (element_lean.hpp).  The rows are phases of the WORKGROUP: all
+// cells emit row r into accumulators that hold that row only (a third of the LDS), the row's
+// planes are streamed out, the next row follows.  168 VGPRs and 29 KB of LDS: four 3-wave
+// workgroups per CU (3 waves/SIMD) instead of two.
 template <int NS, int NR, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void assemble_lean_kernel(
     FEDM_PATCH_PARAMS) {
-    assemble_patch_body<NS, true, NR, 2, THREADS, true, true>(FEDM_PATCH_ARGS);
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    extern __shared__ __align__(16) double lds[];
+    double *acc = lds;                          // [width][NEQ][64]: one row of every block
+    double *Fl = acc + acc_doubles;             // [64][NEQ]
+    double *vx = Fl + SLICE * NEQ;              // [max_verts][2]
+    double *Ul = vx + 2 * max_verts;            // [max_verts][NEQ]
+    double *Hl = Ul + NEQ * max_verts;          // [max_verts][NS]
+    double *nql = Hl + NS * max_verts;          // [3 * NS][THREADS]
+    const int S = blockIdx.x;
+    const int b0 = boff[S], width = boff[S + 1] - b0;
+    const int n_acc = width * NEQ * SLICE;      // a multiple of 64: 16-byte LDS / HBM accesses
+    {
+        double2 *acc2 = reinterpret_cast<double2 *>(acc);
+        for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) acc2[k] = make_double2(0.0, 0.0);
+    }
+    for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) Fl[k] = 0.0;
+    const int h0 = halo_ptr[S], n_local = SLICE + halo_ptr[S + 1] - h0;
+    for (int i = threadIdx.x; i < n_local; i += THREADS) {
+        const int g = (i < SLICE) ? S * SLICE + i : halo[h0 + i - SLICE];
+        if (g < nv) {
+            vx[2 * i] = coords[2 * (size_t)g];
+            vx[2 * i + 1] = coords[2 * (size_t)g + 1];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) Ul[i * NEQ + s] = u[(size_t)g * NEQ + s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                Hl[i * NS + s] = sc.c_old * uold[(size_t)g * NEQ + s] + sc.c_old1 * uold1[(size_t)g * NEQ + s];
+        }
+    }
+    __syncthreads();
+    const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
+    const bool active = (int)threadIdx.x < n_cells;   // one cell per thread (n_cells <= THREADS)
+    LeanCell lc = {0, 0, 0, 0};
+    if (active) lc = lean_prologue<NS>(pcells[c0 + threadIdx.x], Ul, nql + threadIdx.x, THREADS);
+#pragma unroll 1
+    for (int row = 0; row < NEQ; ++row) {
+        asm volatile("" : "+v"(lc.wl), "+v"(lc.wj0), "+v"(lc.wj1), "+v"(lc.wj2));  // nothing hoisted out of the row
+        if (active) lean_row<NS, NR>(md, row, lc, vx, Ul, Hl, sc, acc, Fl, nql + threadIdx.x, THREADS);
+        __syncthreads();
+        // the row's planes of every block: NEQ * 64 consecutive doubles per block in HBM
+        for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
+            const int bc = k / (NEQ * SLICE / 2), rem = k - bc * (NEQ * SLICE / 2);
+            double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
+            double2 *src = reinterpret_cast<double2 *>(acc) + k;
+            dst[rem] = *src;
+            *src = make_double2(0.0, 0.0);
+        }
+        lds_only_barrier();   // accumulators zero again; the stores above stay in flight
+    }
+    double *fdst = F + (size_t)S * SLICE * NEQ;
+    for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) fdst[k] = Fl[k];
 }
 #undef FEDM_PATCH_PARAMS
 #undef FEDM_PATCH_ARGS
@@ -296,11 +351,13 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
         bool ext = false;
         for (int s_ = 0; s_ < NS; ++s_) ext = ext || c.model.ext_nodes[s_] > 0;
         if (jacobian && mode == 0 && !ext && c.assembly_lean && c.pat.max_patch_cells <= 192) {
-            hipLaunchKernelGGL((assemble_lean_kernel<NS, NR, 192>), dim3(c.pat.n_slices), dim3(192),
-                               patch_lds_bytes(c, true) + sizeof(double) * 3 * NS * 192, c.stream, c.d_model,
-                               c.nv, c.d_slice_boff, c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr,
-                               c.d_patch_halo, c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0],
-                               c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_doubles,
+            const int acc_row = c.pat.max_patch_width * NEQ * SLICE;
+            const size_t lds_bytes = sizeof(double) * ((size_t)acc_row + SLICE * NEQ + 2 * c.pat.max_patch_verts +
+                                                       (size_t)(NEQ + NS) * c.pat.max_patch_verts + 3 * NS * 192);
+            hipLaunchKernelGGL((assemble_lean_kernel<NS, NR, 192>), dim3(c.pat.n_slices), dim3(192), lds_bytes,
+                               c.stream, c.d_model, c.nv, c.d_slice_boff, c.d_patch_cell_ptr, c.d_patch_cells,
+                               c.d_patch_halo_ptr, c.d_patch_halo, c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc,
+                               c.d_ext[0], c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_row,
                                c.pat.max_patch_verts);
             return;
         }
