@@ -239,6 +239,67 @@ def test_composite_multigrid_levels_are_the_same_cycle(monkeypatch):
     assert np.allclose(out["0"][2], out["1"][2], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("three_species", [False, True])
+def test_row_at_a_time_assembly_matches_the_unrolled_element(monkeypatch, three_species):
+    """F + J patches run through element_lean.hpp (one equation row at a time, rows as workgroup
+    phases); FEDM_ASSEMBLY_LEAN=0 selects the unrolled element routine the oracle parity tests were
+    written against.  Two implementations of the same tensors: residual and Jacobian must agree to
+    rounding -- on the streamer model and on a model that exercises what the streamer does not
+    (three species, a species drifting with a constant velocity, a reaction that is a loss for two
+    species and a gain for the third, with a field-dependent rate)."""
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import DeviceProblem, Model, Reaction
+    from fedm_amd.mesh import Marking_boundaries, Mesh
+    from fedm_amd.termsum import TermSum, parse
+    msh = streamer.mesh(24, 2.0)
+    m = Mesh(msh.coords, msh.cells)
+    tags = Marking_boundaries(m, streamer.BOUNDARIES)
+    nv = m.coords.shape[0]
+    rng = np.random.default_rng(3)
+    x, y = m.coords[:, 0] / streamer.BOX, m.coords[:, 1] / streamer.BOX
+    if three_species:
+        mu = parse(streamer.MU_E)
+        ionisation = parse(streamer.ALPHA) * mu * TermSum.field()
+        model = Model(n_species=3, poisson=True,
+                      eq_type=["diffusion-reaction", "drift-diffusion-reaction", "drift-diffusion-reaction"],
+                      Z=[1.0, -1.0, -1.0], mu=[TermSum.const(0.0), mu, TermSum.const(0.0)],
+                      D=[TermSum.const(5e-4), parse(streamer.D_E), TermSum.const(2e-3)],
+                      reactions=[Reaction(ionisation * TermSum.const(1e-21), power=[1, 1, 0], net=[-1, -1, 1])],
+                      drift_w=[None, None, (1.0e3, -2.0e3)], quadrature_degree=2)
+        neq = 4
+    else:
+        model = streamer.model()
+        neq = 3
+    ddofs, dvals = streamer.dirichlet(m.coords)
+    ddofs = (ddofs // 3) * neq + (neq - 1)
+    U = np.zeros((nv, neq))
+    U[:, 0] = 30.0 + 2.0 * np.sin(5 * x) * np.cos(3 * y)
+    U[:, 1] = 28.0 + 3.0 * np.cos(4 * x) * np.sin(6 * y)
+    if three_species:
+        U[:, 2] = 25.0 + np.sin(3 * x + 2 * y)
+    U[:, neq - 1] = streamer.U_W * y + 50.0 * np.sin(3 * x) * np.sin(np.pi * y)
+    U0 = U + 0.01 * rng.standard_normal(U.shape)
+    U1 = U + 0.02 * rng.standard_normal(U.shape)
+    out = {}
+    for lean in ("1", "0"):
+        monkeypatch.setenv("FEDM_ASSEMBLY_LEAN", lean)
+        prob = DeviceProblem(m.coords, m.cells, model, facet_tags=tags if not three_species else None,
+                             dirichlet_dofs=ddofs.astype(np.int32), dirichlet_vals=dvals)
+        prob.set_state(U, U0, U1)
+        prob.set_step(5e-12, 4e-12)
+        prob.jacobian()
+        F, _ = prob.residual()
+        prob.jacobian()
+        out[lean] = (F, prob.jacobian_csr())
+        prob.close()
+    F1, J1 = out["1"]
+    F0, J0 = out["0"]
+    assert np.abs(F1 - F0).max() <= 1e-12 * np.abs(F0).max()
+    d = abs(J1 - J0)
+    rowmax = abs(J0).max(axis=1).toarray().ravel()
+    assert (d.max(axis=1).toarray().ravel() <= 1e-11 * rowmax + 1e-300).all()
+
+
 def test_preconditioner_side_left_and_right_agree():
     """The Newton systems are solved by flexible GMRES with the field split on the right (true
     residual norm) or, selectable, on the left (preconditioned residual norm).  Both solve
