@@ -470,23 +470,44 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         std::fill(gvec.begin(), gvec.end(), 0.0);
         gvec[0] = beta;
         int j = 0;
-        bool done = false;
+        bool done = false, ahead = false;
+        unsigned long long seq_ahead = 0;
         for (; j < m && its < max_it; ++j) {
             double *w = c.d_V + (size_t)(j + 1) * c.np;
             // classical Gram-Schmidt with ONE reduction and ONE host wait per iteration:
             // h_i = v_i.w and ww = w.w together; |w - V h|^2 = ww - |h|^2 on the device;
             // the update and the normalisation read their coefficients from device memory.
-            if (right) {
-                double *z = c.d_Z + (size_t)j * c.np;
-                if (!iter_graph_launch_right(c, j, vp.data(), z, w)) right_step_plain(c, j, vp.data(), z, w);
-            } else if (!iter_graph_launch(c, j, vp.data(), w)) {
-                apply_operator(c, vp[j], w);
-                for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
-                dotp[j + 1] = w;
-                launch_dots(c, dotp.data(), w, j + 2, true);
-                launch_cgs_update(c, j + 1, vp.data(), w);
+            auto launch_step = [&](int jj) {
+                double *ww = c.d_V + (size_t)(jj + 1) * c.np;
+                if (right) {
+                    double *z = c.d_Z + (size_t)jj * c.np;
+                    if (!iter_graph_launch_right(c, jj, vp.data(), z, ww)) right_step_plain(c, jj, vp.data(), z, ww);
+                } else if (!iter_graph_launch(c, jj, vp.data(), ww)) {
+                    apply_operator(c, vp[jj], ww);
+                    for (int i = 0; i <= jj; ++i) dotp[i] = vp[i];
+                    dotp[jj + 1] = ww;
+                    launch_dots(c, dotp.data(), ww, jj + 2, true);
+                    launch_cgs_update(c, jj + 1, vp.data(), ww);
+                }
+                return c.mail_seq;  // the sequence number of this step's publication
+            };
+            // A Krylov step needs nothing from the host (coefficients and normalisation stay on the
+            // device), so the next one can be queued before this one's numbers arrive: the GPU does
+            // not idle through the host's round trip and graph launch.  Done while the previous solve
+            // says that step will be needed (one GPU: no collectives in between); a step launched in
+            // vain only writes vectors nobody reads.
+            unsigned long long seq_j;
+            if (ahead) {
+                seq_j = seq_ahead;
+                ahead = false;
+            } else {
+                seq_j = launch_step(j);
             }
-            wait_red(c);  // published by the finish kernel: the host works while the update runs
+            if (right && !c.comm && j + 1 < m && its + 1 < max_it && j + 1 < c.krylov_steps_hint) {
+                seq_ahead = launch_step(j + 1);
+                ahead = true;
+            }
+            wait_red_seq(c, seq_j);  // published by the finish kernel: the host works while the update runs
             if (deferred && j == 0) {
                 beta = std::sqrt(c.h_red[RED_SPARE]);
                 if (!std::isfinite(beta)) {
@@ -508,7 +529,12 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             double hn;
             if (!(hn2 > 1e-8 * ww && hn2 > 0.0) && std::isfinite(ww) && ww > 0.0) {
                 // strong cancellation: w was left unscaled; refine (second CGS pass) and
-                // take the norm explicitly
+                // take the norm explicitly (a step launched ahead used the unrefined vector: let it
+                // finish, its results are dropped and the step is repeated)
+                if (ahead) {
+                    wait_red_seq(c, seq_ahead);
+                    ahead = false;
+                }
                 launch_dots(c, vp.data(), w, j + 1, false);
                 read_red(c, j + 1);
                 for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] += c.h_red[i];
@@ -577,6 +603,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             break;
         }
     }
+    c.krylov_steps_hint = its;
     *its_out = its;
     *rnorm_out = rnorm;
     const double tol = std::max(rtol * r0, atol);
@@ -929,8 +956,9 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (alloc_zero(*v, (size_t)c.np, c.stream)) return -1;
     if (alloc_zero(c.d_partials, (size_t)RED_BLOCKS * RED_K, c.stream)) return -1;
     if (alloc_zero(c.d_red, RED_K, c.stream)) return -1;
-    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_red, sizeof(double) * (RED_K + 1), hipHostMallocDefault));
-    std::memset(c.h_red, 0, sizeof(double) * (RED_K + 1));
+    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_mail, sizeof(double) * 2 * (RED_K + 1), hipHostMallocDefault));
+    std::memset(c.h_mail, 0, sizeof(double) * 2 * (RED_K + 1));
+    c.h_red = c.h_mail;
     FEDM_HIP_CHECK(hipMalloc((void **)&c.d_mail_seq, sizeof(unsigned long long)));
     FEDM_HIP_CHECK(hipMemset(c.d_mail_seq, 0, sizeof(unsigned long long)));
 
@@ -968,7 +996,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     for (auto &e : c.prof.ev) hipEventDestroy(e);
     iter_graphs_clear(c);
     if (c.d_mail_seq) hipFree(c.d_mail_seq);
-    if (c.h_red) hipHostFree(c.h_red);
+    if (c.h_mail) hipHostFree(c.h_mail);
     if (c.d_val32) hipFree(c.d_val32);
     if (c.d_s16) hipFree(c.d_s16);
     if (c.d_Z) hipFree(c.d_Z);

@@ -130,6 +130,7 @@ struct Ctx {
     double fs_switch_above = 5.0, fs_back_below = 3.5;
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
+    int krylov_steps_hint = 0;   // Krylov steps of the previous solve: how far ahead steps are queued
     // Flexible GMRES with the field split on the right: z_j = Minv v_j is kept, so the update is
     // Z y and no preconditioner application is spent on the right-hand side.
     double *d_Z = nullptr;
@@ -137,7 +138,8 @@ struct Ctx {
     // reductions
     double *d_partials = nullptr;  // [RED_BLOCKS][RED_K]
     double *d_red = nullptr;       // [RED_K]
-    double *h_red = nullptr;       // pinned, host-mapped: [RED_K] values + sequence tag, written
+    double *h_mail = nullptr;      // pinned, host-mapped: two slots of [RED_K] values + sequence tag
+    double *h_red = nullptr;       // the slot of the publication last waited for (wait_red); written
                                    // by the last kernel of a reduction and polled by the host
     unsigned long long mail_seq = 0;      // publications queued so far (host count)
     unsigned long long *d_mail_seq = nullptr;  // same count on the device: replayed graphs cannot
@@ -189,6 +191,7 @@ void launch_multi_axpy(Ctx &c, const double *coef_host, int k, const double *con
                        double *y, double sign);                             // y += sign*sum c_i x_i
 void launch_field_error(Ctx &c, int comp);  // d_red[0]=|new-old+eps|^2, d_red[1]=|old+eps|^2
 void launch_set_dirichlet_state(Ctx &c);    // u[dof] = g
+void wait_red_seq(Ctx &c, unsigned long long seq);  // a particular publication (steps launched ahead)
 void read_red(Ctx &c, int k);               // publish d_red[0..k) to h_red and wait for it
 void wait_red(Ctx &c);                      // wait for the publication launch_dots(finish) queued
 

@@ -880,12 +880,15 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partials, int 
 // The tag is a launch counter kept in device memory (a replayed graph has fixed arguments).
 __device__ __forceinline__ void publish(const double *__restrict__ red, int k, double *mail,
                                         unsigned long long *seq) {
-    for (int i = threadIdx.x; i < k; i += 64) mail[i] = red[i];
+    // one wave; two mailbox slots, chosen by the tag's parity: the host may still be reading
+    // publication n when n+1 (a Krylov step launched ahead) arrives
+    const unsigned long long tag = *seq + 1;
+    double *slot = mail + (tag & 1) * (RED_K + 1);
+    for (int i = threadIdx.x; i < k; i += 64) slot[i] = red[i];
     __threadfence_system();
     if (threadIdx.x == 0) {
-        const unsigned long long tag = *seq + 1;
         *seq = tag;
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + RED_K), tag, __ATOMIC_RELEASE,
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot + RED_K), tag, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -978,15 +981,16 @@ __global__ __launch_bounds__(256) void reduce_finish_kernel(const double *__rest
     }
     __syncthreads();
     if (threadIdx.x < 64) {
+        const unsigned long long tag = *seq + 1;
+        double *slot = mail + (tag & 1) * (RED_K + 1);
         for (int i = threadIdx.x; i < RED_K; i += 64) {
             out[i] = fin[i];
-            mail[i] = fin[i];
+            slot[i] = fin[i];
         }
         __threadfence_system();
         if (threadIdx.x == 0) {
-            const unsigned long long tag = *seq + 1;
             *seq = tag;
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + RED_K), tag, __ATOMIC_RELEASE,
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot + RED_K), tag, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -1036,7 +1040,7 @@ void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool f
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
     comm_allreduce(c, c.d_red, k);
     if (finish) {
-        hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red, c.h_red,
+        hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red, c.h_mail,
                            c.d_mail_seq);
         if (!c.capturing) ++c.mail_seq;  // a captured launch counts when its graph is launched
     }
@@ -1045,7 +1049,7 @@ void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool f
 // single-GPU Krylov step: dots (+ the scatter of the V-cycle result x0 into the potential
 // component of y), then reduction + finish + publication
 void launch_cgs_finish(Ctx &c, int k) {
-    hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red, c.h_red, c.d_mail_seq);
+    hipLaunchKernelGGL(cgs_finish_kernel, dim3(1), dim3(64), 0, c.stream, k, c.d_red, c.h_mail, c.d_mail_seq);
     if (!c.capturing) ++c.mail_seq;
 }
 
@@ -1083,7 +1087,7 @@ void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const 
         return;
     }
     hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, c.stream, c.d_partials, grid, k, c.d_red,
-                       c.h_red, c.d_mail_seq);
+                       c.h_mail, c.d_mail_seq);
     if (!c.capturing) ++c.mail_seq;
 }
 
@@ -1132,29 +1136,34 @@ void launch_norm2(Ctx &c, const double *x, int slot) {
     comm_allreduce(c, c.d_red + slot, 1);
 }
 
-void wait_red(Ctx &c) {
-    const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(c.h_red + RED_K);
+// wait for publication `seq` and point c.h_red at its slot
+void wait_red_seq(Ctx &c, unsigned long long seq) {
+    double *slot = c.h_mail + (seq & 1) * (RED_K + 1);
+    c.h_red = slot;
+    const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(slot + RED_K);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
-        if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == c.mail_seq) return;
+        if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == seq) return;
         __builtin_ia32_pause();
         if ((spins & 0xffff) == 0xffff) {
             // a faulted or lost queue never publishes: fall back to the runtime's own wait
             const bool failed = hipStreamQuery(c.stream) != hipErrorNotReady &&
-                                __atomic_load_n(tag, __ATOMIC_ACQUIRE) != c.mail_seq;
+                                __atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq;
             const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120);
             if (failed || late) {
                 hipStreamSynchronize(c.stream);
-                if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != c.mail_seq)
-                    for (int i = 0; i < RED_K; ++i) c.h_red[i] = std::nan("");
+                if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq)
+                    for (int i = 0; i < RED_K; ++i) slot[i] = std::nan("");
                 return;
             }
         }
     }
 }
 
+void wait_red(Ctx &c) { wait_red_seq(c, c.mail_seq); }
+
 void read_red(Ctx &c, int k) {
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_red, c.d_mail_seq);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_mail, c.d_mail_seq);
     ++c.mail_seq;
     wait_red(c);
 }
