@@ -371,11 +371,13 @@ void Amg::release() {
 }
 
 // ---- field split -----------------------------------------------------------------------------
-// z_u = omega * Duu^-1 (alpha t_u) per vertex; b0 = alpha t_phi
+// z_u = omega * Duu^-1 (alpha t_u) per vertex; b0 = alpha t_phi.  compact32: the species iterate is
+// the compact single-precision vector the sweeps work on ([vertex][NS] floats), else the
+// interleaved fp64 vector itself (no sweeps to follow)
 template <int NS>
 __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
                                   const double *__restrict__ t, double *__restrict__ z,
-                                  double *__restrict__ b0, double alpha, double omega) {
+                                  double *__restrict__ b0, double alpha, double omega, int compact32) {
     constexpr int NEQ = NS + 1;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nvp) return;
@@ -389,9 +391,10 @@ __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
         double acc = 0.0;
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx) acc += dp[(size_t)(r * NS + cidx) * SLICE] * tv[cidx];
-        z[(size_t)v * NEQ + r] = omega * acc;
+        if (compact32) reinterpret_cast<float *>(z)[(size_t)v * NS + r] = (float)(omega * acc);
+        else z[(size_t)v * NEQ + r] = omega * acc;
     }
-    z[(size_t)v * NEQ + NS] = 0.0;
+    if (!compact32) z[(size_t)v * NEQ + NS] = 0.0;
     b0[v] = tv[NS];
 }
 
@@ -404,11 +407,14 @@ __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
 // fp64 bytes, and neither t nor Duu^-1 is read again.  Vectors and accumulation stay fp64.
 // Block Jacobi alone leaves a mass-matrix-like operator with eigenvalues in ~[0.5, 2]; a few
 // damped sweeps cut the outer GMRES iterations from 8 to 5 per Newton step.
-template <int NS>
+// The iterate is a compact single-precision vector between the sweeps ([vertex][NS] floats: a
+// third of the bytes of the interleaved fp64 vector; accumulation in fp64); the LAST sweep writes
+// the interleaved fp64 vector that the Krylov method sees.
+template <int NS, bool LAST>
 __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
-    const _Float16 *__restrict__ s16, const double *__restrict__ g, const double *__restrict__ zin,
-    double *__restrict__ zout, double zs, double omega) {
+    const _Float16 *__restrict__ s16, const float *__restrict__ g, const float *__restrict__ zin,
+    float *__restrict__ zout32, double *__restrict__ zout, double zs, double omega) {
     constexpr int NEQ = NS + 1, PL = NS * NS;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     double gv[NS], zv[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
-        gv[r] = g[v * NEQ + r];
-        zv[r] = zin[v * NEQ + r];
+        gv[r] = g[v * NS + r];
+        zv[r] = zin[v * NS + r];
     }
     double acc[NS];
 #pragma unroll
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
         const int col = colidx[(size_t)bc * SLICE + lane];
         double zj[NS];
 #pragma unroll
-        for (int cidx = 0; cidx < NS; ++cidx) zj[cidx] = zin[(size_t)col * NEQ + cidx];
+        for (int cidx = 0; cidx < NS; ++cidx) zj[cidx] = zin[(size_t)col * NS + cidx];
         const _Float16 *vp = s16 + (size_t)bc * PL * SLICE + lane;
 #pragma unroll
         for (int r = 0; r < NS; ++r)
@@ -438,8 +444,12 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
                 acc[r] += (double)(float)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
     }
 #pragma unroll
-    for (int r = 0; r < NS; ++r) zout[v * NEQ + r] = zs * zv[r] + omega * (gv[r] - zs * acc[r]);
-    zout[v * NEQ + NS] = 0.0;  // full-line stores; the potential entry is set by fs_scatter_kernel
+    for (int r = 0; r < NS; ++r) {
+        const double zn = zs * zv[r] + omega * (gv[r] - zs * acc[r]);
+        if (LAST) zout[v * NEQ + r] = zn;
+        else zout32[v * NS + r] = (float)zn;
+    }
+    if (LAST) zout[v * NEQ + NS] = 0.0;  // full-line stores; the potential entry is set by the V-cycle
 }
 
 // b0 -= J_phi,u z_u   (reads only the n_species value planes of the potential row)
@@ -524,6 +534,7 @@ __device__ __forceinline__ void invert_species_block(double (&A)[NS][NS], double
 // every sweep reads; the iterate then ping-pongs between z and the scratch vector so that the last
 // sweep writes z.  Without sweeps the first stage writes z itself.
 static double *fs_first_target(Ctx &c, double *z) { return c.fs_sweeps > 1 ? c.d_fs_g : z; }
+static bool fs_first_compact(const Ctx &c) { return c.fs_sweeps > 1; }
 
 // stages after the first: remaining species sweeps, coupling, V-cycle on the potential block
 template <int NS>
@@ -531,13 +542,21 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     const dim3 gs((c.pat.n_slices + 3) / 4);
     const int n_sweeps = (c.fs_sweeps < 1 ? 1 : c.fs_sweeps) - 1;
-    const double *in = c.d_fs_g;
+    // g in c.d_fs_g, the iterate ping-pongs between the two halves of c.d_fs (floats), the last
+    // sweep writes z
+    const float *g32 = reinterpret_cast<const float *>(c.d_fs_g), *in = g32;
+    float *ping[2] = {reinterpret_cast<float *>(c.d_fs), reinterpret_cast<float *>(c.d_fs) + (size_t)c.nvp * NS};
     for (int s = 1; s <= n_sweeps; ++s) {
-        double *out = ((n_sweeps - s) % 2 == 0) ? z : c.d_fs;
-        hipLaunchKernelGGL(fs_species_sweep_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
-                           c.d_slice_boff, c.d_colidx, c.d_s16, c.d_fs_g, in, out, s == 1 ? c.fs_w[0] : 1.0,
-                           c.fs_w[s]);
-        in = out;
+        const double zs = s == 1 ? c.fs_w[0] : 1.0;
+        if (s == n_sweeps) {
+            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true>), gs, dim3(256), 0, c.stream, c.pat.n_slices,
+                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in, (float *)nullptr, z, zs, c.fs_w[s]);
+        } else {
+            float *out = ping[s & 1];
+            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, false>), gs, dim3(256), 0, c.stream, c.pat.n_slices,
+                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in, out, (double *)nullptr, zs, c.fs_w[s]);
+            in = out;
+        }
     }
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
                        c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
@@ -550,7 +569,7 @@ template <int NS>
 static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter, bool with_cycle) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
-                       amg.levels[0].b, alpha, 1.0);
+                       amg.levels[0].b, alpha, 1.0, fs_first_compact(c) ? 1 : 0);
     fs_finish_t<NS>(c, amg, z, scatter, with_cycle);
 }
 
@@ -578,7 +597,7 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
 // z = Minv (J v): the SpMV's epilogue is the first stage (t = J v is kept for the sweeps)
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter) {
     prof_begin(c, 1);
-    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, 1.0);
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, 1.0, nullptr, 0, fs_first_compact(c));
     prof_end(c);
     switch (c.ns) {
         case 1: fs_finish_t<1>(c, amg, z, scatter); break;
@@ -591,7 +610,7 @@ void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, dou
 
 void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter,
                                     int part, const int *slices, int n_slices) {
-    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, 1.0, slices, n_slices);
+    launch_spmv_fieldsplit(c, v, t, fs_first_target(c, z), amg.levels[0].b, 1.0, slices, n_slices, fs_first_compact(c));
     if (part == 0) return;
     const bool cyc = part == 1;  // part 2: stop after the coupling product (amg.levels[0].b is ready)
     switch (c.ns) {

@@ -173,7 +173,7 @@ void launch_block_inverse(Ctx &c);                              // d_dinv from d
 void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int *slice_list = nullptr,
                  int n_list = 0);
 void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale,
-                            const int *slice_list = nullptr, int n_list = 0);
+                            const int *slice_list = nullptr, int n_list = 0, bool compact32 = false);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
 void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0,

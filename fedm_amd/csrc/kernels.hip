@@ -676,7 +676,8 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
                                                    double *__restrict__ y,
                                                    const double *__restrict__ dinv,
                                                    double *__restrict__ fs_z, double *__restrict__ fs_b0,
-                                                   double fs_scale, const int *__restrict__ slice_list) {
+                                                   double fs_scale, const int *__restrict__ slice_list,
+                                                   int fs_compact32 = 0) {
     constexpr int NEQ2 = NEQ * NEQ;
     const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -721,9 +722,11 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
             double z = 0.0;
 #pragma unroll
             for (int cc = 0; cc < NS; ++cc) z += dv[r * NS + cc] * acc[cc];
-            fs_z[vtx * NEQ + r] = fs_scale * z;
+            // (with sweeps to follow the first species iterate is a compact single-precision vector)
+            if (fs_compact32) reinterpret_cast<float *>(fs_z)[vtx * NS + r] = (float)(fs_scale * z);
+            else fs_z[vtx * NEQ + r] = fs_scale * z;
         }
-        fs_z[vtx * NEQ + NS] = 0.0;  // whole lines are written; the V-cycle result lands here later
+        if (!fs_compact32) fs_z[vtx * NEQ + NS] = 0.0;  // whole lines are written; the V-cycle result lands here later
         fs_b0[vtx] = acc[NS];
     } else if (dinv) {
 #pragma unroll
@@ -763,13 +766,13 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int 
 // t = A x together with the first field-split stage (c.d_dinv holds the species-block inverses);
 // slice_list != nullptr: only those n_list matrix slices (interior / boundary halves across GPUs)
 void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale,
-                            const int *slice_list, int n_list) {
+                            const int *slice_list, int n_list, bool compact32) {
     const int n = slice_list ? n_list : c.pat.n_slices;
     if (n == 0) return;
     const dim3 g((n + 3) / 4), b(256);
 #define FEDM_SPMV(NEQ)                                                                            \
     hipLaunchKernelGGL((spmv_kernel<NEQ, true>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
-                       c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale, slice_list)
+                       c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale, slice_list, compact32 ? 1 : 0)
     switch (c.neq) {
         case 2: FEDM_SPMV(2); break;
         case 3: FEDM_SPMV(3); break;
