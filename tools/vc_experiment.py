@@ -5,7 +5,10 @@ sys.path.insert(0, '.')
 import numpy as np
 from fedm_amd.cases import streamer
 msh = streamer.mesh(576, 4.0)
-variants = [("V(1,1)", dict(nu=1)), ("V(0,1)", dict(nu=-1)), ("V(0,2)", dict(nu=-2)), ("V(2,2)", dict(nu=2))]
+variants = [("V(1,1)", dict(nu=1)), ("V(0,1)", dict(nu=-1)), ("V(0,2)", dict(nu=-2)), ("V(2,2)", dict(nu=2)),
+            ("V(3,3)", dict(nu=3)), ("V(4,4)", dict(nu=4))]
+if len(sys.argv) > 1:
+    variants = [v for v in variants if v[0] in sys.argv[1:]]
 for name, mg in variants:
     prob = streamer.device_problem(msh.coords, msh.cells)
     st = streamer.Stepper(prob)
