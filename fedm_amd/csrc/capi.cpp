@@ -1162,8 +1162,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         } else {
             eval_jacobian(c, 0);
         }
-        launch_norm2(c, c.d_F, 0);
-        read_red(c, 3);  // |F|, and |dx|, |x| of the previous update (slots 1, 2) in one wait
+        norm2_read(c, c.d_F, 0, 3);  // |F|, and |dx|, |x| of the previous update (slots 1, 2) in one wait
         fnorm = std::sqrt(c.h_red[0]);
         if (it > 0) {
             snorm = std::sqrt(c.h_red[1]);

@@ -1165,6 +1165,43 @@ void wait_red_seq(Ctx &c, unsigned long long seq) {
 
 void wait_red(Ctx &c) { wait_red_seq(c, c.mail_seq); }
 
+// |x|^2 into d_red[slot] and publication of d_red[0..k) in one go: on one GPU the reduction of the
+// partial sums and the mailbox write are one kernel
+__global__ __launch_bounds__(64) void reduce_slot_publish_kernel(const double *__restrict__ partials, int nblocks,
+                                                                 int k_src, double *__restrict__ out, int slot,
+                                                                 int k, double *mail, unsigned long long *seq) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + k_src];
+    s = wave_sum(s);
+    s = __shfl(s, 0, 64);
+    if (threadIdx.x == 0) out[slot] = s;
+    const unsigned long long tag = *seq + 1;
+    double *m = mail + (tag & 1) * (RED_K + 1);
+    for (int i = threadIdx.x; i < k; i += 64) m[i] = (i == slot) ? s : out[i];
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        *seq = tag;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(m + RED_K), tag, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+void norm2_read(Ctx &c, const double *x, int slot, int k) {
+    if (c.comm) {  // the all-reduce sits between the reduction and the publication
+        launch_norm2(c, x, slot);
+        read_red(c, k);
+        return;
+    }
+    const int grid = red_grid(c);
+    PtrPack8 pk;
+    for (int i = 0; i < 8; ++i) pk.p[i] = x;
+    hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, x, (size_t)c.n_dot, c.d_partials, RED_K - 1);
+    hipLaunchKernelGGL(reduce_slot_publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_partials, grid, RED_K - 1,
+                       c.d_red, slot, k, c.h_mail, c.d_mail_seq);
+    ++c.mail_seq;
+    wait_red(c);
+}
+
 void read_red(Ctx &c, int k) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_mail, c.d_mail_seq);
     ++c.mail_seq;
