@@ -546,8 +546,13 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     // sweep writes z
     const float *g32 = reinterpret_cast<const float *>(c.d_fs_g), *in = g32;
     float *ping[2] = {reinterpret_cast<float *>(c.d_fs), reinterpret_cast<float *>(c.d_fs) + (size_t)c.nvp * NS};
+    // several GPUs, c.fs_halo: the species iterate of the ghost vertices comes from their owners
+    // before every sweep (otherwise the sweeps see zeros there: block Jacobi over the ranks)
+    const bool halo = c.comm && c.fs_halo && !c.capturing && n_sweeps > 0;
+    if (halo) comm_halo_f32(c, reinterpret_cast<float *>(c.d_fs_g), NS);
     for (int s = 1; s <= n_sweeps; ++s) {
         const double zs = s == 1 ? c.fs_w[0] : 1.0;
+        if (halo && s > 1) comm_halo_f32(c, const_cast<float *>(in), NS);
         if (s == n_sweeps) {
             hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true>), gs, dim3(256), 0, c.stream, c.pat.n_slices,
                                c.d_slice_boff, c.d_colidx, c.d_s16, g32, in, (float *)nullptr, z, zs, c.fs_w[s]);

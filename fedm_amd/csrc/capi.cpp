@@ -347,7 +347,10 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         ++c.mail_seq;
         return true;
     }
-    if (hipGraphLaunch(c.iter_graph_pre[j], c.stream) != hipSuccess) {
+    if (c.fs_halo) {
+        // exchanges between the sweeps: the rank-local part of the preconditioner is not one graph
+        with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct, !c.amg->global); });
+    } else if (hipGraphLaunch(c.iter_graph_pre[j], c.stream) != hipSuccess) {
         hipGetLastError();
         c.iter_graphs_ok = false;
         return false;  // nothing has been communicated yet: the caller repeats the step plainly
@@ -937,6 +940,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         // fedm_set_preconditioner_side override.
         c.right_precond = c.model_kind == 0;
         if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] != '0';
+        if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;
         if (side && std::string(side) == "right") c.right_precond = true;

@@ -83,11 +83,12 @@ void Comm::release() {
     stream = nullptr;
     if (d_send_idx) hipFree(d_send_idx);
     if (d_sendbuf) hipFree(d_sendbuf);
+    if (d_recvtmp) hipFree(d_recvtmp);
     if (h_send) hipHostFree(h_send);
     if (h_recv) hipHostFree(h_recv);
     if (h_red) hipHostFree(h_red);
     d_send_idx = nullptr;
-    d_sendbuf = nullptr;
+    d_sendbuf = d_recvtmp = nullptr;
     h_send = h_recv = h_red = nullptr;
     kind = 0;
 }
@@ -114,6 +115,7 @@ int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const in
     if (cm.n_send)
         FEDM_HIP_CHECK(hipMemcpy(cm.d_send_idx, send_idx, sizeof(int) * cm.n_send, hipMemcpyHostToDevice));
     FEDM_HIP_CHECK(hipMalloc((void **)&cm.d_sendbuf, sizeof(double) * ns * c.neq));
+    FEDM_HIP_CHECK(hipMalloc((void **)&cm.d_recvtmp, sizeof(double) * ng * c.neq));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_send, sizeof(double) * ns * c.neq));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_recv, sizeof(double) * ng * c.neq));
     FEDM_HIP_CHECK(hipHostMalloc((void **)&cm.h_red, sizeof(double) * 16384));
@@ -191,11 +193,9 @@ __global__ void halo_pack_kernel(int n_send, int neq, const int *__restrict__ id
     buf[t] = vec[(size_t)idx[i] * neq + s];
 }
 
-static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st, int w) {
-    if (cm->n_send)
-        hipLaunchKernelGGL(halo_pack_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, st,
-                           cm->n_send, w, cm->d_send_idx, d_vec, cm->d_sendbuf);
-    double *ghost = d_vec + (size_t)c.n_owned * w;
+// the packed send buffer goes out, the neighbours' values arrive in recv_dst (n_ghost * w doubles,
+// grouped by owner in neighbour order)
+static void exchange_packed(Ctx &c, Comm *cm, double *recv_dst, hipStream_t st, int w) {
     if (cm->kind == 2) {
         g_nccl.GroupStart();
         for (int k = 0; k < cm->n_nb; ++k) {
@@ -205,7 +205,7 @@ static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st, int 
                 g_nccl.Send(cm->d_sendbuf + (size_t)cm->send_ptr[k] * w, (size_t)ns * w, kNcclDouble,
                             cm->nb_rank[k], cm->nccl, st);
             if (nr)
-                g_nccl.Recv(ghost + (size_t)cm->recv_ptr[k] * w, (size_t)nr * w, kNcclDouble,
+                g_nccl.Recv(recv_dst + (size_t)cm->recv_ptr[k] * w, (size_t)nr * w, kNcclDouble,
                             cm->nb_rank[k], cm->nccl, st);
         }
         g_nccl.GroupEnd();
@@ -216,7 +216,40 @@ static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st, int 
     hipStreamSynchronize(st);
     cm->exchange_cb(cm->h_send, cm->h_recv, w, cm->user);
     if (cm->n_ghost)
-        hipMemcpyAsync(ghost, cm->h_recv, sizeof(double) * cm->n_ghost * w, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(recv_dst, cm->h_recv, sizeof(double) * cm->n_ghost * w, hipMemcpyHostToDevice, st);
+}
+
+static void halo_on_stream(Ctx &c, Comm *cm, double *d_vec, hipStream_t st, int w) {
+    if (cm->n_send)
+        hipLaunchKernelGGL(halo_pack_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, st,
+                           cm->n_send, w, cm->d_send_idx, d_vec, cm->d_sendbuf);
+    exchange_packed(c, cm, d_vec + (size_t)c.n_owned * w, st, w);
+}
+
+// the same for a compact single-precision vector ([vertex][w] floats: the iterate of the species
+// sweeps): values travel as doubles through the same buffers
+__global__ void halo_pack_f32_kernel(int n_send, int w, const int *__restrict__ idx,
+                                     const float *__restrict__ vec, double *__restrict__ buf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_send * w) return;
+    const int i = t / w, s = t - i * w;
+    buf[t] = (double)vec[(size_t)idx[i] * w + s];
+}
+__global__ void halo_unpack_f32_kernel(int n, const double *__restrict__ buf, float *__restrict__ ghost) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) ghost[t] = (float)buf[t];
+}
+
+void comm_halo_f32(Ctx &c, float *d_vec, int w) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
+    if (cm->n_send)
+        hipLaunchKernelGGL(halo_pack_f32_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, c.stream,
+                           cm->n_send, w, cm->d_send_idx, d_vec, cm->d_sendbuf);
+    exchange_packed(c, cm, cm->d_recvtmp, c.stream, w);
+    if (cm->n_ghost)
+        hipLaunchKernelGGL(halo_unpack_f32_kernel, dim3((cm->n_ghost * w + 255) / 256), dim3(256), 0, c.stream,
+                           cm->n_ghost * w, cm->d_recvtmp, d_vec + (size_t)c.n_owned * w);
 }
 
 void comm_halo(Ctx &c, double *d_vec) {

@@ -20,7 +20,7 @@ struct Comm {
     std::vector<int> nb_rank, send_ptr, recv_ptr;
     int n_send = 0, n_ghost = 0;
     int *d_send_idx = nullptr;
-    double *d_sendbuf = nullptr;
+    double *d_sendbuf = nullptr, *d_recvtmp = nullptr;  // packed values out; staging for non-fp64 vectors
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;
     int h_red_cap = 0;  // doubles (host-staged all-reduce)
     fedm_allreduce_fn allreduce_cb = nullptr;
@@ -45,6 +45,7 @@ void comm_allreduce(Ctx &c, double *d_buf, int n);  // sum over ranks, in place,
 int comm_reserve_reduction(Ctx &c, int n);          // host-staged transport: room for n doubles
 void comm_halo(Ctx &c, double *d_vec);              // refresh ghost vertices of a block vector
 void comm_halo_scalar(Ctx &c, double *d_vec);       // the same for one value per vertex
+void comm_halo_f32(Ctx &c, float *d_vec, int w);    // the same for [vertex][w] floats
 // The same exchange on the communication stream, overlapped with compute work: comm_halo_begin
 // marks the point of the compute stream at which the vector is complete; work queued on the
 // compute stream after it runs concurrently with comm_halo_exchange, which performs the exchange

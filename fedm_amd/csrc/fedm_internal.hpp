@@ -127,6 +127,7 @@ struct Ctx {
     int fs_main_sweeps = 1, fs_alt_sweeps = 0;
     double fs_main_w[16] = {1}, fs_alt_w[16] = {1};
     bool fs_alt_active = false;
+    bool fs_halo = true;    // several GPUs: ghost exchange of the species iterate before every sweep
     double fs_switch_above = 5.0, fs_back_below = 3.5;
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
