@@ -548,6 +548,8 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     float *ping[2] = {reinterpret_cast<float *>(c.d_fs), reinterpret_cast<float *>(c.d_fs) + (size_t)c.nvp * NS};
     // several GPUs, c.fs_halo: the species iterate of the ghost vertices comes from their owners
     // before every sweep (otherwise the sweeps see zeros there: block Jacobi over the ranks)
+    // (across GPUs the field split is always on the right -- flexible GMRES --, so the applications
+    // need not be one fixed operator; inside a captured step there is no exchange)
     const bool halo = c.comm && c.fs_halo && !c.capturing && n_sweeps > 0;
     if (halo) comm_halo_f32(c, reinterpret_cast<float *>(c.d_fs_g), NS);
     for (int s = 1; s <= n_sweeps; ++s) {

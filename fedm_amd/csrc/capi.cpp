@@ -112,7 +112,9 @@ static void apply_operator(Ctx &c, const double *v, double *w) {
 }
 
 // the field split sits on the right of the operator (flexible GMRES)
-static bool right_preconditioned(const Ctx &c) { return c.right_precond && c.amg && c.poisson; }
+// (across GPUs always: the left variant is kept for one GPU only -- its restarted cycles were never
+// made to work over several ranks)
+static bool right_preconditioned(const Ctx &c) { return (c.right_precond || c.comm) && c.amg && c.poisson; }
 
 // rhs = -Minv F (preconditioner on the left) or -F (on the right), after the Jacobian has been assembled
 static void prepare_preconditioner_and_rhs(Ctx &c) {

@@ -312,7 +312,8 @@ int fedm_profile_read(fedm_ctx *ctx, int kind, double *ms_total, int64_t *count)
 int fedm_set_assembly(fedm_ctx *ctx, int kind);
 /* side of the field-split preconditioner in the Newton linear solves: 1 = right (flexible GMRES,
  * convergence on the true residual norm; default for LFA models), 0 = left (convergence on the
- * preconditioned residual norm; default for LMEA models).  Both solve J delta = -F to ksp_rtol.
+ * preconditioned residual norm; default for LMEA models; one GPU only: across GPUs the field split
+ * is always on the right).  Both solve J delta = -F to ksp_rtol.
  * Environment: FEDM_PRECOND_SIDE=left|right sets the default of new contexts. */
 int fedm_set_preconditioner_side(fedm_ctx *ctx, int right);
 /* sizes the roofline model needs */
