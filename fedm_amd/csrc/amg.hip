@@ -414,11 +414,13 @@ template <int NS, bool LAST>
 __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
     const _Float16 *__restrict__ s16, const float *__restrict__ g, const float *__restrict__ zin,
-    float *__restrict__ zout32, double *__restrict__ zout, double zs, double omega) {
+    float *__restrict__ zout32, double *__restrict__ zout, double zs, double omega,
+    const int *__restrict__ slice_list) {
     constexpr int NEQ = NS + 1, PL = NS * NS;
-    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (slice >= n_slices) return;
+    if (wave_id >= n_slices) return;   // n_slices: number of slices this launch covers
+    const int slice = slice_list ? slice_list[wave_id] : wave_id;
     // this row's own operands first: their latency hides behind the gather loop
     const size_t v = (size_t)slice * SLICE + lane;
     double gv[NS], zv[NS];
@@ -551,19 +553,38 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     // (across GPUs the field split is always on the right -- flexible GMRES --, so the applications
     // need not be one fixed operator; inside a captured step there is no exchange)
     const bool halo = c.comm && c.fs_halo && !c.capturing && n_sweeps > 0;
-    if (halo) comm_halo_f32(c, reinterpret_cast<float *>(c.d_fs_g), NS);
+    // ... and the exchange overlaps with the sweep's interior slices (those without ghost columns):
+    // mark the iterate complete, sweep the interior, exchange on the communication stream, wait,
+    // sweep the boundary slices -- as the Krylov halo does with the Jacobian product
+    static const bool overlap_ok = [] {
+        const char *e = std::getenv("FEDM_FS_HALO_OVERLAP");
+        return !(e && e[0] == '0');
+    }();
+    const bool overlap = halo && overlap_ok && c.comm->n_interior > 0;
+    auto sweep = [&](bool last, const float *in_, float *out32, double zs, double w, const int *list, int n) {
+        if (n == 0) return;
+        const dim3 g((n + 3) / 4);
+        if (last)
+            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true>), g, dim3(256), 0, c.stream, n, c.d_slice_boff,
+                               c.d_colidx, c.d_s16, g32, in_, (float *)nullptr, z, zs, w, list);
+        else
+            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, false>), g, dim3(256), 0, c.stream, n, c.d_slice_boff,
+                               c.d_colidx, c.d_s16, g32, in_, out32, (double *)nullptr, zs, w, list);
+    };
     for (int s = 1; s <= n_sweeps; ++s) {
         const double zs = s == 1 ? c.fs_w[0] : 1.0;
-        if (halo && s > 1) comm_halo_f32(c, const_cast<float *>(in), NS);
-        if (s == n_sweeps) {
-            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true>), gs, dim3(256), 0, c.stream, c.pat.n_slices,
-                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in, (float *)nullptr, z, zs, c.fs_w[s]);
+        const bool last = s == n_sweeps;
+        float *out = last ? nullptr : ping[s & 1];
+        if (overlap) {
+            comm_halo_begin(c);
+            sweep(last, in, out, zs, c.fs_w[s], c.comm->d_interior, c.comm->n_interior);
+            comm_halo_exchange_f32(c, const_cast<float *>(in), NS);
+            sweep(last, in, out, zs, c.fs_w[s], c.comm->d_boundary, c.comm->n_boundary);
         } else {
-            float *out = ping[s & 1];
-            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, false>), gs, dim3(256), 0, c.stream, c.pat.n_slices,
-                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in, out, (double *)nullptr, zs, c.fs_w[s]);
-            in = out;
+            if (halo) comm_halo_f32(c, const_cast<float *>(in), NS);
+            sweep(last, in, out, zs, c.fs_w[s], nullptr, c.pat.n_slices);
         }
+        if (!last) in = out;
     }
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
                        c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);

@@ -240,16 +240,30 @@ __global__ void halo_unpack_f32_kernel(int n, const double *__restrict__ buf, fl
     if (t < n) ghost[t] = (float)buf[t];
 }
 
+static void halo_f32_on_stream(Ctx &c, Comm *cm, float *d_vec, int w, hipStream_t st) {
+    if (cm->n_send)
+        hipLaunchKernelGGL(halo_pack_f32_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, st,
+                           cm->n_send, w, cm->d_send_idx, d_vec, cm->d_sendbuf);
+    exchange_packed(c, cm, cm->d_recvtmp, st, w);
+    if (cm->n_ghost)
+        hipLaunchKernelGGL(halo_unpack_f32_kernel, dim3((cm->n_ghost * w + 255) / 256), dim3(256), 0, st,
+                           cm->n_ghost * w, cm->d_recvtmp, d_vec + (size_t)c.n_owned * w);
+}
+
 void comm_halo_f32(Ctx &c, float *d_vec, int w) {
     Comm *cm = c.comm;
     if (!cm || cm->kind == 0 || (cm->n_send == 0 && cm->n_ghost == 0)) return;
-    if (cm->n_send)
-        hipLaunchKernelGGL(halo_pack_f32_kernel, dim3((cm->n_send * w + 255) / 256), dim3(256), 0, c.stream,
-                           cm->n_send, w, cm->d_send_idx, d_vec, cm->d_sendbuf);
-    exchange_packed(c, cm, cm->d_recvtmp, c.stream, w);
-    if (cm->n_ghost)
-        hipLaunchKernelGGL(halo_unpack_f32_kernel, dim3((cm->n_ghost * w + 255) / 256), dim3(256), 0, c.stream,
-                           cm->n_ghost * w, cm->d_recvtmp, d_vec + (size_t)c.n_owned * w);
+    halo_f32_on_stream(c, cm, d_vec, w, c.stream);
+}
+
+// ... on the communication stream, after comm_halo_begin (see comm_halo_exchange)
+void comm_halo_exchange_f32(Ctx &c, float *d_vec, int w) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0) return;
+    hipStreamWaitEvent(cm->stream, cm->ev_ready, 0);
+    if (cm->n_send || cm->n_ghost) halo_f32_on_stream(c, cm, d_vec, w, cm->stream);
+    hipEventRecord(cm->ev_halo, cm->stream);
+    hipStreamWaitEvent(c.stream, cm->ev_halo, 0);
 }
 
 void comm_halo(Ctx &c, double *d_vec) {

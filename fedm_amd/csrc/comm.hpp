@@ -52,5 +52,6 @@ void comm_halo_f32(Ctx &c, float *d_vec, int w);    // the same for [vertex][w] 
 // on the communication stream and makes the compute stream wait for its end.
 void comm_halo_begin(Ctx &c);
 void comm_halo_exchange(Ctx &c, double *d_vec);
+void comm_halo_exchange_f32(Ctx &c, float *d_vec, int w);
 
 }  // namespace fedm
