@@ -107,10 +107,12 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
                                                        const double *__restrict__ x,
                                                        const double *__restrict__ b,
                                                        double *__restrict__ y, double omega,
-                                                       double *__restrict__ aux, int ystride, int yoff) {
-    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+                                                       double *__restrict__ aux, int ystride, int yoff,
+                                                       const int *__restrict__ slice_list) {
+    const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (slice >= n_slices) return;
+    if (wave_id >= n_slices) return;   // n_slices: number of slices this launch covers
+    const int slice = slice_list ? slice_list[wave_id] : wave_id;
     const int b0 = width > 0 ? slice * width : boff[slice];
     const int b1 = width > 0 ? b0 + width : boff[slice + 1];
     const size_t r = ((size_t)slice * SLICE + lane) >> log2_split;
@@ -166,12 +168,15 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
 
 static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const double *b,
                        double *y, double omega, double *aux = nullptr, int ystride = 1, int yoff = 0,
-                       const double *dinv = nullptr /* default: the matrix's own */) {
-    const dim3 g((A.n_slices + 3) / 4), bl(256);
+                       const double *dinv = nullptr /* default: the matrix's own */,
+                       const int *slice_list = nullptr, int n_list = 0 /* only these matrix slices */) {
+    const int n = slice_list ? n_list : A.n_slices;
+    if (n == 0) return;
+    const dim3 g((n + 3) / 4), bl(256);
     if (!dinv) dinv = A.dinv;
 #define FEDM_ELL(M)                                                                                  \
-    hipLaunchKernelGGL(ell_spmv_kernel<M>, g, bl, 0, c.stream, A.n_slices, A.n_rows, A.log2_split,   \
-                       A.width, A.boff, A.col, A.val, dinv, x, b, y, omega, aux, ystride, yoff)
+    hipLaunchKernelGGL(ell_spmv_kernel<M>, g, bl, 0, c.stream, n, A.n_rows, A.log2_split,            \
+                       A.width, A.boff, A.col, A.val, dinv, x, b, y, omega, aux, ystride, yoff, slice_list)
     switch (mode) {
         case 0: FEDM_ELL(0); break;
         case 1: FEDM_ELL(1); break;
@@ -277,12 +282,27 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
     // right-hand side (before the first sweep, whose neighbours' values are formed from b) and of
     // the iterate (before the post-smoothing) come from their owners.
     const bool exact0 = l == 0 && global && c.comm && !c.capturing;
-    if (exact0 && down) comm_halo_scalar(c, L.b);
+    // (when the slices of A are classified -- interior: no ghost column -- the exchange runs on the
+    // communication stream while the interior slices are processed)
+    static const bool mg_overlap_ok = [] {
+        const char *e = std::getenv("FEDM_MG_HALO_OVERLAP");
+        return !(e && e[0] == '0');
+    }();
+    const bool split0 = exact0 && mg_overlap_ok && n_interior0 > 0 && nu == 1;
+    auto launch_A_halo = [&](int mode, double *halo_vec, const double *xx, double *yy, double *aux_,
+                             int ystr, int yoffs) {
+        comm_halo_begin(c);
+        ell_launch(c, L.A, mode, xx, L.b, yy, omega, aux_, ystr, yoffs, nullptr, d_interior0, n_interior0);
+        comm_halo_exchange_scalar(c, halo_vec);
+        ell_launch(c, L.A, mode, xx, L.b, yy, omega, aux_, ystr, yoffs, nullptr, d_boundary0, n_boundary0);
+    };
+    if (exact0 && down && !split0) comm_halo_scalar(c, L.b);
     const bool dc = L.down_composite && nu == 1;
     if (dc) {
         if (down) ell_launch(c, L.C, 0, L.b, nullptr, levels[l + 1].b, 0.0);  // b_c = R (b - A w Dinv b)
     } else if (nu == 1) {
-        if (down) ell_launch(c, L.A, 4, nullptr, L.b, L.r, omega, x);    // x = w Dinv b;  r = b - A x
+        if (down && split0) launch_A_halo(4, L.b, nullptr, L.r, x, 1, 0);
+        else if (down) ell_launch(c, L.A, 4, nullptr, L.b, L.r, omega, x);    // x = w Dinv b;  r = b - A x
     } else {
         if (down)
             hipLaunchKernelGGL(jacobi_first_kernel, dim3((np + 255) / 256), dim3(256), 0, c.stream, np,
@@ -299,12 +319,18 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
     if (dc) ell_launch(c, L.P, 5, levels[l + 1].x, L.b, x, omega, nullptr, 1, 0, L.A.dinv);  // x = w Dinv b + P x_c
     else ell_launch(c, L.P, 3, levels[l + 1].x, nullptr, x, 0.0);    // x += P x_c
     for (int s = 0; s < nu; ++s) {
-        if (exact0) comm_halo_scalar(c, x);
+        if (exact0 && !split0) comm_halo_scalar(c, x);
         if (l == 0 && s == nu - 1 && out) {
             // the cycle's result goes straight into the potential component of the caller's
             // interleaved vector (no scatter kernel afterwards)
-            ell_launch(c, L.A, 2, x, L.b, out, omega, nullptr, out_stride, out_offset);
+            if (split0) launch_A_halo(2, x, x, out, nullptr, out_stride, out_offset);
+            else ell_launch(c, L.A, 2, x, L.b, out, omega, nullptr, out_stride, out_offset);
             break;
+        }
+        if (split0) {
+            launch_A_halo(2, x, x, y, nullptr, 1, 0);
+            std::swap(x, y);
+            continue;
         }
         ell_launch(c, L.A, 2, x, L.b, y, omega);
         std::swap(x, y);
@@ -357,6 +383,10 @@ void Amg::release() {
             if (p) hipFree(p);
     }
     levels.clear();
+    if (d_interior0) hipFree(d_interior0);
+    if (d_boundary0) hipFree(d_boundary0);
+    d_interior0 = d_boundary0 = nullptr;
+    n_interior0 = n_boundary0 = 0;
     if (graph_exec) hipGraphExecDestroy(graph_exec);
     graph_exec = nullptr;
     if (coarse_inv) hipFree(coarse_inv);

@@ -57,6 +57,10 @@ struct Amg {
     // rank takes its segment of the result.  Aggregates never cross rank boundaries; everything
     // else is the single-GPU cycle.
     int n_global = 0, g_offset = 0;
+    // slices of the finest operator without / with ghost columns (several GPUs): the two scalar
+    // halo exchanges of a cycle overlap with the interior ones
+    int *d_interior0 = nullptr, *d_boundary0 = nullptr;
+    int n_interior0 = 0, n_boundary0 = 0;
     double *d_gb = nullptr;   // alias, owned by `global`
     Amg *global = nullptr;
     // levels[level].b -> levels[level].x; phase 0 whole cycle, 1 down leg, 2 coarse solve + up leg

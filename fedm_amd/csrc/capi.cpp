@@ -1692,6 +1692,34 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
             }
         }
     }
+    if (!coarse_inverse && composite_from == 1 && n_levels > 1 && c.n_owned < c.nv) {
+        // several GPUs: which slices of the finest operator touch ghost columns
+        const EllMat &A0 = amg->levels[0].A;
+        const int l2s = A0.log2_split;
+        std::vector<int> in_list, bd_list;
+        for (int sl = 0; sl < A0.n_slices; ++sl) {
+            bool ghost = false;
+            for (int lane = 0; lane < SLICE && !ghost; lane += (1 << l2s)) {
+                const int64_t r = ((int64_t)sl * SLICE + lane) >> l2s;
+                if (r >= A[0].n_rows) break;
+                for (int64_t k = A[0].indptr[r]; k < A[0].indptr[r + 1]; ++k)
+                    if (A[0].indices[k] >= c.n_owned) {
+                        ghost = true;
+                        break;
+                    }
+            }
+            (ghost ? bd_list : in_list).push_back(sl);
+        }
+        amg->n_interior0 = (int)in_list.size();
+        amg->n_boundary0 = (int)bd_list.size();
+        if (hipMalloc((void **)&amg->d_interior0, sizeof(int) * std::max<size_t>(in_list.size(), 1)) != hipSuccess ||
+            hipMalloc((void **)&amg->d_boundary0, sizeof(int) * std::max<size_t>(bd_list.size(), 1)) != hipSuccess ||
+            hipMemcpy(amg->d_interior0, in_list.data(), sizeof(int) * in_list.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(amg->d_boundary0, bd_list.data(), sizeof(int) * bd_list.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("out of device memory for the multigrid slice lists");
+            return fail(-1);
+        }
+    }
     amg->n_coarse = A[n_levels - 1].n_rows;
     amg->coarse_ld = ((amg->n_coarse + 255) / 256) * 256;
     if (coarse_inverse) {  // nullptr: the coarsest problem will be handed to a global hierarchy

@@ -256,6 +256,15 @@ void comm_halo_f32(Ctx &c, float *d_vec, int w) {
     halo_f32_on_stream(c, cm, d_vec, w, c.stream);
 }
 
+void comm_halo_exchange_scalar(Ctx &c, double *d_vec) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0) return;
+    hipStreamWaitEvent(cm->stream, cm->ev_ready, 0);
+    if (cm->n_send || cm->n_ghost) halo_on_stream(c, cm, d_vec, cm->stream, 1);
+    hipEventRecord(cm->ev_halo, cm->stream);
+    hipStreamWaitEvent(c.stream, cm->ev_halo, 0);
+}
+
 // ... on the communication stream, after comm_halo_begin (see comm_halo_exchange)
 void comm_halo_exchange_f32(Ctx &c, float *d_vec, int w) {
     Comm *cm = c.comm;

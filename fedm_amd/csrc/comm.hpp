@@ -53,5 +53,6 @@ void comm_halo_f32(Ctx &c, float *d_vec, int w);    // the same for [vertex][w] 
 void comm_halo_begin(Ctx &c);
 void comm_halo_exchange(Ctx &c, double *d_vec);
 void comm_halo_exchange_f32(Ctx &c, float *d_vec, int w);
+void comm_halo_exchange_scalar(Ctx &c, double *d_vec);
 
 }  // namespace fedm
