@@ -121,6 +121,33 @@ def cpu_baseline(n, steps):
                       f"{os.cpu_count()} cores"}
 
 
+def pin_to_gpu_numa_node(torch, local_rank):
+    """Run this process on the CPUs next to its GPU (what `numactl --cpunodebind` would do): the
+    solver's host side polls a mailbox in pinned host memory and launches a graph per Krylov step,
+    so a remote NUMA node costs microseconds at every one of a dozen waits per time step.  Best
+    effort: any failure leaves the placement as it was."""
+    if os.environ.get("FEDM_BENCH_PIN", "1") == "0":
+        return "unchanged (FEDM_BENCH_PIN=0)"
+    try:
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(local_rank), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(local_rank), "pci_device_id", 0)
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0/local_cpulist"
+        cpus = set()
+        for part in open(path).read().strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        target = cpus & allowed
+        if target and target != allowed:
+            os.sched_setaffinity(0, target)
+            return f"cpus of the GPU's NUMA node ({len(target)} of {len(allowed)} allowed)"
+        return "unchanged (all allowed CPUs are local, or none is)"
+    except Exception as exc:   # noqa: BLE001 - placement is an optimisation only
+        return f"unchanged ({type(exc).__name__})"
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +165,8 @@ def main():
         entry.build()
     from fedm_amd.cases import streamer
     from fedm_amd import functions as ff
+
+    placement = pin_to_gpu_numa_node(torch, local_rank)
 
     distributed = world > 1
     if distributed:
@@ -248,7 +277,8 @@ def main():
                            f"the axis, per GPU",
                    "dofs_total": total_dofs, "vertices_per_gpu": sz["n_vertices"],
                    "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": "flexible, restart 30, rtol 1e-5 on the true residual, right-preconditioned: "
-                   "field split, Chebyshev(4) block Jacobi on species + multigrid V(1,1) on the potential", "partition": runner.partition_name},
+                   "field split, Chebyshev(6) block Jacobi on species (degree 4 once a Newton system needs >= 5 Krylov steps) + multigrid V(1,1) on the potential", "partition": runner.partition_name,
+                   "host_placement": placement},
         "newton_iterations_per_step": (n1[0] - n0[0]) / args.steps,
         "gmres_iterations_per_step": (n1[1] - n0[1]) / args.steps,
         "roofline": dominant,
