@@ -282,9 +282,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
     double *Ul = vx + 2 * max_verts;            // [max_verts][NEQ]
     double *Hl = Ul + NEQ * max_verts;          // [max_verts][NS]
     double *nql = Hl + NS * max_verts;          // [3 * NS][THREADS]
+#ifdef FEDM_PHASE_TIMING
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     const int S = blockIdx.x;
     const int b0 = boff[S], width = boff[S + 1] - b0;
     const int n_acc = width * NEQ * SLICE;      // a multiple of 64: 16-byte LDS / HBM accesses
+    // the thread's cell record is requested first: its two dependent global loads travel with the
+    // staging loads below instead of after them
+    const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
+    const bool active = (int)threadIdx.x < n_cells;   // one cell per thread (n_cells <= THREADS)
+    PatchCell pc_own = {};
+    if (active) pc_own = pcells[c0 + threadIdx.x];
     {
         double2 *acc2 = reinterpret_cast<double2 *>(acc);
         for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) acc2[k] = make_double2(0.0, 0.0);
@@ -303,16 +312,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 Hl[i * NS + s] = sc.c_old * uold[(size_t)g * NEQ + s] + sc.c_old1 * uold1[(size_t)g * NEQ + s];
         }
     }
+    FEDM_T(0)   // zero + stage (issue)
     __syncthreads();
-    const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
-    const bool active = (int)threadIdx.x < n_cells;   // one cell per thread (n_cells <= THREADS)
+    FEDM_T(1)   // barrier: the staged loads arrive
     LeanCell lc = {0, 0, 0, 0};
-    if (active) lc = lean_prologue<NS>(pcells[c0 + threadIdx.x], Ul, nql + threadIdx.x, THREADS);
+    if (active) lc = lean_prologue<NS>(pc_own, Ul, nql + threadIdx.x, THREADS);
+    FEDM_T(2)   // prologue: cell record, exp(u) at the quadrature points
 #pragma unroll 1
     for (int row = 0; row < NEQ; ++row) {
         asm volatile("" : "+v"(lc.wl), "+v"(lc.wj0), "+v"(lc.wj1), "+v"(lc.wj2));  // nothing hoisted out of the row
         if (active) lean_row<NS, NR>(md, row, lc, vx, Ul, Hl, sc, acc, Fl, nql + threadIdx.x, THREADS);
+        FEDM_T(3)   // the row (wave 0's view)
         __syncthreads();
+        FEDM_T(4)   // barrier: the other waves finish the row
         // the row's planes of every block: NEQ * 64 consecutive doubles per block in HBM
         for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
             const int bc = k / (NEQ * SLICE / 2), rem = k - bc * (NEQ * SLICE / 2);
@@ -321,10 +333,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
             dst[rem] = *src;
             *src = make_double2(0.0, 0.0);
         }
+        FEDM_T(5)   // stream-out + zeroing (issue)
         lds_only_barrier();   // accumulators zero again; the stores above stay in flight
+        FEDM_T(6)
     }
     double *fdst = F + (size_t)S * SLICE * NEQ;
     for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) fdst[k] = Fl[k];
+    FEDM_T(7)
 }
 #undef FEDM_PATCH_PARAMS
 #undef FEDM_PATCH_ARGS

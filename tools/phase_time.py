@@ -13,8 +13,16 @@ lib.fedm_debug_phase(out, 1)
 n = 10
 for _ in range(n): prob.jacobian()
 lib.fedm_debug_phase(out, 1)
-names = ["zero LDS", "stage vertices (global loads)", "barrier 1", "cell record + LDS reads", "setup",
-         "rows: moments + emission + atomics", "barrier 2", "stream out"]
+# the row-at-a-time kernel (assemble_lean_kernel); the unrolled one (FEDM_ASSEMBLY_LEAN=0) has the
+# phases zero / stage / barrier / cell record / setup / rows / barrier / stream out
+import os
+if os.environ.get("FEDM_ASSEMBLY_LEAN", "1") == "0":
+    names = ["zero LDS", "stage vertices (global loads)", "barrier 1", "cell record + LDS reads", "setup",
+             "rows: moments + emission + atomics", "barrier 2", "stream out"]
+else:
+    names = ["zero + stage vertices (issue)", "barrier: staged loads arrive", "prologue: cell record, exp(u)",
+             "rows (3x): set-up, moments, emission", "barriers after the rows", "stream-out + zeroing (3x, issue)",
+             "LDS-only barriers", "F stream-out"]
 tot = sum(out)
 for k, v in zip(names, out):
     print(f"{k:38s} {100.0 * v / tot:5.1f} %   {v / n / 5203 / 100.0:7.2f} us per patch (100 MHz clock)")
