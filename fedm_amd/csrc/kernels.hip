@@ -326,12 +326,24 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
         __syncthreads();
         FEDM_T(4)   // barrier: the other waves finish the row
         // the row's planes of every block: NEQ * 64 consecutive doubles per block in HBM
-        for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
-            const int bc = k / (NEQ * SLICE / 2), rem = k - bc * (NEQ * SLICE / 2);
-            double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
-            double2 *src = reinterpret_cast<double2 *>(acc) + k;
-            dst[rem] = *src;
-            *src = make_double2(0.0, 0.0);
+        constexpr int PER = NEQ * SLICE / 2;   // 16-byte pieces per block column
+        if constexpr (THREADS % PER == 0) {
+            // a thread keeps its place within the block column and strides over the columns
+            const int rem = threadIdx.x % PER;
+            for (int bc = threadIdx.x / PER; bc < width; bc += THREADS / PER) {
+                double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
+                double2 *src = reinterpret_cast<double2 *>(acc) + bc * PER + rem;
+                dst[rem] = *src;
+                *src = make_double2(0.0, 0.0);
+            }
+        } else {
+            for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
+                const int bc = k / PER, rem = k - bc * PER;
+                double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
+                double2 *src = reinterpret_cast<double2 *>(acc) + k;
+                dst[rem] = *src;
+                *src = make_double2(0.0, 0.0);
+            }
         }
         FEDM_T(5)   // stream-out + zeroing (issue)
         lds_only_barrier();   // accumulators zero again; the stores above stay in flight
