@@ -4,11 +4,22 @@
 ``python bench.py --gpus N --steps K --warmup W``.  A *step* is one accepted
 adaptive BDF2 time step of examples/streamer_discharge/fedm-streamer.py:304-340
 (shift states, Newton solve with F/J assembly and GMRES, error norm, step
-controller) on the state resident in HBM.  Workload (BASELINE.json configs[3]):
+controller) on the state resident in HBM.  Workload at N = 1 (BASELINE.json configs[3]):
 2-D axisymmetric streamer, 576x576 "right" mesh graded towards the axis
-(332 929 vertices x 3 equations = 998 787 DOFs).  Prints ONE JSON line (rank 0).
+(332 929 vertices x 3 equations = 998 787 DOFs); N > 1: the same mesh size PER GPU (weak
+scaling), plus -- at N = 8 -- a second record on BASELINE configs[4] (1152x1152, ~4 M DOFs).
+Prints ONE JSON line (rank 0).
+
+Records in the line, besides the driver's contract:
+* ``roofline`` / ``roofline_other`` / ``assembly_plus_spmv``: HIP-event timings of the hot kernels
+  against the 8 TB/s HBM3E peak (and against the copy rate measured on this box);
+* ``late_window``: the same K steps timed again from the developed streamer (step 200, t ~ 1 ns),
+  where a step needs several times the Krylov iterations of the first steps;
+* ``multi_gpu`` (N > 1): transport, ranks, halo exchanges / all-reduces per step and their latency;
+* ``cpu_baseline`` (N = 1): the C/OpenMP restatement under oracle/ on the same mesh.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,6 +32,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md, chip-level parameters (spec)
+PMC_PROFILE = ROOT / "profiles" / "r02_pmc_traffic.json"
+KERNEL_SOURCES = ["kernels.hip", "element.hpp", "element_lean.hpp", "prep.cpp", "fedm_internal.hpp"]
 
 
 def parse_args():
@@ -31,8 +44,18 @@ def parse_args():
     ap.add_argument("--mesh", type=int, default=576, help="cells per side (per GPU)")
     ap.add_argument("--grading", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-mesh", type=int, default=144)
+    ap.add_argument("--cpu-mesh", type=int, default=None, help="CPU baseline mesh (default: --mesh)")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0: every core this process may use")
+    ap.add_argument("--late-start", type=int, default=200,
+                    help="accepted steps before the late window (0 disables it)")
+    ap.add_argument("--configs4", choices=["auto", "on", "off"], default="auto",
+                    help="second record on the ~4 M-DOF mesh of BASELINE configs[4] (auto: at 8 GPUs)")
+    ap.add_argument("--configs4-mesh", type=int, default=1152, help="global cells per side of that record")
+    # The data path across GPUs is RCCL.  When its set-up fails, every rank agrees on a host-staged
+    # transport (gloo), which is correct but measures the host, not xGMI: the run then stops with a
+    # non-zero exit code unless this flag says that such a number is wanted.
+    ap.add_argument("--allow-fallback", action="store_true")
     # rehearsal of the N > 1 path on a one-GPU box: all ranks on cuda:0, gloo process group (RCCL
     # refuses two ranks on one device, so the library falls back to its host-staged transport)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true")
@@ -55,24 +78,43 @@ def assembly_bytes(sz):
     return nv * (16 + 24 * neq) + nc * (12 + 36) + nnzb * neq * neq * 8 + nv * neq * 8
 
 
+def residual_bytes(sz):
+    """SURVEY 8(d), residual only: no matrix values, no cell slots."""
+    neq, nv, nc = sz["n_eq"], sz["n_vertices"], sz["n_cells"]
+    return nv * (16 + 24 * neq) + nc * 12 + nv * neq * 8
+
+
+def kernel_source_sha():
+    """Identity of the kernel sources a PMC profile belongs to (profiles/*_pmc_traffic.json carry
+    it): counters cannot be read from inside the run, so the HBM traffic in the bench line comes
+    from the committed rocprofv3 passes -- and is dropped when they were taken on other kernels."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update((ROOT / "fedm_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed PMC passes of this same workload
-    (profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied);
-    counters cannot be read from inside the run, so None when the file is absent."""
-    f = ROOT / "profiles" / "r01_pmc_traffic.json"
-    if not f.exists():
-        return {}
-    k = json.loads(f.read_text())["kernels"]
-    out = {}
-    for name, v in k.items():
-        if "traffic_bytes_corrected" in v:
-            out[name] = v["traffic_bytes_corrected"]
-    # the Krylov SpMV is the plain instantiation (<n_eq, false>: the field split sits on the right)
-    spmv = [n for n in out if "spmv_kernel" in n and "ell_" not in n]
-    plain = [n for n in spmv if "false>" in n]
-    if spmv:
-        out["spmv"] = out[(plain or spmv)[0]]
-    return out
+    (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied).  {} when the profile is absent or was
+    measured on other kernel sources."""
+    if not PMC_PROFILE.exists():
+        return {}, "no committed PMC profile"
+    prof = json.loads(PMC_PROFILE.read_text())
+    sha = kernel_source_sha()
+    if prof.get("kernel_source_sha") != sha:
+        return {}, (f"{PMC_PROFILE.name} was measured on kernel sources {prof.get('kernel_source_sha')}, "
+                    f"this run uses {sha}: traffic dropped")
+    out = {n: v["traffic_bytes_corrected"] for n, v in prof["kernels"].items() if "traffic_bytes_corrected" in v}
+    return out, f"{PMC_PROFILE.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, kernel sources {sha})"
+
+
+def pick(tr, *needles):
+    for n in needles:
+        for k, v in tr.items():
+            if n in k:
+                return v
+    return None
 
 
 def measured_copy_ceiling(device):
@@ -98,27 +140,12 @@ def measured_copy_ceiling(device):
     return 2 * n * 8 / (ms * 1e-3) / 1e9
 
 
-def cpu_baseline(n, steps):
-    """The oracle (numpy assembly + SuperLU, 'CPU restatement, not FEniCS') on a bounded
-    sample of the same workload, timed on this box's host cores."""
-    from oracle import streamer as ost
-    from oracle.mesh import graded_axis, rectangle_right
-    import warnings
-    mesh = rectangle_right(0.0, 0.0, ost.BOX, ost.BOX, n, n, xs=graded_axis(ost.BOX, n, 4.0))
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        model = ost.build(mesh)
-        ost.initial_state(model)          # untimed warm-up of the code path
-        t0 = time.perf_counter()
-        _, st, _, _ = ost.run(mesh=mesh, max_steps=steps)
-        el = time.perf_counter() - t0
-    ndof = mesh.nv * 3
-    return {"value": ndof * steps / el, "unit": "DOF-updates/s", "cores": 1, "kind": "port",
-            "timesteps_per_sec": steps / el,
-            "sample": f"{steps} accepted BDF2 steps (incl. initial Poisson solve) of the same "
-                      f"streamer case on a {n}x{n} graded mesh ({ndof} DOFs); oracle = numpy "
-                      f"assembly + SuperLU direct solve, single thread; host has "
-                      f"{os.cpu_count()} cores"}
+def cpu_baseline(n, grading, steps, threads):
+    """oracle/cpu_backend (C + OpenMP: coloured element loop -> block CSR -> Newton -> flexible
+    GMRES with the same field split, Chebyshev sweeps and multigrid V-cycle as the device path),
+    'CPU restatement, not FEniCS', on the same mesh, timed on this box's host cores."""
+    from oracle import cpu_backend
+    return cpu_backend.bench(n, grading, steps, threads)
 
 
 def pin_to_gpu_numa_node(torch, local_rank):
@@ -148,6 +175,27 @@ def pin_to_gpu_numa_node(torch, local_rank):
         return f"unchanged ({type(exc).__name__})"
 
 
+def timed_steps(runner, steps, barrier, torch, dist, distributed):
+    """K steps between two barriers; wall time is the MAX over ranks.  Returns (seconds, Newton
+    iterations, GMRES iterations, assembly profile)."""
+    runner.profile(1)             # HIP events around the assembly kernels, on the library's stream
+    barrier()
+    t0 = time.perf_counter()
+    n0 = (runner.newton_iterations, runner.linear_iterations)
+    for _ in range(steps):
+        runner.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n1 = (runner.newton_iterations, runner.linear_iterations)
+    prof = runner.profile_read()
+    runner.profile(False)
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, n1[0] - n0[0], n1[1] - n0[1], prof
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,7 +212,6 @@ def main():
     if not entry.LIB.exists():
         entry.build()
     from fedm_amd.cases import streamer
-    from fedm_amd import functions as ff
 
     placement = pin_to_gpu_numa_node(torch, local_rank)
 
@@ -183,28 +230,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def make_runner(n_per_gpu=None, global_n=None):
+        if distributed:
+            from fedm_amd.cases import streamer_distributed
+            r = streamer_distributed.Runner(None, rank, world, local_rank, args.grading,
+                                            n_per_gpu=n_per_gpu, global_n=global_n)
+            if r.transport != "rccl" and not (args.allow_fallback or args.rehearse_on_one_gpu):
+                if rank == 0:
+                    print(json.dumps({"error": "RCCL transport unavailable", "reason": r.fallback_reason,
+                                      "hint": "--allow-fallback times the host-staged (gloo) transport instead"}))
+                dist.destroy_process_group()
+                raise SystemExit(3)
+            return r
+        msh = streamer.mesh(n_per_gpu, args.grading)
+        return streamer.Stepper(streamer.device_problem(msh.coords, msh.cells, device=local_rank))
+
     n = args.mesh
-    msh = streamer.mesh(n, args.grading)
-    if distributed:
-        from fedm_amd.cases import streamer_distributed
-        runner = streamer_distributed.Runner(msh, rank, world, local_rank, args.grading)
-    else:
-        prob = streamer.device_problem(msh.coords, msh.cells, device=local_rank)
-        runner = streamer.Stepper(prob)
+    t_setup = time.perf_counter()
+    runner = make_runner(n_per_gpu=n)
     runner.initialise()
+    setup_s = time.perf_counter() - t_setup
     for _ in range(args.warmup):
         runner.step()
 
-    runner.profile(1)             # HIP events around the assembly kernel, on the library's stream
-    barrier()
-    t0 = time.perf_counter()
-    n0 = (runner.newton_iterations, runner.linear_iterations)
-    for _ in range(args.steps):
-        runner.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    n1 = (runner.newton_iterations, runner.linear_iterations)
-    prof = runner.profile_read()
+    # ---- the timed region: K steps right after the warm-up (SURVEY 8(d)'s window) -------------
+    elapsed, newton, gmres, prof = timed_steps(runner, args.steps, barrier, torch, dist, distributed)
+    comm0 = runner.prob.comm_stats() if distributed else None
+
     # Second, untimed pass for the kernels inside the Krylov iterations: timing them needs plain
     # launches (HIP events cannot sit inside the replayed per-iteration graphs).
     pass_steps = max(1, min(args.steps, 5))
@@ -217,10 +269,6 @@ def main():
     elapsed2 = time.perf_counter() - t1
     prof2 = runner.profile_read()
     runner.profile(False)
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     total_dofs = runner.total_dofs
     sz = runner.sizes()
@@ -228,40 +276,55 @@ def main():
     ms_asm = prof["assembly_FJ"][0] / max(prof["assembly_FJ"][1], 1)
     ms_spmv = prof2["spmv"][0] / max(prof2["spmv"][1], 1)
     ms_res = prof["assembly_F"][0] / max(prof["assembly_F"][1], 1)
-    b_spmv, b_asm = spmv_bytes(sz), assembly_bytes(sz)
+    b_spmv, b_asm, b_res = spmv_bytes(sz), assembly_bytes(sz), residual_bytes(sz)
     gbs_spmv = b_spmv / (ms_spmv * 1e-3) / 1e9
     gbs_asm = b_asm / (ms_asm * 1e-3) / 1e9
     share = {k: v[0] / (elapsed * 1e3) for k, v in prof.items()}
     share2 = {k: v[0] / (elapsed2 * 1e3) for k, v in prof2.items()}
     second_pass = (f"separate profiling pass of {pass_steps} steps right after the timed region, "
                    f"kernels launched one by one ({1e3 * elapsed2 / pass_steps:.2f} ms/step)")
+    copy_gbs = measured_copy_ceiling(torch.device("cuda", local_rank)) if rank == 0 else None
+    tr, tr_source = pmc_traffic() if (world == 1 and n == 576) else ({}, "not the profiled workload")
     rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3,false> (Jacobian SpMV, sliced block-ELL)",
                "achieved": gbs_spmv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": gbs_spmv / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": b_spmv,
+               "frac": gbs_spmv / HBM_PEAK_GBS,
+               "frac_of_measured_copy": gbs_spmv / copy_gbs if copy_gbs else None,
+               "traffic": pick(tr, "spmv_kernel<3, false>", "spmv_kernel<3,false>", "spmv"),
+               "algorithmic_bytes": b_spmv,
                "ms_per_launch": ms_spmv, "launches": prof2["spmv"][1],
                "share_of_profiling_pass": share2["spmv"], "measured": second_pass}
     rl_asm = {"bound": "hbm", "kernel": runner.assembly_kernel_name,
               "achieved": gbs_asm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-              "frac": gbs_asm / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": b_asm,
+              "frac": gbs_asm / HBM_PEAK_GBS,
+              "frac_of_measured_copy": gbs_asm / copy_gbs if copy_gbs else None,
+              "traffic": pick(tr, "assemble_lean2", "assemble_lean", "assemble_patch"),
+              "traffic_source": tr_source, "algorithmic_bytes": b_asm,
               "ms_per_launch": ms_asm, "launches": prof["assembly_FJ"][1],
-              "ms_residual_only": ms_res, "share_of_timed_region": share["assembly_FJ"]}
-    tr = pmc_traffic() if (world == 1 and n == 576) else {}
-    rl_spmv["traffic"] = tr.get("spmv")
-    rl_asm["traffic"] = next((v for k, v in tr.items() if "assemble_lean" in k),
-                             next((v for k, v in tr.items() if "assemble_patch" in k), None))
-    dominant, other = rl_asm, rl_spmv   # the assembly kernel is timed inside the timed region
+              "ms_residual_only": ms_res, "residual_only_algorithmic_bytes": b_res,
+              "residual_only_frac": b_res / (ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_res else None,
+              "share_of_timed_region": share["assembly_FJ"]}
     # BASELINE.json's target is quoted on the assembly + SpMV path together: algorithmic bytes of
     # all assemblies and Krylov SpMVs of a step over the time their kernels take
-    n_asm = prof["assembly_FJ"][1] / args.steps
-    n_res = prof["assembly_F"][1] / args.steps          # residual-only assemblies (final Newton checks)
-    n_spmv = (n1[1] - n0[1]) / args.steps               # one Jacobian SpMV per GMRES iteration
-    neq_, nv_, nc_ = sz["n_eq"], sz["n_vertices"], sz["n_cells"]
-    b_res = nv_ * (16 + 24 * neq_) + nc_ * 12 + nv_ * neq_ * 8      # no matrix values / slots
-    path_bytes = n_asm * b_asm + n_res * b_res + n_spmv * b_spmv
-    path_ms = n_asm * ms_asm + n_res * ms_res + n_spmv * ms_spmv
-    path_gbs = path_bytes / (path_ms * 1e-3) / 1e9
-    copy_gbs = measured_copy_ceiling(torch.device("cuda", local_rank)) if rank == 0 else None
 
+    def path_record(prof_w, gmres_w, steps_w):
+        n_asm = prof_w["assembly_FJ"][1] / steps_w
+        n_res = prof_w["assembly_F"][1] / steps_w        # residual-only assemblies (final Newton checks)
+        n_spmv = gmres_w / steps_w                       # one Jacobian SpMV per GMRES iteration
+        m_asm = prof_w["assembly_FJ"][0] / max(prof_w["assembly_FJ"][1], 1)
+        m_res = prof_w["assembly_F"][0] / max(prof_w["assembly_F"][1], 1)
+        path_bytes = n_asm * b_asm + n_res * b_res + n_spmv * b_spmv
+        path_ms = n_asm * m_asm + n_res * m_res + n_spmv * ms_spmv
+        path_gbs = path_bytes / (path_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": path_gbs / HBM_PEAK_GBS, "assemblies_per_step": n_asm,
+                "residual_only_assemblies_per_step": n_res, "spmv_per_step": n_spmv,
+                "algorithmic_bytes_per_step": path_bytes, "kernel_ms_per_step": path_ms,
+                "measured_copy_ceiling_GBs": copy_gbs,
+                "frac_of_measured_copy": (path_gbs / copy_gbs) if copy_gbs else None}
+
+    gmres_text = ("flexible, restart 30, rtol 1e-5 on the true residual, right-preconditioned: field split, "
+                  "Chebyshev(6) block Jacobi on species (degree 4 once a Newton system needs >= 5 Krylov "
+                  "steps) + multigrid V(1,1) on the potential")
     out = {
         "metric": "BDF2 DOF-updates/sec (streamer_discharge 2D axisym)",
         "value": total_dofs * args.steps / elapsed,
@@ -272,30 +335,84 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "streamer_discharge 2D axisymmetric, LFA, 3 equations "
-                               "(ions, electrons, Poisson), analytic Bagheri-2018 seed",
+                               "(ions, electrons, Poisson), analytic Bagheri-2018 seed"
+                               + ("" if world == 1 else f"; weak scaling: {n}x{n} cells per GPU"),
+                   "baseline_config": "configs[3] (~1M DOFs, 1 GPU)" if world == 1 and n == 576 else
+                                      f"configs[3]'s mesh size per GPU x {world} GPUs (configs[4] itself: see 'configs4')",
                    "mesh": f"{n}x{n} right-diagonal, geometric grading {args.grading} towards "
                            f"the axis, per GPU",
                    "dofs_total": total_dofs, "vertices_per_gpu": sz["n_vertices"],
-                   "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": "flexible, restart 30, rtol 1e-5 on the true residual, right-preconditioned: "
-                   "field split, Chebyshev(6) block Jacobi on species (degree 4 once a Newton system needs >= 5 Krylov steps) + multigrid V(1,1) on the potential", "partition": runner.partition_name,
-                   "host_placement": placement},
-        "newton_iterations_per_step": (n1[0] - n0[0]) / args.steps,
-        "gmres_iterations_per_step": (n1[1] - n0[1]) / args.steps,
-        "roofline": dominant,
-        "roofline_other": other,
-        "assembly_plus_spmv": {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": path_gbs / HBM_PEAK_GBS, "assemblies_per_step": n_asm,
-                               "residual_only_assemblies_per_step": n_res,
-                               "spmv_per_step": n_spmv, "algorithmic_bytes_per_step": path_bytes,
-                               "kernel_ms_per_step": path_ms,
-                               "measured_copy_ceiling_GBs": copy_gbs,
-                               "frac_of_measured_copy": (path_gbs / copy_gbs) if copy_gbs else None},
+                   "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": gmres_text,
+                   "partition": runner.partition_name, "host_placement": placement,
+                   "setup_seconds": setup_s},
+        "window": f"steps {args.warmup + 1}..{args.warmup + args.steps} from the initial condition "
+                  "(SURVEY 8(d)); the developed streamer is 'late_window'",
+        "newton_iterations_per_step": newton / args.steps,
+        "gmres_iterations_per_step": gmres / args.steps,
+        "roofline": rl_asm,
+        "roofline_other": rl_spmv,
+        "assembly_plus_spmv": path_record(prof, gmres, args.steps),
         "vcycle": {"ms_per_cycle": prof2["vcycle"][0] / max(prof2["vcycle"][1], 1),
                    "cycles": prof2["vcycle"][1], "share_of_profiling_pass": share2["vcycle"],
                    "levels": runner.multigrid_levels, "measured": second_pass},
     }
+
+    # ---- the developed streamer: the same K steps from step `late_start` on ---------------------
+    if args.late_start > 0:
+        while runner.steps < args.late_start:
+            runner.step()
+        t_late = runner.t
+        l_elapsed, l_newton, l_gmres, l_prof = timed_steps(runner, args.steps, barrier, torch, dist, distributed)
+        out["late_window"] = {
+            "what": f"{args.steps} accepted steps timed the same way from step {args.late_start + 1} on "
+                    f"(t = {t_late:.3e} s: the streamer has formed and propagates)",
+            "value": total_dofs * args.steps / l_elapsed, "unit": "DOF-updates/s",
+            "timesteps_per_sec": args.steps / l_elapsed, "ms_per_step": 1e3 * l_elapsed / args.steps,
+            "newton_iterations_per_step": l_newton / args.steps,
+            "gmres_iterations_per_step": l_gmres / args.steps,
+            "assembly_plus_spmv": path_record(l_prof, l_gmres, args.steps)}
+        out["sustained_timesteps_per_sec"] = args.steps / l_elapsed
+
+    # ---- multi-GPU plumbing: what travelled, and what one exchange / reduction costs ------------
+    if distributed:
+        cs = comm0
+        steps_done = args.warmup + args.steps
+        lat = {}
+        for name, kind in (("halo_state_us", 0), ("halo_scalar_us", 1), ("allreduce_32_doubles_us", 2)):
+            barrier()
+            lat[name] = 1e3 * runner.prob.time_comm(kind, 50)
+        out["multi_gpu"] = {
+            "transport": runner.transport, "transport_requested": runner.transport_requested,
+            "ranks_in_communicator": cs["ranks"], "neighbours_rank0": cs["neighbours"],
+            "halo_exchanges_per_step": cs["halo_exchanges"] / steps_done,
+            "allreduces_per_step": cs["allreduces"] / steps_done,
+            "assembly_patches_rank0": {"interior (assembled while the state halo travels)": cs["interior_patches"],
+                                       "boundary": cs["boundary_patches"]},
+            **lat,
+            "halo_ms_per_step_if_serial": cs["halo_exchanges"] / steps_done * lat["halo_state_us"] * 1e-3,
+            "allreduce_ms_per_step_if_serial": cs["allreduces"] / steps_done * lat["allreduce_32_doubles_us"] * 1e-3,
+            "note": "latencies are back-to-back micro-benchmarks on the compute stream after the run; in the "
+                    "run the exchanges overlap interior SpMV rows / sweeps / assembly patches"}
+
+    # ---- BASELINE configs[4]: ~4 M DOFs over 8 GPUs (strong-scaled counterpart of the line above) ----
+    want4 = args.configs4 == "on" or (args.configs4 == "auto" and world == 8)
+    if want4 and distributed:
+        del runner
+        r4 = make_runner(global_n=args.configs4_mesh)
+        r4.initialise()
+        for _ in range(args.warmup):
+            r4.step()
+        e4, nw4, gm4, _ = timed_steps(r4, args.steps, barrier, torch, dist, distributed)
+        out["configs4"] = {
+            "workload": f"BASELINE configs[4]: streamer_discharge, {args.configs4_mesh}x{args.configs4_mesh} "
+                        f"global mesh over {world} GPUs",
+            "dofs_total": r4.total_dofs, "value": r4.total_dofs * args.steps / e4, "unit": "DOF-updates/s",
+            "timesteps_per_sec": args.steps / e4, "ms_per_step": 1e3 * e4 / args.steps,
+            "newton_iterations_per_step": nw4 / args.steps, "gmres_iterations_per_step": gm4 / args.steps,
+            "partition": r4.partition_name}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_mesh, args.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n, args.grading, args.cpu_steps, args.cpu_threads)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -158,6 +158,10 @@ _SIGNATURES = {
     "fedm_comm_init_callbacks": (C.c_int, [_P, C.c_int] + [C.POINTER(C.c_int32)] * 4
                                  + [ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p, C.c_int, C.c_int]),
     "fedm_sync_ghosts": (C.c_int, [_P]),
+    "fedm_comm_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "fedm_time_comm": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "fedm_debug_comm_fault": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
+    "fedm_pattern_stats": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_int64)]),
     "fedm_profile": (C.c_int, [_P, C.c_int]),
     "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
     "fedm_set_assembly": (C.c_int, [_P, C.c_int]),

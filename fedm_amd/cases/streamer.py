@@ -123,7 +123,8 @@ class Stepper:
     """The script-level time loop of fedm-streamer.py:304-340 around one device problem."""
 
     partition_name = "single GPU"
-    assembly_kernel_name = "assemble_lean_kernel<2,1,192> (LDS patches, one equation row at a time, F+J)"
+    assembly_kernel_name = ("assemble_lean2_kernel<2,1,192> (LDS patches with micro-coloured cell order, one "
+                            "equation row at a time, F+J)")
 
     @property
     def multigrid_levels(self):

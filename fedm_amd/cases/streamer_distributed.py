@@ -4,6 +4,8 @@ ghost exchange + all-reduces inside libfedm_hip.so (RCCL over xGMI).
 Weak scaling: the mesh handed in is the per-GPU mesh size; the global mesh has
 ``world`` times as many cells (the box is fixed, the resolution grows).
 """
+import os
+
 import numpy as np
 
 from .. import partition
@@ -19,11 +21,18 @@ def global_mesh(n_per_gpu, world, grading):
 
 
 class Runner(streamer.Stepper):
+    fallback_reason = None
+
     def __init__(self, per_gpu_mesh, rank, world, local_rank, grading=4.0, transport="rccl",
-                 group=None, n_per_gpu=None, **kw):
+                 group=None, n_per_gpu=None, global_n=None, **kw):
+        """Mesh size: ``global_n`` cells per side of the whole mesh (strong scaling, e.g. BASELINE
+        configs[4]), else ``n_per_gpu`` (or the size of ``per_gpu_mesh``) cells per side PER GPU."""
         import torch.distributed as dist
-        n_per_gpu = n_per_gpu or int(round(np.sqrt(per_gpu_mesh.num_cells() / 2)))
-        gmesh, n = global_mesh(n_per_gpu, world, grading)
+        if global_n:
+            gmesh, n = streamer.mesh(int(global_n), grading), int(global_n)
+        else:
+            n_per_gpu = n_per_gpu or int(round(np.sqrt(per_gpu_mesh.num_cells() / 2)))
+            gmesh, n = global_mesh(n_per_gpu, world, grading)
         part = partition.partition_rcb(gmesh.coords, world)
         lm = partition.local_mesh(gmesh.coords, gmesh.cells, part, rank)
         self.lm, self.world, self.rank = lm, world, rank
@@ -35,27 +44,55 @@ class Runner(streamer.Stepper):
         prob = DeviceProblem(lm.coords, lm.cells, streamer.model(), facet_tags=tags,
                              dirichlet_dofs=ddofs, dirichlet_vals=dvals, device=local_rank,
                              n_owned=lm.n_owned)
+        self.transport_requested = transport
         if transport == "rccl":
-            # every rank must take the same branch: agree on the outcome of the RCCL set-up
-            ok = 1
+            # Every rank must take the same branch, and no rank may enter ncclCommInitRank alone
+            # (the others would block in it for ever): agree BEFORE the call on what can be known
+            # beforehand -- librccl loads, and no two ranks sit on one device (RCCL refuses that) --
+            # and AFTER it on its outcome.
+            reason = None
             try:
-                uid = [rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0, group=group)
-                prob.init_comm_rccl(lm, uid[0], rank, world)
-            except Exception as exc:                     # noqa: BLE001 - reported, then the fallback
-                ok = 0
-                print(f"[fedm_amd] rank {rank}: RCCL transport unavailable ({exc}); "
-                      f"falling back to host-staged exchanges", flush=True)
-            flags = [None] * world
-            dist.all_gather_object(flags, ok, group=group)
-            if not all(flags):
+                import torch
+                props = torch.cuda.get_device_properties(local_rank)
+                ident = (os.uname().nodename, str(getattr(props, "uuid", "")) or f"{props.pci_bus_id}")
+                uid = rccl_unique_id() if rank == 0 else None
+                mine = (ident, None)
+            except Exception as exc:                     # noqa: BLE001 - reported below, by every rank
+                uid, mine = None, (None, f"{type(exc).__name__}: {exc}")
+            seen = [None] * world
+            dist.all_gather_object(seen, mine, group=group)
+            errors = [f"rank {r}: {e}" for r, (_, e) in enumerate(seen) if e]
+            idents = [i for i, _ in seen]
+            if errors:
+                reason = "; ".join(errors)
+            elif len(set(idents)) < world:
+                reason = "several ranks share one GPU"
+            ok = 0
+            if reason is None:
+                box = [uid]
+                dist.broadcast_object_list(box, src=0, group=group)
+                try:
+                    prob.init_comm_rccl(lm, box[0], rank, world)
+                    ok = 1
+                except Exception as exc:                 # noqa: BLE001 - reported, then agreed on
+                    reason = f"rank {rank}: {exc}"
+                flags = [None] * world
+                dist.all_gather_object(flags, (ok, reason), group=group)
+                bad = [r for f, r in flags if not f]
+                if bad:
+                    ok, reason = 0, "; ".join(str(b) for b in bad)
+            if not ok:
+                print(f"[fedm_amd] rank {rank}: RCCL transport unavailable ({reason}); "
+                      f"falling back to host-staged exchanges -- NOT the xGMI data path", flush=True)
                 transport = "torch-gloo (RCCL set-up failed)"
+                self.fallback_reason = reason
                 prob.init_comm_torch(lm, dist.new_group(backend="gloo"))
         else:
             prob.init_comm_torch(lm, group)
         self._group = group if transport != "torch-gloo (RCCL set-up failed)" else None
         super().__init__(prob, **kw)
         self.world_size = world
+        self.transport = transport
         self.total_dofs = gmesh.num_vertices() * 3
         self.partition_name = (f"RCB vertex partition, {world} parts, global mesh {n}x{n}, "
                                f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices on rank {rank}, "

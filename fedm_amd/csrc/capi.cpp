@@ -513,6 +513,11 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 ahead = true;
             }
             wait_red_seq(c, seq_j);  // published by the finish kernel: the host works while the update runs
+            if (comm_failed(c)) {  // a lost peer is an error, not a NaN
+                *its_out = its;
+                *rnorm_out = rnorm;
+                return -1;
+            }
             if (deferred && j == 0) {
                 beta = std::sqrt(c.h_red[RED_SPARE]);
                 if (!std::isfinite(beta)) {
@@ -727,6 +732,23 @@ int fedm_abi_version(void) { return 1; }
 static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *model,
                            const fedm_gd_desc *gd, int device, fedm_ctx **out);
 
+// every error exit of the set-up releases what had been allocated so far (context, stream, device
+// and pinned memory): a caller that retries after an out-of-memory must not accumulate leaked HBM
+static int ctx_create_guarded(const fedm_mesh_desc *mesh, const fedm_model_desc *model,
+                              const fedm_gd_desc *gd, int device, fedm_ctx **out) {
+    *out = nullptr;
+    fedm_ctx *h = nullptr;
+    const int rc = ctx_create_impl(mesh, model, gd, device, &h);
+    if (rc != 0) {
+        const std::string msg = g_error;  // destroy may overwrite it
+        if (h) fedm_ctx_destroy(h);
+        g_error = msg;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
 int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, int device,
                     fedm_ctx **out) {
     if (!mesh || !model || !out) {
@@ -737,7 +759,7 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
         set_error("unsupported model descriptor (species/reaction/quadrature counts)");
         return -2;
     }
-    return ctx_create_impl(mesh, model, nullptr, device, out);
+    return ctx_create_guarded(mesh, model, nullptr, device, out);
 }
 
 int fedm_ctx_create_gd(const fedm_mesh_desc *mesh, const fedm_gd_desc *gd, int device,
@@ -752,7 +774,7 @@ int fedm_ctx_create_gd(const fedm_mesh_desc *mesh, const fedm_gd_desc *gd, int d
         set_error("unsupported LMEA model descriptor");
         return -2;
     }
-    return ctx_create_impl(mesh, nullptr, gd, device, out);
+    return ctx_create_guarded(mesh, nullptr, gd, device, out);
 }
 
 int fedm_gd_prep_setup(fedm_ctx *h, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
@@ -838,6 +860,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
     }
     FEDM_HIP_CHECK(hipSetDevice(device));
     fedm_ctx *h = new fedm_ctx();
+    *out = h;  // from here on the caller (ctx_create_guarded) owns it, error exits included
     Ctx &c = h->c;
     c.device = device;
     const int n_tags_model = model ? model->n_tags : gd->n_tags;
@@ -864,7 +887,6 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
     for (int i = 0; i < mesh->n_dirichlet; ++i)
         if (mesh->dirichlet_dofs[i] < 0 || mesh->dirichlet_dofs[i] >= c.n) {
             set_error("Dirichlet dof out of range");
-            delete h;
             return -2;
         }
     FEDM_HIP_CHECK(hipStreamCreate(&c.stream));
@@ -941,7 +963,9 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         // (glow discharge, 402k DOFs: 70 against 100 steps per time step).  FEDM_PRECOND_SIDE or
         // fedm_set_preconditioner_side override.
         c.right_precond = c.model_kind == 0;
-        if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] != '0';
+        if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] >= '0' && lean[0] <= '2' ? lean[0] - '0' : 2;
+        if (const char *e = getenv("FEDM_XCD_REMAP")) c.xcd_remap = e[0] != '0';
+        if (const char *e = getenv("FEDM_ASSEMBLY_OVERLAP")) c.assembly_overlap = e[0] != '0';
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;
@@ -973,7 +997,6 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (model->ext_nodes[s] > 0)
             if (alloc_zero(c.d_ext[s], (size_t)c.nc * model->ext_nodes[s], c.stream)) return -1;
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
-    *out = h;
     return 0;
 }
 
@@ -1029,6 +1052,7 @@ static int get_vec(Ctx &c, double *dst, const double *src) {
 int fedm_set_state(fedm_ctx *h, const double *u_new, const double *u_old, const double *u_old1) {
     Ctx &c = h->c;
     FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (u_new) c.halo_pending = false;  // the caller's vector carries its own ghost values
     if (put_vec(c, c.d_u, u_new) || put_vec(c, c.d_uold, u_old) || put_vec(c, c.d_uold1, u_old1)) return -1;
     return 0;
 }
@@ -1198,8 +1222,8 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         const int lrc = gmres(c, o->ksp_restart, o->ksp_rtol, o->ksp_atol, o->ksp_max_it, &lits, &lres,
                               right ? c.d_F : c.d_rhs, right ? -1.0 : 1.0, right ? fnorm : -1.0, c.d_u, &updated);
         lin_total += lits;
-        if (lrc != 0) {
-            rc = lrc < 0 ? lrc : (lrc == FEDM_DIVERGED_NAN ? FEDM_DIVERGED_NAN : FEDM_DIVERGED_LINEAR);
+        if (lrc != 0 || comm_failed(c)) {
+            rc = (lrc < 0 || comm_failed(c)) ? -1 : (lrc == FEDM_DIVERGED_NAN ? FEDM_DIVERGED_NAN : FEDM_DIVERGED_LINEAR);
             break;
         }
         // |dx| and |x| for the stol test (slots 1, 2) are read with the next |F|
@@ -1208,9 +1232,16 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             launch_norm2(c, c.d_delta, 1);
             launch_norm2(c, c.d_u, 2);
         }
-        comm_halo(c, c.d_u);
+        // ghost entries of the new state: exchanged by the next assembly, behind its interior patches
+        if (c.comm && c.assembly_overlap) c.halo_pending = true;
+        else comm_halo(c, c.d_u);
+        if (comm_failed(c)) {
+            rc = -1;
+            break;
+        }
         ++it;
     }
+    if (comm_failed(c)) rc = -1;  // the message is in fedm_last_error (Comm::error)
     if (rc == 0) c.newton_its_hint = it;
     if (c.fs_alt_sweeps > 0 && it > 0) {
         // same counts on every rank, so every rank takes the same decision
@@ -1232,6 +1263,10 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     r.reason = rc > 0 ? rc : 0;
     r.converged = rc == 0 ? 1 : 0;
     if (rep) *rep = r;
+    if (comm_failed(c)) {
+        set_error(c.comm->error);
+        return -1;
+    }
     if (hipGetLastError() != hipSuccess) {
         set_error("HIP error during Newton solve");
         return -1;
@@ -1302,6 +1337,10 @@ int fedm_poisson_solve(fedm_ctx *h, double rtol, int max_it, int *iterations) {
     comm_halo(c, c.d_u);
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     if (iterations) *iterations = it;
+    if (comm_failed(c)) {
+        set_error(c.comm->error);
+        return -1;
+    }
     if (!std::isfinite(rn)) return FEDM_DIVERGED_NAN;
     return rn <= rtol * r0 || r0 == 0.0 ? 0 : FEDM_DIVERGED_LINEAR;
 }
@@ -1316,6 +1355,10 @@ int fedm_field_error(fedm_ctx *h, int component, double *rel_err) {
     launch_field_error(c, component);
     read_red(c, 2);
     *rel_err = std::sqrt(c.h_red[0]) / std::sqrt(c.h_red[1]);
+    if (comm_failed(c)) {
+        set_error(c.comm->error);
+        return -1;
+    }
     return 0;
 }
 
@@ -1345,6 +1388,43 @@ int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) 
     *ms_per_launch = (double)ms / repeats;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    return 0;
+}
+
+// latency of the multi-GPU primitives on this context's transport, back to back on the compute
+// stream: kind 0 = halo exchange of a block vector, 1 = of a scalar vector, 2 = all-reduce of 32
+// doubles (what a Krylov step's dot products need)
+int fedm_time_comm(fedm_ctx *h, int kind, int repeats, double *ms_per_op) {
+    Ctx &c = h->c;
+    if (!c.comm || kind < 0 || kind > 2 || repeats < 1 || !ms_per_op) {
+        set_error("fedm_time_comm: no transport installed, or bad arguments");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    hipEvent_t e0, e1;
+    FEDM_HIP_CHECK(hipEventCreate(&e0));
+    FEDM_HIP_CHECK(hipEventCreate(&e1));
+    auto run = [&]() {
+        if (kind == 0) comm_halo(c, c.d_w);
+        else if (kind == 1) comm_halo_scalar(c, c.d_w);
+        else comm_allreduce(c, c.d_red, 32);
+    };
+    FEDM_HIP_CHECK(hipMemsetAsync(c.d_w, 0, sizeof(double) * c.np, c.stream));
+    run();
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    FEDM_HIP_CHECK(hipEventRecord(e0, c.stream));
+    for (int i = 0; i < repeats; ++i) run();
+    FEDM_HIP_CHECK(hipEventRecord(e1, c.stream));
+    FEDM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FEDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_op = (double)ms / repeats;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (comm_failed(c)) {
+        set_error(c.comm->error);
+        return -1;
+    }
     return 0;
 }
 
@@ -1405,13 +1485,77 @@ int fedm_comm_init_callbacks(fedm_ctx *h, int n_nb, const int32_t *nb_rank, cons
     return 0;
 }
 
+int fedm_comm_stats(fedm_ctx *h, int64_t out[8]) {
+    Ctx &c = h->c;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!c.comm) return 0;
+    const Comm &cm = *c.comm;
+    out[0] = cm.kind;
+    out[1] = cm.nranks;
+    out[2] = cm.n_exchanges;
+    out[3] = cm.n_allreduces;
+    out[4] = cm.failed ? 1 : 0;
+    out[5] = cm.n_nb;
+    out[6] = cm.n_patch_interior;
+    out[7] = cm.n_patch_boundary;
+    return 0;
+}
+
+int fedm_debug_comm_fault(int fail_at, int64_t out[4]) { return comm_fault_selftest(fail_at, out); }
+
+int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[8]) {
+    if (!mesh || !out || mesh->n_vertices < 3 || mesh->n_cells < 1) {
+        set_error("null or empty mesh");
+        return -2;
+    }
+    for (int i = 0; i < 3 * mesh->n_cells; ++i)
+        if (mesh->cells[i] < 0 || mesh->cells[i] >= mesh->n_vertices) {
+            set_error("cell vertex index out of range");
+            return -2;
+        }
+    Pattern pat;
+    build_pattern(*mesh, pat);
+    // LDS-atomic clashes of the patch cell order: for each lane group of 16 cells and each local
+    // vertex index a, owned a-vertices that fall into an accumulator bank class (id mod 16) another
+    // cell of the group already uses
+    int64_t pairs = 0, clashes = 0;
+    for (int s = 0; s < pat.n_slices; ++s) {
+        const int c0 = pat.patch_cell_ptr[s], c1 = pat.patch_cell_ptr[s + 1];
+        for (int g0 = c0; g0 < c1; g0 += 16)
+            for (int a = 0; a < 3; ++a) {
+                uint32_t used = 0;
+                for (int k = g0; k < std::min(g0 + 16, c1); ++k) {
+                    const int lv = pat.patch_cells[k].lv[a];
+                    if (lv >= SLICE) continue;
+                    ++pairs;
+                    if ((used >> (lv & 15)) & 1u) ++clashes;
+                    used |= 1u << (lv & 15);
+                }
+            }
+    }
+    out[0] = pat.n_slices;
+    out[1] = pat.max_patch_cells;
+    out[2] = pat.max_patch_width;
+    out[3] = pat.max_patch_verts;
+    out[4] = (int64_t)pat.patch_cells.size();
+    out[5] = pairs;
+    out[6] = clashes;
+    out[7] = pat.nnz_blocks;
+    return 0;
+}
+
 int fedm_sync_ghosts(fedm_ctx *h) {
     Ctx &c = h->c;
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     comm_halo(c, c.d_u);
     comm_halo(c, c.d_uold);
     comm_halo(c, c.d_uold1);
+    c.halo_pending = false;
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    if (comm_failed(c)) {
+        set_error(c.comm->error);
+        return -1;
+    }
     return 0;
 }
 

@@ -22,6 +22,7 @@ struct NcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommGetAsyncError)(void *, int *) = nullptr;  // optional
 };
 NcclApi g_nccl;
 constexpr int kNcclDouble = 8;  // ncclFloat64
@@ -54,9 +55,102 @@ int load_nccl() {
     FEDM_SYM(GroupEnd, "ncclGroupEnd")
     FEDM_SYM(GetErrorString, "ncclGetErrorString")
 #undef FEDM_SYM
+    *(void **)(&g_nccl.CommGetAsyncError) = dlsym(g_nccl.lib, "ncclCommGetAsyncError");
     return 0;
 }
+
+// every RCCL return code goes through here: the first failure is latched in the Comm
+bool nccl_ok(Comm *cm, int rc, const char *what) {
+    if (rc == 0) return true;
+    if (!cm->failed) {
+        cm->failed = true;
+        const char *msg = g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "unknown error";
+        cm->error = std::string("RCCL transport failed in ") + what + ": " + (msg ? msg : "unknown error") +
+                    " (rank " + std::to_string(cm->rank) + " of " + std::to_string(cm->nranks) + ")";
+        set_error(cm->error);
+    }
+    return false;
+}
 }  // namespace
+
+bool comm_failed(const Ctx &c) { return c.comm && c.comm->failed; }
+
+// ---- fault injection for the error path (tests/test_host_logic.py; runs without a GPU) --------
+// A stub API table whose `fail_at`-th call returns ncclSystemError drives the same
+// exchange_packed / comm_allreduce code the RCCL transport uses (host pointers, no kernels).
+namespace {
+int g_stub_calls = 0, g_stub_fail_at = -1, g_stub_after_failure = 0;
+bool g_stub_failed = false;
+int stub_rc() {
+    if (g_stub_failed) ++g_stub_after_failure;
+    if (g_stub_calls++ == g_stub_fail_at) {
+        g_stub_failed = true;
+        return 2;  // ncclSystemError
+    }
+    return 0;
+}
+int stub_allreduce(const void *, void *, size_t, int, int, void *, hipStream_t) { return stub_rc(); }
+int stub_send(const void *, size_t, int, int, void *, hipStream_t) { return stub_rc(); }
+int stub_recv(void *, size_t, int, int, void *, hipStream_t) { return stub_rc(); }
+int stub_group() { return stub_rc(); }
+const char *stub_errstr(int) { return "stub system error"; }
+}  // namespace
+static void exchange_packed(Ctx &c, Comm *cm, double *recv_dst, hipStream_t st, int w);
+
+int comm_fault_selftest(int fail_at, int64_t out[4]) {
+    const NcclApi saved = g_nccl;
+    g_nccl = NcclApi{};
+    g_nccl.AllReduce = stub_allreduce;
+    g_nccl.Send = stub_send;
+    g_nccl.Recv = stub_recv;
+    g_nccl.GroupStart = stub_group;
+    g_nccl.GroupEnd = stub_group;
+    g_nccl.GetErrorString = stub_errstr;
+    g_stub_calls = 0;
+    g_stub_fail_at = fail_at;
+    g_stub_after_failure = 0;
+    g_stub_failed = false;
+    Ctx c;
+    Comm cm;
+    cm.kind = 2;
+    cm.rank = 1;
+    cm.nranks = 2;
+    cm.n_nb = 1;
+    cm.nb_rank = {0};
+    cm.send_ptr = {0, 1};
+    cm.recv_ptr = {0, 1};
+    cm.n_send = cm.n_ghost = 1;
+    double sendbuf[4] = {0}, recvbuf[4] = {0}, red[4] = {0};
+    cm.d_sendbuf = sendbuf;
+    cm.nccl = &cm;  // never dereferenced by the stubs
+    c.comm = &cm;
+    set_error("");
+    // two rounds of what a Krylov step issues: halo group (4 calls), all-reduce (1 call)
+    for (int round = 0; round < 2; ++round) {
+        exchange_packed(c, &cm, recvbuf, nullptr, 1);
+        comm_allreduce(c, red, 3);
+    }
+    out[0] = cm.failed ? 1 : 0;
+    out[1] = g_stub_calls;           // API calls that reached the transport
+    out[2] = g_stub_after_failure;   // ... of which after the failing one (only the group's close may follow)
+    out[3] = comm_failed(c) ? 1 : 0;
+    c.comm = nullptr;
+    cm.d_sendbuf = nullptr;
+    cm.nccl = nullptr;
+    cm.kind = 0;
+    g_nccl = saved;
+    return cm.failed ? 1 : 0;
+}
+
+bool comm_poll_async_error(Ctx &c) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind != 2 || !cm->nccl || !g_nccl.CommGetAsyncError) return cm && cm->failed;
+    int async = 0;
+    if (!nccl_ok(cm, g_nccl.CommGetAsyncError(cm->nccl, &async), "ncclCommGetAsyncError")) return true;
+    // ncclInProgress (7) is not an error
+    if (async != 0 && async != 7) nccl_ok(cm, async, "an asynchronous operation (ncclCommGetAsyncError)");
+    return cm->failed;
+}
 
 int comm_unique_id(void *out128) {
     if (load_nccl()) return -1;
@@ -75,6 +169,9 @@ void Comm::release() {
     nccl = nullptr;
     if (d_interior) hipFree(d_interior);
     if (d_boundary) hipFree(d_boundary);
+    if (d_patch_interior) hipFree(d_patch_interior);
+    if (d_patch_boundary) hipFree(d_patch_boundary);
+    d_patch_interior = d_patch_boundary = nullptr;
     if (ev_ready) hipEventDestroy(ev_ready);
     if (ev_halo) hipEventDestroy(ev_halo);
     if (stream) hipStreamDestroy(stream);
@@ -141,6 +238,25 @@ int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const in
         FEDM_HIP_CHECK(hipMemcpy(cm.d_interior, interior.data(), sizeof(int) * interior.size(), hipMemcpyHostToDevice));
     if (cm.n_boundary)
         FEDM_HIP_CHECK(hipMemcpy(cm.d_boundary, boundary.data(), sizeof(int) * boundary.size(), hipMemcpyHostToDevice));
+    // assembly patches (= slices) that stage no ghost vertex: their owned lanes and halo vertices
+    // are all owned.  The state halo travels while they are assembled (kernels.hip, lean2 launch).
+    {
+        std::vector<int> pin, pbd;
+        for (int sl = 0; sl < c.pat.n_slices; ++sl) {
+            bool ghost = (sl + 1) * SLICE > c.n_owned;  // ghost (or padding) lanes
+            for (int k = c.pat.patch_halo_ptr[sl]; k < c.pat.patch_halo_ptr[sl + 1] && !ghost; ++k)
+                ghost = c.pat.patch_halo[k] >= c.n_owned;
+            (ghost ? pbd : pin).push_back(sl);
+        }
+        cm.n_patch_interior = (int)pin.size();
+        cm.n_patch_boundary = (int)pbd.size();
+        FEDM_HIP_CHECK(hipMalloc((void **)&cm.d_patch_interior, sizeof(int) * std::max<size_t>(pin.size(), 1)));
+        FEDM_HIP_CHECK(hipMalloc((void **)&cm.d_patch_boundary, sizeof(int) * std::max<size_t>(pbd.size(), 1)));
+        if (!pin.empty())
+            FEDM_HIP_CHECK(hipMemcpy(cm.d_patch_interior, pin.data(), sizeof(int) * pin.size(), hipMemcpyHostToDevice));
+        if (!pbd.empty())
+            FEDM_HIP_CHECK(hipMemcpy(cm.d_patch_boundary, pbd.data(), sizeof(int) * pbd.size(), hipMemcpyHostToDevice));
+    }
     FEDM_HIP_CHECK(hipStreamCreateWithFlags(&cm.stream, hipStreamNonBlocking));
     FEDM_HIP_CHECK(hipEventCreateWithFlags(&cm.ev_ready, hipEventDisableTiming));
     FEDM_HIP_CHECK(hipEventCreateWithFlags(&cm.ev_halo, hipEventDisableTiming));
@@ -174,9 +290,11 @@ int comm_reserve_reduction(Ctx &c, int n) {
 
 void comm_allreduce(Ctx &c, double *d_buf, int n) {
     Comm *cm = c.comm;
-    if (!cm || cm->kind == 0) return;
+    if (!cm || cm->kind == 0 || cm->failed) return;
+    ++cm->n_allreduces;
     if (cm->kind == 2) {
-        g_nccl.AllReduce(d_buf, d_buf, (size_t)n, kNcclDouble, kNcclSum, cm->nccl, c.stream);
+        nccl_ok(cm, g_nccl.AllReduce(d_buf, d_buf, (size_t)n, kNcclDouble, kNcclSum, cm->nccl, c.stream),
+                "ncclAllReduce");
         return;
     }
     hipMemcpyAsync(cm->h_red, d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c.stream);
@@ -196,19 +314,22 @@ __global__ void halo_pack_kernel(int n_send, int neq, const int *__restrict__ id
 // the packed send buffer goes out, the neighbours' values arrive in recv_dst (n_ghost * w doubles,
 // grouped by owner in neighbour order)
 static void exchange_packed(Ctx &c, Comm *cm, double *recv_dst, hipStream_t st, int w) {
+    if (cm->failed) return;
+    ++cm->n_exchanges;
     if (cm->kind == 2) {
-        g_nccl.GroupStart();
+        // a group that was opened is always closed, whatever its members returned
+        if (!nccl_ok(cm, g_nccl.GroupStart(), "ncclGroupStart")) return;
         for (int k = 0; k < cm->n_nb; ++k) {
             const int ns = cm->send_ptr[k + 1] - cm->send_ptr[k];
             const int nr = cm->recv_ptr[k + 1] - cm->recv_ptr[k];
             if (ns)
-                g_nccl.Send(cm->d_sendbuf + (size_t)cm->send_ptr[k] * w, (size_t)ns * w, kNcclDouble,
-                            cm->nb_rank[k], cm->nccl, st);
+                nccl_ok(cm, g_nccl.Send(cm->d_sendbuf + (size_t)cm->send_ptr[k] * w, (size_t)ns * w, kNcclDouble,
+                                        cm->nb_rank[k], cm->nccl, st), "ncclSend");
             if (nr)
-                g_nccl.Recv(recv_dst + (size_t)cm->recv_ptr[k] * w, (size_t)nr * w, kNcclDouble,
-                            cm->nb_rank[k], cm->nccl, st);
+                nccl_ok(cm, g_nccl.Recv(recv_dst + (size_t)cm->recv_ptr[k] * w, (size_t)nr * w, kNcclDouble,
+                                        cm->nb_rank[k], cm->nccl, st), "ncclRecv");
         }
-        g_nccl.GroupEnd();
+        nccl_ok(cm, g_nccl.GroupEnd(), "ncclGroupEnd");
         return;
     }
     if (cm->n_send)

@@ -34,6 +34,16 @@ struct Comm {
     hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
     int n_interior = 0, n_boundary = 0;
     int *d_interior = nullptr, *d_boundary = nullptr;
+    // the same split for the assembly patches (a patch = a matrix slice): interior patches stage
+    // no ghost vertex, so the state halo can travel while they are assembled
+    int n_patch_interior = 0, n_patch_boundary = 0;
+    int *d_patch_interior = nullptr, *d_patch_boundary = nullptr;
+    // A transport error latches here (first message kept, also in fedm_last_error): from then on
+    // every exchange / reduction is skipped and the solver entry points return -1 -- a lost peer
+    // must read as an error, not as NaNs or a hang.
+    bool failed = false;
+    std::string error;
+    long n_exchanges = 0, n_allreduces = 0;   // issued so far (bench.py reports them per step)
     void release();
 };
 
@@ -54,5 +64,8 @@ void comm_halo_begin(Ctx &c);
 void comm_halo_exchange(Ctx &c, double *d_vec);
 void comm_halo_exchange_f32(Ctx &c, float *d_vec, int w);
 void comm_halo_exchange_scalar(Ctx &c, double *d_vec);
+int comm_fault_selftest(int fail_at, int64_t out[4]);  // error-path test hook (no GPU needed)
+bool comm_failed(const Ctx &c);                     // a transport error has been latched
+bool comm_poll_async_error(Ctx &c);                 // RCCL's asynchronous error state; latches, true on error
 
 }  // namespace fedm

@@ -12,6 +12,15 @@
 
 namespace fedm {
 
+// The ghost entries of the state are refreshed lazily: the Newton loop only marks them stale
+// (Ctx::halo_pending) and the next assembly either overlaps the exchange with its interior
+// patches or, on every other path, performs it here first.
+static void flush_pending_halo(Ctx &c) {
+    if (!c.halo_pending) return;
+    comm_halo(c, c.d_u);
+    c.halo_pending = false;
+}
+
 // =============================================================================================
 // Assembly, variant 0: one thread per cell, one launch per colour (cells of a colour share
 // no vertex, so the read-modify-write of matrix blocks and residual entries is conflict-free
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(256) void assemble_colour_kernel(
 template <int NS, bool PO, int NR, int CACHE>
 static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
+    flush_pending_halo(c);
     hipMemsetAsync(c.d_F, 0, sizeof(double) * c.np, c.stream);
     if (jacobian)
         hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * NEQ * NEQ, c.stream);
@@ -353,6 +363,122 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
     for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) fdst[k] = Fl[k];
     FEDM_T(7)
 }
+
+// Workgroups b, b + 8, b + 16, ... are observed to share an XCD (round-robin dispatch; a speed
+// heuristic, never relied upon for correctness): give every XCD a contiguous range of patches so
+// that the halo vertices two neighbouring patches both stage are served by ONE L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int per = n >> 3, full = per << 3;
+    return b < full ? (b & 7) * per + (b >> 3) : b;
+}
+
+// Second generation of the row-phase kernel (element_lean.hpp, lean2_*): per-vertex exponentials,
+// cell constants kept in an LDS column between the rows; JAC = false is the residual-only assembly.
+template <int NS, int NR, int THREADS, bool JAC>
+__device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    constexpr int NST = LeanStash<NR>::N;
+    extern __shared__ __align__(16) double lds[];
+    double *acc = lds;                          // [width][NEQ][64]: one row of every block (JAC)
+    double *Fl = acc + acc_doubles;             // [64][NEQ]
+    double *vx = Fl + SLICE * NEQ;              // [max_verts][2]
+    double *Ul = vx + 2 * max_verts;            // [max_verts][NEQ]
+    double *Hl = Ul + NEQ * max_verts;          // [max_verts][NS]
+    double *Al = Hl + NS * max_verts;           // [max_verts][NS]: exp(u / 6)
+    double *cst = Al + NS * max_verts;          // [NST][THREADS]
+#ifdef FEDM_PHASE_TIMING
+    unsigned long long t_prev_ = wall_clock64();
+#endif
+    // patch_list: the launch covers those patches only (interior / boundary halves across GPUs)
+    const int blk = xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int S = patch_list ? patch_list[blk] : blk;
+    const int b0 = boff[S], width = boff[S + 1] - b0;
+    const int n_acc = JAC ? width * NEQ * SLICE : 0;
+    const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
+    const bool active = (int)threadIdx.x < n_cells;   // one cell per thread (n_cells <= THREADS)
+    PatchCell pc_own = {};
+    if (active) pc_own = pcells[c0 + threadIdx.x];
+    if constexpr (JAC) {
+        double2 *acc2 = reinterpret_cast<double2 *>(acc);
+        for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) acc2[k] = make_double2(0.0, 0.0);
+    }
+    for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) Fl[k] = 0.0;
+    const int h0 = halo_ptr[S], n_local = SLICE + halo_ptr[S + 1] - h0;
+    for (int i = threadIdx.x; i < n_local; i += THREADS) {
+        const int g = (i < SLICE) ? S * SLICE + i : halo[h0 + i - SLICE];
+        if (g < nv) {
+            vx[2 * i] = coords[2 * (size_t)g];
+            vx[2 * i + 1] = coords[2 * (size_t)g + 1];
+            double un[NEQ];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) un[s] = u[(size_t)g * NEQ + s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                Hl[i * NS + s] = sc.c_old * uold[(size_t)g * NEQ + s] + sc.c_old1 * uold1[(size_t)g * NEQ + s];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) Ul[i * NEQ + s] = un[s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Al[i * NS + s] = exp(un[s] * (1.0 / 6.0));
+        }
+    }
+    FEDM_T(0)   // zero + stage (issue) + vertex exponentials
+    __syncthreads();
+    FEDM_T(1)   // barrier: the staged loads arrive
+    LeanCell lc = {0, 0, 0, 0};
+    if (active) lc = lean2_prologue<NS, NR>(md, pc_own, vx, Ul, cst + threadIdx.x, THREADS);
+    FEDM_T(2)   // prologue: cell record, field, rate coefficient
+#pragma unroll 1
+    for (int row = 0; row < NEQ; ++row) {
+        asm volatile("" : "+v"(lc.wl), "+v"(lc.wj0), "+v"(lc.wj1), "+v"(lc.wj2));  // nothing hoisted out of the row
+        if (active)
+            lean2_row<NS, NR, JAC>(md, row, lc, vx, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS);
+        FEDM_T(3)   // the row (wave 0's view)
+        if constexpr (JAC) {
+            __syncthreads();
+            FEDM_T(4)   // barrier: the other waves finish the row
+            constexpr int PER = NEQ * SLICE / 2;   // 16-byte pieces per block column
+            if constexpr (THREADS % PER == 0) {
+                const int rem = threadIdx.x % PER;
+                for (int bc = threadIdx.x / PER; bc < width; bc += THREADS / PER) {
+                    double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
+                    double2 *src = reinterpret_cast<double2 *>(acc) + bc * PER + rem;
+                    dst[rem] = *src;
+                    *src = make_double2(0.0, 0.0);
+                }
+            } else {
+                for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
+                    const int bc = k / PER, rem = k - bc * PER;
+                    double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
+                    double2 *src = reinterpret_cast<double2 *>(acc) + k;
+                    dst[rem] = *src;
+                    *src = make_double2(0.0, 0.0);
+                }
+            }
+            FEDM_T(5)   // stream-out + zeroing (issue)
+            lds_only_barrier();   // accumulators zero again; the stores above stay in flight
+            FEDM_T(6)
+        }
+    }
+    if constexpr (!JAC) __syncthreads();
+    double *fdst = F + (size_t)S * SLICE * NEQ;
+    for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) fdst[k] = Fl[k];
+    FEDM_T(7)
+}
+
+#ifndef FEDM_LEAN2_WAVES
+#define FEDM_LEAN2_WAVES 3
+#endif
+template <int NS, int NR, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_LEAN2_WAVES, FEDM_LEAN2_WAVES))) void assemble_lean2_kernel(
+    FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
+    assemble_lean2_body<NS, NR, THREADS, true>(FEDM_PATCH_ARGS, xcd, patch_list);
+}
+
+template <int NS, int NR, int THREADS>
+__global__ __launch_bounds__(THREADS) void residual_lean2_kernel(FEDM_PATCH_PARAMS, int xcd,
+                                                                 const int *__restrict__ patch_list) {
+    assemble_lean2_body<NS, NR, THREADS, false>(FEDM_PATCH_ARGS, xcd, patch_list);
+}
 #undef FEDM_PATCH_PARAMS
 #undef FEDM_PATCH_ARGS
 
@@ -377,6 +503,45 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     if constexpr (PO && CACHE == 2 && NS >= 1) {
         bool ext = false;
         for (int s_ = 0; s_ < NS; ++s_) ext = ext || c.model.ext_nodes[s_] > 0;
+        if (mode == 0 && !ext && c.assembly_lean >= 2 && c.pat.max_patch_cells <= 192) {
+            const int acc_row = jacobian ? c.pat.max_patch_width * NEQ * SLICE : 0;
+            const size_t lds_bytes = sizeof(double) * ((size_t)acc_row + SLICE * NEQ + 2 * c.pat.max_patch_verts +
+                                                       (size_t)(NEQ + 2 * NS) * c.pat.max_patch_verts +
+                                                       (size_t)LeanStash<NR>::N * 192);
+#define FEDM_LEAN2_LAUNCH(KERNEL, LIST, N)                                                                  \
+    hipLaunchKernelGGL((KERNEL<NS, NR, 192>), dim3(N), dim3(192), lds_bytes, c.stream, c.d_model,           \
+                       c.nv, c.d_slice_boff, c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr,       \
+                       c.d_patch_halo, c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],  \
+                       c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_row, c.pat.max_patch_verts,        \
+                       c.xcd_remap ? 1 : 0, LIST)
+#define FEDM_LEAN2_BOTH(LIST, N)                                                                            \
+    do {                                                                                                    \
+        if ((N) <= 0) break;                                                                                \
+        if (jacobian) {                                                                                     \
+            FEDM_LEAN2_LAUNCH(assemble_lean2_kernel, LIST, N);                                              \
+        } else {                                                                                            \
+            FEDM_LEAN2_LAUNCH(residual_lean2_kernel, LIST, N);                                              \
+        }                                                                                                   \
+    } while (0)
+            if (c.halo_pending && c.comm && c.comm->d_patch_interior) {
+                // the ghost values of the new state travel on the communication stream while the
+                // patches that stage no ghost vertex are assembled (north_star: "ghost exchange
+                // overlapped with interior assembly"); the patches that do follow the exchange
+                Comm &cm = *c.comm;
+                comm_halo_begin(c);
+                FEDM_LEAN2_BOTH(cm.d_patch_interior, cm.n_patch_interior);
+                comm_halo_exchange(c, c.d_u);
+                FEDM_LEAN2_BOTH(cm.d_patch_boundary, cm.n_patch_boundary);
+                c.halo_pending = false;
+            } else {
+                flush_pending_halo(c);
+                FEDM_LEAN2_BOTH((const int *)nullptr, c.pat.n_slices);
+            }
+#undef FEDM_LEAN2_BOTH
+#undef FEDM_LEAN2_LAUNCH
+            return;
+        }
+        flush_pending_halo(c);
         if (jacobian && mode == 0 && !ext && c.assembly_lean && c.pat.max_patch_cells <= 192) {
             const int acc_row = c.pat.max_patch_width * NEQ * SLICE;
             const size_t lds_bytes = sizeof(double) * ((size_t)acc_row + SLICE * NEQ + 2 * c.pat.max_patch_verts +
@@ -389,6 +554,7 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
             return;
         }
     }
+    flush_pending_halo(c);
     if (jacobian) {
         if (c.pat.max_patch_cells <= 192) FEDM_PATCH_LAUNCH(assemble_patch_kernel, 192);
         else FEDM_PATCH_LAUNCH(assemble_patch_kernel, 320);
@@ -490,6 +656,7 @@ static void assemble_dispatch(Ctx &c, bool jacobian, int mode) {
 
 void launch_assemble(Ctx &c, bool jacobian, int mode) {
     if (c.model_kind == 1) {
+        flush_pending_halo(c);
         prof_begin(c, jacobian ? 0 : 2);
         launch_assemble_gd(c, jacobian, mode);
         prof_end(c);
@@ -704,9 +871,11 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
                                                    const double *__restrict__ dinv,
                                                    double *__restrict__ fs_z, double *__restrict__ fs_b0,
                                                    double fs_scale, const int *__restrict__ slice_list,
-                                                   int fs_compact32 = 0) {
+                                                   int fs_compact32 = 0, int xcd = 0) {
     constexpr int NEQ2 = NEQ * NEQ;
-    const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // xcd: consecutive slices (neighbours in the Z-curve, sharing most of their x entries) on one XCD
+    const int blk = xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int wave_id = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave_id >= n_slices) return;  // n_slices: number of slices this launch covers
     const int slice = slice_list ? slice_list[wave_id] : wave_id;
@@ -778,7 +947,7 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int 
 #define FEDM_SPMV(NEQ)                                                                             \
     hipLaunchKernelGGL((spmv_kernel<NEQ, false>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
                        c.d_colidx, c.d_val, x, y, dinv, (double *)nullptr, (double *)nullptr, 0.0,         \
-                       slice_list)
+                       slice_list, 0, (c.xcd_remap && !slice_list) ? 1 : 0)
     switch (c.neq) {
         case 1: FEDM_SPMV(1); break;
         case 2: FEDM_SPMV(2); break;
@@ -799,7 +968,8 @@ void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, doubl
     const dim3 g((n + 3) / 4), b(256);
 #define FEDM_SPMV(NEQ)                                                                            \
     hipLaunchKernelGGL((spmv_kernel<NEQ, true>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
-                       c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale, slice_list, compact32 ? 1 : 0)
+                       c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale, slice_list, compact32 ? 1 : 0,      \
+                       (c.xcd_remap && !slice_list) ? 1 : 0)
     switch (c.neq) {
         case 2: FEDM_SPMV(2); break;
         case 3: FEDM_SPMV(3); break;
@@ -1180,6 +1350,11 @@ void wait_red_seq(Ctx &c, unsigned long long seq) {
             const bool failed = hipStreamQuery(c.stream) != hipErrorNotReady &&
                                 __atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq;
             const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120);
+            // a peer that died leaves an RCCL kernel spinning on this stream: ask the communicator
+            if (comm_poll_async_error(c)) {
+                for (int i = 0; i < RED_K; ++i) slot[i] = std::nan("");
+                return;
+            }
             if (failed || late) {
                 hipStreamSynchronize(c.stream);
                 if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq)

@@ -2,11 +2,53 @@
 // slots, greedy cell colouring.  Replaces what DOLFIN builds when it creates the
 // FunctionSpace / sparsity pattern for `assemble` (fedm/functions.py:192,200).
 #include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 
 #include "fedm_internal.hpp"
 
 namespace fedm {
+
+// Micro-colouring of one patch's cell list (what `north_star` calls conflict-free writes via
+// colouring, at the scale where it pays: the LDS accumulators of one workgroup).  Lane t of the
+// workgroup adds cell t's entries with ds_add_f64; for a fixed (a, b, component) the lanes of one
+// LDS lane group (`group` consecutive lanes) hit the accumulator column of their cell's a-th
+// vertex, whose bank is the owned vertex id modulo `mod`.  Cells are dealt to the lane groups so
+// that within a group, for each local index a, those bank classes are distinct wherever
+// possible (greedy, first group with the fewest clashes; the order within a group is kept).
+static void order_patch_cells(PatchCell *cells, int n, int group, int mod) {
+    if (n <= group) return;
+    const int n_groups = (n + group - 1) / group;
+    std::vector<std::vector<int>> members(n_groups);
+    std::vector<std::array<uint64_t, 3>> used(n_groups, std::array<uint64_t, 3>{0, 0, 0});
+    for (int c = 0; c < n; ++c) {
+        int best = -1, best_cost = 1 << 30;
+        for (int g = 0; g < n_groups; ++g) {
+            if ((int)members[g].size() >= group) continue;
+            int cost = 0;
+            for (int a = 0; a < 3; ++a)
+                if (cells[c].lv[a] < SLICE && ((used[g][a] >> (cells[c].lv[a] % mod)) & 1ULL)) ++cost;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = g;
+            }
+            if (cost == 0) break;
+        }
+        members[best].push_back(c);
+        for (int a = 0; a < 3; ++a)
+            if (cells[c].lv[a] < SLICE) used[best][a] |= 1ULL << (cells[c].lv[a] % mod);
+    }
+    std::vector<PatchCell> out;
+    out.reserve(n);
+    // full groups first: only the last lane group of the workgroup may be partial
+    std::stable_sort(members.begin(), members.end(),
+                     [](const std::vector<int> &x, const std::vector<int> &y) { return x.size() > y.size(); });
+    for (const auto &m : members)
+        for (int c : m) out.push_back(cells[c]);
+    std::copy(out.begin(), out.end(), cells);
+}
 
 void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
     const int nv = mesh.n_vertices, nc = mesh.n_cells;
@@ -115,6 +157,15 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
 
     // --- patches: every slice with the cells that touch one of its vertices ---------------
     {
+        // thread t of a patch's workgroup evaluates cell t: FEDM_PATCH_ORDER="group,mod" (0 = by
+        // cell number) chooses the micro-colouring of order_patch_cells
+        int order_group = 16, order_mod = 16;
+        if (const char *e = std::getenv("FEDM_PATCH_ORDER")) {
+            order_group = std::atoi(e);
+            const char *comma = std::strchr(e, ',');
+            order_mod = comma ? std::atoi(comma + 1) : order_group;
+            if (order_group < 0 || order_group > 64 || order_mod < 1 || order_mod > 64) order_group = 0;
+        }
         std::vector<int64_t> vc_ptr(nv + 1, 0);
         for (int c = 0; c < nc; ++c)
             for (int a = 0; a < 3; ++a) vc_ptr[cells[3 * c + a] + 1]++;
@@ -145,6 +196,7 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
             halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
             const int width = pat.slice_boff[s + 1] - pat.slice_boff[s];
             if (halo.size() + SLICE > 255 || width > 254) pat.patch_ok = false;
+            size_t first_cell = pat.patch_cells.size();
             for (int c : pc) {
                 PatchCell e{};
                 e.cell = c;
@@ -170,6 +222,9 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
                 }
                 pat.patch_cells.push_back(e);
             }
+            if (order_group > 0)
+                order_patch_cells(pat.patch_cells.data() + first_cell, (int)(pat.patch_cells.size() - first_cell),
+                                  order_group, order_mod);
             pat.patch_halo.insert(pat.patch_halo.end(), halo.begin(), halo.end());
             pat.patch_cell_ptr[s + 1] = (int)pat.patch_cells.size();
             pat.patch_halo_ptr[s + 1] = (int)pat.patch_halo.size();

@@ -213,6 +213,31 @@ def locality_order(coords):
     return np.argsort(key, kind="stable")
 
 
+def pattern_stats(coords, cells, reorder=True):
+    """Host-side preprocessing alone (``fedm_pattern_stats``; runs without a GPU): slices, patch
+    sizes and the LDS-accumulator clashes of the patch cell order, for the mesh as the device would
+    number it."""
+    lib = _lib.load()
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    order = locality_order(coords) if reorder else np.arange(coords.shape[0])
+    inv = np.empty(coords.shape[0], dtype=np.int64)
+    inv[order] = np.arange(coords.shape[0])
+    cdev = np.ascontiguousarray(coords[order])
+    kdev = np.ascontiguousarray(inv[cells], dtype=np.int32)
+    mesh = _lib.MeshDesc()
+    mesh.n_vertices, mesh.n_cells = coords.shape[0], cells.shape[0]
+    mesh.coords = _dp(cdev)
+    mesh.cells = kdev.ctypes.data_as(C.POINTER(C.c_int32))
+    out = (C.c_int64 * 8)()
+    rc = lib.fedm_pattern_stats(C.byref(mesh), out)
+    if rc != 0:
+        raise RuntimeError(f"fedm_pattern_stats failed ({rc}): {_lib.last_error()}")
+    keys = ("n_slices", "max_patch_cells", "max_patch_width", "max_patch_verts", "cell_visits",
+            "owned_pairs", "bank_clashes", "nnz_blocks")
+    return dict(zip(keys, (int(v) for v in out)))
+
+
 class DeviceProblem:
     """Mesh + model + state resident on one MI355X."""
 
@@ -466,6 +491,21 @@ class DeviceProblem:
 
     def sync_ghosts(self):
         self._check(self.lib.fedm_sync_ghosts(self._h), "fedm_sync_ghosts")
+
+    def time_comm(self, kind, repeats=50):
+        """ms per halo exchange (kind 0: block vector, 1: scalar) or all-reduce of 32 doubles (2)."""
+        ms = C.c_double()
+        self._check(self.lib.fedm_time_comm(self._h, int(kind), int(repeats), C.byref(ms)), "fedm_time_comm")
+        return ms.value
+
+    def comm_stats(self):
+        """Transport kind and counters of the multi-GPU plumbing (``fedm_comm_stats``)."""
+        out = (C.c_int64 * 8)()
+        self._check(self.lib.fedm_comm_stats(self._h, out), "fedm_comm_stats")
+        kind = {0: "none", 1: "host-staged callbacks", 2: "rccl"}[int(out[0])]
+        return dict(transport=kind, ranks=int(out[1]), halo_exchanges=int(out[2]), allreduces=int(out[3]),
+                    failed=bool(out[4]), neighbours=int(out[5]), interior_patches=int(out[6]),
+                    boundary_patches=int(out[7]))
 
     # -- linear-solver set-up ---------------------------------------------------
     def block_csr(self, cr, cc):

@@ -292,6 +292,27 @@ int fedm_comm_init_callbacks(fedm_ctx *ctx, int n_neighbours, const int32_t *nb_
                              fedm_exchange_fn exchange, void *user, int rank, int n_ranks);
 /* refresh the ghost entries of u_new, u_old, u_old1 from their owners */
 int fedm_sync_ghosts(fedm_ctx *ctx);
+/* Transport errors: every RCCL return code is checked; the first failure is latched in the
+ * context (message in fedm_last_error), all later exchanges / reductions are skipped and
+ * fedm_newton_solve, fedm_poisson_solve, fedm_sync_ghosts and fedm_field_error return -1.
+ * fedm_comm_stats: out = {transport kind (0 none, 1 host callbacks, 2 RCCL), ranks, halo
+ * exchanges issued, all-reduces issued, failed flag, neighbours, assembly patches without /
+ * with ghost vertices (the former are assembled while the state halo travels)}. */
+int fedm_comm_stats(fedm_ctx *ctx, int64_t out[8]);
+/* latency of the transport's primitives, back to back on the compute stream (all ranks must call
+ * it together): kind 0 = halo exchange of a block vector, 1 = of one value per vertex,
+ * 2 = all-reduce of 32 doubles.  ms per operation. */
+int fedm_time_comm(fedm_ctx *ctx, int kind, int repeats, double *ms_per_op);
+/* Test hook (no GPU needed): drives the RCCL code path with a stub transport whose
+ * `fail_at`-th call fails.  out = {failed flag latched, transport calls made, calls made after
+ * the failing one, comm_failed()}; returns 1 when a failure was latched. */
+int fedm_debug_comm_fault(int fail_at, int64_t out[4]);
+/* Host-side preprocessing alone (no GPU needed): what DOLFIN builds with the FunctionSpace /
+ * sparsity pattern (fedm/functions.py:192,200).  out = {matrix slices (= assembly patches),
+ * max cells per patch, max block columns per slice, max staged vertices per patch, cell visits
+ * of all patches, owned (cell, local vertex) pairs, pairs that clash with another cell of their
+ * 16-lane group on an LDS accumulator bank (FEDM_PATCH_ORDER, see csrc/prep.cpp), structural blocks}. */
+int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[8]);
 
 /* |new - old + eps| / |old + eps| on one component        fedm/functions.py:1062-1064 */
 int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);

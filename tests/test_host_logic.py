@@ -367,3 +367,45 @@ def test_missing_library_fails_loudly(tmp_path):
     env = dict(os.environ, FEDM_HIP_LIB=str(tmp_path / "libfedm_hip_missing.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert "REFUSED" in out.stdout and "not found" in out.stdout
+
+
+# ---- C-ABI host logic that needs no GPU ----------------------------------------------------
+def test_rccl_failure_is_latched_and_reported():
+    """Every RCCL return code is checked (csrc/comm.hip): a stub transport whose k-th call fails
+    drives the exchange / all-reduce code of the RCCL path.  Whatever call fails, the failure is
+    latched with the call's name in fedm_last_error, nothing but the closing ncclGroupEnd of an
+    open group is issued afterwards, and without a fault all ten calls of two Krylov-step rounds
+    (group start, send, recv, group end, all-reduce) go through."""
+    import ctypes as C
+    from fedm_amd import _lib
+    lib = _lib.load()
+    out = (C.c_int64 * 4)()
+    assert lib.fedm_debug_comm_fault(-1, out) == 0 and list(out) == [0, 10, 0, 0]
+    names = ["ncclGroupStart", "ncclSend", "ncclRecv", "ncclGroupEnd", "ncclAllReduce"]
+    for k in range(10):
+        assert lib.fedm_debug_comm_fault(k, out) == 1
+        failed, calls, after, reported = list(out)
+        assert failed == 1 and reported == 1
+        msg = _lib.last_error()
+        assert names[k % 5] in msg and "rank 1 of 2" in msg
+        inside_group = k % 5 in (1, 2)              # send / recv failed: the group is still closed
+        assert after <= (2 if k % 5 == 1 else 1 if inside_group else 0)
+        assert calls <= k + 1 + (3 if inside_group else 0)
+
+
+def test_patch_micro_colouring_removes_lds_bank_clashes(monkeypatch):
+    """csrc/prep.cpp orders every assembly patch's cells so that the 16 lanes of an LDS lane group
+    add into distinct accumulator banks (the `north_star`'s colouring, at workgroup scale).  On a
+    graded structured mesh numbered along the Z-curve the clashing (cell, vertex) pairs drop from
+    about half of all pairs to a few percent; the pattern itself is untouched."""
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import pattern_stats
+    msh = streamer.mesh(96, 4.0)
+    monkeypatch.setenv("FEDM_PATCH_ORDER", "0")
+    plain = pattern_stats(msh.coords, msh.cells)
+    monkeypatch.delenv("FEDM_PATCH_ORDER")
+    ordered = pattern_stats(msh.coords, msh.cells)
+    for k in ("n_slices", "max_patch_cells", "max_patch_width", "cell_visits", "owned_pairs", "nnz_blocks"):
+        assert plain[k] == ordered[k]
+    assert plain["bank_clashes"] > 0.4 * plain["owned_pairs"]
+    assert ordered["bank_clashes"] < 0.06 * ordered["owned_pairs"]
