@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--grading", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=int, default=None, help="CPU baseline mesh (default: --mesh)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="0: as many as --steps")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: every core this process may use")
     ap.add_argument("--late-start", type=int, default=200,
                     help="accepted steps before the late window (0 disables it)")
@@ -412,7 +412,8 @@ def main():
             "partition": r4.partition_name}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n, args.grading, args.cpu_steps, args.cpu_threads)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n, args.grading, args.cpu_steps or args.steps,
+                                           args.cpu_threads)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -20,9 +20,12 @@ if os.environ.get("FEDM_ASSEMBLY_LEAN", "1") == "0":
     names = ["zero LDS", "stage vertices (global loads)", "barrier 1", "cell record + LDS reads", "setup",
              "rows: moments + emission + atomics", "barrier 2", "stream out"]
 else:
-    names = ["zero + stage vertices (issue)", "barrier: staged loads arrive", "prologue: cell record, exp(u)",
+    names = ["zero + stage vertices (issue) [+ vertex exponentials, lean2]", "barrier: staged loads arrive",
+             "prologue: cell record, exp(u) [lean2: field, rate coefficient]",
              "rows (3x): set-up, moments, emission", "barriers after the rows", "stream-out + zeroing (3x, issue)",
              "LDS-only barriers", "F stream-out"]
 tot = sum(out)
 for k, v in zip(names, out):
-    print(f"{k:38s} {100.0 * v / tot:5.1f} %   {v / n / 5203 / 100.0:7.2f} us per patch (100 MHz clock)")
+    print(f"{k:62s} {100.0 * v / tot:5.1f} %   {v / n / 5203 / 100.0:7.2f} us per patch (100 MHz clock)")
+print(f"workgroup lifetime (wave 0): {tot / n / 5203 / 100.0:.2f} us;  kernel: {1e3 * prob.time_kernel(0, 20):.1f} us "
+      f"for 5203 workgroups")
