@@ -81,6 +81,18 @@ class Files:
 files = Files()
 
 
+def output_files(file_type, type_of_output, output_file_names):
+    """fedm/file_io.py:148-188: one writer per name under ``<output>/<type_of_output>/<name>/``
+    ('pvd': VTU series, 'xdmf': XDMF + HDF5 checkpoints in DOLFIN's layout); the mesh is taken from
+    the first Function written."""
+    from . import mesh_io
+    kinds = {"pvd": mesh_io.PVDFile, "xdmf": mesh_io.XDMFFile}
+    if file_type not in kinds:
+        raise ValueError(f"fedm.output_files: file type '{file_type}' is not valid. Options are 'pvd' or 'xdmf'.")
+    out = files.output_folder_path / type_of_output
+    return [kinds[file_type](out / name / f"{name}.{file_type}") for name in output_file_names]
+
+
 # ---------------------------------------------------------------------------
 # Deck files.  Every deck file is text with '#' comments; what differs is how the payload is
 # shaped (one number, one expression string, two columns, key/value lines).  One small class

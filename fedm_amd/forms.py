@@ -28,6 +28,94 @@ def near(a, b, eps=DOLFIN_EPS):
 
 
 # ---------------------------------------------------------------------------------------
+# Opaque symbolic nodes.  The LMEA scripts (examples/glow_discharge/fedm-gd.py:205-385) combine
+# nodal Functions, unknowns and constants into expressions -- the semi-implicit mean energy, the
+# electron thermal velocity, 5/3 of a coefficient, the ion flux through a wall.  The device
+# kernels implement those expressions natively, so the facade only has to RECOGNISE them: a Sym
+# records the operation and its operands, `fedm_amd.lmea` matches the structure and evaluates the
+# numeric parts (``evaluate``), nothing here does arithmetic on fields.
+# ---------------------------------------------------------------------------------------
+class _Ops:
+    def __add__(self, o):
+        return Sym("add", self, o)
+
+    def __radd__(self, o):
+        return self if (isinstance(o, Real) and o == 0) else Sym("add", o, self)
+
+    def __sub__(self, o):
+        return Sym("sub", self, o)
+
+    def __rsub__(self, o):
+        return Sym("sub", o, self)
+
+    def __mul__(self, o):
+        return Sym("mul", self, o)
+
+    def __rmul__(self, o):
+        return Sym("mul", o, self)
+
+    def __truediv__(self, o):
+        return Sym("div", self, o)
+
+    def __rtruediv__(self, o):
+        return Sym("div", o, self)
+
+    def __neg__(self):
+        return Sym("neg", self)
+
+    def __pow__(self, n):
+        return Sym("pow", self, n)
+
+    def __abs__(self):
+        return Sym("abs", self)
+
+
+class Sym(_Ops):
+    def __init__(self, op, *args):
+        self.op, self.args = op, args
+
+    def __float__(self):
+        return float(evaluate(self))
+
+    def leaves(self, kind=None):
+        out = []
+        for a in self.args:
+            if isinstance(a, Sym):
+                out.extend(a.leaves(kind))
+            elif kind is None or isinstance(a, kind):
+                out.append(a)
+        return out
+
+
+def evaluate(x, env=None):
+    """Numeric value of an expression whose leaves are numbers, Constants, parameter Expressions
+    and nodal Functions (-> arrays); ``env`` maps objects (by id) to substitute values.  Unknowns
+    and cell-wise operations are not values: TypeError."""
+    env = env or {}
+    if id(x) in env:
+        return env[id(x)]
+    if isinstance(x, Real):
+        return float(x)
+    if isinstance(x, np.ndarray):
+        return x
+    if isinstance(x, Constant):
+        return float(x.value)
+    if isinstance(x, (Function, FunctionComponent)):
+        return np.asarray(x.vector(), dtype=float)
+    if isinstance(x, Expression):
+        return x.value()
+    if isinstance(x, Sym):
+        a = [evaluate(v, env) for v in x.args] if x.op not in ("pow",) else [evaluate(x.args[0], env), x.args[1]]
+        ops = {"add": lambda: a[0] + a[1], "sub": lambda: a[0] - a[1], "mul": lambda: a[0] * a[1],
+               "div": lambda: a[0] / a[1], "neg": lambda: -a[0], "pow": lambda: a[0] ** a[1],
+               "abs": lambda: np.abs(a[0]), "exp": lambda: np.exp(a[0]), "sqrt": lambda: np.sqrt(a[0]),
+               "log": lambda: np.log(a[0])}
+        if x.op in ops:
+            return ops[x.op]()
+    raise TypeError(f"cannot evaluate {type(x).__name__}{'(' + x.op + ')' if isinstance(x, Sym) else ''} numerically")
+
+
+# ---------------------------------------------------------------------------------------
 # scalars, nodal functions, device state handles
 # ---------------------------------------------------------------------------------------
 class Expression:
@@ -44,11 +132,31 @@ class Expression:
 
     def __call__(self, x):
         if self.python is None:
-            raise NotImplementedError("C++ expression strings are not compiled here; pass python=")
-        return self.python(np.asarray(x))
+            try:
+                return np.full(np.shape(x)[:-1], float(self.code))      # Expression('3.0', degree=1)
+            except (TypeError, ValueError):
+                raise NotImplementedError("C++ expression strings are not compiled here; pass python=") from None
+        import inspect
+        n_args = len(inspect.signature(self.python).parameters)
+        return self.python(np.asarray(x)) if n_args == 1 else self.python(np.asarray(x), self)
+
+    def value(self):
+        """Value of a parameter-only expression (``Expression('u_p', u_p=5.0)``,
+        ``Expression('U0*(1-exp(-t/1e-9))', U0=..., t=..., python=lambda x, e: ...)``)."""
+        if self.python is not None:
+            return float(np.asarray(self(np.zeros((1, 2)))).ravel()[0])
+        if self.code in self.__dict__:
+            return float(self.__dict__[self.code])
+        return float(self.code)
+
+    def __mul__(self, o):
+        return Sym("mul", self, o)
+
+    def __rmul__(self, o):
+        return Sym("mul", o, self)
 
 
-class Constant:
+class Constant(_Ops):
     def __init__(self, value):
         self.value = value
 
@@ -56,19 +164,62 @@ class Constant:
         return float(self.value)
 
 
-class Function:
-    """A nodal array on the host (coefficients, post-processing fields)."""
+class Function(_Ops):
+    """A nodal array on the host (coefficients, post-processing fields).  On a mixed space
+    (``Function(ME)``) it is the handle of a device state once a Problem is bound to it; its
+    components ``f[i]`` are descriptors."""
 
     def __init__(self, space=None, values=None):
         self.space = space
         n = space.mesh.num_vertices() if hasattr(space, "mesh") else 0
+        self.n_eq = getattr(space, "n_eq", 1)
         self._v = np.zeros(n) if values is None else np.asarray(values, dtype=float)
+        self.state = None          # DeviceState once bound (mixed functions)
+        self.name = None
 
     def vector(self):
-        return self._v
+        return self.state if self.state is not None else self._v
+
+    def rename(self, name, label=None):
+        self.name = name
+
+    def __getitem__(self, i):
+        return FunctionComponent(self, i)
+
+    def __add__(self, o):
+        # a zero Function used as an accumulator of source terms (fedm-streamer.py:164,246)
+        if isinstance(o, (RateSum, Rate, Density)):
+            return NotImplemented
+        return Sym("add", self, o)
 
     def assign(self, other):
-        self._v = np.array(other.vector() if hasattr(other, "vector") else other, dtype=float)
+        if self.state is not None:
+            return self.state.assign(getattr(other, "state", other))
+        if isinstance(other, Expression) and self.space is not None:
+            self._v = np.array(other(self.space.mesh.coords), dtype=float)
+        elif isinstance(other, (Constant, Real)):
+            self._v = np.full_like(self._v, float(other))
+        elif isinstance(other, Sym):
+            self._v = np.array(evaluate(other), dtype=float) + np.zeros_like(self._v)
+        else:
+            self._v = np.array(other.vector() if hasattr(other, "vector") else other, dtype=float)
+
+
+class FunctionComponent(_Ops):
+    """``u_old[i]`` of a mixed Function."""
+
+    def __init__(self, function, index):
+        self.function, self.index = function, index
+
+    def vector(self):
+        raise TypeError("a component of a mixed Function lives on the device; use the assigner")
+
+
+def interpolate(expr, space):
+    """``interpolate(Expression(...), V)`` / ``interpolate(Constant(c), V)``: nodal values."""
+    f = Function(space)
+    f.assign(expr)
+    return f
 
 
 class DeviceState:
@@ -93,18 +244,45 @@ class DeviceState:
             self.device.set_state(**{"u_" + self.which: np.asarray(other)})
 
     def array(self):
-        if self.which != "new":
-            raise RuntimeError("only the current state can be downloaded")
-        return self.device.get_state()
+        if self.which == "new":
+            return self.device.get_state()
+        if self.which == "old":
+            return self.device.get_state_old()
+        raise RuntimeError("u_old1 cannot be downloaded")
 
 
 class FunctionAssigner:
-    """``assigner.assign(var_list, u)``: per-field views are cut on demand; no copy."""
+    """``FunctionAssigner(receiving_space, assigning_space)``.
+
+    * ``assigner.assign([f_0, ..., f_k], u)`` with ``u`` a device state (or a mixed Function bound
+      to one): downloads that state once and fills the host Functions (entries that are None are
+      skipped; with ``receiving=None`` nothing moves -- the LFA drivers keep everything on the device);
+    * ``rev_assigner.assign(u, [f_0, ..., f_k])``: the reverse, one upload."""
 
     def __init__(self, *spaces):
         self.spaces = spaces
 
     def assign(self, receiving, assigning):
+        state = lambda x: x if isinstance(x, DeviceState) else getattr(x, "state", None)
+        if receiving is None:
+            return None
+        if isinstance(receiving, (list, tuple)):
+            src = state(assigning)
+            if src is None:
+                if isinstance(assigning, Function):        # mixed Function not bound yet: remember the parts
+                    assigning.parts = list(receiving)
+                    return None
+                raise TypeError("FunctionAssigner: the assigning function is not a device state")
+            U = src.array()
+            for i, f in enumerate(receiving):
+                if f is not None:
+                    f.vector()[:] = U[:, i]
+            return None
+        dst = state(receiving)
+        if dst is None:                                    # rev_assigner before the Problem exists
+            receiving.parts = list(assigning)
+            return None
+        dst.assign(np.stack([np.asarray(f.vector(), dtype=float) for f in assigning], axis=1))
         return None
 
 
@@ -136,7 +314,7 @@ class FunctionSpace:
         return SubSpace(self, i)
 
 
-class Unknown:
+class Unknown(_Ops):
     """Component ``i`` of the mixed trial function."""
 
     def __init__(self, space, index):
@@ -258,7 +436,7 @@ class RateSum:
     __rmul__ = __mul__
 
     def __truediv__(self, o):
-        o = TermSum.coerce(float(o) if isinstance(o, Constant) else o)
+        o = TermSum.coerce(float(o) if isinstance(o, (Constant, Sym)) else o)
         return RateSum([Rate(t.coef / o, t.powers) for t in self.terms])
 
     def __pow__(self, n):
@@ -274,7 +452,16 @@ def _rate_ops(cls):
     for name in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__",
                  "__truediv__", "__neg__", "__pow__"):
         def op(self, *a, _n=name):
-            return getattr(RateSum([Rate(1.0, {self.index: 1})]), _n)(*a)
+            try:
+                if any(isinstance(x, (Function, FunctionComponent, Sym)) for x in a):
+                    raise TypeError("nodal operand")
+                return getattr(RateSum([Rate(1.0, {self.index: 1})]), _n)(*a)
+            except TypeError:            # an operand that is no function of |E|: nodal coefficients (LMEA)
+                sym_op = {"__add__": "add", "__radd__": "add", "__sub__": "sub", "__rsub__": "rsub",
+                          "__mul__": "mul", "__rmul__": "mul", "__truediv__": "div", "__pow__": "pow"}[_n]
+                if sym_op == "rsub":
+                    return Sym("sub", a[0], self)
+                return Sym(sym_op, self, *a)
         setattr(cls, name, op)
     return cls
 
@@ -316,15 +503,24 @@ class FieldSquared:
 
 
 def grad(u):
+    if isinstance(u, Function):
+        return Sym("grad", u)                    # of a nodal Function: cell-wise constant (project())
     if not isinstance(u, Unknown):
-        raise NotImplementedError("grad() of the potential unknown only")
+        raise NotImplementedError("grad() of the potential unknown or of a nodal Function")
     return GradOf(u)
 
 
 def inner(a, b):
+    from .functions import FluxDesc
     if isinstance(a, GradOf) and isinstance(b, GradOf) and a.unknown is b.unknown:
         return FieldSquared(a.unknown.index)
-    raise NotImplementedError("inner() is defined for the electric field with itself")
+    if isinstance(a, FluxDesc) and isinstance(b, FacetNormal):
+        return Sym("normal_flux", a)             # Gamma . n on a wall (fedm-gd.py:351)
+    if isinstance(a, FluxDesc) and isinstance(b, GradOf):
+        return Sym("flux_dot_field", a, b)       # Gamma . E: Joule heating (fedm-gd.py:359)
+    if isinstance(a, Sym) and isinstance(b, Sym):
+        return Sym("dot", a, b)
+    raise NotImplementedError("inner()/dot() of these operands is not part of the device models")
 
 
 dot = inner
@@ -335,6 +531,8 @@ def sqrt(x):
         return TermSum.field()                   # E_m
     if isinstance(x, TermSum):
         return x ** 0.5
+    if isinstance(x, (Sym, Function)):
+        return Sym("sqrt", x)
     return math.sqrt(x)
 
 
@@ -343,10 +541,64 @@ def exp(x):
         return Density(x.index)
     if isinstance(x, TermSum):
         return x.exp()
+    if isinstance(x, (Sym, Function, FunctionComponent)):
+        return Sym("exp", x)
     return math.exp(x)
 
 
+def project(expr, space=None, solver_type=None):
+    """L2 projection onto P1 of ``c * sqrt(dot(grad(f), grad(f)))``-type expressions of nodal
+    Functions (fedm-gd.py:309,432: the reduced electric field): the gradient of a P1 Function is
+    constant per cell; consistent mass matrix, factorised once per mesh (host, post-processing
+    size -- the device-resident pipeline is `fedm_gd_prep_step`)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    funcs = [f for f in expr.leaves(Function)] if isinstance(expr, Sym) else []
+    if not funcs:
+        raise NotImplementedError("project() of an expression without nodal Functions")
+    mesh = funcs[0].space.mesh
+    x = mesh.coords[mesh.cells]
+    d1, d2 = x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]
+    det = d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]
+
+    def cellwise(e):
+        if isinstance(e, Sym) and e.op == "grad":
+            P = np.asarray(e.args[0].vector(), dtype=float)[mesh.cells]
+            gx = (P[:, 0] * (x[:, 1, 1] - x[:, 2, 1]) + P[:, 1] * (x[:, 2, 1] - x[:, 0, 1])
+                  + P[:, 2] * (x[:, 0, 1] - x[:, 1, 1])) / det
+            gy = (P[:, 0] * (x[:, 2, 0] - x[:, 1, 0]) + P[:, 1] * (x[:, 0, 0] - x[:, 2, 0])
+                  + P[:, 2] * (x[:, 1, 0] - x[:, 0, 0])) / det
+            return np.stack([gx, gy], axis=1)
+        if isinstance(e, Sym) and e.op == "dot":
+            return np.einsum("cd,cd->c", cellwise(e.args[0]), cellwise(e.args[1]))
+        if isinstance(e, Sym):
+            a = [cellwise(v) for v in e.args]
+            return {"neg": lambda: -a[0], "sqrt": lambda: np.sqrt(a[0]), "mul": lambda: a[0] * a[1],
+                    "div": lambda: a[0] / a[1], "add": lambda: a[0] + a[1], "sub": lambda: a[0] - a[1]}[e.op]()
+        if isinstance(e, Function):
+            raise NotImplementedError("project(): nodal values outside grad() are not supported")
+        return evaluate(e)
+    f = cellwise(expr)
+    lu = getattr(mesh, "_p1_mass_lu", None)
+    n = mesh.num_vertices()
+    if lu is None:
+        vals = np.abs(det)[:, None, None] * ((np.ones((3, 3)) + np.eye(3)) / 24.0)[None]
+        c = mesh.cells.astype(np.int64)
+        rows = np.broadcast_to(c[:, :, None], vals.shape).ravel()
+        cols = np.broadcast_to(c[:, None, :], vals.shape).ravel()
+        lu = mesh._p1_mass_lu = spla.splu(sp.coo_matrix((vals.ravel(), (rows, cols)), shape=(n, n)).tocsc())
+    rhs = np.bincount(mesh.cells.ravel(), weights=np.repeat(f * np.abs(det) / 6.0, 3), minlength=n)
+    return Function(space or funcs[0].space, values=lu.solve(rhs))
+
+
 def action(form, u):
+    """``F = action(F, u_new)``: the form evaluated at u_new; the facade notes which mixed Function
+    that is (it becomes the handle of the device's current state in Problem())."""
+    if isinstance(u, Function):
+        try:
+            form.u_new = u
+        except AttributeError:
+            pass
     return form
 
 

@@ -170,8 +170,11 @@ def Boundary_flux(bc_type, equation_type, particle_type, sign, mu, E, normal, u,
         raise ValueError(f"fedm.Boundary_flux: particle type '{particle_type}' not recognised.\n"
                          f"Must be one of {comma_separated(['Heavy', 'electrons'])}.")
     if bc_type == "flux source" and equation_type != "reaction":
-        raise NotImplementedError(
-            "'flux source' boundaries (glow-discharge model) are not on the device path yet")
+        # (1-ref)/(1+ref) * [vth/2 (+ |sign mu E.n|)] exp(u) [- 2 gamma Ion_flux/(1+ref) for electrons],
+        # functions.py:514-522: lowered onto the LMEA device model by fedm_amd.lmea.compile_lmea
+        return BoundaryTerm(kind="flux source", equation_type=equation_type, particle_type=particle_type,
+                            u=u, sign=sign, mu=mu, gamma=gamma, tag=ds_temp.tag, ds=ds_temp, r=r, vth=vth,
+                            ref=ref, Ion_flux=Ion_flux)
     if bc_type == "Neumann" and equation_type == "drift-diffusion-reaction":
         return BoundaryTerm(kind="Neumann", u=u, sign=sign, mu=mu, tag=ds_temp.tag,
                             ds=ds_temp, r=r)
@@ -195,6 +198,14 @@ def compile_forms(F, quadrature_degree=None):
     from .physical_constants import elementary_charge as q_e, epsilon_0 as eps0
     from .termsum import TermSum
     pieces = F.pieces if isinstance(F, FormSum) else [F]
+    from . import lmea
+    if lmea.is_lmea(pieces):
+        qd = quadrature_degree if quadrature_degree is not None else forms.parameters["form_compiler"]["quadrature_degree"]
+        if qd is None or qd < 0:
+            raise NotImplementedError("set parameters['form_compiler']['quadrature_degree'] (fedm-gd.py:28)")
+        model, mesh, tags, binding = lmea.compile_lmea(pieces, qd)
+        model.field_binding = binding
+        return model, mesh, tags
     balances = sorted([p for p in pieces if isinstance(p, BalanceEq)], key=lambda p: p.u.index)
     poissons = [p for p in pieces if isinstance(p, PoissonEq)]
     bterms = [p for p in pieces if isinstance(p, BoundaryTerm)]
@@ -282,7 +293,9 @@ class Problem:
         self.bilinear_form = J
         self.linear_form = F
         self.bcs = bcs
+        self.before_solve = None
         if device_problem is None and isinstance(F, (FormSum, FormPiece)):
+            from . import forms
             from .device import DeviceProblem
             model, mesh, tags = compile_forms(F)
             dofs = [np.zeros(0, dtype=np.int64)]
@@ -294,6 +307,36 @@ class Problem:
             device_problem = DeviceProblem(mesh.coords, mesh.cells, model, facet_tags=tags,
                                            dirichlet_dofs=np.concatenate(dofs),
                                            dirichlet_vals=np.concatenate(vals), device=device)
+            # mixed Functions of the script become handles of the device-resident states
+            # (u_new from action(F, u_new), u_old / u_old1 from the balance equations); what a
+            # rev_assigner put into them before this point is uploaded now
+            pieces = F.pieces if isinstance(F, FormSum) else [F]
+            owners = {"new": getattr(F, "u_new", None)}
+            for p in pieces:
+                for which, comp in (("old", getattr(p, "u_old", None)), ("old1", getattr(p, "u_old1", None))):
+                    if isinstance(comp, forms.FunctionComponent):
+                        owners[which] = comp.function
+            initial = {}
+            for which, fn in owners.items():
+                if isinstance(fn, forms.Function):
+                    fn.state = forms.DeviceState(device_problem, which)
+                    if getattr(fn, "parts", None):
+                        initial["u_" + which] = np.stack([np.asarray(f.vector(), dtype=float) for f in fn.parts], axis=1)
+            if initial:
+                device_problem.set_state(**initial)
+            binding = getattr(model, "field_binding", None)
+            timed = [bc for bc in (bcs or []) if isinstance(bc.value, forms.Expression)]
+
+            def refresh():
+                # time-dependent Dirichlet values (functions.py:1042-1044 advances their `t`) and the
+                # nodal coefficient Functions the script has just interpolated on the host
+                if timed:
+                    device_problem.set_dirichlet_values(
+                        np.concatenate([bc.rows(mesh, model.n_eq)[1] for bc in bcs]))
+                if binding is not None:
+                    device_problem.set_gd_fields(binding.stack(mesh.num_vertices()))
+            if timed or binding is not None:
+                self.before_solve = refresh
         self.device = device_problem if device_problem is not None else getattr(F, "device", None)
         if self.device is None:
             raise ValueError("fedm.Problem: the form is not bound to a device problem")
@@ -338,10 +381,18 @@ class PETScSNESSolver:
 
 
 def Max(a, b):
+    """(a + b + |a - b|)/2, fedm/functions.py:205-209; symbolic operands: the wall flux of an ion
+    species, Max(dot(Gamma, normal), 0) (fedm-gd.py:351)."""
+    from . import forms, lmea
+    if isinstance(a, forms.Sym) or isinstance(b, forms.Sym):
+        return lmea.positive_part(a, b)
     return (a + b + abs(a - b)) / 2.0
 
 
 def Min(a, b):
+    from . import forms, lmea
+    if isinstance(a, forms.Sym) or isinstance(b, forms.Sym):
+        return lmea.positive_part(None, None)
     return (a + b - abs(a - b)) / 2.0
 
 
@@ -515,6 +566,12 @@ def semi_implicit_coefficients(dependences, mean_energy_new, mean_energy_old, co
     depend on the mean energy, c otherwise."""
     _equal_lengths("semi_implicit_coefficients", "The lists 'dependences', 'coefficients', and 'coefficient_diffs'",
                    dependences, coefficients, coefficient_diffs)
+    from . import forms, lmea
+    if any(isinstance(c, forms.Function) for c in coefficients):
+        # nodal coefficients of a device model: the kernels form c + c' (eps_new - eps_old) at the
+        # quadrature points themselves (csrc/gd.hip, gd_point)
+        return [lmea.SemiImplicit(c, dc, tag == "Umean", mean_energy_new, mean_energy_old)
+                for c, dc, tag in zip(coefficients, coefficient_diffs, dependences)]
     shift = mean_energy_new - mean_energy_old
     return [c + dc * shift if tag == "Umean" else c
             for c, dc, tag in zip(coefficients, coefficient_diffs, dependences)]
@@ -526,6 +583,11 @@ def semi_implicit_coefficients(dependences, mean_energy_new, mean_energy_old, co
 def _exp(x):
     from . import forms
     return forms.exp(x)
+
+
+def _nodal(k_coeffs):
+    from . import forms, lmea
+    return any(isinstance(k, (forms.Function, lmea.SemiImplicit)) for k in k_coeffs)
 
 
 def _reaction_rates(p_matrix, densities, k_coeffs):
@@ -550,6 +612,10 @@ def Source_term(coupling, approx, p_matrix, l_matrix, g_matrix, k_coeffs, N0, u)
         raise ValueError("fedm.Source_term: approx must be 'LFA' or 'LMEA'.")
     first = 0 if (coupling, approx) == ("coupled", "LFA") else 1
     last = len(u) - (1 if coupling == "coupled" else 0)
+    if _nodal(k_coeffs):      # nodal rate coefficients: the device evaluates the rates (csrc/gd.hip)
+        from . import lmea
+        return [lmea.LmeaSource(i, p_matrix, l_matrix, g_matrix, k_coeffs, N0)
+                for i in range(np.asarray(g_matrix).shape[1])]
     rates = _reaction_rates(p_matrix, [N0] + [_exp(u[i]) for i in range(first, last)], k_coeffs)
     net = (np.asarray(g_matrix) - np.asarray(l_matrix)).astype(int)
     sources = []
@@ -566,6 +632,9 @@ def Energy_Source_term(coupling, p_matrix, l_matrix, g_matrix, k_coeffs, u_loss,
     """fedm/functions.py:845-912: -sum_j rate_j * loss_j, where the two sentinel loss values of
     the decks stand for (Ei - mean energy) and the mean energy itself."""
     last = len(n) - (1 if coupling == "coupled" else 0)
+    if _nodal(k_coeffs):
+        from . import lmea
+        return lmea.LmeaEnergySource(p_matrix, k_coeffs, u_loss, N0)
     rates = _reaction_rates(p_matrix, [N0] + [_exp(n[i]) for i in range(1, last)], k_coeffs)
     total = 0.0
     for rate, loss in zip(rates, u_loss):

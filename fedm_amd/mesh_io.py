@@ -46,12 +46,22 @@ def write_dolfin_xml(mesh, path):
 class PVDFile:
     """``File("dir/name.pvd")``: each ``write(values, name, t)`` adds ``name%06d.vtu``."""
 
-    def __init__(self, path, mesh):
+    def __init__(self, path, mesh=None):
         self.path, self.mesh = Path(path), mesh
         self.path.parent.mkdir(parents=True, exist_ok=True)
         self.entries = []
 
+    def __lshift__(self, item):
+        """``vtkfile << (function, t)`` (fedm-gd.py:306)."""
+        f, t = item if isinstance(item, tuple) else (item, 0.0)
+        if self.mesh is None:
+            self.mesh = f.space.mesh
+        self.write(f.vector(), getattr(f, "name", None) or self.path.stem, t)
+        return self
+
     def write(self, values, field_name, t):
+        if self.mesh is None and hasattr(values, "space"):
+            self.mesh, values = values.space.mesh, values.vector()
         idx = len(self.entries)
         vtu = self.path.with_name(f"{self.path.stem}{idx:06d}.vtu")
         write_vtu(vtu, self.mesh, np.asarray(values, dtype=np.float64), field_name)
@@ -98,15 +108,24 @@ class XDMFFile:
     (tests/integrated_tests/testing_utils.py:21-24) -- and rewrites the light ``.xdmf`` index.
     The dof numbering is the vertex numbering (``cell_dofs`` = flattened topology)."""
 
-    def __init__(self, path, mesh):
+    class Encoding:
+        HDF5 = "HDF5"
+
+    def __init__(self, path, mesh=None):
         self.path = Path(path)
+        self.path.parent.mkdir(parents=True, exist_ok=True)
         self.mesh = mesh
         self.h5path = self.path.with_suffix(".h5")
         self.counts = {}
         self.times = {}
+        self.parameters = {}
 
     def write_checkpoint(self, values, name, t, encoding=None, append=True):
         from . import h5
+        if hasattr(values, "space"):                  # a nodal Function: its mesh, its vector
+            if self.mesh is None:
+                self.mesh = values.space.mesh
+            values = values.vector()
         values = np.asarray(values, dtype=np.float64).ravel()
         if values.size != len(self.mesh.coords):
             raise ValueError("write_checkpoint: one value per mesh vertex expected")
@@ -195,7 +214,10 @@ def file_output(t, t_old, t_out, step, t_out_list, step_list, file_type, output_
         index = next(x for x, val in enumerate(t_out_list) if val > t)
     while t_out <= t:
         for i in range(len(output_file_list)):
-            new, old = np.asarray(u_old[i]), np.asarray(u_old1[i])
+            vec = lambda f: np.asarray(f.vector() if hasattr(f, "vector") else f, dtype=np.float64)
+            new, old = vec(u_old[i]), vec(u_old1[i])
+            if getattr(output_file_list[i], "mesh", 0) is None and hasattr(u_old[i], "space"):
+                output_file_list[i].mesh = u_old[i].space.mesh
             temp = old + (t_out - t_old) * (new - old) / (t - t_old)
             if file_type[i] == "pvd":
                 output_file_list[i].write(temp, particle_name[i], t_out * scale)

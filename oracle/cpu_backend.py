@@ -330,13 +330,37 @@ def run_streamer(prob, mesh, steps, dt_init=5e-12, dt_max=5e-12, dt_min=1e-15, t
     return U, st, t, dict(seconds=elapsed, newton=count["newton"], linear=count["linear"], poisson_iterations=pits)
 
 
+def usable_cores():
+    """CPUs this process can actually run on at once: its affinity mask, capped by the cgroup CPU
+    quota (a GPU box hands a one-GPU job a share of the host -- 16 of 256 cores -- while the
+    affinity mask still lists every core; 128 spinning OpenMP threads on 16 cores take 20x longer
+    than 16 threads).  Without a readable quota: at most 16."""
+    avail = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        txt = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if txt[0] != "max":
+            quota = int(txt[0]) / int(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is None:
+        return min(avail, 16), avail, "no cgroup quota readable: capped at 16"
+    return max(1, min(avail, int(quota))), avail, f"cgroup quota {quota:g} CPUs"
+
+
 def bench(n, grading, steps, threads):
     """bench.py's cpu_baseline record: `steps` accepted BDF2 steps of the streamer case on the
     n x n mesh, timed after set-up (mesh, pattern, multigrid hierarchy, initial Poisson solve are
     untimed on the device side too)."""
     lib = load()
-    avail = len(os.sched_getaffinity(0))
-    used = avail if threads <= 0 else min(threads, avail)
+    cores, avail, why = usable_cores()
+    used = cores if threads <= 0 else min(threads, avail)
     lib.cpu_set_threads(used)
     prob, mesh = streamer_problem(n, grading)
     _, _, t, stats = run_streamer(prob, mesh, steps)
@@ -350,7 +374,7 @@ def bench(n, grading, steps, threads):
                      f"({ndof} DOFs), timed after set-up like the device run; oracle/cpu/fedm_cpu.c: C + OpenMP, "
                      f"coloured element loop -> block CSR -> Newton -> flexible GMRES(30) with the same field "
                      f"split (Chebyshev(6) species sweeps + smoothed-aggregation V(1,1)) -- 'CPU restatement, not "
-                     f"FEniCS'; {used} OpenMP threads of {os.cpu_count()} host CPUs ({avail} usable by this process)",
+                     f"FEniCS'; {used} OpenMP threads ({why}; affinity mask {avail} of {os.cpu_count()} host CPUs)",
            "spmv_count": counters["spmv"]}
     prob.close()
     return out

@@ -409,3 +409,49 @@ def test_patch_micro_colouring_removes_lds_bank_clashes(monkeypatch):
         assert plain[k] == ordered[k]
     assert plain["bank_clashes"] > 0.4 * plain["owned_pairs"]
     assert ordered["bank_clashes"] < 0.06 * ordered["owned_pairs"]
+
+
+def test_lmea_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):
+    """examples/glow_discharge.py follows fedm-gd.py:196-408 call for call; `Problem()` hands the
+    form to fedm_amd.lmea.compile_lmea, which must recover the parameters of the device's LMEA
+    model from the script's own objects (and refuse what the kernels do not implement).  Runs up to
+    the point where the device context would be created."""
+    import importlib.util
+    import fedm_amd.functions as ff
+    from fedm_amd import lmea
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("gd_example_cpu", root / "examples" / "glow_discharge.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def capture(J, F, bcs):
+        seen.update(F=F, bcs=bcs)
+        raise Stop
+    monkeypatch.setattr(mod, "Problem", capture)
+    with pytest.raises(Stop):
+        mod.main(nx=6, ny=6, output_dir=tmp_path)
+    model, mesh, tags = ff.compile_forms(seen["F"])
+    assert model.n_species == 4 and model.n_eq == 5 and model.N0 == pytest.approx(3.21877e22)
+    assert model.eq_type == ["reaction", "diffusion-reaction", "drift-diffusion-reaction", "drift-diffusion-reaction"]
+    assert model.sign == [0.0, 0.0, 1.0, -1.0] and model.grad_diffusion == [False, False, False, True]
+    assert model.is_ion == [False, False, True, False]
+    assert model.electron_mass == pytest.approx(9.10938215e-31, rel=1e-6)
+    assert model.vth[1] == pytest.approx(398.7495614691132) and model.vth[3] == 0.0
+    assert model.gamma == [0.06, 0.06, 0.0, 0.0] and model.we_secondary == 5.0
+    assert model.ref[0][1:] == [0.3, 5e-4, 0.3] and model.ref[2][1:] == [1.0, 1.0, 1.0]
+    assert model.energy_loss == [11.55, 15.76, -11.55, 4.21, -7.34, 0.0, 1.0]
+    assert np.array(model.power).shape == (7, 4) and model.quadrature_degree == 4
+    rows = model.field_binding.rows
+    assert len(rows) == model.n_fields == 33
+    assert rows[0] is None and all(r is not None for r in rows[1:4])          # gas has no mobility row
+    assert rows[-1] is not rows[-2] and rows[-3] is not rows[-2]              # me_old, me, u_old_e
+    # a script that deviates from what the kernels implement is refused, not approximated
+    pieces = seen["F"].pieces
+    energy = next(p for p in pieces if isinstance(getattr(p, "f", None), lmea.LmeaEnergySource))
+    energy.Gamma.mu = energy.Gamma.mu * 2.0
+    with pytest.raises(NotImplementedError, match="factor of the electron mobility in the energy flux"):
+        ff.compile_forms(seen["F"])
