@@ -966,6 +966,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] >= '0' && lean[0] <= '2' ? lean[0] - '0' : 2;
         if (const char *e = getenv("FEDM_XCD_REMAP")) c.xcd_remap = e[0] != '0';
         if (const char *e = getenv("FEDM_ASSEMBLY_OVERLAP")) c.assembly_overlap = e[0] != '0';
+        if (const char *e = getenv("FEDM_SKIP_PHIPHI")) c.skip_phiphi = e[0] != '0';
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;

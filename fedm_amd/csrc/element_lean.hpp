@@ -358,41 +358,47 @@ __device__ __forceinline__ LeanCell lean2_prologue(const fedm_model_desc *__rest
     return lc;
 }
 
-template <int NS, int NR, bool JAC>
-__device__ __forceinline__ void lean2_row(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
-                                          const double *__restrict__ vx, const double *__restrict__ Ul,
-                                          const double *__restrict__ Hl, const double *__restrict__ Al,
-                                          const StepCoef sc, double *__restrict__ acc, double *__restrict__ Fl,
-                                          const double *__restrict__ cst, int stride) {
-    constexpr int NEQ = NS + 1, IPHI = NS;
+// geometry of the cell: gradients of the P1 basis and the three quadrature weights times 2 pi r
+__device__ __forceinline__ void lean2_geometry(const fedm_model_desc *__restrict__ md, const LeanCell &lc,
+                                               const double *__restrict__ vx, int (&lv)[3], double (&G)[3][2],
+                                               double (&W)[3]) {
     const double two_pi = 6.283185307179586476925286766559;
-    const int wl = lc.wl, wj0 = lc.wj0, wj1 = lc.wj1, wj2 = lc.wj2;
-    int lv[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) lv[a] = (wl >> (8 * a)) & 255;
-    double G[3][2], W[3];
-    {
-        double x[3][2];
+    for (int a = 0; a < 3; ++a) lv[a] = (lc.wl >> (8 * a)) & 255;
+    double x[3][2];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            x[a][0] = vx[2 * lv[a]];
-            x[a][1] = vx[2 * lv[a] + 1];
-        }
-        CellGeom cg;
-        cg.init(x, md->axisymmetric);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            G[a][0] = cg.G[a][0];
-            G[a][1] = cg.G[a][1];
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double rq = 0.0;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) rq += cg.rn[a] * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
-            W[q] = (1.0 / 6.0) * cg.detJ * two_pi * rq;
-        }
+    for (int a = 0; a < 3; ++a) {
+        x[a][0] = vx[2 * lv[a]];
+        x[a][1] = vx[2 * lv[a] + 1];
     }
+    CellGeom cg;
+    cg.init(x, md->axisymmetric);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        G[a][0] = cg.G[a][0];
+        G[a][1] = cg.G[a][1];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double rq = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rq += cg.rn[a] * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
+        W[q] = (1.0 / 6.0) * cg.detJ * two_pi * rq;
+    }
+}
+
+// SKIPPP: the potential-potential plane 2 pi r grad(phi_a).grad(phi_b) never changes (mesh and
+// weights only): once a full assembly has written it, later assemblies neither accumulate nor
+// stream it out again (a ninth of the atomics of the Poisson row and of the matrix bytes).
+template <int NS, int NR, bool JAC, bool SKIPPP = false>
+__device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
+                                               const int (&lv)[3], const double (&G)[3][2], const double (&W)[3],
+                                               const double *__restrict__ Ul,
+                                               const double *__restrict__ Hl, const double *__restrict__ Al,
+                                               const StepCoef sc, double *__restrict__ acc, double *__restrict__ Fl,
+                                               const double *__restrict__ cst, int stride) {
+    constexpr int NEQ = NS + 1, IPHI = NS;
+    const int wj0 = lc.wj0, wj1 = lc.wj1, wj2 = lc.wj2;
     const double E[2] = {cst[0 * stride], cst[1 * stride]};
     // a0 a1 a2 per species: exp((u0+u1+u2)/6)
     double P[NS];
@@ -448,7 +454,7 @@ __device__ __forceinline__ void lean2_row(const fedm_model_desc *__restrict__ md
                     double *dst = acc + (size_t)jab * NEQ * SLICE + lane;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) unsafeAtomicAdd(&dst[i * SLICE], m2[i][k]);
-                    unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
+                    if constexpr (!SKIPPP) unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
                 }
             }
         }
@@ -599,6 +605,19 @@ __device__ __forceinline__ void lean2_row(const fedm_model_desc *__restrict__ md
             }
         }
     }
+}
+
+// one equation row with the geometry recomputed (F + J: nothing but the packed indices lives across rows)
+template <int NS, int NR, bool JAC, bool SKIPPP = false>
+__device__ __forceinline__ void lean2_row(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
+                                          const double *__restrict__ vx, const double *__restrict__ Ul,
+                                          const double *__restrict__ Hl, const double *__restrict__ Al,
+                                          const StepCoef sc, double *__restrict__ acc, double *__restrict__ Fl,
+                                          const double *__restrict__ cst, int stride) {
+    int lv[3];
+    double G[3][2], W[3];
+    lean2_geometry(md, lc, vx, lv, G, W);
+    lean2_row_core<NS, NR, JAC, SKIPPP>(md, row, lc, lv, G, W, Ul, Hl, Al, sc, acc, Fl, cst, stride);
 }
 
 }  // namespace fedm

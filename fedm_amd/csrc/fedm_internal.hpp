@@ -85,6 +85,8 @@ struct Ctx {
     int assembly_lean = 2;   // patch assembly through element_lean.hpp where it applies: 0 unrolled element,
                              // 1 first generation (F + J only), 2 second (F + J and residual-only)
     bool xcd_remap = true;   // patch / slice -> workgroup mapping contiguous per XCD
+    bool skip_phiphi = true;    // keep the constant potential-potential plane of the Jacobian between assemblies
+    bool phiphi_valid = false;  // ... once a full assembly of this context has written it
     bool halo_pending = false;  // several GPUs: ghost entries of d_u are stale (kernels.hip, flush_pending_halo)
     bool assembly_overlap = true;  // ... and the next assembly hides their exchange behind its interior patches
     int model_kind = 0;  // 0: LFA family (fedm_model_desc), 1: LMEA family (fedm_gd_desc)

@@ -374,7 +374,7 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 
 // Second generation of the row-phase kernel (element_lean.hpp, lean2_*): per-vertex exponentials,
 // cell constants kept in an LDS column between the rows; JAC = false is the residual-only assembly.
-template <int NS, int NR, int THREADS, bool JAC>
+template <int NS, int NR, int THREADS, bool JAC, bool SKIPPP = false>
 __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
     constexpr int NST = LeanStash<NR>::N;
@@ -427,27 +427,56 @@ __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, 
     LeanCell lc = {0, 0, 0, 0};
     if (active) lc = lean2_prologue<NS, NR>(md, pc_own, vx, Ul, cst + threadIdx.x, THREADS);
     FEDM_T(2)   // prologue: cell record, field, rate coefficient
+    if constexpr (!JAC) {
+        // residual only: no accumulators, no row phases -- the rows share the cell's geometry
+        if (active) {
+            int lv[3];
+            double G[3][2], W[3];
+            lean2_geometry(md, lc, vx, lv, G, W);
+#pragma unroll
+            for (int row = 0; row < NEQ; ++row)
+                lean2_row_core<NS, NR, false>(md, row, lc, lv, G, W, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS);
+        }
+    }
 #pragma unroll 1
-    for (int row = 0; row < NEQ; ++row) {
+    for (int row = 0; JAC && row < NEQ; ++row) {
         asm volatile("" : "+v"(lc.wl), "+v"(lc.wj0), "+v"(lc.wj1), "+v"(lc.wj2));  // nothing hoisted out of the row
         if (active)
-            lean2_row<NS, NR, JAC>(md, row, lc, vx, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS);
+            lean2_row<NS, NR, JAC, SKIPPP>(md, row, lc, vx, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS);
         FEDM_T(3)   // the row (wave 0's view)
         if constexpr (JAC) {
             __syncthreads();
             FEDM_T(4)   // barrier: the other waves finish the row
             constexpr int PER = NEQ * SLICE / 2;   // 16-byte pieces per block column
+            // the constant potential-potential plane is the last 32 pieces of the Poisson row's columns
+            const int per_live = (SKIPPP && row == NS) ? PER - SLICE / 2 : PER;
             if constexpr (THREADS % PER == 0) {
-                const int rem = threadIdx.x % PER;
-                for (int bc = threadIdx.x / PER; bc < width; bc += THREADS / PER) {
-                    double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
-                    double2 *src = reinterpret_cast<double2 *>(acc) + bc * PER + rem;
-                    dst[rem] = *src;
-                    *src = make_double2(0.0, 0.0);
+                // a thread keeps its place within the block column and strides over the columns: all
+                // its LDS reads are issued before the first store waits for one of them
+                int tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));   // keeps the addresses below out of the row loop's live state
+                const int rem = tid % PER;
+                constexpr int STEP = THREADS / PER;
+                double2 *srcs = reinterpret_cast<double2 *>(acc) + rem;
+                if (rem < per_live) {
+                    // two block columns per pass: both LDS reads are in flight before the first store
+                    int bc = tid / PER;
+                    for (; bc + STEP < width; bc += 2 * STEP) {
+                        const double2 a = srcs[bc * PER], b = srcs[(bc + STEP) * PER];
+                        reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE)[rem] = a;
+                        reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc + STEP) * NEQ2 + row * NEQ) * SLICE)[rem] = b;
+                        srcs[bc * PER] = make_double2(0.0, 0.0);
+                        srcs[(bc + STEP) * PER] = make_double2(0.0, 0.0);
+                    }
+                    if (bc < width) {
+                        reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE)[rem] = srcs[bc * PER];
+                        srcs[bc * PER] = make_double2(0.0, 0.0);
+                    }
                 }
             } else {
                 for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
                     const int bc = k / PER, rem = k - bc * PER;
+                    if (rem >= per_live) continue;
                     double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
                     double2 *src = reinterpret_cast<double2 *>(acc) + k;
                     dst[rem] = *src;
@@ -472,6 +501,12 @@ template <int NS, int NR, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_LEAN2_WAVES, FEDM_LEAN2_WAVES))) void assemble_lean2_kernel(
     FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
     assemble_lean2_body<NS, NR, THREADS, true>(FEDM_PATCH_ARGS, xcd, patch_list);
+}
+
+template <int NS, int NR, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_LEAN2_WAVES, FEDM_LEAN2_WAVES))) void assemble_lean2_skip_kernel(
+    FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
+    assemble_lean2_body<NS, NR, THREADS, true, true>(FEDM_PATCH_ARGS, xcd, patch_list);
 }
 
 template <int NS, int NR, int THREADS>
@@ -517,12 +552,16 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
 #define FEDM_LEAN2_BOTH(LIST, N)                                                                            \
     do {                                                                                                    \
         if ((N) <= 0) break;                                                                                \
-        if (jacobian) {                                                                                     \
+        if (jacobian && skip_pp) {                                                                          \
+            FEDM_LEAN2_LAUNCH(assemble_lean2_skip_kernel, LIST, N);                                         \
+        } else if (jacobian) {                                                                              \
             FEDM_LEAN2_LAUNCH(assemble_lean2_kernel, LIST, N);                                              \
         } else {                                                                                            \
             FEDM_LEAN2_LAUNCH(residual_lean2_kernel, LIST, N);                                              \
         }                                                                                                   \
     } while (0)
+            // the constant potential-potential plane: written by the first full assembly, kept afterwards
+            const bool skip_pp = jacobian && c.skip_phiphi && c.phiphi_valid;
             if (c.halo_pending && c.comm && c.comm->d_patch_interior) {
                 // the ghost values of the new state travel on the communication stream while the
                 // patches that stage no ghost vertex are assembled (north_star: "ghost exchange
@@ -539,6 +578,7 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
             }
 #undef FEDM_LEAN2_BOTH
 #undef FEDM_LEAN2_LAUNCH
+            if (jacobian) c.phiphi_valid = true;
             return;
         }
         flush_pending_halo(c);

@@ -28,54 +28,63 @@ def truncate_file(path):
     open(path, "w").close()
 
 
+class _Directory:
+    """A directory role of the run.  ``must_exist``: assigning a path that is not a directory is
+    an error (the deck); otherwise the directory is created on assignment (the output)."""
+
+    def __init__(self, default, must_exist):
+        self.default, self.must_exist = default, must_exist
+
+    def __set_name__(self, owner, name):
+        self.name, self.slot = name, "_dir_" + name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        return obj.__dict__.get(self.slot) or Path.cwd() / self.default
+
+    def __set__(self, obj, value):
+        value = Path(value)
+        if self.must_exist:
+            if not value.is_dir():
+                raise RuntimeError(f"fedm.files.{self.name}: '{value}' is not a directory")
+        else:
+            if value.resolve() != self.__get__(obj).resolve():
+                obj.fresh_logs()             # another output directory: its logs start empty
+            value.mkdir(exist_ok=True)
+        obj.__dict__[self.slot] = value
+
+
+class _LogFile:
+    """A log in the output directory, emptied the first time it is asked for there."""
+
+    def __init__(self, file_name):
+        self.file_name = file_name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        target = obj.output_folder_path / self.file_name
+        if self.file_name not in obj._started:
+            truncate_file(target)
+            obj._started.add(self.file_name)
+        return target
+
+
 class Files:
-    """``file_input`` / ``output_folder_path`` / ``error_file`` / ``model_log`` with the
-    reference's semantics: assigning ``file_input`` to a missing directory raises
-    RuntimeError; log files are truncated on first access per output directory."""
+    """The path roles of a FEDM run (``fedm.file_io.files``): where the decks are read from, where
+    results go, and the two logs kept there."""
+
+    file_input = _Directory("file_input", must_exist=True)
+    output_folder_path = _Directory("output", must_exist=False)
+    error_file = _LogFile("relative error.log")
+    model_log = _LogFile("model.log")
 
     def __init__(self):
-        self._input_dir = Path.cwd() / "file_input"
-        self._output_dir = Path.cwd() / "output"
-        self._touched = set()
+        self._started = set()
 
-    @property
-    def file_input(self):
-        return self._input_dir
-
-    @file_input.setter
-    def file_input(self, value):
-        value = Path(value)
-        if not value.is_dir():
-            raise RuntimeError(f"fedm.files.file_input: '{value}' is not a directory")
-        self._input_dir = value
-
-    @property
-    def output_folder_path(self):
-        return self._output_dir
-
-    @output_folder_path.setter
-    def output_folder_path(self, value):
-        value = Path(value)
-        if value.resolve() != self._output_dir.resolve():
-            self._touched.clear()
-        if not value.is_dir():
-            value.mkdir()
-        self._output_dir = value
-
-    def _log_file(self, name):
-        result = self.output_folder_path / name
-        if name not in self._touched:
-            truncate_file(result)
-            self._touched.add(name)
-        return result
-
-    @property
-    def error_file(self):
-        return self._log_file("relative error.log")
-
-    @property
-    def model_log(self):
-        return self._log_file("model.log")
+    def fresh_logs(self):
+        self._started.clear()
 
 
 files = Files()

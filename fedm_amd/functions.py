@@ -358,8 +358,11 @@ class Problem:
 
 class PETScSNESSolver:
     """Newton solver with the parameter names FEDM scripts set
-    (fedm-streamer.py:294-299, fedm-tof.py:130-135).  ``linear_solver`` is accepted
-    for compatibility; the device path always runs GMRES + point-block Jacobi."""
+    (fedm-streamer.py:294-299, fedm-tof.py:130-135).  ``linear_solver`` / ``preconditioner`` are
+    accepted for compatibility: the device path always solves the Newton systems with restarted
+    (flexible) GMRES -- preconditioned by the field split (Chebyshev sweeps on the species block
+    + one multigrid V-cycle on the potential block) once ``setup_multigrid`` has installed a
+    hierarchy, by point-block Jacobi otherwise -- to ``krylov_relative_tolerance``."""
 
     def __init__(self):
         self.parameters = {"relative_tolerance": 1e-9, "absolute_tolerance": 1e-10,

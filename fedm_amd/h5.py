@@ -73,8 +73,12 @@ class File:
         if mode == "w":
             self.id = lib.H5Fcreate(p, _H5F_ACC_TRUNC, _H5P_DEFAULT, _H5P_DEFAULT)
         elif mode == "a":
-            self.id = lib.H5Fopen(p, _H5F_ACC_RDWR, _H5P_DEFAULT)
-            if self.id < 0:
+            # append: create the file only when it does not exist -- a file that exists but cannot be
+            # opened (locked, unreadable, not HDF5) is an error, never a reason to truncate a checkpoint
+            import os
+            if os.path.exists(path):
+                self.id = lib.H5Fopen(p, _H5F_ACC_RDWR, _H5P_DEFAULT)
+            else:
                 self.id = lib.H5Fcreate(p, _H5F_ACC_TRUNC, _H5P_DEFAULT, _H5P_DEFAULT)
         elif mode == "r":
             self.id = lib.H5Fopen(p, _H5F_ACC_RDONLY, _H5P_DEFAULT)

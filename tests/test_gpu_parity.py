@@ -380,3 +380,87 @@ def test_bad_descriptors_are_hard_errors():
     rc = lib.fedm_set_fieldsplit(prob._h, 0, None)
     assert rc < 0 and b"sweeps" in lib.fedm_last_error()
     prob.close()
+
+
+def test_streamer_parity_at_128_squared_against_both_cpu_statements():
+    """The streamer's |E|-dependent coefficients, alpha(E) source and Neumann drift flux have no
+    reference-held vector behind them (mesh.xml and the field goldens are missing blobs upstream),
+    so the HIP path is held against TWO independent CPU statements of the same forms on a 128 x 128
+    graded mesh (16 641 vertices, 130 patches: several full LDS patches in every direction, unlike
+    the 441-vertex meshes above): the vectorised numpy oracle (direct quadrature, oracle/forms.py)
+    and the C/OpenMP element loop (oracle/cpu/fedm_cpu.c), for a developed-looking state with
+    steep density gradients and a non-uniform field."""
+    from oracle import cpu_backend as cb
+    from oracle import streamer as ost
+    from oracle.mesh import graded_axis, rectangle_right
+    from fedm_amd.cases import streamer
+    n = 128
+    mesh = rectangle_right(0.0, 0.0, ost.BOX, ost.BOX, n, n, xs=graded_axis(ost.BOX, n, 4.0))
+    omodel = ost.build(mesh)
+    r, z = mesh.coords[:, 0], mesh.coords[:, 1]
+    rng = np.random.default_rng(11)
+    U = np.zeros((mesh.nv, 3))
+    head = np.exp(-(r ** 2 + (z - 0.008) ** 2) / (0.6e-3) ** 2)
+    U[:, 0] = np.log(1e13 + 4e19 * head) + 0.02 * rng.standard_normal(mesh.nv)
+    U[:, 1] = np.log(1e13 + 3e19 * head) + 0.02 * rng.standard_normal(mesh.nv)
+    U[:, 2] = ost.U_W * z / ost.BOX * (1.0 + 0.3 * head) + 5.0 * rng.standard_normal(mesh.nv)
+    Uo = U + 0.01 * rng.standard_normal(U.shape)
+    Uo1 = U + 0.02 * rng.standard_normal(U.shape)
+    dt, dt_old = 5e-12, 4.977e-12
+    F_np, J_np = omodel.residual_jacobian(U, Uo, Uo1, dt, dt_old)
+    cprob = cb.CpuProblem(omodel)
+    cprob.set_state(U, Uo, Uo1)
+    F_c, J_c = cprob.residual_jacobian(dt, dt_old)
+    cprob.close()
+    prob = streamer.device_problem(mesh.coords, mesh.cells)
+    prob.set_state(U, Uo, Uo1)
+    prob.set_step(dt, dt_old)
+    F_gpu, _ = prob.residual()          # residual-only kernel
+    prob.jacobian()                     # F + J kernel
+    J_gpu = prob.jacobian_csr()
+    prob.close()
+    scale = np.abs(F_np).reshape(-1, 3).max(axis=0)
+    for F_ref in (F_np, F_c):
+        assert (np.abs(F_gpu - F_ref).reshape(-1, 3) / scale).max() < 1e-11
+    assert _rel_rows(J_gpu, J_np) < 1e-10
+    assert _rel_rows(J_gpu, J_c) < 1e-10
+
+
+@pytest.mark.parametrize("n", [128, 192])
+def test_streamer_error_log_has_the_structure_of_the_reference_log(n, golden_dir):
+    """The one streamer artefact the reference still holds is its 21-row error log
+    (tests/integrated_tests/streamer_discharge/20220707_results/relative error.log): accepted
+    steps only, dt = dt_max = 5e-12 throughout (one step shortened to 4.977e-12 by the controller
+    because the logged change, 6.7e-4, sits just under ttol = 1e-3), the per-step relative change
+    of ln n_e falling by 6-8 parts in 1e4 from step to step.  The value of that change is the
+    ratio of two vector norms over the vertices, i.e. it depends on how the (missing) reference mesh
+    distributes its vertices and cannot be reproduced on another mesh; what does carry over is
+    checked on two of our meshes: no rejected step up to 1e-10 s, every dt the controller proposes
+    stays at dt_max once the change is far below ttol, the change decays monotonically by about
+    one part in a thousand per step like the reference's (0.7e-3 there, 1.4e-3 on these meshes: the
+    same order, the norm's vertex weighting again), and it is mesh-converged between the two
+    resolutions."""
+    import json
+    from fedm_amd.cases import streamer
+    ref = np.array(json.loads((golden_dir / "error_logs.json").read_text())["streamer_discharge"])
+    assert ref.shape == (21, 3) and np.all(ref[:, 0] < 1e-3)              # all accepted
+    ref_decay = ref[5:20, 0] / ref[4:19, 0]                                # constant-dt stretch
+    msh = streamer.mesh(n, 4.0)
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    out = streamer.run(prob, T_final=1e-10)
+    prob.close()
+    log = np.array(out["log"])
+    assert out["steps"] == len(log) == 20                                  # no rejection, no retry
+    assert np.all(log[:, 2] == 5e-12) and log[0, 1] == 1e30 and np.all(log[1:, 1] == 5e-12)
+    assert out["t"] == pytest.approx(1e-10, rel=1e-9)
+    decay = log[5:, 0] / log[4:-1, 0]
+    assert np.all(decay < 1.0) and np.all(np.diff(decay) < 0)             # monotone, slowly steepening: as in the reference
+    assert np.all(np.diff(ref_decay) < 0)
+    assert 0.3 < (1.0 - decay.mean()) / (1.0 - ref_decay.mean()) < 3.0
+    _CHANGE[n] = log[:, 0]
+    if len(_CHANGE) == 2:                                                  # mesh convergence of the logged quantity
+        a, b = _CHANGE[128], _CHANGE[192]
+        assert np.abs(a / b - (a / b).mean()).max() < 2e-3
+
+
+_CHANGE = {}

@@ -11,7 +11,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-CONFIGS = [
+CONFIGS_R1 = [
     dict(FEDM_ASSEMBLY_LEAN="1", FEDM_XCD_REMAP="0", FEDM_PATCH_ORDER="0"),
     dict(FEDM_ASSEMBLY_LEAN="2", FEDM_XCD_REMAP="0", FEDM_PATCH_ORDER="0"),
     dict(FEDM_ASSEMBLY_LEAN="2", FEDM_XCD_REMAP="1", FEDM_PATCH_ORDER="0"),
@@ -23,13 +23,22 @@ CONFIGS = [
 ]
 
 
+# round-2 session 5: constant potential-potential plane kept / rewritten
+CONFIGS = [
+    dict(FEDM_SKIP_PHIPHI="0"),
+    dict(FEDM_SKIP_PHIPHI="1"),
+    dict(FEDM_SKIP_PHIPHI="1", FEDM_PATCH_ORDER="0"),
+]
+
+
 def child(n):
     from fedm_amd.cases import streamer
     msh = streamer.mesh(n, 4.0)
     prob = streamer.device_problem(msh.coords, msh.cells)
     streamer.initialise(prob, multigrid=False)
     prob.set_step(5e-12, 5e-12)
-    out = {k: os.environ.get(k) for k in ("FEDM_ASSEMBLY_LEAN", "FEDM_XCD_REMAP", "FEDM_PATCH_ORDER")}
+    out = {k: os.environ.get(k) for k in ("FEDM_ASSEMBLY_LEAN", "FEDM_XCD_REMAP", "FEDM_PATCH_ORDER", "FEDM_SKIP_PHIPHI")
+           if os.environ.get(k) is not None}
     for name, kind in (("FJ", 0), ("F", 2), ("spmv", 1)):
         prob.time_kernel(kind, 5)
         out[name + "_us"] = round(1e3 * min(prob.time_kernel(kind, 40) for _ in range(3)), 2)
