@@ -966,7 +966,20 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] >= '0' && lean[0] <= '2' ? lean[0] - '0' : 2;
         if (const char *e = getenv("FEDM_XCD_REMAP")) c.xcd_remap = e[0] != '0';
         if (const char *e = getenv("FEDM_ASSEMBLY_OVERLAP")) c.assembly_overlap = e[0] != '0';
-        if (const char *e = getenv("FEDM_SKIP_PHIPHI")) c.skip_phiphi = e[0] != '0';
+        if (const char *e = getenv("FEDM_SKIP_CONST_PLANES")) c.skip_const_planes = e[0] != '0';
+        if (model && c.poisson) {
+            // potential-potential: geometry only.  Species (s, i), i != s: zero unless a reaction that
+            // changes species s has species i among its reactants (fedm/functions.py:835-843).
+            c.const_plane_mask = 1u << (c.ns * c.neq + c.ns);
+            for (int s_ = 0; s_ < c.ns; ++s_)
+                for (int i = 0; i < c.ns; ++i) {
+                    if (i == s_) continue;
+                    bool coupled = false;
+                    for (int j = 0; j < model->n_reactions; ++j)
+                        coupled = coupled || (model->net[j][s_] != 0 && model->power[j][i] > 0);
+                    if (!coupled) c.const_plane_mask |= 1u << (s_ * c.neq + i);
+                }
+        }
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;

@@ -387,18 +387,22 @@ __device__ __forceinline__ void lean2_geometry(const fedm_model_desc *__restrict
     }
 }
 
-// SKIPPP: the potential-potential plane 2 pi r grad(phi_a).grad(phi_b) never changes (mesh and
-// weights only): once a full assembly has written it, later assemblies neither accumulate nor
-// stream it out again (a ninth of the atomics of the Poisson row and of the matrix bytes).
-template <int NS, int NR, bool JAC, bool SKIPPP = false>
+// cmask: bit (row * NEQ + col) marks a plane of the Jacobian that never changes -- the
+// potential-potential plane 2 pi r grad(phi_a).grad(phi_b) (mesh and weights only) and the species
+// planes that are structurally zero (no reaction couples the two species: d(electron row)/d(ion
+// density) of the streamer model).  Once a full assembly has written them, later assemblies neither
+// accumulate nor stream them out again (18 of the streamer's 90 LDS atomics per cell and two
+// ninths of its matrix bytes).  The tests are wave-uniform.
+template <int NS, int NR, bool JAC>
 __device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
                                                const int (&lv)[3], const double (&G)[3][2], const double (&W)[3],
                                                const double *__restrict__ Ul,
                                                const double *__restrict__ Hl, const double *__restrict__ Al,
                                                const StepCoef sc, double *__restrict__ acc, double *__restrict__ Fl,
-                                               const double *__restrict__ cst, int stride) {
+                                               const double *__restrict__ cst, int stride, uint32_t cmask = 0) {
     constexpr int NEQ = NS + 1, IPHI = NS;
     const int wj0 = lc.wj0, wj1 = lc.wj1, wj2 = lc.wj2;
+    const uint32_t rmask = cmask >> (row * NEQ);   // this row's planes
     const double E[2] = {cst[0 * stride], cst[1 * stride]};
     // a0 a1 a2 per species: exp((u0+u1+u2)/6)
     double P[NS];
@@ -454,7 +458,7 @@ __device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict
                     double *dst = acc + (size_t)jab * NEQ * SLICE + lane;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) unsafeAtomicAdd(&dst[i * SLICE], m2[i][k]);
-                    if constexpr (!SKIPPP) unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
+                    if (!((rmask >> IPHI) & 1u)) unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
                 }
             }
         }
@@ -600,7 +604,8 @@ __device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict
                 double *dst = acc + (size_t)jab * NEQ * SLICE + lane;
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
-                    unsafeAtomicAdd(&dst[i * SLICE], m2[i][k] + ((i == s) ? DGm * ggk - velG[a] * m1n[b] : 0.0));
+                    if (!((rmask >> i) & 1u))
+                        unsafeAtomicAdd(&dst[i * SLICE], m2[i][k] + ((i == s) ? DGm * ggk - velG[a] * m1n[b] : 0.0));
                 unsafeAtomicAdd(&dst[IPHI * SLICE], Kd * ggk - dEb * T[a]);
             }
         }
@@ -608,16 +613,16 @@ __device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict
 }
 
 // one equation row with the geometry recomputed (F + J: nothing but the packed indices lives across rows)
-template <int NS, int NR, bool JAC, bool SKIPPP = false>
+template <int NS, int NR, bool JAC>
 __device__ __forceinline__ void lean2_row(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
                                           const double *__restrict__ vx, const double *__restrict__ Ul,
                                           const double *__restrict__ Hl, const double *__restrict__ Al,
                                           const StepCoef sc, double *__restrict__ acc, double *__restrict__ Fl,
-                                          const double *__restrict__ cst, int stride) {
+                                          const double *__restrict__ cst, int stride, uint32_t cmask) {
     int lv[3];
     double G[3][2], W[3];
     lean2_geometry(md, lc, vx, lv, G, W);
-    lean2_row_core<NS, NR, JAC, SKIPPP>(md, row, lc, lv, G, W, Ul, Hl, Al, sc, acc, Fl, cst, stride);
+    lean2_row_core<NS, NR, JAC>(md, row, lc, lv, G, W, Ul, Hl, Al, sc, acc, Fl, cst, stride, cmask);
 }
 
 }  // namespace fedm

@@ -85,8 +85,10 @@ struct Ctx {
     int assembly_lean = 2;   // patch assembly through element_lean.hpp where it applies: 0 unrolled element,
                              // 1 first generation (F + J only), 2 second (F + J and residual-only)
     bool xcd_remap = true;   // patch / slice -> workgroup mapping contiguous per XCD
-    bool skip_phiphi = true;    // keep the constant potential-potential plane of the Jacobian between assemblies
-    bool phiphi_valid = false;  // ... once a full assembly of this context has written it
+    // Planes (row, col) of the Jacobian that never change: potential-potential, and species planes that
+    // are structurally zero.  bit row * neq + col; kept between assemblies once a full one has written them.
+    uint32_t const_plane_mask = 0;
+    bool skip_const_planes = true, const_planes_valid = false;
     bool halo_pending = false;  // several GPUs: ghost entries of d_u are stale (kernels.hip, flush_pending_halo)
     bool assembly_overlap = true;  // ... and the next assembly hides their exchange behind its interior patches
     int model_kind = 0;  // 0: LFA family (fedm_model_desc), 1: LMEA family (fedm_gd_desc)
@@ -164,6 +166,10 @@ struct Ctx {
 constexpr int RED_BLOCKS = 512;
 constexpr int RED_K = 40;
 constexpr int RED_SPARE = RED_K - 3;  // a norm that rides along with the next Krylov publication
+// per-block partial sums, one contiguous row per slot: the single workgroup that finishes a
+// reduction reads a slot's RED_BLOCKS partials as 4 KB of consecutive doubles (with [block][slot]
+// it gathered one double per 320-byte stride: most of reduce_finish_kernel's 10 us)
+#define PARTIAL_AT(block, slot) ((size_t)(slot) * RED_BLOCKS + (size_t)(block))
 
 // ---- kernel launchers (kernels.hip) -----------------------------------------------------
 // mode: 0 = full model, 1 = Poisson row only (species rows become identity)

@@ -79,13 +79,13 @@ __global__ __launch_bounds__(256) void sdot2_kernel(int n, const double *__restr
     }
     __syncthreads();
     if (threadIdx.x < 2)
-        partials[(size_t)blockIdx.x * RED_K + threadIdx.x] =
+        partials[PARTIAL_AT(blockIdx.x, threadIdx.x)] =
             sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3];
 }
 __global__ void sreduce_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
     const int i = blockIdx.x;
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[PARTIAL_AT(b, i)];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (threadIdx.x == 0) out[i] = s;
 }

@@ -374,8 +374,9 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 
 // Second generation of the row-phase kernel (element_lean.hpp, lean2_*): per-vertex exponentials,
 // cell constants kept in an LDS column between the rows; JAC = false is the residual-only assembly.
-template <int NS, int NR, int THREADS, bool JAC, bool SKIPPP = false>
-__device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
+template <int NS, int NR, int THREADS, bool JAC>
+__device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list,
+                                                    uint32_t cmask) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
     constexpr int NST = LeanStash<NR>::N;
     extern __shared__ __align__(16) double lds[];
@@ -442,14 +443,14 @@ __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, 
     for (int row = 0; JAC && row < NEQ; ++row) {
         asm volatile("" : "+v"(lc.wl), "+v"(lc.wj0), "+v"(lc.wj1), "+v"(lc.wj2));  // nothing hoisted out of the row
         if (active)
-            lean2_row<NS, NR, JAC, SKIPPP>(md, row, lc, vx, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS);
+            lean2_row<NS, NR, JAC>(md, row, lc, vx, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS, cmask);
         FEDM_T(3)   // the row (wave 0's view)
         if constexpr (JAC) {
             __syncthreads();
             FEDM_T(4)   // barrier: the other waves finish the row
             constexpr int PER = NEQ * SLICE / 2;   // 16-byte pieces per block column
-            // the constant potential-potential plane is the last 32 pieces of the Poisson row's columns
-            const int per_live = (SKIPPP && row == NS) ? PER - SLICE / 2 : PER;
+            // planes that never change (cmask) are neither read out nor zeroed: 32 pieces per plane
+            const uint32_t rmask = cmask >> (row * NEQ);
             if constexpr (THREADS % PER == 0) {
                 // a thread keeps its place within the block column and strides over the columns: all
                 // its LDS reads are issued before the first store waits for one of them
@@ -458,7 +459,7 @@ __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, 
                 const int rem = tid % PER;
                 constexpr int STEP = THREADS / PER;
                 double2 *srcs = reinterpret_cast<double2 *>(acc) + rem;
-                if (rem < per_live) {
+                if (!((rmask >> (rem / (SLICE / 2))) & 1u)) {
                     // two block columns per pass: both LDS reads are in flight before the first store
                     int bc = tid / PER;
                     for (; bc + STEP < width; bc += 2 * STEP) {
@@ -476,7 +477,7 @@ __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, 
             } else {
                 for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
                     const int bc = k / PER, rem = k - bc * PER;
-                    if (rem >= per_live) continue;
+                    if ((rmask >> (rem / (SLICE / 2))) & 1u) continue;
                     double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
                     double2 *src = reinterpret_cast<double2 *>(acc) + k;
                     dst[rem] = *src;
@@ -499,20 +500,14 @@ __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, 
 #endif
 template <int NS, int NR, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_LEAN2_WAVES, FEDM_LEAN2_WAVES))) void assemble_lean2_kernel(
-    FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
-    assemble_lean2_body<NS, NR, THREADS, true>(FEDM_PATCH_ARGS, xcd, patch_list);
-}
-
-template <int NS, int NR, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_LEAN2_WAVES, FEDM_LEAN2_WAVES))) void assemble_lean2_skip_kernel(
-    FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list) {
-    assemble_lean2_body<NS, NR, THREADS, true, true>(FEDM_PATCH_ARGS, xcd, patch_list);
+    FEDM_PATCH_PARAMS, int xcd, const int *__restrict__ patch_list, uint32_t cmask) {
+    assemble_lean2_body<NS, NR, THREADS, true>(FEDM_PATCH_ARGS, xcd, patch_list, cmask);
 }
 
 template <int NS, int NR, int THREADS>
 __global__ __launch_bounds__(THREADS) void residual_lean2_kernel(FEDM_PATCH_PARAMS, int xcd,
-                                                                 const int *__restrict__ patch_list) {
-    assemble_lean2_body<NS, NR, THREADS, false>(FEDM_PATCH_ARGS, xcd, patch_list);
+                                                                 const int *__restrict__ patch_list, uint32_t cmask) {
+    assemble_lean2_body<NS, NR, THREADS, false>(FEDM_PATCH_ARGS, xcd, patch_list, cmask);
 }
 #undef FEDM_PATCH_PARAMS
 #undef FEDM_PATCH_ARGS
@@ -548,20 +543,18 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
                        c.nv, c.d_slice_boff, c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr,       \
                        c.d_patch_halo, c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],  \
                        c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_row, c.pat.max_patch_verts,        \
-                       c.xcd_remap ? 1 : 0, LIST)
+                       c.xcd_remap ? 1 : 0, LIST, cmask)
 #define FEDM_LEAN2_BOTH(LIST, N)                                                                            \
     do {                                                                                                    \
         if ((N) <= 0) break;                                                                                \
-        if (jacobian && skip_pp) {                                                                          \
-            FEDM_LEAN2_LAUNCH(assemble_lean2_skip_kernel, LIST, N);                                         \
-        } else if (jacobian) {                                                                              \
+        if (jacobian) {                                                                              \
             FEDM_LEAN2_LAUNCH(assemble_lean2_kernel, LIST, N);                                              \
         } else {                                                                                            \
             FEDM_LEAN2_LAUNCH(residual_lean2_kernel, LIST, N);                                              \
         }                                                                                                   \
     } while (0)
             // the constant potential-potential plane: written by the first full assembly, kept afterwards
-            const bool skip_pp = jacobian && c.skip_phiphi && c.phiphi_valid;
+            const uint32_t cmask = (jacobian && c.skip_const_planes && c.const_planes_valid) ? c.const_plane_mask : 0u;
             if (c.halo_pending && c.comm && c.comm->d_patch_interior) {
                 // the ghost values of the new state travel on the communication stream while the
                 // patches that stage no ghost vertex are assembled (north_star: "ghost exchange
@@ -578,7 +571,7 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
             }
 #undef FEDM_LEAN2_BOTH
 #undef FEDM_LEAN2_LAUNCH
-            if (jacobian) c.phiphi_valid = true;
+            if (jacobian) c.const_planes_valid = true;
             return;
         }
         flush_pending_halo(c);
@@ -1074,7 +1067,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[K], double *par
     __syncthreads();
     if (threadIdx.x < K) {
         const double s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-        partials[(size_t)blockIdx.x * RED_K + kbase + threadIdx.x] = s;
+        partials[PARTIAL_AT(blockIdx.x, kbase + threadIdx.x)] = s;
     }
 }
 
@@ -1104,7 +1097,7 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partials, int 
     const int i = blockIdx.x;
     if (i >= k) return;
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[PARTIAL_AT(b, i)];
     s = wave_sum(s);
     if (threadIdx.x == 0) out[i] = s;
 }
@@ -1196,16 +1189,17 @@ __global__ __launch_bounds__(256) void dots_scatter_kernel(PtrPack8 xs, double *
     block_reduce_store<K>(acc, partials, kbase);
 }
 
-__global__ __launch_bounds__(256) void reduce_finish_kernel(const double *__restrict__ partials, int nblocks,
+__global__ __launch_bounds__(1024) void reduce_finish_kernel(const double *__restrict__ partials, int nblocks,
                                                             int k, double *__restrict__ out, double *mail,
                                                             unsigned long long *seq) {
     __shared__ double fin[RED_K];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < RED_K) fin[threadIdx.x] = (threadIdx.x == RED_SPARE) ? out[RED_SPARE] : 0.0;
     __syncthreads();
-    for (int i = wave; i < k; i += 4) {
+    // 16 waves, one slot each per pass: a Krylov step's j + 2 slots finish in one or two passes
+    for (int i = wave; i < k; i += 16) {
         double sum = 0.0;
-        for (int b = lane; b < nblocks; b += 64) sum += partials[(size_t)b * RED_K + i];
+        for (int b = lane; b < nblocks; b += 64) sum += partials[PARTIAL_AT(b, i)];
         sum = wave_sum(sum);
         if (lane == 0) fin[i] = sum;
     }
@@ -1326,7 +1320,7 @@ void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const 
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(k), dim3(64), 0, c.stream, c.d_partials, grid, k, c.d_red);
         return;
     }
-    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, c.stream, c.d_partials, grid, k, c.d_red,
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(1024), 0, c.stream, c.d_partials, grid, k, c.d_red,
                        c.h_mail, c.d_mail_seq);
     if (!c.capturing) ++c.mail_seq;
 }
@@ -1362,7 +1356,7 @@ void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y) {
 __global__ void reduce_partials_slot_kernel(const double *__restrict__ partials, int nblocks,
                                             int k_src, double *__restrict__ out, int slot) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + k_src];
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[PARTIAL_AT(b, k_src)];
     s = wave_sum(s);
     if (threadIdx.x == 0) out[slot] = s;
 }
@@ -1413,7 +1407,7 @@ __global__ __launch_bounds__(64) void reduce_slot_publish_kernel(const double *_
                                                                  int k_src, double *__restrict__ out, int slot,
                                                                  int k, double *mail, unsigned long long *seq) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + k_src];
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[PARTIAL_AT(b, k_src)];
     s = wave_sum(s);
     s = __shfl(s, 0, 64);
     if (threadIdx.x == 0) out[slot] = s;
@@ -1555,7 +1549,7 @@ __global__ void reduce_partials_range_kernel(const double *__restrict__ partials
                                              double *__restrict__ out) {
     const int i = k0 + blockIdx.x;  // one wave per output; fixed summation order
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * RED_K + i];
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[PARTIAL_AT(b, i)];
     s = wave_sum(s);
     if (threadIdx.x == 0) out[i] = s;
 }

@@ -23,13 +23,24 @@ static void order_patch_cells(PatchCell *cells, int n, int group, int mod) {
     const int n_groups = (n + group - 1) / group;
     std::vector<std::vector<int>> members(n_groups);
     std::vector<std::array<uint64_t, 3>> used(n_groups, std::array<uint64_t, 3>{0, 0, 0});
+    // second criterion: the gathers of the staged vertex data (coordinates, unknowns, history) are
+    // ds_read_b64 over lane groups of 32 -- two adjacent groups of 16 -- whose bank is the local
+    // vertex id (owned or halo) modulo 32 for the interleaved arrays' widest stride
+    static const int read_weight = [] {
+        const char *e = std::getenv("FEDM_PATCH_ORDER_READS");
+        return e ? std::atoi(e) : 1;
+    }();
+    const int per_half = 32 / group > 0 ? 32 / group : 1;
+    std::vector<std::array<uint32_t, 3>> read_used((n_groups + per_half - 1) / per_half, std::array<uint32_t, 3>{0, 0, 0});
     for (int c = 0; c < n; ++c) {
         int best = -1, best_cost = 1 << 30;
         for (int g = 0; g < n_groups; ++g) {
             if ((int)members[g].size() >= group) continue;
             int cost = 0;
-            for (int a = 0; a < 3; ++a)
-                if (cells[c].lv[a] < SLICE && ((used[g][a] >> (cells[c].lv[a] % mod)) & 1ULL)) ++cost;
+            for (int a = 0; a < 3; ++a) {
+                if (cells[c].lv[a] < SLICE && ((used[g][a] >> (cells[c].lv[a] % mod)) & 1ULL)) cost += 4;
+                if (read_weight && ((read_used[g / per_half][a] >> (cells[c].lv[a] & 31)) & 1u)) cost += read_weight;
+            }
             if (cost < best_cost) {
                 best_cost = cost;
                 best = g;
@@ -37,12 +48,15 @@ static void order_patch_cells(PatchCell *cells, int n, int group, int mod) {
             if (cost == 0) break;
         }
         members[best].push_back(c);
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 3; ++a) {
             if (cells[c].lv[a] < SLICE) used[best][a] |= 1ULL << (cells[c].lv[a] % mod);
+            read_used[best / per_half][a] |= 1u << (cells[c].lv[a] & 31);
+        }
     }
     std::vector<PatchCell> out;
     out.reserve(n);
-    // full groups first: only the last lane group of the workgroup may be partial
+    // groups keep their place (pairs of groups form the 32-lane halves); a group that is not full
+    // is padded at the end only when it is the last one: move short groups behind the full ones
     std::stable_sort(members.begin(), members.end(),
                      [](const std::vector<int> &x, const std::vector<int> &y) { return x.size() > y.size(); });
     for (const auto &m : members)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the round's profile evidence on the GPU box (run through gpurun from the repo root):
+#   profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the default bench command
+#   profiles/<tag>_bench_under_rocprof.json   the bench line of that same run
+#   profiles/<tag>_pmc_traffic.json      FETCH_SIZE / WRITE_SIZE passes (separate runs), gfx950 corrections
+#   profiles/<tag>_pmc_assembly_sq.txt   SQ counters of the F + J assembly kernel (three passes)
+# Everything is written under gpurun_out/<tag>_prof/ (merged back by gpurun); copy_profiles.py then
+# copies the summaries into profiles/.  The program follows `--` directly (no env/bash hop).
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/${TAG}_prof
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+BENCH="bench.py --steps 20 --warmup 5 --no-cpu-baseline --late-start 0"
+SHORT="bench.py --steps 2 --warmup 0 --no-cpu-baseline --late-start 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err" || exit 1
+rm -f "$OUT"/trace/t_kernel_trace.csv "$OUT"/trace/*/t_kernel_trace.csv      # tens of MB; the stats are what is kept
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 $SHORT > /dev/null 2> "$OUT/fetch.err" || exit 2
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 $SHORT > /dev/null 2> "$OUT/write.err" || exit 3
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA \
+    --output-format csv -d "$OUT/sq1" -o s -- python3 $SHORT > /dev/null 2> "$OUT/sq1.err" || exit 4
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS \
+    --output-format csv -d "$OUT/sq2" -o s -- python3 $SHORT > /dev/null 2> "$OUT/sq2.err" || exit 5
+find "$OUT" -name "*counter_collection.csv" | head
+python3 tools/copy_profiles.py "$TAG" "$OUT"

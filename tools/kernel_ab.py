@@ -23,11 +23,14 @@ CONFIGS_R1 = [
 ]
 
 
-# round-2 session 5: constant potential-potential plane kept / rewritten
+# round-2: micro-colouring with / without the gather-read criterion
 CONFIGS = [
-    dict(FEDM_SKIP_PHIPHI="0"),
-    dict(FEDM_SKIP_PHIPHI="1"),
-    dict(FEDM_SKIP_PHIPHI="1", FEDM_PATCH_ORDER="0"),
+    dict(FEDM_PATCH_ORDER_READS="0"),
+    dict(FEDM_PATCH_ORDER_READS="1"),
+    dict(FEDM_PATCH_ORDER_READS="2"),
+    dict(FEDM_PATCH_ORDER_READS="4"),
+    dict(FEDM_PATCH_ORDER_READS="0"),
+    dict(FEDM_PATCH_ORDER_READS="1"),
 ]
 
 
@@ -37,7 +40,7 @@ def child(n):
     prob = streamer.device_problem(msh.coords, msh.cells)
     streamer.initialise(prob, multigrid=False)
     prob.set_step(5e-12, 5e-12)
-    out = {k: os.environ.get(k) for k in ("FEDM_ASSEMBLY_LEAN", "FEDM_XCD_REMAP", "FEDM_PATCH_ORDER", "FEDM_SKIP_PHIPHI")
+    out = {k: os.environ.get(k) for k in ("FEDM_ASSEMBLY_LEAN", "FEDM_XCD_REMAP", "FEDM_PATCH_ORDER", "FEDM_SKIP_CONST_PLANES", "FEDM_PATCH_ORDER_READS")
            if os.environ.get(k) is not None}
     for name, kind in (("FJ", 0), ("F", 2), ("spmv", 1)):
         prob.time_kernel(kind, 5)
