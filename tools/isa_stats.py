@@ -13,7 +13,7 @@ import sys
 def kernel_bodies(path):
     name, body = None, []
     for ln in open(path, errors="replace"):
-        if ln.startswith("_Z") and ln.rstrip().split(":")[0].endswith(tuple("iIvEdfPKS_0123456789")) and ":" in ln:
+        if ln.startswith("_Z") and "; @_Z" in ln:
             name, body = ln.split(":")[0], []
             continue
         if name is None:
