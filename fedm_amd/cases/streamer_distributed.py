@@ -5,6 +5,7 @@ Weak scaling: the mesh handed in is the per-GPU mesh size; the global mesh has
 ``world`` times as many cells (the box is fixed, the resolution grows).
 """
 import os
+import sys
 
 import numpy as np
 
@@ -83,7 +84,7 @@ class Runner(streamer.Stepper):
                     ok, reason = 0, "; ".join(str(b) for b in bad)
             if not ok:
                 print(f"[fedm_amd] rank {rank}: RCCL transport unavailable ({reason}); "
-                      f"falling back to host-staged exchanges -- NOT the xGMI data path", flush=True)
+                      f"falling back to host-staged exchanges -- NOT the xGMI data path", file=sys.stderr, flush=True)
                 transport = "torch-gloo (RCCL set-up failed)"
                 self.fallback_reason = reason
                 prob.init_comm_torch(lm, dist.new_group(backend="gloo"))
