@@ -69,13 +69,16 @@ __host__ __device__ inline StepCoef step_coef(double dt, double dt_old) {
 // cell geometry: gradients of the P1 basis, |det J|, vertex radii
 struct CellGeom {
     double G[3][2];
-    double detJ;
+    double detJ, inv_det;
     double rn[3];
-    __device__ __forceinline__ void init(const double x[3][2], int axisymmetric) {
+    // idet_known != 0: 1/det from an earlier evaluation of the same cell (the division is a couple
+    // of dozen fp64 instructions; the row-at-a-time routine revisits a cell once per equation row)
+    __device__ __forceinline__ void init(const double x[3][2], int axisymmetric, double idet_known = 0.0) {
         const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
         const double d2x = x[2][0] - x[0][0], d2y = x[2][1] - x[0][1];
         const double det = d1x * d2y - d1y * d2x;
-        const double idet = 1.0 / det;
+        const double idet = idet_known != 0.0 ? idet_known : 1.0 / det;
+        inv_det = idet;
         detJ = fabs(det);
         G[0][0] = (x[1][1] - x[2][1]) * idet;
         G[0][1] = (x[2][0] - x[1][0]) * idet;

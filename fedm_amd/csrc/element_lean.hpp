@@ -314,7 +314,8 @@ __device__ __forceinline__ void lean_row(const fedm_model_desc *__restrict__ md,
 template <int NR>
 struct LeanStash {
     static constexpr bool K = NR == 1;                 // rate coefficients of one reaction fit the column
-    static constexpr int N = 4 + (K ? 2 * NR : 0);     // doubles per thread
+    static constexpr int N = 5 + (K ? 2 * NR : 0);     // doubles per thread: E (2), 1/|E|, ln|E|, 1/det [, k, k']
+    static constexpr int IDET = 4, KV = 5;
 };
 
 template <int NS, int NR>
@@ -342,18 +343,22 @@ __device__ __forceinline__ LeanCell lean2_prologue(const fedm_model_desc *__rest
         E[0] -= p * cg.G[a][0];
         E[1] -= p * cg.G[a][1];
     }
-    const double Em = sqrt(E[0] * E[0] + E[1] * E[1]);
-    const double invEm = 1.0 / Em;
-    const double lnE = log(Em);
+    // 1/|E| by reciprocal square root, |E| = E^2 / |E|, ln|E| = ln(E^2)/2: one transcendental chain
+    // (rsqrt) instead of two (sqrt, division)
+    const double E2 = E[0] * E[0] + E[1] * E[1];
+    const double invEm = rsqrt(E2);
+    const double Em = E2 * invEm;
+    const double lnE = 0.5 * log(E2);
     cst[0 * stride] = E[0];
     cst[1 * stride] = E[1];
     cst[2 * stride] = invEm;
     cst[3 * stride] = lnE;
+    cst[LeanStash<NR>::IDET * stride] = cg.inv_det;
     if constexpr (LeanStash<NR>::K) {
         double kv = 0.0, kd = 0.0;
         if (md->n_reactions > 0) termsum_eval(md->k[0], Em, invEm, lnE, kv, kd);
-        cst[4 * stride] = kv;
-        cst[5 * stride] = kd;
+        cst[LeanStash<NR>::KV * stride] = kv;
+        cst[(LeanStash<NR>::KV + 1) * stride] = kd;
     }
     return lc;
 }
@@ -361,7 +366,7 @@ __device__ __forceinline__ LeanCell lean2_prologue(const fedm_model_desc *__rest
 // geometry of the cell: gradients of the P1 basis and the three quadrature weights times 2 pi r
 __device__ __forceinline__ void lean2_geometry(const fedm_model_desc *__restrict__ md, const LeanCell &lc,
                                                const double *__restrict__ vx, int (&lv)[3], double (&G)[3][2],
-                                               double (&W)[3]) {
+                                               double (&W)[3], double idet_known = 0.0) {
     const double two_pi = 6.283185307179586476925286766559;
 #pragma unroll
     for (int a = 0; a < 3; ++a) lv[a] = (lc.wl >> (8 * a)) & 255;
@@ -372,7 +377,7 @@ __device__ __forceinline__ void lean2_geometry(const fedm_model_desc *__restrict
         x[a][1] = vx[2 * lv[a] + 1];
     }
     CellGeom cg;
-    cg.init(x, md->axisymmetric);
+    cg.init(x, md->axisymmetric, idet_known);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         G[a][0] = cg.G[a][0];
@@ -393,14 +398,17 @@ __device__ __forceinline__ void lean2_geometry(const fedm_model_desc *__restrict
 // density) of the streamer model).  Once a full assembly has written them, later assemblies neither
 // accumulate nor stream them out again (18 of the streamer's 90 LDS atomics per cell and two
 // ninths of its matrix bytes).  The tests are wave-uniform.
-template <int NS, int NR, bool JAC>
-__device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
+// ROW >= 0: the equation row is known at compile time (the selects on the row index fold away, the
+// model scalars of the row become constant-offset loads); ROW = -1: run-time row.
+template <int NS, int NR, bool JAC, int ROW = -1>
+__device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict__ md, int row_rt, const LeanCell &lc,
                                                const int (&lv)[3], const double (&G)[3][2], const double (&W)[3],
                                                const double *__restrict__ Ul,
                                                const double *__restrict__ Hl, const double *__restrict__ Al,
                                                const StepCoef sc, double *__restrict__ acc, double *__restrict__ Fl,
                                                const double *__restrict__ cst, int stride, uint32_t cmask = 0) {
     constexpr int NEQ = NS + 1, IPHI = NS;
+    const int row = ROW >= 0 ? ROW : row_rt;
     const int wj0 = lc.wj0, wj1 = lc.wj1, wj2 = lc.wj2;
     const uint32_t rmask = cmask >> (row * NEQ);   // this row's planes
     const double E[2] = {cst[0 * stride], cst[1 * stride]};
@@ -471,8 +479,8 @@ __device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict
     const int nreac = md->n_reactions;
     double kv[NR], kd[NR];
     if constexpr (LeanStash<NR>::K) {
-        kv[0] = cst[4 * stride];
-        kd[0] = cst[5 * stride];
+        kv[0] = cst[LeanStash<NR>::KV * stride];
+        kd[0] = cst[(LeanStash<NR>::KV + 1) * stride];
     } else {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
@@ -565,7 +573,8 @@ __device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict
                 for (int b = a; b < 3; ++b) {
                     const double pp = pa * (b == q ? 2.0 / 3.0 : 1.0 / 6.0);
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) m2[i][sym6(a, b)] += pp * g[i];
+                    for (int i = 0; i < NS; ++i)
+                        if (!((rmask >> i) & 1u)) m2[i][sym6(a, b)] += pp * g[i];   // wave-uniform: planes kept
                 }
             }
         }
@@ -613,7 +622,7 @@ __device__ __forceinline__ void lean2_row_core(const fedm_model_desc *__restrict
 }
 
 // one equation row with the geometry recomputed (F + J: nothing but the packed indices lives across rows)
-template <int NS, int NR, bool JAC>
+template <int NS, int NR, bool JAC, int ROW = -1>
 __device__ __forceinline__ void lean2_row(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
                                           const double *__restrict__ vx, const double *__restrict__ Ul,
                                           const double *__restrict__ Hl, const double *__restrict__ Al,
@@ -621,8 +630,8 @@ __device__ __forceinline__ void lean2_row(const fedm_model_desc *__restrict__ md
                                           const double *__restrict__ cst, int stride, uint32_t cmask) {
     int lv[3];
     double G[3][2], W[3];
-    lean2_geometry(md, lc, vx, lv, G, W);
-    lean2_row_core<NS, NR, JAC>(md, row, lc, lv, G, W, Ul, Hl, Al, sc, acc, Fl, cst, stride, cmask);
+    lean2_geometry(md, lc, vx, lv, G, W, cst[LeanStash<NR>::IDET * stride]);
+    lean2_row_core<NS, NR, JAC, ROW>(md, row, lc, lv, G, W, Ul, Hl, Al, sc, acc, Fl, cst, stride, cmask);
 }
 
 }  // namespace fedm

@@ -433,7 +433,7 @@ __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, 
         if (active) {
             int lv[3];
             double G[3][2], W[3];
-            lean2_geometry(md, lc, vx, lv, G, W);
+            lean2_geometry(md, lc, vx, lv, G, W, cst[LeanStash<NR>::IDET * THREADS + threadIdx.x]);
 #pragma unroll
             for (int row = 0; row < NEQ; ++row)
                 lean2_row_core<NS, NR, false>(md, row, lc, lv, G, W, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS);
@@ -442,8 +442,26 @@ __device__ __forceinline__ void assemble_lean2_body(FEDM_PATCH_PARAMS, int xcd, 
 #pragma unroll 1
     for (int row = 0; JAC && row < NEQ; ++row) {
         asm volatile("" : "+v"(lc.wl), "+v"(lc.wj0), "+v"(lc.wj1), "+v"(lc.wj2));  // nothing hoisted out of the row
-        if (active)
+        if (active) {
+#ifndef FEDM_LEAN2_ROW_GENERIC
+            // one body per equation row: the row index is a compile-time constant inside each (the
+            // selects on it fold away: 161 -> 144 VGPRs, -3 %; -DFEDM_LEAN2_ROW_GENERIC: one shared body)
+#define FEDM_ROW_CASE(R)                                                                                   \
+    case R:                                                                                                \
+        if constexpr (NEQ > R)                                                                             \
+            lean2_row<NS, NR, JAC, R>(md, row, lc, vx, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS, cmask); \
+        break;
+            switch (row) {
+                FEDM_ROW_CASE(0)
+                FEDM_ROW_CASE(1)
+                FEDM_ROW_CASE(2)
+                FEDM_ROW_CASE(3)
+            }
+#undef FEDM_ROW_CASE
+#else
             lean2_row<NS, NR, JAC>(md, row, lc, vx, Ul, Hl, Al, sc, acc, Fl, cst + threadIdx.x, THREADS, cmask);
+#endif
+        }
         FEDM_T(3)   // the row (wave 0's view)
         if constexpr (JAC) {
             __syncthreads();
