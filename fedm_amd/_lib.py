@@ -40,6 +40,7 @@ class ModelDesc(C.Structure):
         ("fqp_t", C.c_double * MAX_FQP), ("fqp_w", C.c_double * MAX_FQP),
         ("ext_nodes", C.c_int32 * MAX_SPECIES),
         ("ext_B", (C.c_double * MAX_EXT_NODES) * MAX_QP),
+        ("linear_representation", C.c_int32), ("pad2_", C.c_int32),
     ]
 
 

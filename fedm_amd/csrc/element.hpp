@@ -98,7 +98,9 @@ struct CellGeom {
 // CACHE = 2 additionally bakes FIAT's degree-2 triangle rule (the only 3-point rule the decks
 // produce) into the code: every model scalar read in the inner loops is a scalar-cache round trip
 // that the few resident waves cannot hide, and the constant weights fold into the arithmetic.
-template <int NS, bool PO, int NR, int CACHE>
+// LIN: the unknowns are the densities themselves (fedm_model_desc::linear_representation); a
+// compile-time switch -- as a run-time flag it costs the logarithmic kernels up to 300 bytes of scratch.
+template <int NS, bool PO, int NR, int CACHE, bool LIN = false>
 struct Element {
     static constexpr int NEQ = NS + (PO ? 1 : 0);
     static constexpr int IPHI = NEQ - 1;
@@ -122,9 +124,11 @@ struct Element {
     double kv[NR > 0 ? NR : 1], kd[NR > 0 ? NR : 1];
     double nq_c[NS][NQC], up_c[NS][NQC];
     bool flux[NS], fdrift[NS], full;
+    static constexpr bool lin = LIN;
     int nreac;
-    // moments of the row being emitted
-    double m2[NS][6], m1h[3], m1n[3], m0n, m1sp[3], m01;
+    // moments of the row being emitted (m01 = sum W, m1w[b] = sum W phi_b: the linear representation's
+    // counterparts of m0n, m1n)
+    double m2[NS][6], m1h[3], m1n[3], m0n, m1sp[3], m01, m1w[3];
     // per cell: G_a.G_b (sym6 order) and d|E|/dPhi_b;  per row (row_prepare): the factors that
     // every (a, b) entry shares, so that an entry costs two FMAs instead of a dozen:
     //   J[s][s](a,b)   = m2 + DGm*gg(a,b) - velG[a]*m1n[b]
@@ -219,7 +223,7 @@ struct Element {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const double u = Uc[0][s] * p0 + Uc[1][s] * xq + Uc[2][s] * yq;
-                    nq_c[s][q] = exp(u);
+                    nq_c[s][q] = lin ? u : exp(u);
                     up_c[s][q] = sc.c_new * u + (Hc[0][s] * p0 + Hc[1][s] * xq + Hc[2][s] * yq);
                 }
             }
@@ -232,7 +236,7 @@ struct Element {
                                                 const StepCoef sc, const double *const ext[NS]) {
         const double two_pi = 6.283185307179586476925286766559;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) m1h[a] = m1n[a] = m1sp[a] = 0.0;
+        for (int a = 0; a < 3; ++a) m1h[a] = m1n[a] = m1sp[a] = m1w[a] = 0.0;
 #pragma unroll
         for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -254,7 +258,10 @@ struct Element {
                 const double xq = md->qp_x[q], yq = md->qp_y[q], p0 = 1.0 - xq - yq;
                 double n[NS];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) n[i] = exp(Uc[0][i] * p0 + Uc[1][i] * xq + Uc[2][i] * yq);
+                for (int i = 0; i < NS; ++i) {
+                    const double ui = Uc[0][i] * p0 + Uc[1][i] * xq + Uc[2][i] * yq;
+                    n[i] = lin ? ui : exp(ui);
+                }
                 const int s = row < NS ? row : 0;
                 const double u = Uc[0][s] * p0 + Uc[1][s] * xq + Uc[2][s] * yq;
                 const double u_part = sc.c_new * u + (Hc[0][s] * p0 + Hc[1][s] * xq + Hc[2][s] * yq);
@@ -281,12 +288,17 @@ struct Element {
             for (int i = 0; i < NS; ++i) {
                 const double cz = md->Z[i] * n[i] * md->charge_over_eps;
                 h -= cz;
-                if (full) g[i] = -cz;
+                if (full) g[i] = lin ? -md->Z[i] * md->charge_over_eps : -cz;   // d n_i / d u_i = 1 (linear) or n_i
             }
         } else if (full) {
             const int s = row < NS ? row : 0;
-            h = n[s] * u_part * sc.inv_dt;
-            g[s] = n[s] * (u_part + sc.c_new) * sc.inv_dt;
+            if (lin) {  // expu_or_1 = 1, fedm/functions.py:352
+                h = u_part * sc.inv_dt;
+                g[s] = sc.c_new * sc.inv_dt;
+            } else {
+                h = n[s] * u_part * sc.inv_dt;
+                g[s] = n[s] * (u_part + sc.c_new) * sc.inv_dt;
+            }
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 if (j >= nreac) break;
@@ -303,7 +315,19 @@ struct Element {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const int P = md->power[j][i];
-                    if (P) g[i] -= nu * kv[j] * (double)P * prod;
+                    if (!P) continue;
+                    if (!lin) {
+                        g[i] -= nu * kv[j] * (double)P * prod;
+                    } else {  // d prod / d u_i = P u_i^(P-1) prod_(k != i) u_k^P_k
+                        double dp = (double)P;
+                        for (int e = 1; e < P; ++e) dp *= n[i];
+#pragma unroll
+                        for (int k2 = 0; k2 < NS; ++k2) {
+                            if (k2 == i) continue;
+                            for (int e = 0; e < md->power[j][k2]; ++e) dp *= n[k2];
+                        }
+                        g[i] -= nu * kv[j] * dp;
+                    }
                 }
             }
             const int nn = md->ext_nodes[s];
@@ -323,49 +347,72 @@ struct Element {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) m2[i][sym6(a, b)] += pp * g[i];
             }
-        if (phi_row) {
-            m01 += W;
-        } else {
+        m01 += W;
+        if (!phi_row) {
             const double ns_ = n[row < NS ? row : 0];
             m0n += W * ns_;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 m1n[a] += W * phi[a] * ns_;
                 m1sp[a] += W * phi[a] * sp;
+                m1w[a] += W * phi[a];
             }
         }
     }
 
-    // shared factors of the row's entries -- after row_moments(row), before residual/block_row
+    // shared factors of the row's entries -- after row_moments(row), before residual/block_row.
+    // Logarithmic representation: Gamma = n vel, vel = -D grad(u) + Z mu E.  Linear: Gamma =
+    // -D grad(u) + Z mu E u, so the diffusive part carries sum W (m01) instead of sum W n (m0n) and
+    // d n / d u_b is phi_b instead of n phi_b (m1w instead of m1n).
+    double PG[3], QG[3], Dcur, zmucur;   // grad(u).G_a, E.G_a (or w.G_a for a constant drift), D, Z mu (linear form)
     __device__ __forceinline__ void row_prepare(const fedm_model_desc *__restrict__ md, int row) {
         if (PO && row == IPHI) return;
         const int s = row < NS ? row : 0;
         DGm = 0.0;
         Kd = 0.0;
+        Dcur = zmucur = 0.0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             velG[a] = 0.0;
             T[a] = m1sp[a];
+            PG[a] = QG[a] = 0.0;
         }
         if (!flux[s]) return;
-        DGm = Dv[s] * m0n;
         const double zmud = fdrift[s] ? md->Z[s] * mud[s] : 0.0;
+        if (!lin) {
+            DGm = Dv[s] * m0n;
+            if (fdrift[s]) Kd = md->Z[s] * muv[s] * m0n;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                velG[a] = vel[s][0] * G[a][0] + vel[s][1] * G[a][1];
+                if (PO) {
+                    const double Pa = gradu[s][0] * G[a][0] + gradu[s][1] * G[a][1];
+                    const double Qa = E[0] * G[a][0] + E[1] * G[a][1];
+                    T[a] += (zmud * Qa - Dd[s] * Pa) * m0n;
+                }
+            }
+            return;
+        }
+        Dcur = Dv[s];
+        DGm = Dv[s] * m01;
+        const bool wdrift = md->eq_type[s] == FEDM_EQ_DRIFT_DIFFUSION_REACTION && md->has_drift_w[s];
+        zmucur = fdrift[s] ? md->Z[s] * muv[s] : (wdrift ? 1.0 : 0.0);
         if (fdrift[s]) Kd = md->Z[s] * muv[s] * m0n;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            velG[a] = vel[s][0] * G[a][0] + vel[s][1] * G[a][1];
-            if (PO) {
-                const double Pa = gradu[s][0] * G[a][0] + gradu[s][1] * G[a][1];
-                const double Qa = E[0] * G[a][0] + E[1] * G[a][1];
-                T[a] += (zmud * Qa - Dd[s] * Pa) * m0n;
-            }
+            PG[a] = gradu[s][0] * G[a][0] + gradu[s][1] * G[a][1];
+            QG[a] = fdrift[s] ? E[0] * G[a][0] + E[1] * G[a][1]
+                              : (wdrift ? md->drift_w[s][0] * G[a][0] + md->drift_w[s][1] * G[a][1] : 0.0);
+            // integral of Gamma . G_a = -D P_a sum W + Z mu Q_a sum W u
+            velG[a] = -Dcur * PG[a] * m01 + zmucur * QG[a] * m0n;
+            if (PO) T[a] += zmud * QG[a] * m0n - Dd[s] * PG[a] * m01;
         }
     }
 
     // residual entry (a, row)
     __device__ __forceinline__ double residual(int row, int a) const {
         if (PO && row == IPHI) return (gradPhi[0] * G[a][0] + gradPhi[1] * G[a][1]) * m01 + m1h[a];
-        return m1h[a] - velG[a] * m0n;
+        return lin ? m1h[a] - velG[a] : m1h[a] - velG[a] * m0n;
     }
 
     // entries d R[a][row] / d U[b][0..NEQ)
@@ -379,7 +426,8 @@ struct Element {
             return;
         }
         const int s = row < NS ? row : 0;
-        B[s] += DGm * gg[k] - velG[a] * m1n[b];
+        if (lin) B[s] += DGm * gg[k] - zmucur * QG[a] * m1w[b];
+        else B[s] += DGm * gg[k] - velG[a] * m1n[b];
         if (PO) B[IPHI] = Kd * gg[k] - dE[b] * T[a];
     }
 };
@@ -427,11 +475,14 @@ __device__ void boundary_facet(const fedm_model_desc *__restrict__ md, const dou
             phi[j] = 1.0 - md->fqp_t[t];
             phi[k] = md->fqp_t[t];
             const double rq = cg.rn[0] * phi[0] + cg.rn[1] * phi[1] + cg.rn[2] * phi[2];
-            const double n = exp(Uc[0][s] * phi[0] + Uc[1][s] * phi[1] + Uc[2][s] * phi[2]);
-            const double We = md->fqp_w[t] * L * two_pi * rq * n;
+            const double uq = Uc[0][s] * phi[0] + Uc[1][s] * phi[1] + Uc[2][s] * phi[2];
+            const bool lin = md->linear_representation != 0;
+            const double n = lin ? uq : exp(uq);
+            const double W0 = md->fqp_w[t] * L * two_pi * rq;
+            const double We = W0 * n, Wd = lin ? W0 : We;   // d n / d u_b = phi_b (linear) or n phi_b
             for (int a = 0; a < 3; ++a) {
                 EM1[a] += We * phi[a];
-                for (int b = 0; b < 3; ++b) EM2[a][b] += We * phi[a] * phi[b];
+                for (int b = 0; b < 3; ++b) EM2[a][b] += Wd * phi[a] * phi[b];
             }
         }
         const double zm = md->Z[s] * muv, zd = md->Z[s] * mud;

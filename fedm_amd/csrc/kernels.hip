@@ -27,7 +27,7 @@ static void flush_pending_halo(Ctx &c) {
 // and the summation order is fixed -> bitwise reproducible).
 // Problem.F / Problem.J, fedm/functions.py:188-202
 // =============================================================================================
-template <int NS, bool PO, int NR, int CACHE>
+template <int NS, bool PO, int NR, int CACHE, bool LIN>
 __global__ __launch_bounds__(256) void assemble_colour_kernel(
     const fedm_model_desc *__restrict__ md, const int *__restrict__ cell_list, int n_cells,
     const int *__restrict__ cells, const double *__restrict__ coords,
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void assemble_colour_kernel(
     for (int s = 0; s < NS; ++s)
         ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)c * md->ext_nodes[s] : nullptr;
 
-    Element<NS, PO, NR, CACHE> el;
+    Element<NS, PO, NR, CACHE, LIN> el;
     el.setup(md, x, Uc, Hc, sc, mode);
     uint32_t slot[9];
     if (jacobian) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void assemble_colour_kernel(
     }
 }
 
-template <int NS, bool PO, int NR, int CACHE>
+template <int NS, bool PO, int NR, int CACHE, bool LIN>
 static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     flush_pending_halo(c);
@@ -100,7 +100,7 @@ static void assemble_colour_t(Ctx &c, bool jacobian, int mode) {
     for (int k = 0; k < ncol; ++k) {
         const int n = c.pat.colour_ptr[k + 1] - c.pat.colour_ptr[k];
         if (n == 0) continue;
-        hipLaunchKernelGGL((assemble_colour_kernel<NS, PO, NR, CACHE>), dim3((n + 255) / 256), dim3(256), 0,
+        hipLaunchKernelGGL((assemble_colour_kernel<NS, PO, NR, CACHE, LIN>), dim3((n + 255) / 256), dim3(256), 0,
                            c.stream, c.d_model, c.d_colour_cells + c.pat.colour_ptr[k], n,
                            c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_uold, c.d_uold1, sc,
                            c.d_ext[0], c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val, c.d_F,
@@ -139,7 +139,7 @@ extern "C" void fedm_debug_phase(unsigned long long *out, int reset) {
 // JAC = false is the residual-only assembly (final Newton check): without the Jacobian code it
 // needs about half the registers and no accumulators, so it is compiled as a kernel of its own
 // that the compiler may run at a higher occupancy.
-template <int NS, bool PO, int NR, int CACHE, int THREADS, bool JAC>
+template <int NS, bool PO, int NR, int CACHE, int THREADS, bool JAC, bool LIN>
 __device__ __forceinline__ void assemble_patch_body(
     const fedm_model_desc *__restrict__ md, int nv, const int *__restrict__ boff,
     const int *__restrict__ cell_ptr, const PatchCell *__restrict__ pcells,
@@ -209,7 +209,7 @@ __device__ __forceinline__ void assemble_patch_body(
             ext[s] = (extp[s] && md->ext_nodes[s]) ? extp[s] + (size_t)pc.cell * md->ext_nodes[s] : nullptr;
 
         FEDM_T(3)
-        Element<NS, PO, NR, CACHE> el;
+        Element<NS, PO, NR, CACHE, LIN> el;
         el.setup(md, x, Uc, Hc, sc, mode);
         FEDM_T(4)
 #pragma unroll
@@ -259,15 +259,15 @@ __device__ __forceinline__ void assemble_patch_body(
     md, nv, boff, cell_ptr, pcells, halo_ptr, halo, coords, u, uold, uold1, sc, ext0, ext1, ext2,  \
         ext3, val, F, mode, acc_doubles, max_verts
 
-template <int NS, bool PO, int NR, int CACHE, int THREADS>
+template <int NS, bool PO, int NR, int CACHE, int THREADS, bool LIN>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void assemble_patch_kernel(
     FEDM_PATCH_PARAMS) {
-    assemble_patch_body<NS, PO, NR, CACHE, THREADS, true>(FEDM_PATCH_ARGS);
+    assemble_patch_body<NS, PO, NR, CACHE, THREADS, true, LIN>(FEDM_PATCH_ARGS);
 }
 
-template <int NS, bool PO, int NR, int CACHE, int THREADS>
+template <int NS, bool PO, int NR, int CACHE, int THREADS, bool LIN>
 __global__ __launch_bounds__(THREADS) void residual_patch_kernel(FEDM_PATCH_PARAMS) {
-    assemble_patch_body<NS, PO, NR, CACHE, THREADS, false>(FEDM_PATCH_ARGS);
+    assemble_patch_body<NS, PO, NR, CACHE, THREADS, false, LIN>(FEDM_PATCH_ARGS);
 }
 
 // workgroup barrier that orders LDS accesses only: global stores issued before it stay in flight
@@ -536,19 +536,19 @@ size_t patch_lds_bytes(const Ctx &c, bool jacobian) {
     return sizeof(double) * (acc + SLICE * neq + 2 * mv + (size_t)(neq + c.ns) * mv);
 }
 
-template <int NS, bool PO, int NR, int CACHE>
+template <int NS, bool PO, int NR, int CACHE, bool LIN>
 static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     constexpr int NEQ = NS + (PO ? 1 : 0);
     const StepCoef sc = step_coef(c.dt, c.dt_old);
     const int acc_doubles = jacobian ? c.pat.max_patch_width * NEQ * NEQ * SLICE : 0;
 #define FEDM_PATCH_LAUNCH(KERNEL, T)                                                              \
-    hipLaunchKernelGGL((KERNEL<NS, PO, NR, CACHE, T>), dim3(c.pat.n_slices), dim3(T),              \
+    hipLaunchKernelGGL((KERNEL<NS, PO, NR, CACHE, T, LIN>), dim3(c.pat.n_slices), dim3(T),         \
                        patch_lds_bytes(c, jacobian), c.stream, c.d_model, c.nv, c.d_slice_boff,    \
                        c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr, c.d_patch_halo,    \
                        c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],         \
                        c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_doubles,                  \
                        c.pat.max_patch_verts)
-    if constexpr (PO && CACHE == 2 && NS >= 1) {
+    if constexpr (PO && CACHE == 2 && NS >= 1 && !LIN) {
         bool ext = false;
         for (int s_ = 0; s_ < NS; ++s_) ext = ext || c.model.ext_nodes[s_] > 0;
         if (mode == 0 && !ext && c.assembly_lean >= 2 && c.pat.max_patch_cells <= 192) {
@@ -680,10 +680,10 @@ static void launch_boundary(Ctx &c, bool jacobian) {
     }
 }
 
-template <int NS, bool PO, int NR, int CACHE>
+template <int NS, bool PO, int NR, int CACHE, bool LIN = false>
 static void assemble_variant(Ctx &c, bool jacobian, int mode) {
-    if (c.assembly_kind == 1) assemble_patch_t<NS, PO, NR, CACHE>(c, jacobian, mode);
-    else assemble_colour_t<NS, PO, NR, CACHE>(c, jacobian, mode);
+    if (c.assembly_kind == 1) assemble_patch_t<NS, PO, NR, CACHE, LIN>(c, jacobian, mode);
+    else assemble_colour_t<NS, PO, NR, CACHE, LIN>(c, jacobian, mode);
 }
 
 template <int NS, bool PO>
@@ -698,7 +698,9 @@ static void assemble_dispatch(Ctx &c, bool jacobian, int mode) {
     const bool stdq = cache && m.n_qp == 3 && m.qp_x[0] == sixth && m.qp_x[1] == sixth && m.qp_x[2] == two3 &&
                       m.qp_y[0] == sixth && m.qp_y[1] == two3 && m.qp_y[2] == sixth && m.qp_w[0] == sixth &&
                       m.qp_w[1] == sixth && m.qp_w[2] == sixth;
-    if (few && stdq) assemble_variant<NS, PO, 1, (NEQ > 1) ? 2 : 0>(c, jacobian, mode);
+    // the non-logarithmic representation runs on the generic (uncached, any reaction count) element only
+    if (m.linear_representation) assemble_variant<NS, PO, FEDM_MAX_REACTIONS, 0, true>(c, jacobian, mode);
+    else if (few && stdq) assemble_variant<NS, PO, 1, (NEQ > 1) ? 2 : 0>(c, jacobian, mode);
     else if (few && cache) assemble_variant<NS, PO, 1, (NEQ > 1) ? 1 : 0>(c, jacobian, mode);
     else if (few) assemble_variant<NS, PO, 1, 0>(c, jacobian, mode);
     else if (cache) assemble_variant<NS, PO, FEDM_MAX_REACTIONS, (NEQ > 1) ? 1 : 0>(c, jacobian, mode);

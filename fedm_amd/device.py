@@ -44,6 +44,7 @@ class Model:
     quadrature_degree: int = 2
     ext_source_degree: Sequence[int] = ()      # 0 = none, k = Expression(degree=k) source
     axisymmetric: bool = True
+    log_representation: bool = True            # False: the unknowns are the densities (functions.py:350-368)
 
     @property
     def n_eq(self):
@@ -52,6 +53,7 @@ class Model:
     def to_c(self):
         md = _lib.ModelDesc()
         ns = self.n_species
+        md.linear_representation = 0 if self.log_representation else 1
         if not 1 <= ns <= _lib.MAX_SPECIES:
             raise ValueError(f"n_species must be 1..{_lib.MAX_SPECIES}")
         md.n_species, md.poisson, md.axisymmetric = ns, int(self.poisson), int(self.axisymmetric)

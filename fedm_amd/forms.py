@@ -190,6 +190,8 @@ class Function(_Ops):
         # a zero Function used as an accumulator of source terms (fedm-streamer.py:164,246)
         if isinstance(o, (RateSum, Rate, Density)):
             return NotImplemented
+        if isinstance(o, (Sym, Unknown)) and not np.any(self._v) and o_is_source(o):
+            return RateSum.coerce(o)                  # zero Function + densities written with bare unknowns
         return Sym("add", self, o)
 
     def assign(self, other):
@@ -379,11 +381,13 @@ class DirichletBC:
 # the little algebra of source terms:  sum_k  coef_k(E_m) * prod_i exp(u_i)^p_ki
 # ---------------------------------------------------------------------------------------
 class Rate:
-    """coef(|E|) * prod_i n_i^powers[i]"""
+    """coef(|E|) * prod_i n_i^powers[i].  ``bare``: the species whose density entered as the
+    unknown itself (``u[i]``, non-logarithmic representation) rather than as ``exp(u[i])``."""
 
-    def __init__(self, coef, powers):
+    def __init__(self, coef, powers, bare=()):
         self.coef = TermSum.coerce(coef)
         self.powers = {i: p for i, p in powers.items() if p}
+        self.bare = frozenset(i for i in bare if i in self.powers)
 
     def exp(self):
         raise ValueError("exp() of a density product is not a supported expression")
@@ -406,6 +410,24 @@ class RateSum:
             return RateSum([])                  # a zero Function used as accumulator (:164,246)
         if isinstance(x, Constant):
             return RateSum.coerce(float(x))
+        if isinstance(x, Unknown):                    # the density itself: non-logarithmic representation
+            return RateSum([Rate(1.0, {x.index: 1}, bare=(x.index,))])
+        if isinstance(x, Density):
+            return RateSum([Rate(1.0, {x.index: 1})])
+        if isinstance(x, Sym):                        # products / sums of unknowns and numbers written before
+            a = x.args                                # it was known that they form a source term
+            if x.op == "add":
+                return RateSum.coerce(a[0]) + RateSum.coerce(a[1])
+            if x.op == "sub":
+                return RateSum.coerce(a[0]) - RateSum.coerce(a[1])
+            if x.op == "mul":
+                return RateSum.coerce(a[0]) * RateSum.coerce(a[1])
+            if x.op == "neg":
+                return -RateSum.coerce(a[0])
+            if x.op == "div" and isinstance(a[1], (Real, Constant, TermSum)) or (x.op == "div" and isinstance(a[1], Sym) and not a[1].leaves((Unknown, Function))):
+                return RateSum.coerce(a[0]) / a[1]
+            if x.op == "pow":
+                return RateSum.coerce(a[0]) ** a[1]
         raise TypeError(f"cannot use {type(x).__name__} in a source-term expression")
 
     def __add__(self, o):
@@ -414,7 +436,7 @@ class RateSum:
     __radd__ = __add__
 
     def __neg__(self):
-        return RateSum([Rate(-t.coef, t.powers) for t in self.terms])
+        return RateSum([Rate(-t.coef, t.powers, t.bare) for t in self.terms])
 
     def __sub__(self, o):
         return self + (-RateSum.coerce(o))
@@ -430,14 +452,14 @@ class RateSum:
                 p = dict(a.powers)
                 for i, e in b.powers.items():
                     p[i] = p.get(i, 0) + e
-                out.append(Rate(a.coef * b.coef, p))
+                out.append(Rate(a.coef * b.coef, p, a.bare | b.bare))
         return RateSum(out)
 
     __rmul__ = __mul__
 
     def __truediv__(self, o):
         o = TermSum.coerce(float(o) if isinstance(o, (Constant, Sym)) else o)
-        return RateSum([Rate(t.coef / o, t.powers) for t in self.terms])
+        return RateSum([Rate(t.coef / o, t.powers, t.bare) for t in self.terms])
 
     def __pow__(self, n):
         n = int(n)
@@ -445,6 +467,16 @@ class RateSum:
         for _ in range(n):
             out = out * self
         return out
+
+
+def o_is_source(x):
+    """True when a symbolic expression consists of unknowns and numbers only (a source term of the
+    non-logarithmic representation)."""
+    try:
+        RateSum.coerce(x)
+        return True
+    except TypeError:
+        return False
 
 
 def _rate_ops(cls):
@@ -480,8 +512,10 @@ _ts_mul = TermSum.__mul__
 
 
 def _ts_mul_dispatch(self, o):
-    if isinstance(o, (RateSum, Density)):
-        return RateSum.coerce(self) * (o if isinstance(o, RateSum) else RateSum([Rate(1.0, {o.index: 1})]))
+    if isinstance(o, (RateSum, Density, Unknown)):
+        return RateSum.coerce(self) * RateSum.coerce(o)
+    if isinstance(o, Sym) and o_is_source(o):
+        return RateSum.coerce(self) * RateSum.coerce(o)
     return _ts_mul(self, o)
 
 

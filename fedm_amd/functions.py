@@ -138,12 +138,8 @@ def weak_form_balance_equation(equation_type, dt, dt_old, dx, u, u_old, u_old1, 
     if D is None and equation_type == "diffusion-reaction":
         raise ValueError(f"fedm.{me}: When 'equation_type' is diffusion-reaction, must also supply "
                          "the diffusion coefficient 'D'.")
-    if not log_representation:
-        raise NotImplementedError(
-            "the device path implements the logarithmic representation "
-            "(weak_form_balance_equation_log_representation), the one every FEDM example uses")
     return BalanceEq(equation_type=equation_type, dt=dt, dt_old=dt_old, dx=dx, u=u, u_old=u_old,
-                     u_old1=u_old1, v=v, f=f, Gamma=Gamma, r=r, D=D)
+                     u_old1=u_old1, v=v, f=f, Gamma=Gamma, r=r, D=D, log=bool(log_representation))
 
 
 def weak_form_balance_equation_log_representation(*args, **kwargs):
@@ -223,14 +219,29 @@ def compile_forms(F, quadrature_degree=None):
     zero = TermSum.const(0.0)
     mu, D, Z = [zero] * ns, [zero] * ns, [0.0] * ns
     reactions = []
+    # one representation per model: log_representation of the balance equations, logarithm_representation
+    # of their fluxes and the way the densities enter the sources (exp(u[i]) or u[i]) must agree
+    log = bool(getattr(balances[0], "log", True))
+    if any(bool(getattr(p, "log", True)) != log for p in balances):
+        raise ValueError("all balance equations of a model must use the same representation (logarithmic or not)")
+
+    def check_densities(terms, where):
+        for term in terms:
+            wrong = set(term.powers) - term.bare if not log else term.bare
+            if wrong:
+                raise ValueError(f"{where}: densities must enter as " + ("exp(u[i])" if log else "u[i]")
+                                 + f" in the {'logarithmic' if log else 'non-logarithmic'} representation")
     for s, p in enumerate(balances):
         if p.equation_type == "drift-diffusion-reaction":
             g = p.Gamma
             if not isinstance(g, FluxDesc):
                 raise ValueError("drift-diffusion-reaction needs Gamma = Flux(...)")
+            if bool(g.log) != log:
+                raise ValueError("Flux(..., logarithm_representation=...) must match the balance equation's representation")
             mu[s], D[s], Z[s] = TermSum.coerce(g.mu), TermSum.coerce(g.D), float(g.sign)
         elif p.equation_type == "diffusion-reaction":
             D[s] = TermSum.coerce(p.D)
+        check_densities(forms.RateSum.coerce(p.f).terms, f"source term of species {s}")
         for term in forms.RateSum.coerce(p.f).terms:
             power = [int(term.powers.get(i, 0)) for i in range(ns)]
             if any(i >= ns for i in term.powers):
@@ -247,6 +258,7 @@ def compile_forms(F, quadrature_degree=None):
         ps = poissons[0]
         if ps.u.index != ns:
             raise ValueError("the potential must be the last component of the mixed space")
+        check_densities(forms.RateSum.coerce(ps.f).terms, "Poisson source")
         for term in forms.RateSum.coerce(ps.f).terms:
             if len(term.powers) != 1 or list(term.powers.values()) != [1] or not term.coef.is_const():
                 raise ValueError("the Poisson source must be sum_i Z_i e/eps0 exp(u_i)")
@@ -273,7 +285,7 @@ def compile_forms(F, quadrature_degree=None):
             "estimation is reproduced only for the time-of-flight case, see DESIGN.md)")
     model = Model(n_species=ns, poisson=bool(poissons), eq_type=eq_type, Z=Z, mu=mu, D=D,
                   reactions=reactions, bc_kind=bc_kind, quadrature_degree=int(qd),
-                  axisymmetric=axis)
+                  axisymmetric=axis, log_representation=log)
     return model, mesh, tags_mf
 
 

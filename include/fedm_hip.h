@@ -81,6 +81,11 @@ typedef struct {
     /* Expression sources (P_k nodal values per cell), fedm-tof.py:116 */
     int32_t ext_nodes[FEDM_MAX_SPECIES];     /* 0: none, else nodes per cell (6 for P2)     */
     double ext_B[FEDM_MAX_QP][FEDM_MAX_EXT_NODES];         /* interpolant at qp_x/qp_y      */
+    /* 0: unknowns are ln(n) (weak_form_balance_equation_log_representation, every reference example);
+     * 1: unknowns are the densities themselves (weak_form_balance_equation(..., log_representation=False),
+     *    Flux(..., logarithm_representation=False), fedm/functions.py:219-237, 350-368) */
+    int32_t linear_representation;
+    int32_t pad2_;
 } fedm_model_desc;
 
 typedef struct {

@@ -64,7 +64,7 @@ class LFAModel:
     def __init__(self, mesh, n_species, poisson, eq_type, Z, mu=None, D=None,
                  drift_w=None, reactions=(), facet_tags=None, bc_type=None,
                  qdeg=2, qdeg_time=None, qdeg_flux=None, qdeg_source=None,
-                 qdeg_ext=None, axisymmetric=True):
+                 qdeg_ext=None, axisymmetric=True, log_representation=True):
         self.mesh = mesh
         self.ns = n_species
         self.poisson = bool(poisson)
@@ -88,6 +88,10 @@ class LFAModel:
         self.dirichlet_dofs = np.zeros(0, dtype=np.int64)
         self.dirichlet_vals = np.zeros(0, dtype=np.float64)
         self.axisymmetric = axisymmetric
+        # fedm/functions.py:350-368: log_representation=False solves for the densities themselves
+        # (time term u_part/dt without the exp(u) factor, flux -grad(D u) + sign mu E u, sources and
+        # the Poisson charge in terms of u)
+        self.log = bool(log_representation)
         self._geometry()
         self._pattern()
 
@@ -141,6 +145,13 @@ class LFAModel:
             Em = np.ones(self.mesh.nc)
         return Uc, E, Em
 
+    def _dens(self, uq):
+        """density and d(density)/du at quadrature points: exp(u), exp(u) or u, 1"""
+        if self.log:
+            n = np.exp(uq)
+            return n, n
+        return uq, np.ones_like(uq)
+
     def element_tensors(self, U, Uold, Uold1, dt, dt_old, jacobian=True):
         nc, ns, neq, G = self.mesh.nc, self.ns, self.neq, self.G
         Uc, E, Em = self.cell_fields(U)
@@ -176,10 +187,14 @@ class LFAModel:
                 u = Uc[:, :, s] @ phi
                 uo = Uoc[:, :, s] @ phi
                 uo1 = Uo1c[:, :, s] @ phi
-                n = np.exp(u)
                 u_part = (u * tr2p1 - trp1 ** 2.0 * uo + tr ** 2.0 * uo1) / trp1
-                T = n * u_part / dt
-                dT = n * (u_part / dt + tr2p1 / (trp1 * dt))
+                if self.log:
+                    n = np.exp(u)
+                    T = n * u_part / dt
+                    dT = n * (u_part / dt + tr2p1 / (trp1 * dt))
+                else:                                   # expu_or_1 = 1.0, functions.py:352
+                    T = u_part / dt
+                    dT = np.full_like(u, tr2p1 / (trp1 * dt))
                 for a in range(3):
                     Re[:, a, s] += W * T * phi[a]
                     if jacobian:
@@ -193,41 +208,66 @@ class LFAModel:
             for s in range(ns):
                 if self.eq_type[s] == REACTION:
                     continue
-                n = np.exp(Uc[:, :, s] @ phi)
+                n, dn = self._dens(Uc[:, :, s] @ phi)
                 Dv, Dd = Dc[s]
-                vel = -Dv[:, None] * gradu[:, s, :]
+                # Gamma = -D grad(u_e) + sign mu E u_e with u_e = exp(u) (grad u_e = u_e grad u) or u
+                gn = gradu[:, s, :] * (n[:, None] if self.log else 1.0)      # grad(u_e)
+                flux = -Dv[:, None] * gn
                 field_drift = False
+                drift = None
                 if self.eq_type[s] == DRIFT_DIFFUSION_REACTION:
                     if self.drift_w[s] is not None:
-                        vel = vel + np.asarray(self.drift_w[s], dtype=np.float64)[None, :]
+                        drift = np.broadcast_to(np.asarray(self.drift_w[s], dtype=np.float64)[None, :], flux.shape)
                     elif self.poisson:
                         muv, mud = mu[s]
-                        vel = vel + (self.Z[s] * muv)[:, None] * E
+                        drift = (self.Z[s] * muv)[:, None] * E
                         field_drift = True
+                if drift is not None:
+                    flux = flux + drift * n[:, None]
                 for a in range(3):
-                    velGa = np.einsum("cd,cd->c", vel, G[:, a])
-                    Re[:, a, s] -= W * n * velGa
+                    Re[:, a, s] -= W * np.einsum("cd,cd->c", flux, G[:, a])
                     if not jacobian:
                         continue
                     for b in range(3):
-                        Ke[:, a, s, b, s] -= W * n * (phi[b] * velGa - Dv * GG[:, a, b])
+                        # d grad(u_e)/du_b = dn phi_b grad u + n G_b (log) or G_b (linear)
+                        if self.log:
+                            dgn = (dn * phi[b])[:, None] * gradu[:, s, :] + n[:, None] * G[:, b]
+                        else:
+                            dgn = G[:, b]
+                        dflux = -Dv[:, None] * dgn
+                        if drift is not None:
+                            dflux = dflux + drift * (dn * phi[b])[:, None]
+                        Ke[:, a, s, b, s] -= W * np.einsum("cd,cd->c", dflux, G[:, a])
                         if self.poisson:
-                            dvel = -(Dd * dEm[:, b])[:, None] * gradu[:, s, :]
+                            dphi = -(Dd * dEm[:, b])[:, None] * gn
                             if field_drift:
-                                dvel = dvel + (self.Z[s] * mud * dEm[:, b])[:, None] * E \
-                                    - (self.Z[s] * muv)[:, None] * G[:, b]
-                            Ke[:, a, s, b, iphi] -= W * n * np.einsum("cd,cd->c", dvel, G[:, a])
+                                dphi = dphi + ((self.Z[s] * mud * dEm[:, b])[:, None] * E
+                                               - (self.Z[s] * muv)[:, None] * G[:, b]) * n[:, None]
+                            Ke[:, a, s, b, iphi] -= W * np.einsum("cd,cd->c", dphi, G[:, a])
 
         # ---- reaction sources and Poisson ------------------------------
         xq, wq = triangle_rule(self.qdeg_source)
         for xi, w in zip(xq, wq):
             phi, W = point(xi, w)
-            nq = [np.exp(Uc[:, :, s] @ phi) for s in range(ns)]
+            dens = [self._dens(Uc[:, :, s] @ phi) for s in range(ns)]
+            nq = [d[0] for d in dens]
+            dnq = [d[1] for d in dens]
             for (kv, kd), (_, P, nu) in zip(kk, self.reactions):
                 prod = np.ones(nc)
                 for i in range(ns):
                     if P[i]:
                         prod = prod * nq[i] ** P[i]
+                # d prod / d u_i = P_i n_i^(P_i - 1) dn_i prod_(k != i) n_k^P_k
+                dprod = []
+                for i in range(ns):
+                    if not P[i]:
+                        dprod.append(None)
+                        continue
+                    d = P[i] * nq[i] ** (P[i] - 1) * dnq[i]
+                    for k2 in range(ns):
+                        if k2 != i and P[k2]:
+                            d = d * nq[k2] ** P[k2]
+                    dprod.append(d)
                 for s in range(ns):
                     if nu[s] == 0:
                         continue
@@ -238,7 +278,7 @@ class LFAModel:
                         for b in range(3):
                             for i in range(ns):
                                 if P[i]:
-                                    Ke[:, a, s, b, i] -= W * nu[s] * kv * P[i] * prod * phi[a] * phi[b]
+                                    Ke[:, a, s, b, i] -= W * nu[s] * kv * dprod[i] * phi[a] * phi[b]
                             if self.poisson:
                                 Ke[:, a, s, b, iphi] -= W * nu[s] * kd * dEm[:, b] * prod * phi[a]
             if self.poisson:
@@ -252,7 +292,7 @@ class LFAModel:
                     for b in range(3):
                         Ke[:, a, iphi, b, iphi] += W * GG[:, a, b]
                         for s in range(ns):
-                            Ke[:, a, iphi, b, s] -= W * self.Z[s] * nq[s] \
+                            Ke[:, a, iphi, b, s] -= W * self.Z[s] * dnq[s] \
                                 * elementary_charge / epsilon_0 * phi[a] * phi[b]
 
         # ---- interpolated (Expression) sources -------------------------
@@ -297,14 +337,14 @@ class LFAModel:
                     phi = np.zeros(3)
                     phi[j], phi[k] = 1.0 - t, t
                     rq = self.rnod[c] @ phi
-                    n = np.exp(Uc[c, :, s] @ phi)
+                    n, dn = self._dens(Uc[c, :, s] @ phi)
                     W = w * L * two_pi * rq
                     for a in (j, k):
                         Re[c, a, s] += W * self.Z[s] * muv * En * n * phi[a]
                         if Ke is None:
                             continue
                         for b in range(3):
-                            Ke[c, a, s, b, s] += W * self.Z[s] * muv * En * n * phi[a] * phi[b]
+                            Ke[c, a, s, b, s] += W * self.Z[s] * muv * En * dn * phi[a] * phi[b]
                             dflux = mud * dEm[c, b] * En \
                                 - muv * np.einsum("cd,cd->c", self.G[c, b], nrm)
                             Ke[c, a, s, b, self.neq - 1] += W * self.Z[s] * dflux * n * phi[a]

@@ -464,3 +464,60 @@ def test_streamer_error_log_has_the_structure_of_the_reference_log(n, golden_dir
 
 
 _CHANGE = {}
+
+
+def test_non_logarithmic_representation_matches_the_oracle():
+    """`weak_form_balance_equation(..., log_representation=False)` / `Flux(...,
+    logarithm_representation=False)` (fedm/functions.py:219-237, 350-368): the unknowns are the
+    densities themselves.  PARITY UNPINNED (no reference example, test or golden uses the form):
+    the device element (generic `Element<..., LIN = true>`, both assembly variants) against the
+    oracle's statement of the same integrals, whose Jacobian is checked against finite differences
+    in tests/test_oracle_linear.py; and a Newton solve against the oracle's."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_oracle_linear import _model, _state
+    from oracle import streamer as ost
+    from oracle.mesh import graded_axis, rectangle_right
+    from oracle.newton import newton_solve
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import DeviceProblem, Model, Reaction
+    from fedm_amd.mesh import Marking_boundaries, Mesh
+    from fedm_amd.termsum import TermSum, parse
+    n = 20
+    mesh = rectangle_right(0.0, 0.0, ost.BOX, ost.BOX, n, n, xs=graded_axis(ost.BOX, n, 3.0))
+    omodel = _model(mesh, log=False)
+    lnn, phi = _state(mesh, seed=9)
+    U = np.column_stack([np.exp(lnn), phi])
+    Uo, Uo1 = U * (1.0 + 1e-3), U * (1.0 - 2e-3)
+    dt, dt_old = 5e-12, 4e-12
+    mu = parse(streamer.MU_E)
+    rate = parse(streamer.ALPHA) * mu * TermSum.field()
+    model = Model(n_species=2, poisson=True, eq_type=["reaction", "drift-diffusion-reaction"], Z=[1.0, -1.0],
+                  mu=[TermSum.const(0.0), mu], D=[TermSum.const(0.0), parse(streamer.D_E)],
+                  reactions=[Reaction(rate, power=[0, 1], net=[1, 1])], bc_kind=streamer.BC_TYPE,
+                  quadrature_degree=2, log_representation=False)
+    m = Mesh(mesh.coords, mesh.cells)
+    tags = Marking_boundaries(m, streamer.BOUNDARIES)
+    ddofs, dvals = streamer.dirichlet(m.coords)
+    F_cpu, J_cpu = omodel.residual_jacobian(U, Uo, Uo1, dt, dt_old)
+    scale = np.abs(F_cpu).reshape(-1, 3).max(axis=0)
+    for kind in ("patch", "colour"):                  # LDS patches, global colouring
+        prob = DeviceProblem(m.coords, m.cells, model, facet_tags=tags, dirichlet_dofs=ddofs, dirichlet_vals=dvals)
+        prob.set_assembly(kind)
+        prob.set_state(U, Uo, Uo1)
+        prob.set_step(dt, dt_old)
+        F_gpu, _ = prob.residual()
+        assert (np.abs(F_gpu - F_cpu).reshape(-1, 3) / scale).max() < 1e-11
+        prob.jacobian()
+        assert _rel_rows(prob.jacobian_csr(), J_cpu) < 1e-10
+        if kind == "patch":
+            # one Newton solve from the old state (point-block Jacobi GMRES: no hierarchy installed)
+            prob.set_state(Uo, Uo, Uo1)
+            its, _ = prob.newton_solve(rtol=1e-9, max_it=20, ksp_rtol=1e-12, ksp_max_it=5000)
+            U_gpu = prob.get_state()
+            U_cpu = Uo.copy()
+            its_cpu, _ = newton_solve(omodel, U_cpu, Uo, Uo1, dt, dt_old, 1e-9, 20)
+            assert its == its_cpu
+            assert (np.abs(U_gpu - U_cpu).max(axis=0) / np.abs(U_cpu).max(axis=0)).max() < 1e-8
+        prob.close()
