@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
     const _Float16 *__restrict__ s16, const float *__restrict__ g, const float *__restrict__ zin,
     float *__restrict__ zout32, double *__restrict__ zout, double zs, double omega,
-    const int *__restrict__ slice_list) {
+    const int *__restrict__ slice_list, const double *__restrict__ x0) {
     constexpr int NEQ = NS + 1, PL = NS * NS;
     const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -481,7 +481,59 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
         if (LAST) zout[v * NEQ + r] = zn;
         else zout32[v * NS + r] = (float)zn;
     }
-    if (LAST) zout[v * NEQ + NS] = 0.0;  // full-line stores; the potential entry is set by the V-cycle
+    // full-line stores; the potential entry is the V-cycle's result when that ran first (upper-
+    // triangular order), else it is set by the V-cycle that follows
+    if (LAST) zout[v * NEQ + NS] = x0 ? x0[v] : 0.0;
+}
+
+// Upper-triangular order, first stage: the potential correction x0 = z_phi is known (the V-cycle ran
+// first), the species block sees t_u - J_u,phi z_phi:
+//   g = Duu^-1 (alpha t_u - J_u,phi x0)
+// (compact32: into the single-precision vector the sweeps work on; else z itself, potential entry
+// included -- plain block Jacobi, no sweeps follow).  J_u,phi comes from the fp32 planes.
+template <int NS>
+__global__ __launch_bounds__(256) void fs_species_upper_kernel(
+    int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
+    const float *__restrict__ val32, const double *__restrict__ dinv_uu, const double *__restrict__ t,
+    const double *__restrict__ x0, double *__restrict__ z, double alpha, int compact32,
+    const int *__restrict__ slice_list) {
+    constexpr int NEQ = NS + 1;
+    const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave_id >= n_slices) return;
+    const int slice = slice_list ? slice_list[wave_id] : wave_id;
+    const size_t v = (size_t)slice * SLICE + lane;
+    double tv[NS], acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        tv[s] = alpha * t[v * NEQ + s];  // requested before the gather loop
+        acc[s] = 0.0;
+    }
+    const double own = x0[v];
+    const int b0 = boff[slice], b1 = boff[slice + 1];
+    for (int bc = b0; bc < b1; ++bc) {
+        const double xp = x0[colidx[(size_t)bc * SLICE + lane]];
+        const float *vp = val32 + (size_t)bc * NS * SLICE + lane;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] += (double)vp[(size_t)s * SLICE] * xp;
+    }
+    const double *dp = dinv_uu + (size_t)slice * NS * NS * SLICE + lane;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        double g = 0.0;
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) g += dp[(size_t)(r * NS + cidx) * SLICE] * (tv[cidx] - acc[cidx]);
+        if (compact32) reinterpret_cast<float *>(z)[v * NS + r] = (float)g;
+        else z[v * NEQ + r] = g;
+    }
+    if (!compact32) z[v * NEQ + NS] = own;
+}
+
+// b0 = alpha t_phi: right-hand side of the V-cycle when it runs first
+__global__ void fs_gather_kernel(int nvp, int neq, const double *__restrict__ t, double *__restrict__ b0,
+                                 double alpha) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nvp) b0[v] = alpha * t[(size_t)v * neq + neq - 1];
 }
 
 // b0 -= J_phi,u z_u   (reads only the n_species value planes of the potential row)
@@ -570,7 +622,8 @@ static bool fs_first_compact(const Ctx &c) { return c.fs_sweeps > 1; }
 
 // stages after the first: remaining species sweeps, coupling, V-cycle on the potential block
 template <int NS>
-static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool with_cycle = true) {
+static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool with_cycle = true,
+                        bool upper = false) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
     const dim3 gs((c.pat.n_slices + 3) / 4);
     const int n_sweeps = (c.fs_sweeps < 1 ? 1 : c.fs_sweeps) - 1;
@@ -596,10 +649,12 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
         const dim3 g((n + 3) / 4);
         if (last)
             hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true>), g, dim3(256), 0, c.stream, n, c.d_slice_boff,
-                               c.d_colidx, c.d_s16, g32, in_, (float *)nullptr, z, zs, w, list);
+                               c.d_colidx, c.d_s16, g32, in_, (float *)nullptr, z, zs, w, list,
+                               upper ? (const double *)amg.levels[0].x : (const double *)nullptr);
         else
             hipLaunchKernelGGL((fs_species_sweep_kernel<NS, false>), g, dim3(256), 0, c.stream, n, c.d_slice_boff,
-                               c.d_colidx, c.d_s16, g32, in_, out32, (double *)nullptr, zs, w, list);
+                               c.d_colidx, c.d_s16, g32, in_, out32, (double *)nullptr, zs, w, list,
+                               (const double *)nullptr);
     };
     for (int s = 1; s <= n_sweeps; ++s) {
         const double zs = s == 1 ? c.fs_w[0] : 1.0;
@@ -616,11 +671,43 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
         }
         if (!last) in = out;
     }
+    if (upper) return;  // the potential came first
     hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
                        c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
     if (!with_cycle) return;  // the caller runs the V-cycle (collectives inside it) and scatters
     amg.run(c);
     if (scatter) hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
+}
+
+bool fieldsplit_upper(const Ctx &c) { return c.fs_upper && (c.right_precond || c.comm) && c.amg && c.poisson; }
+
+// upper-triangular order, part 1: z_phi = V-cycle(alpha t_phi) into amg.levels[0].x (ghost entries
+// from their owners across GPUs: the coupling product reads them)
+void fieldsplit_upper_potential(Ctx &c, Amg &amg, const double *t, double alpha) {
+    hipLaunchKernelGGL(fs_gather_kernel, dim3((c.nvp + 255) / 256), dim3(256), 0, c.stream, c.nvp, c.neq, t,
+                       amg.levels[0].b, alpha);
+    amg.run(c);
+    if (c.comm && !c.capturing) comm_halo_scalar(c, amg.levels[0].x);
+}
+
+// part 2: species sweeps on alpha t_u - J_u,phi z_phi; the last one writes z, potential entry included
+template <int NS>
+static void fs_upper_species_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+    const dim3 gs((c.pat.n_slices + 3) / 4);
+    hipLaunchKernelGGL(fs_species_upper_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices, c.d_slice_boff,
+                       c.d_colidx, c.d_val32, c.d_dinv, t, amg.levels[0].x, fs_first_target(c, z), alpha,
+                       fs_first_compact(c) ? 1 : 0, (const int *)nullptr);
+    if (fs_first_compact(c)) fs_finish_t<NS>(c, amg, z, false, false, true);
+}
+
+void fieldsplit_upper_species(Ctx &c, Amg &amg, const double *t, double *z, double alpha) {
+    switch (c.ns) {
+        case 1: fs_upper_species_t<1>(c, amg, t, z, alpha); break;
+        case 2: fs_upper_species_t<2>(c, amg, t, z, alpha); break;
+        case 3: fs_upper_species_t<3>(c, amg, t, z, alpha); break;
+        case 4: fs_upper_species_t<4>(c, amg, t, z, alpha); break;
+        case 5: fs_upper_species_t<5>(c, amg, t, z, alpha); break;
+    }
 }
 
 template <int NS>
@@ -643,6 +730,11 @@ void fieldsplit_scatter(Ctx &c, Amg &amg, double *z) {
 }
 
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter, bool with_cycle) {
+    if (fieldsplit_upper(c)) {  // (scatter / with_cycle belong to the lower-triangular order)
+        fieldsplit_upper_potential(c, amg, t, alpha);
+        fieldsplit_upper_species(c, amg, t, z, alpha);
+        return;
+    }
     switch (c.ns) {
         case 1: fs_apply_t<1>(c, amg, t, z, alpha, scatter, with_cycle); break;
         case 2: fs_apply_t<2>(c, amg, t, z, alpha, scatter, with_cycle); break;
@@ -690,7 +782,8 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
                                                              const double *__restrict__ val,
                                                              const uint32_t *__restrict__ diag_slot,
                                                              double *__restrict__ dinv_uu,
-                                                             _Float16 *__restrict__ s16, float *__restrict__ val32) {
+                                                             _Float16 *__restrict__ s16, float *__restrict__ val32,
+                                                             int upper) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -730,7 +823,8 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
             }
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx)
-            val32[((size_t)bc * NS + cidx) * SLICE + lane] = (float)vp[(size_t)(NS * NEQ + cidx) * SLICE];
+            val32[((size_t)bc * NS + cidx) * SLICE + lane] =
+                (float)vp[(size_t)(upper ? cidx * NEQ + NS : NS * NEQ + cidx) * SLICE];
     }
 }
 
@@ -747,7 +841,7 @@ void fieldsplit_setup(Ctx &c) {
     const dim3 gs((c.pat.n_slices + 3) / 4);
 #define FEDM_PLANES(NS_)                                                                                   \
     hipLaunchKernelGGL(species_planes_kernel<NS_>, gs, b, 0, c.stream, c.pat.n_slices, c.d_slice_boff, c.d_val, \
-                       c.d_diag_slot, c.d_dinv, c.d_s16, c.d_val32)
+                       c.d_diag_slot, c.d_dinv, c.d_s16, c.d_val32, fieldsplit_upper(c) ? 1 : 0)
     switch (c.ns) {
         case 1: FEDM_PLANES(1); break;
         case 2: FEDM_PLANES(2); break;

@@ -79,6 +79,9 @@ void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
 // after the coupling product (the caller runs the V-cycle, whose right-hand side is ready)
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter = true,
                       bool with_cycle = true);
+bool fieldsplit_upper(const Ctx &c);  // upper-triangular order in force (Ctx::fs_upper, split on the right)
+void fieldsplit_upper_potential(Ctx &c, Amg &amg, const double *t, double alpha);
+void fieldsplit_upper_species(Ctx &c, Amg &amg, const double *t, double *z, double alpha);
 void fieldsplit_scatter(Ctx &c, Amg &amg, double *z);  // potential component of z <- the V-cycle's result
 // z = Minv (J v); scatter = false leaves the potential component in amg.levels[0].x
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter);

@@ -297,8 +297,10 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         c.iter_graph_pre.resize(j + 1, nullptr);
     }
     // the V-cycle's last sweep writes the potential component of z itself (V(nu,nu) with more
-    // than one level); otherwise a scatter kernel does
-    const bool direct = c.amg->pre_smooth && c.amg->levels.size() > 1;
+    // than one level); otherwise a scatter kernel does.  Upper-triangular order: the V-cycle comes
+    // first and the last species sweep writes the whole of z.
+    const bool upper = fieldsplit_upper(c);
+    const bool direct = !upper && c.amg->pre_smooth && c.amg->levels.size() > 1;
     auto with_direct_output = [&](const std::function<void()> &f) {
         if (direct) {
             c.amg->out = z;
@@ -324,7 +326,8 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
             Comm &cm = *c.comm;
             const bool cycle_inside = !c.amg->global;  // no collectives in the V-cycle
             ok = capture_graph(c, &c.iter_graph_pre[j], [&] {
-                with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct, cycle_inside); });
+                if (upper) fieldsplit_upper_species(c, *c.amg, vp[j], z, 1.0);  // the V-cycle and its halo come before
+                else with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct, cycle_inside); });
             });
             if (cm.n_interior)
                 ok = ok && capture_graph(c, &c.iter_graph_interior[j], [&] {
@@ -349,7 +352,18 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         ++c.mail_seq;
         return true;
     }
-    if (c.fs_halo) {
+    if (upper) {
+        // potential first (the V-cycle with its collectives, then the ghost entries of its result),
+        // then the species part: plain launches with the exchanges between the sweeps, or its graph
+        fieldsplit_upper_potential(c, *c.amg, vp[j], 1.0);
+        if (c.fs_halo) {
+            fieldsplit_upper_species(c, *c.amg, vp[j], z, 1.0);
+        } else if (hipGraphLaunch(c.iter_graph_pre[j], c.stream) != hipSuccess) {
+            hipGetLastError();
+            c.iter_graphs_ok = false;
+            fieldsplit_upper_species(c, *c.amg, vp[j], z, 1.0);  // same result with plain launches
+        }
+    } else if (c.fs_halo) {
         // exchanges between the sweeps: the rank-local part of the preconditioner is not one graph
         with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct, !c.amg->global); });
     } else if (hipGraphLaunch(c.iter_graph_pre[j], c.stream) != hipSuccess) {
@@ -357,7 +371,7 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         c.iter_graphs_ok = false;
         return false;  // nothing has been communicated yet: the caller repeats the step plainly
     }
-    if (c.amg->global) {  // V-cycle with its collectives
+    if (!upper && c.amg->global) {  // V-cycle with its collectives
         with_direct_output([&] { c.amg->run(c); });
         if (!direct) fieldsplit_scatter(c, *c.amg, z);
     }
@@ -981,6 +995,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
                 }
         }
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
+        if (const char *e = getenv("FEDM_FS_ORDER")) c.fs_upper = std::string(e) != "lower";
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;
         if (side && std::string(side) == "right") c.right_precond = true;
@@ -1678,6 +1693,20 @@ int fedm_set_preconditioner_side(fedm_ctx *h, int right) {
         hipStreamSynchronize(c.stream);
         iter_graphs_clear(c);  // captured for the other variant
         c.right_precond = right == 1;
+    }
+    return 0;
+}
+
+int fedm_set_fieldsplit_order(fedm_ctx *h, int upper) {
+    Ctx &c = h->c;
+    if (upper != 0 && upper != 1) {
+        set_error("field-split order must be 0 (lower) or 1 (upper)");
+        return -2;
+    }
+    if (c.fs_upper != (upper == 1)) {
+        hipStreamSynchronize(c.stream);
+        iter_graphs_clear(c);  // captured for the other order
+        c.fs_upper = upper == 1;
     }
     return 0;
 }

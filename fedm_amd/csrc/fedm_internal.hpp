@@ -120,7 +120,9 @@ struct Ctx {
     double *d_val = nullptr;
     double *d_dinv = nullptr;  // sliced: [(slice*NEQ2 + e)*64 + lane]
     // copies for the field-split preconditioner (species_planes_kernel):
-    float *d_val32 = nullptr;   // potential row's species columns J_phi,u in fp32: [(bc*NS + c)*64 + lane]
+    float *d_val32 = nullptr;   // coupling planes in fp32, [(bc*NS + c)*64 + lane]: the potential row's species
+                                // columns J_phi,u (lower-triangular order) or the species rows' potential
+                                // column J_u,phi (upper-triangular order, fs_upper)
     _Float16 *d_s16 = nullptr;  // Duu^-1 J_uu in fp16: [(bc*NS*NS + r*NS + c)*64 + lane]
     // Dirichlet
     int n_dir = 0;
@@ -136,6 +138,13 @@ struct Ctx {
     double fs_main_w[16] = {1}, fs_alt_w[16] = {1};
     bool fs_alt_active = false;
     bool fs_halo = true;    // several GPUs: ghost exchange of the species iterate before every sweep
+    // Order of the block-triangular split when it sits on the right of the operator.  Upper: the
+    // V-cycle on the potential block first, then the species sweeps on t_u - J_u,phi z_phi (the drift
+    // terms' dependence on the potential is the strong coupling: 3-4 instead of 8 Krylov steps per
+    // Newton system once the streamer has formed, tests/studies/precond_structure.py).  Lower: species
+    // first, potential right-hand side minus J_phi,u z_u (what the left-preconditioned path, whose
+    // first stage is the SpMV's epilogue, always uses).  FEDM_FS_ORDER=lower|upper.
+    bool fs_upper = true;
     double fs_switch_above = 5.0, fs_back_below = 3.5;
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;

@@ -266,11 +266,13 @@ int fedm_amg_set_global_hierarchy(fedm_ctx *ctx, int n_global, int offset, int n
 /* Richardson sweeps z += w_k Duu^-1 (r - Juu z) on the species block inside the field split;
  * one weight per sweep (equal weights = damped block Jacobi, Chebyshev roots = polynomial) */
 int fedm_set_fieldsplit(fedm_ctx *ctx, int sweeps, const double *weights);
-/* A second, cheaper set of sweeps for hard systems: after a Newton solve that needed at least
+/* A second set of sweeps for hard systems: after a Newton solve that needed at least
  * `switch_above` Krylov steps per Newton iteration the field split uses the alternative set, after
  * one that needed at most `back_below` the set of fedm_set_fieldsplit again (which also resets this).
- * A long polynomial pays while it saves whole Krylov steps; once the potential block limits the
- * convergence it only costs.  alt_sweeps = 0 switches the rule off. */
+ * A long polynomial pays while it saves whole Krylov steps: with the potential first in the split
+ * (fedm_set_fieldsplit_order) the species polynomial decides the Krylov count and the alternative is
+ * a HIGHER degree; with the species first the potential block limits the convergence late in a run
+ * and the alternative is a cheaper one.  alt_sweeps = 0 switches the rule off. */
 int fedm_set_fieldsplit_alternative(fedm_ctx *ctx, int alt_sweeps, const double *alt_weights,
                                     double switch_above, double back_below);
 /* host-side greedy aggregation on a strength graph (set-up helper, no GPU needed) */
@@ -342,6 +344,11 @@ int fedm_set_assembly(fedm_ctx *ctx, int kind);
  * is always on the right).  Both solve J delta = -F to ksp_rtol.
  * Environment: FEDM_PRECOND_SIDE=left|right sets the default of new contexts. */
 int fedm_set_preconditioner_side(fedm_ctx *ctx, int right);
+/* order of the block-triangular field split when it sits on the right: 1 = upper (default: V-cycle on
+ * the potential block first, then the species sweeps on t_u - J_u,phi z_phi), 0 = lower (species
+ * first, potential right-hand side minus J_phi,u z_u).  The left-preconditioned path is always lower.
+ * Takes effect with the next Jacobian assembly.  Environment: FEDM_FS_ORDER=lower|upper. */
+int fedm_set_fieldsplit_order(fedm_ctx *ctx, int upper);
 /* sizes the roofline model needs */
 int fedm_sizes(fedm_ctx *ctx, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq,
                int64_t *nnz_blocks, int64_t *stored_blocks, int64_t *n_colours);
