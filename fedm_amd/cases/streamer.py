@@ -106,14 +106,13 @@ def initialise(prob, multigrid=True):
     if multigrid:
         prob.setup_multigrid(**MULTIGRID)
         # species block ~ diagonally scaled P1 mass matrix (spectrum in [0.5, 2]): a Chebyshev
-        # polynomial in Duu^-1 Juu instead of plain block Jacobi.  With the potential first in the
-        # block-triangular split (the library's default order on the right) the species polynomial
-        # is what the Krylov count depends on: degree 6 makes a Newton system cost 2 Krylov steps
-        # early in the run (degree 4: 3); once the streamer has formed degree 6 needs 4 and degree 8
-        # needs 3 (the species-first order of round 1: 8): the library switches on the count
-        # (tools/fs_order.py, tests/studies/precond_structure.py)
+        # polynomial in Duu^-1 Juu instead of plain block Jacobi.  Degree 6 makes a Newton system
+        # cost 2 Krylov steps early in the run (degree 4: 3, block Jacobi: 5); later the potential
+        # block limits the convergence (8-9 steps whatever the degree) and degree 4 is cheaper:
+        # the library switches on the iteration count (tools/fs_sweeps.py).  (The potential-first
+        # order of the split halves the late count but not the error: tools/fs_order_accuracy.py.)
         from ..device import chebyshev_weights
-        prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(8), switch_above=3.4, back_below=2.2)
+        prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(4))
     its = prob.poisson_solve(rtol=1e-12)
     U = prob.get_state()
     prob.set_state(U, U, U)

@@ -110,7 +110,7 @@ class Runner(streamer.Stepper):
             prob.setup_multigrid_distributed(self.lm, self._group, **streamer.MULTIGRID)
         else:
             prob.setup_multigrid(**streamer.MULTIGRID)
-        prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(8), switch_above=3.4, back_below=2.2)
+        prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(4))
         its = prob.poisson_solve(rtol=1e-12)
         U = prob.get_state()
         prob.set_state(U, U, U)

@@ -995,7 +995,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
                 }
         }
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
-        if (const char *e = getenv("FEDM_FS_ORDER")) c.fs_upper = std::string(e) != "lower";
+        if (const char *e = getenv("FEDM_FS_ORDER")) c.fs_upper = std::string(e) == "upper";
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;
         if (side && std::string(side) == "right") c.right_precond = true;

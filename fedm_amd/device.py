@@ -634,8 +634,8 @@ class DeviceProblem:
 
     def set_fieldsplit(self, weights=(0.8, 0.8, 0.8), hard_weights=None, switch_above=5.0, back_below=3.5):
         """Richardson weights of the species-block sweeps; :func:`chebyshev_weights` gives the
-        optimal ones for a spectrum interval of Duu^-1 Juu.  `hard_weights`: a second set (a higher
-        degree with the potential-first order, a cheaper one with the species-first order) used
+        optimal ones for a spectrum interval of Duu^-1 Juu.  `hard_weights`: a second set (a cheaper
+        one with the default species-first order, a higher degree with the potential-first order) used
         while Newton solves need >= `switch_above` Krylov steps per Newton iteration (until one
         needs <= `back_below` again)."""
         w = np.ascontiguousarray(weights, dtype=np.float64)
@@ -683,9 +683,12 @@ class DeviceProblem:
         self._check(self.lib.fedm_set_preconditioner_side(self._h, code), "fedm_set_preconditioner_side")
 
     def set_fieldsplit_order(self, order):
-        """'upper' (default: V-cycle on the potential block first, species sweeps on the residual
-        minus J_u,phi z_phi) or 'lower' (species first); order of the block-triangular split when it
-        is on the right of the operator.  Takes effect with the next Jacobian assembly."""
+        """'lower' (default: species first; the true residual tracks the error of the iterate) or
+        'upper' (V-cycle on the potential block first, species sweeps on the residual minus
+        J_u,phi z_phi: the residual test passes in half the Krylov steps late in a streamer run, but
+        the potential is left at V-cycle accuracy -- include/fedm_hip.h); order of the
+        block-triangular split when it is on the right of the operator.  Takes effect with the next
+        Jacobian assembly."""
         code = {"lower": 0, "upper": 1}[order]
         self._check(self.lib.fedm_set_fieldsplit_order(self._h, code), "fedm_set_fieldsplit_order")
 

@@ -270,9 +270,9 @@ int fedm_set_fieldsplit(fedm_ctx *ctx, int sweeps, const double *weights);
  * `switch_above` Krylov steps per Newton iteration the field split uses the alternative set, after
  * one that needed at most `back_below` the set of fedm_set_fieldsplit again (which also resets this).
  * A long polynomial pays while it saves whole Krylov steps: with the potential first in the split
- * (fedm_set_fieldsplit_order) the species polynomial decides the Krylov count and the alternative is
- * a HIGHER degree; with the species first the potential block limits the convergence late in a run
- * and the alternative is a cheaper one.  alt_sweeps = 0 switches the rule off. */
+ * (fedm_set_fieldsplit_order, opt-in) the species polynomial decides the Krylov count and the
+ * alternative is a HIGHER degree; with the species first (default) the potential block limits the
+ * convergence late in a run and the alternative is a cheaper one.  alt_sweeps = 0 switches the rule off. */
 int fedm_set_fieldsplit_alternative(fedm_ctx *ctx, int alt_sweeps, const double *alt_weights,
                                     double switch_above, double back_below);
 /* host-side greedy aggregation on a strength graph (set-up helper, no GPU needed) */
@@ -344,9 +344,16 @@ int fedm_set_assembly(fedm_ctx *ctx, int kind);
  * is always on the right).  Both solve J delta = -F to ksp_rtol.
  * Environment: FEDM_PRECOND_SIDE=left|right sets the default of new contexts. */
 int fedm_set_preconditioner_side(fedm_ctx *ctx, int right);
-/* order of the block-triangular field split when it sits on the right: 1 = upper (default: V-cycle on
- * the potential block first, then the species sweeps on t_u - J_u,phi z_phi), 0 = lower (species
- * first, potential right-hand side minus J_phi,u z_u).  The left-preconditioned path is always lower.
+/* Order of the block-triangular field split when it sits on the right of the operator (the
+ * left-preconditioned path is always lower):
+ *   0 = lower (default): species sweeps first, then the V-cycle on the potential right-hand side
+ *       minus J_phi,u z_u.  The true residual tracks the error of the iterate.
+ *   1 = upper: V-cycle on the potential block first, then the species sweeps on t_u - J_u,phi z_phi.
+ *       Passes the residual test in 3-4 instead of 8 Krylov steps once a streamer has formed, but
+ *       leaves the potential at V-cycle accuracy: the unscaled residual norm (PETSc's and this
+ *       library's test) is dominated by the species rows and does not see the Poisson row.  2x
+ *       faster late in a run, 4e-3 instead of 6e-6 deviation from a tightly solved run after 220
+ *       steps of the bench case (tools/fs_order_accuracy.py): an explicit trade, not the default.
  * Takes effect with the next Jacobian assembly.  Environment: FEDM_FS_ORDER=lower|upper. */
 int fedm_set_fieldsplit_order(fedm_ctx *ctx, int upper);
 /* sizes the roofline model needs */

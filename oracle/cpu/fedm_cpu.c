@@ -14,8 +14,7 @@
  *   Newton with PETSc SNES newtonls/basic rules                                fedm/functions.py:1047
  *   flexible GMRES(m), preconditioner on the right: field split --
  *     Chebyshev/Richardson sweeps with the point-block diagonal on the species block,
- *     smoothed-aggregation V(1,1) cycle on the (constant) potential block, coupled upper-triangularly
- *     (potential first, species on t_u - J_u,phi z_phi)
+ *     smoothed-aggregation V(1,1) cycle on the (constant) potential block, coupled lower-triangularly
  *   error norm of adaptive_solver                                               fedm/functions.py:1062-1064
  *
  * Its residual and Jacobian are checked against oracle/forms.py (numpy) in tests/test_cpu_backend.py.
@@ -628,30 +627,15 @@ static void fieldsplit_setup(cpu_ctx *c) {
 static void fieldsplit_apply(cpu_ctx *c, const double *t, double *z) {
     const int ns = c->ns, neq = c->neq, neq2 = neq * neq, nv = c->nv;
     double *g = c->g, *zt = c->tmp;
-    /* upper-triangular order (what the device library does): one V-cycle on the potential block
-     * first, z_phi = V(t_phi) ... */
+    /* first stage: g = Duu^-1 t_u, z_u = w0 g */
 #pragma omp parallel for schedule(static)
-    for (int v = 0; v < nv; ++v) c->lev[0].b[v] = t[(size_t)v * neq + ns];
-    c->vcycle_count++;
-    vcycle(c, 0);
-    const double *x0 = c->lev[0].x;
-    /* ... then the species block on t_u - J_u,phi z_phi.  First stage: g = Duu^-1 (t_u - J_u,phi z_phi),
-     * z_u = w0 g */
-#pragma omp parallel for schedule(static)
-    for (int v = 0; v < nv; ++v) {
-        double tu[MAXS];
-        for (int q = 0; q < ns; ++q) tu[q] = t[(size_t)v * neq + q];
-        for (int64_t k = c->rowptr[v]; k < c->rowptr[v + 1]; ++k) {
-            const double *blk = c->val + (size_t)k * neq2, xp = x0[c->col[k]];
-            for (int q = 0; q < ns; ++q) tu[q] -= blk[q * neq + ns] * xp;
-        }
+    for (int v = 0; v < nv; ++v)
         for (int r = 0; r < ns; ++r) {
             double s = 0.0;
-            for (int q = 0; q < ns; ++q) s += c->dinv_uu[((size_t)v * ns + r) * ns + q] * tu[q];
+            for (int q = 0; q < ns; ++q) s += c->dinv_uu[((size_t)v * ns + r) * ns + q] * t[(size_t)v * neq + q];
             g[(size_t)v * neq + r] = s;
             z[(size_t)v * neq + r] = c->cheb_w[0] * s;
         }
-    }
     /* sweeps: z <- z + w (g - Duu^-1 J_uu z) */
     for (int sw = 1; sw < c->cheb_n; ++sw) {
         const double w = c->cheb_w[sw];
@@ -671,6 +655,20 @@ static void fieldsplit_apply(cpu_ctx *c, const double *t, double *z) {
 #pragma omp parallel for schedule(static)
         for (int v = 0; v < nv; ++v) for (int r = 0; r < ns; ++r) z[(size_t)v * neq + r] = zt[(size_t)v * neq + r];
     }
+    /* coupling: b_phi = t_phi - J_phi,u z_u; then one V-cycle */
+    double *b0 = c->lev[0].b;
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < nv; ++v) {
+        double s = 0.0;
+        for (int64_t k = c->rowptr[v]; k < c->rowptr[v + 1]; ++k) {
+            const double *blk = c->val + (size_t)k * neq2 + ns * neq, *zj = z + (size_t)c->col[k] * neq;
+            for (int q = 0; q < ns; ++q) s += blk[q] * zj[q];
+        }
+        b0[v] = t[(size_t)v * neq + ns] - s;
+    }
+    c->vcycle_count++;
+    vcycle(c, 0);
+    const double *x0 = c->lev[0].x;
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < nv; ++v) z[(size_t)v * neq + ns] = x0[v];
 }

@@ -108,6 +108,38 @@ V22 = make_cycle(lv, [(2, 2)] * nl)
 C22 = make_cycle(lv, [(2, 2)] * nl, cheb_frac=8.0)
 C33 = make_cycle(lv, [(3, 3)] * nl, cheb_frac=10.0)
 lpp = spla.splu(Jpp0.tocsc())
+V10 = make_cycle(lv, [(1, 0)] * nl)
+V01 = make_cycle(lv, [(0, 1)] * nl)
+dinv0 = 1.0 / Jpp0.diagonal()
+
+
+def truncated(levels_kept, sweeps):
+    """V(1,1) on the first levels; the last kept level gets `sweeps` damped-Jacobi sweeps instead of a solve"""
+    sub = lv[:levels_kept]
+    A_last = lv[levels_kept - 1][0]
+    dl = 1.0 / A_last.diagonal()
+
+    def cyc(l, b):
+        a, p = lv[l]
+        if l == levels_kept - 1:
+            x = 0.85 * dl * b
+            for _ in range(sweeps - 1):
+                x = x + 0.85 * dl * (b - a @ x)
+            return x
+        d = 1.0 / a.diagonal()
+        x = 0.85 * d * b
+        x = x + p @ cyc(l + 1, p.T @ (b - a @ x))
+        return x + 0.85 * d * (b - a @ x)
+    return lambda b: cyc(0, b)
+
+
+def jacobi_only(k):
+    def f(b):
+        x = 0.85 * dinv0 * b
+        for _ in range(k - 1):
+            x = x + 0.85 * dinv0 * (b - Jpp0 @ x)
+        return x
+    return f
 
 
 def study(J, F, label):
@@ -201,11 +233,22 @@ def study(J, F, label):
     run("upper: exact potential, then Chebyshev(4)", upper(4, lpp.solve))
     run("upper: V(1,1), then Chebyshev(3)", upper(3, V11))
     run("upper: V(1,1), then Chebyshev(2)", upper(2, V11))
+    run("upper: V(1,1), then Chebyshev(8)", upper(8, V11))
+    run("upper: exact potential, then Chebyshev(8)", upper(8, lpp.solve))
+    run("upper: V(1,0), then Chebyshev(8)", upper(8, V10))
+    run("upper: V(0,1), then Chebyshev(8)", upper(8, V01))
+    run("upper: V(2,2) Chebyshev, then Chebyshev(8)", upper(8, C22))
+    run("upper: two levels, 2 Jacobi sweeps on level 1, then Chebyshev(8)", upper(8, truncated(2, 2)))
+    run("upper: two levels, 4 Jacobi sweeps on level 1, then Chebyshev(8)", upper(8, truncated(2, 4)))
+    if nl >= 2:
+        run("upper: three levels, 2 Jacobi sweeps on level 2, then Chebyshev(8)", upper(8, truncated(3, 2)))
+    run("upper: 2 Jacobi sweeps (no multigrid), then Chebyshev(8)", upper(8, jacobi_only(2)))
+    run("upper: exact potential, exact species", lambda r: (lambda zp: join(luu.solve(r[iu] - Jup @ zp), zp))(lpp.solve(r[ip])))
     run("approximate upper (zu -= D^-1 Jup zp): Chebyshev(4), V(1,1)", approx_upper(4, V11))
     run("lower + approximate upper factor: Chebyshev(4), V(1,1)", ldu_approx(4, V11))
     run("lower + approximate upper factor: Chebyshev(4), exact potential", ldu_approx(4, lpp.solve))
 
 
-for k, (J, F) in enumerate(systems):
+for k, (J, F) in enumerate(systems if "noexec" not in sys.argv else []):
     print(f"Newton system {k}: |F| = {np.linalg.norm(F):.3e}", flush=True)
     study(J, F, f"[{k}]")

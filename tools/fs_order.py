@@ -1,7 +1,8 @@
 """Order of the block-triangular field split (lower: species first; upper: potential first) and the
 degree of the species polynomial, early (steps 6..25) and late (from step 201) in the bench run.
 python tools/fs_order.py [n=576] [late_start=200]     (tests/studies/precond_structure.py is the
-CPU study behind it).  Round-2 results: DESIGN.md section 4."""
+CPU study behind it; tools/fs_order_accuracy.py shows what the faster order costs in accuracy).
+Round-2 results: DESIGN.md section 4."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -15,7 +16,7 @@ prob = streamer.device_problem(msh.coords, msh.cells)
 st = streamer.Stepper(prob)
 st.initialise()
 
-CONFIGS = [("lower, Chebyshev(6) / (4) when hard  [round-1 default]", "lower", 6, 4),
+CONFIGS = [("lower, Chebyshev(6) / (4) when hard  [default]", "lower", 6, 4),
            ("upper, Chebyshev(6)", "upper", 6, None),
            ("upper, Chebyshev(6) / (4) when hard", "upper", 6, 4),
            ("upper, Chebyshev(4)", "upper", 4, None),
@@ -44,8 +45,8 @@ for _ in range(5):
 print(f"early window (t = {st.t:.2e} s)", flush=True)
 for cfg in CONFIGS:
     measure(*cfg, steps=10)
-prob.set_fieldsplit_order("upper")
-prob.set_fieldsplit(chebyshev_weights(6))
+prob.set_fieldsplit_order("lower")
+prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(4))
 while st.t < late * 5e-12:
     st.step()
 print(f"late window (t = {st.t:.2e} s); every variant starts from the same stored state", flush=True)
