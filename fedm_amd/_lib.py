@@ -143,6 +143,8 @@ _SIGNATURES = {
     "fedm_jacobian_poisson_only": (C.c_int, [_P]),
     "fedm_amg_setup": (C.c_int, [_P, C.c_int, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), _D,
                                  C.c_int, C.c_double]),
+    "fedm_amg_setup_poly": (C.c_int, [_P, C.c_int, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), _D,
+                                      C.c_int, _D, C.c_int]),
     "fedm_amg_clear": (C.c_int, [_P]),
     "fedm_amg_set_global_hierarchy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(Csr), C.POINTER(Csr),
                                                  C.POINTER(Csr), _D, C.c_int, C.c_double]),

@@ -154,6 +154,43 @@ def install(handle, levels, nu=2, omega=0.67, dense_coarse=True):
     return [a.shape[0] for a, _ in levels]
 
 
+def chebyshev_smoother_weights(levels, degree, fraction=8.0, safety=1.05, power_iterations=40):
+    """Richardson weights (reciprocals of the Chebyshev roots on [lambda_max / fraction, lambda_max]
+    of Dinv A, lambda_max from a power iteration) for every level but the coarsest: array
+    [n_levels - 1, degree]."""
+    out = np.empty((len(levels) - 1, degree))
+    rng = np.random.default_rng(0)
+    k = np.arange(1, degree + 1)
+    for l, (A, _) in enumerate(levels[:-1]):
+        dinv = 1.0 / A.diagonal()
+        x = rng.standard_normal(A.shape[0])
+        lam = 1.0
+        for _ in range(power_iterations):
+            y = dinv * (A @ x)
+            lam = float(np.linalg.norm(y) / np.linalg.norm(x))
+            x = y / np.linalg.norm(y)
+        hi = safety * lam
+        lo = hi / fraction
+        out[l] = 1.0 / (0.5 * (hi + lo) + 0.5 * (hi - lo) * np.cos((2 * k - 1) * np.pi / (2 * degree)))
+    return out
+
+
+def install_poly(handle, levels, degree=2, fraction=8.0, alternative=False, weights=None):
+    """The hierarchy of :func:`build_hierarchy` with a Chebyshev polynomial smoother of `degree`
+    sweeps per leg (``fedm_amg_setup_poly``); `alternative`: next to the installed V-cycle, for
+    the Newton solves that need many Krylov steps."""
+    lib = _lib.load()
+    n, A, P, R, coarse, keep = _pack(levels, True)
+    if weights is None:
+        weights = chebyshev_smoother_weights(levels, degree, fraction)
+    w = np.ascontiguousarray(np.broadcast_to(np.asarray(weights, dtype=np.float64), (len(levels) - 1, degree)))
+    rc = lib.fedm_amg_setup_poly(handle, n, A, P, R, coarse.ctypes.data_as(C.POINTER(C.c_double)), int(degree),
+                                 w.ctypes.data_as(C.POINTER(C.c_double)), 1 if alternative else 0)
+    if rc != 0:
+        raise RuntimeError(f"fedm_amg_setup_poly failed ({rc}): {_lib.last_error()}")
+    return [a.shape[0] for a, _ in levels]
+
+
 def install_global(handle, levels, n_global, offset, nu=2, omega=0.67):
     """Several GPUs: the replicated hierarchy below the rank-local finest level."""
     lib = _lib.load()

@@ -95,7 +95,10 @@ def device_problem(coords, cells, device=0, **model_kw):
 # V(1,1): as effective as V(2,2) here at 75 % of the cost; Jacobi damping 0.85 instead of the
 # default 2/3: the same 6 Krylov steps per time step early in the run, 35 instead of 38 later
 # (tools/omega_sweep.py; 0.95: 40)
-MULTIGRID = dict(nu=1, omega=0.85)
+# V(1,1) with damped Jacobi; next to it a cycle with two Chebyshev sweeps per leg for the Newton
+# solves that need many Krylov steps (once the streamer has formed: 27 instead of 37 Krylov steps
+# per time step for 29 us more per cycle, tools/poly_cycle.py)
+MULTIGRID = dict(nu=1, omega=0.85, hard_poly_degree=2)
 
 
 def initialise(prob, multigrid=True):

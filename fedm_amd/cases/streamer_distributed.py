@@ -107,7 +107,9 @@ class Runner(streamer.Stepper):
         U[:, 0], U[:, 1] = streamer.initial_log_densities(prob.coords)
         prob.set_state(U, U, U)
         if self.world_size > 1:
-            prob.setup_multigrid_distributed(self.lm, self._group, **streamer.MULTIGRID)
+            # (the distributed finest level keeps the V(1,1) cycle: no alternative for hard systems)
+            prob.setup_multigrid_distributed(self.lm, self._group, nu=streamer.MULTIGRID["nu"],
+                                             omega=streamer.MULTIGRID["omega"])
         else:
             prob.setup_multigrid(**streamer.MULTIGRID)
         prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(4))

@@ -263,6 +263,26 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
         if (up) ell_launch(c, L.GQ, 0, L.b, nullptr, L.x, 0.0);                // [b ; x_c] -> x
         return;
     }
+    if (poly) {
+        // finest level of a polynomial-smoother hierarchy (one GPU): leg down as one product
+        // b_c = R (I - A S) b; leg up x = S b + P x_c as one product on [b ; x_c] (the next level's x
+        // is the tail of this level's b), then the k sweeps backwards.  k buffer swaps must end in L.x.
+        if (down) ell_launch(c, L.C, 0, L.b, nullptr, levels[l + 1].b, 0.0);
+        vcycle(c, l + 1, phase);
+        if (!up) return;
+        const int k = (int)L.w.size();
+        double *x = (k % 2 == 0) ? L.x : L.x2, *y = (k % 2 == 0) ? L.x2 : L.x;
+        ell_launch(c, L.S, 0, L.b, nullptr, x, 0.0);  // [S | P] on [b ; x_c]
+        for (int s_ = k - 1; s_ >= 0; --s_) {
+            if (l == 0 && s_ == 0 && out) {
+                ell_launch(c, L.A, 2, x, L.b, out, L.w[s_], nullptr, out_stride, out_offset);
+                break;
+            }
+            ell_launch(c, L.A, 2, x, L.b, y, L.w[s_]);
+            std::swap(x, y);
+        }
+        return;
+    }
     const int np = L.A.n_rows_p;
     double *x = L.x2, *y = L.x;  // x: current iterate, y: the other buffer
     if (!pre_smooth) {
@@ -378,6 +398,7 @@ void Amg::release() {
         L.R.release();
         L.C.release();
         L.GQ.release();
+        L.S.release();
         if (L.x_is_alias) L.x = nullptr;
         for (double *p : {L.x, L.x2, L.b, L.r})
             if (p) hipFree(p);

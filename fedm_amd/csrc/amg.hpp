@@ -38,6 +38,13 @@ struct Amg {
         // prolongation and sweep, the prolongation kernel forming x = w Dinv b + P x_c itself
         bool down_composite = false;
         bool x_is_alias = false;   // x points into the previous level's b
+        // Polynomial smoother (Amg::poly): k Richardson sweeps x += w_i Dinv (b - A x), weights w in
+        // the order of the pre-smoother (the post-smoother runs them backwards: a symmetric cycle).
+        // From a zero guess the pre-smoother is one product x = S b, S = (I - prod(I - w_i Dinv A)) Ainv
+        // (sparsity of A^(k-1)); composite levels fold S into C and GQ, the finest level streams
+        // [S | P] (on [b ; x_c]) and k sweeps of A.
+        EllMat S;
+        std::vector<double> w;
     };
     std::vector<Level> levels;
     double *coarse_inv = nullptr;  // dense inverse of the coarsest operator, rows padded to ld
@@ -49,6 +56,7 @@ struct Amg {
     double *out = nullptr;
     int out_stride = 1, out_offset = 0;
     double omega = 0.67;
+    bool poly = false;  // Level::w / Level::S in force instead of nu sweeps with one omega
     hipGraphExec_t graph_exec = nullptr;
     // Across GPUs only the finest level is rank-local (smoothed as a distributed operator, with
     // halo exchanges); below it the hierarchy is GLOBAL and replicated on every rank: the rank's

@@ -86,6 +86,19 @@ static int check_model(const fedm_model_desc &m) {
     return 0;
 }
 
+// the alternative set of species sweeps and (when installed) the alternative V-cycle, together
+static void set_hard_mode(Ctx &c, bool hard) {
+    if (c.fs_alt_active == hard) return;
+    hipStreamSynchronize(c.stream);
+    iter_graphs_clear(c);  // the captured steps contain the other sweeps / the other cycle
+    c.fs_alt_active = hard;
+    if (c.fs_alt_sweeps > 0) {
+        c.fs_sweeps = hard ? c.fs_alt_sweeps : c.fs_main_sweeps;
+        for (int i = 0; i < c.fs_sweeps; ++i) c.fs_w[i] = hard ? c.fs_alt_w[i] : c.fs_main_w[i];
+    }
+    if (c.amg_alt) std::swap(c.amg, c.amg_alt);
+}
+
 static int ensure_krylov(Ctx &c, int restart) {
     if (restart + 1 <= c.krylov_cap) return 0;
     iter_graphs_clear(c);  // they hold the old Krylov vectors' addresses
@@ -1272,18 +1285,12 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     }
     if (comm_failed(c)) rc = -1;  // the message is in fedm_last_error (Comm::error)
     if (rc == 0) c.newton_its_hint = it;
-    if (c.fs_alt_sweeps > 0 && it > 0) {
+    if ((c.fs_alt_sweeps > 0 || c.amg_alt) && it > 0) {
         // same counts on every rank, so every rank takes the same decision
         const double per_solve = (double)lin_total / it;
         const bool to_alt = !c.fs_alt_active && per_solve >= c.fs_switch_above;
         const bool to_main = c.fs_alt_active && per_solve <= c.fs_back_below;
-        if (to_alt || to_main) {
-            hipStreamSynchronize(c.stream);
-            iter_graphs_clear(c);  // the captured steps contain the other number of sweeps
-            c.fs_alt_active = to_alt;
-            c.fs_sweeps = to_alt ? c.fs_alt_sweeps : c.fs_main_sweeps;
-            for (int i = 0; i < c.fs_sweeps; ++i) c.fs_w[i] = to_alt ? c.fs_alt_w[i] : c.fs_main_w[i];
-        }
+        if (to_alt || to_main) set_hard_mode(c, to_alt);
     }
     r.iterations = it;
     r.linear_iterations = lin_total;
@@ -1402,6 +1409,8 @@ int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) 
             launch_assemble(c, true, 0);
         } else if (kind == 1) {
             launch_spmv(c, c.d_u, c.d_w, false);
+        } else if (kind == 3) {
+            if (c.amg) c.amg->run(c);  // one multigrid cycle on the potential block (its replayed graph)
         } else {
             launch_assemble(c, false, 0);
         }
@@ -1635,10 +1644,10 @@ int fedm_set_fieldsplit(fedm_ctx *h, int sweeps, const double *weights) {
     hipStreamSynchronize(h->c.stream);
     iter_graphs_clear(h->c);
     Ctx &c = h->c;
+    set_hard_mode(c, false);
     c.fs_sweeps = c.fs_main_sweeps = sweeps;
     for (int i = 0; i < sweeps; ++i) c.fs_w[i] = c.fs_main_w[i] = weights[i];
     c.fs_alt_sweeps = 0;
-    c.fs_alt_active = false;
     return 0;
 }
 
@@ -1654,14 +1663,8 @@ int fedm_set_fieldsplit_alternative(fedm_ctx *h, int alt_sweeps, const double *a
             set_error("field-split weights must be positive");
             return -2;
         }
-    if (c.fs_alt_active) {  // back to the main set first
-        hipSetDevice(c.device);
-        hipStreamSynchronize(c.stream);
-        iter_graphs_clear(c);
-        c.fs_sweeps = c.fs_main_sweeps;
-        for (int i = 0; i < c.fs_main_sweeps; ++i) c.fs_w[i] = c.fs_main_w[i];
-        c.fs_alt_active = false;
-    }
+    hipSetDevice(c.device);
+    set_hard_mode(c, false);  // back to the main set first
     c.fs_alt_sweeps = alt_sweeps;
     for (int i = 0; i < alt_sweeps; ++i) c.fs_alt_w[i] = alt_weights[i];
     c.fs_switch_above = switch_above;
@@ -1771,13 +1774,17 @@ int fedm_jacobian_poisson_only(fedm_ctx *h) {
 
 int fedm_amg_clear(fedm_ctx *h) {
     Ctx &c = h->c;
-    if (c.amg) {
+    if (c.amg || c.amg_alt) {
         hipSetDevice(c.device);
+        set_hard_mode(c, false);
         hipStreamSynchronize(c.stream);
         iter_graphs_clear(c);
-        c.amg->release();
-        delete c.amg;
-        c.amg = nullptr;
+        for (Amg **a : {&c.amg, &c.amg_alt})
+            if (*a) {
+                (*a)->release();
+                delete *a;
+                *a = nullptr;
+            }
     }
     return 0;
 }
@@ -1785,7 +1792,7 @@ int fedm_amg_clear(fedm_ctx *h) {
 // shared by the rank-local hierarchy and the replicated global one (several GPUs)
 static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, const fedm_csr *P,
                      const fedm_csr *R, const double *coarse_inverse, int nu, double omega, Amg **out,
-                     int composite_from) {
+                     int composite_from, const double *poly_w = nullptr /* [n_levels - 1][nu] */) {
     if (n_levels < 1 || !A || (n_levels > 1 && (!P || !R)) || nu == 0) {
         set_error("bad multigrid description");
         return -2;
@@ -1804,6 +1811,7 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
     amg->nu = nu < 0 ? -nu : nu;  // nu < 0 selects V(0,|nu|) cycles
     amg->pre_smooth = nu > 0;
     amg->omega = omega;
+    amg->poly = poly_w != nullptr;
     amg->levels.resize(n_levels);
     auto fail = [&](int rc) {
         amg->release();
@@ -1815,8 +1823,55 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
         int rc = 0;
         const char *composite_env = std::getenv("FEDM_AMG_COMPOSITE");  // "0": four kernels per level everywhere
         const bool composite_ok = !(composite_env && composite_env[0] == '0');
-        L.composite = composite_ok && l + 1 < n_levels && l >= composite_from && nu == 1;
-        if (L.composite) {
+        L.composite = composite_ok && l + 1 < n_levels && l >= composite_from && (nu == 1 || poly_w);
+        if (poly_w && l + 1 < n_levels) {
+            // polynomial smoother: S_pre (weights in order), S_post (backwards), built by the
+            // recurrence S <- S + w Dinv (I - A S) from S = w_0 Dinv
+            const int n = A[l].n_rows, np = ((n + SLICE - 1) / SLICE) * SLICE;
+            std::vector<double> dinv((size_t)n, 1.0);
+            for (int i = 0; i < n; ++i)
+                for (int64_t k = A[l].indptr[i]; k < A[l].indptr[i + 1]; ++k)
+                    if (A[l].indices[k] == i && A[l].values[k] != 0.0) dinv[i] = 1.0 / A[l].values[k];
+            const HostCsr I = csr_identity(n);
+            const fedm_csr Iv = I.view();
+            L.w.assign(poly_w + (size_t)l * nu, poly_w + (size_t)(l + 1) * nu);
+            auto smoother = [&](const std::vector<double> &ws) {
+                HostCsr S = csr_identity(n);
+                for (int i = 0; i < n; ++i) S.values[i] = ws[0] * dinv[i];
+                std::vector<double> wd((size_t)n);
+                for (size_t k = 1; k < ws.size(); ++k) {
+                    const HostCsr AS = csr_product(A[l], nullptr, S.view(), 1.0);
+                    const HostCsr T = csr_combine(Iv, 1.0, AS.view(), -1.0, 0, n, nullptr);  // I - A S
+                    for (int i = 0; i < n; ++i) wd[i] = ws[k] * dinv[i];
+                    const HostCsr WT = csr_combine(T.view(), 1.0, T.view(), 0.0, 0, n, wd.data());
+                    S = csr_combine(S.view(), 1.0, WT.view(), 1.0, 0, n, nullptr);
+                }
+                return S;
+            };
+            const HostCsr Spre = smoother(L.w);
+            const HostCsr ASp = csr_product(A[l], nullptr, Spre.view(), 1.0);
+            const HostCsr Tpre = csr_combine(Iv, 1.0, ASp.view(), -1.0, 0, n, nullptr);         // I - A S_pre
+            const HostCsr Cm = csr_product(R[l], nullptr, Tpre.view(), 1.0);                     // R (I - A S_pre)
+            rc |= L.C.from_csr(Cm.view(), false);
+            if (L.composite) {
+                const HostCsr Spost = smoother(std::vector<double>(L.w.rbegin(), L.w.rend()));
+                const HostCsr SA = csr_product(Spost.view(), nullptr, A[l], 1.0);
+                const HostCsr E = csr_combine(Iv, 1.0, SA.view(), -1.0, 0, n, nullptr);          // I - S_post A
+                const HostCsr ES = csr_product(E.view(), nullptr, Spre.view(), 1.0);
+                const HostCsr G = csr_combine(ES.view(), 1.0, Spost.view(), 1.0, 0, n, nullptr);  // E S_pre + S_post
+                const HostCsr Q = csr_product(E.view(), nullptr, P[l], 1.0);                       // E P
+                const HostCsr GQ = csr_combine(G.view(), 1.0, Q.view(), 1.0, np, np + P[l].n_cols, nullptr);
+                rc |= L.GQ.from_csr(GQ.view(), false);
+                L.A.n_rows = n;
+                L.A.n_rows_p = np;
+            } else {
+                // leg up as one product on the concatenated vector [b ; x_c]: x = S b + P x_c
+                const HostCsr SP = csr_combine(Spre.view(), 1.0, P[l], 1.0, np, np + P[l].n_cols, nullptr);
+                rc |= L.A.from_csr(A[l], true);
+                rc |= L.S.from_csr(SP.view(), false);
+                L.down_composite = true;
+            }
+        } else if (L.composite) {
             const int n = A[l].n_rows, np = ((n + SLICE - 1) / SLICE) * SLICE;
             std::vector<double> wd((size_t)n, omega);  // w / A_ii (EllMat::from_csr's rule for dinv)
             for (int i = 0; i < n; ++i)
@@ -1866,8 +1921,9 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
             return fail(rc < -1 ? -2 : -1);
         }
         const size_t n = (size_t)L.A.n_rows_p;
-        const size_t n_next = L.composite ? (size_t)(((A[l + 1].n_rows + SLICE - 1) / SLICE) * SLICE) : 0;
-        L.x_is_alias = l > 0 && amg->levels[l - 1].composite;
+        const bool tail = L.composite || (poly_w && l + 1 < n_levels);  // b = [b ; next level's x]
+        const size_t n_next = tail ? (size_t)(((A[l + 1].n_rows + SLICE - 1) / SLICE) * SLICE) : 0;
+        L.x_is_alias = l > 0 && (amg->levels[l - 1].composite || poly_w);
         if (L.x_is_alias) L.x = amg->levels[l - 1].b + amg->levels[l - 1].A.n_rows_p;
         for (double **p : {&L.x, &L.x2, &L.b, &L.r}) {
             if (p == &L.x && L.x_is_alias) continue;
@@ -1940,6 +1996,45 @@ int fedm_amg_setup(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr 
     if (coarse_inverse && amg->capture(c) != 0) {
         hipGetLastError();  // graph capture unavailable: fall back to plain launches
     }
+    return 0;
+}
+
+int fedm_amg_setup_poly(fedm_ctx *h, int n_levels, const fedm_csr *A, const fedm_csr *P, const fedm_csr *R,
+                        const double *coarse_inverse, int degree, const double *weights, int as_alternative) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (degree < 1 || degree > 4 || !weights || !coarse_inverse || n_levels < 2) {
+        set_error("polynomial-smoother hierarchy: degree 1..4, one weight per sweep and level, dense coarsest level");
+        return -2;
+    }
+    for (int i = 0; i < (n_levels - 1) * degree; ++i)
+        if (!(weights[i] > 0.0 && weights[i] < 8.0)) {
+            set_error("polynomial-smoother weights must be positive");
+            return -2;
+        }
+    if (c.comm) {
+        set_error("polynomial-smoother hierarchy is for one GPU (the distributed finest level keeps V(1,1))");
+        return -2;
+    }
+    if (as_alternative && !c.amg) {
+        set_error("install the main hierarchy (fedm_amg_setup) before its alternative");
+        return -2;
+    }
+    if (as_alternative) {
+        set_hard_mode(c, false);
+        if (c.amg_alt) {
+            c.amg_alt->release();
+            delete c.amg_alt;
+            c.amg_alt = nullptr;
+        }
+    } else {
+        fedm_amg_clear(h);
+    }
+    Amg *amg = nullptr;
+    if (int rc = build_amg(c, c.nv, n_levels, A, P, R, coarse_inverse, degree, 1.0, &amg, 1, weights)) return rc;
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    (as_alternative ? c.amg_alt : c.amg) = amg;
+    if (amg->capture(c) != 0) hipGetLastError();  // graph capture unavailable: plain launches
     return 0;
 }
 

@@ -72,6 +72,9 @@ struct Prof {
 
 struct Ctx {
     Amg *amg = nullptr;  // potential-block multigrid (optional)
+    // a second cycle for hard systems (stronger smoothing: fedm_amg_setup_poly with as_alternative):
+    // swapped with `amg` together with the alternative set of species sweeps (fs_alt_active)
+    Amg *amg_alt = nullptr;
     Prof prof;
     Comm *comm = nullptr;  // multi-GPU transport (optional)
     int n_owned = 0;       // owned vertices (== nv on a single GPU)

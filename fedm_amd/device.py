@@ -521,10 +521,14 @@ class DeviceProblem:
             indices.ctypes.data_as(C.POINTER(C.c_int32)), _dp(values)), "fedm_block_csr")
         return sp.csr_matrix((values, indices, indptr), shape=(self.nv, self.nv))
 
-    def setup_multigrid(self, theta=0.08, nu=2, omega=0.67, max_coarse=2000, max_sparse_levels=None):
+    def setup_multigrid(self, theta=0.08, nu=2, omega=0.67, max_coarse=2000, max_sparse_levels=None,
+                        poly_degree=None, poly_fraction=8.0, hard_poly_degree=None):
         """Build (host, once) and install the multigrid hierarchy of the constant potential
         block; afterwards Newton uses GMRES + field split (block Jacobi on the species,
-        one V-cycle on the potential) and poisson_solve uses V-cycle-preconditioned CG."""
+        one V-cycle on the potential) and poisson_solve uses V-cycle-preconditioned CG.
+        `poly_degree`: Chebyshev polynomial smoother of that many sweeps per leg instead of `nu`
+        damped-Jacobi sweeps.  `hard_poly_degree`: such a cycle installed NEXT to the V(nu,nu)
+        one, used with the alternative species sweeps of :meth:`set_fieldsplit` (one GPU)."""
         from . import amg
         if not self.model.poisson:
             raise ValueError("the model has no potential equation")
@@ -537,7 +541,15 @@ class DeviceProblem:
         fixed[self.n_owned:] = True  # ghost rows are identity rows of the local block
         levels = amg.build_hierarchy(K, theta=theta, max_coarse=max_coarse, fixed=fixed,
                                      coords=self._coords_dev, max_sparse_levels=max_sparse_levels)
-        self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
+        self._last_hierarchy = levels
+        if len(levels) < 2:                 # the whole block fits the dense coarsest solve: nothing to smooth
+            poly_degree = hard_poly_degree = None
+        if poly_degree:
+            self.multigrid_levels = amg.install_poly(self._h, levels, poly_degree, poly_fraction)
+        else:
+            self.multigrid_levels = amg.install(self._h, levels, nu=nu, omega=omega)
+        if hard_poly_degree:
+            amg.install_poly(self._h, levels, hard_poly_degree, poly_fraction, alternative=True)
         return self.multigrid_levels
 
     def setup_multigrid_distributed(self, lm, group=None, theta=0.08, nu=1, omega=0.67, max_coarse=2000,

@@ -263,6 +263,18 @@ int fedm_amg_clear(fedm_ctx *ctx);
 int fedm_amg_set_global_hierarchy(fedm_ctx *ctx, int n_global, int offset, int n_levels,
                                   const fedm_csr *A, const fedm_csr *P, const fedm_csr *R,
                                   const double *coarse_inverse, int nu, double omega);
+/* The same hierarchy with a polynomial smoother: `degree` Richardson sweeps x += w Dinv (b - A x)
+ * per leg, weights[level * degree + i] in the order of the pre-smoother (the post-smoother runs them
+ * backwards: the cycle stays symmetric for the Poisson-only CG); Chebyshev roots on
+ * [lambda_max / a, lambda_max] of Dinv A are the intended choice.  Costs two more streams of the
+ * finest operator per cycle at degree 2 (the coarse levels stay two kernels each: the polynomial is
+ * folded into their composite matrices) and contracts 0.38 instead of 0.68 per cycle on the bench
+ * mesh.  as_alternative = 0: replaces the hierarchy of fedm_amg_setup.  1: installed next to it and
+ * used together with the alternative species sweeps (fedm_set_fieldsplit_alternative: Newton solves
+ * that need many Krylov steps), one GPU only. */
+int fedm_amg_setup_poly(fedm_ctx *ctx, int n_levels, const fedm_csr *A, const fedm_csr *P,
+                        const fedm_csr *R, const double *coarse_inverse, int degree,
+                        const double *weights, int as_alternative);
 /* Richardson sweeps z += w_k Duu^-1 (r - Juu z) on the species block inside the field split;
  * one weight per sweep (equal weights = damped block Jacobi, Chebyshev roots = polynomial) */
 int fedm_set_fieldsplit(fedm_ctx *ctx, int sweeps, const double *weights);
@@ -325,7 +337,8 @@ int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[8]);
 int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
 
 /* timed micro-benchmarks on the resident state (HIP events on the library's stream):
- * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only.  ms per launch. */
+ * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only, 3 = one multigrid cycle on the
+ * potential block.  ms per launch. */
 int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
 /* in-run kernel timing with HIP events on the library's stream.  kind: 0 = assembly F+J,
  * 1 = Jacobian SpMV, 2 = assembly F only, 3 = multigrid V-cycle (whole graph).  Kinds 1 and 3

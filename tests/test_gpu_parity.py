@@ -239,6 +239,56 @@ def test_composite_multigrid_levels_are_the_same_cycle(monkeypatch):
     assert np.allclose(out["0"][2], out["1"][2], rtol=1e-9, atol=1e-9)
 
 
+def test_polynomial_smoother_cycle_is_the_richardson_cycle_and_contracts_faster():
+    """fedm_amg_setup_poly folds k Richardson sweeps per leg into the composite products of the
+    coarse levels and into [S | P] on the finest one.  With one sweep of weight w it is the V(1,1)
+    cycle with damping w (same CG count, same solution); with two Chebyshev sweeps the Poisson-only
+    CG needs fewer steps and reaches the same potential; installed as the alternative for hard
+    systems it leaves the trajectory of the time steps alone."""
+    from fedm_amd import amg
+    from fedm_amd.cases import streamer
+    msh = streamer.mesh(128, 4.0)
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    U0 = np.zeros((prob.nv, 3))
+    U0[:, 0], U0[:, 1] = streamer.initial_log_densities(prob.coords)
+
+    def poisson(install):
+        prob.set_state(U0, U0, U0)
+        install()
+        its = prob.poisson_solve(rtol=1e-12)
+        return its, prob.get_state()[:, 2].copy()
+
+    def poly(degree, weights=None):
+        def f():
+            prob.setup_multigrid(nu=1, omega=0.85)                       # builds the hierarchy ...
+            levels = prob._last_hierarchy
+            amg.install_poly(prob._h, levels, degree, weights=weights)   # ... installed with the polynomial
+        return f
+    its_v, phi_v = poisson(lambda: prob.setup_multigrid(nu=1, omega=0.85))
+    its_1, phi_1 = poisson(poly(1, weights=0.85))
+    its_2, phi_2 = poisson(poly(2))
+    assert len(prob.multigrid_levels) >= 3
+    assert its_1 == its_v and np.allclose(phi_1, phi_v, rtol=1e-10, atol=1e-10 * np.abs(phi_v).max())
+    assert its_2 < its_v and np.allclose(phi_2, phi_v, rtol=0, atol=1e-8 * np.abs(phi_v).max())
+    prob.close()
+    # as the alternative for hard systems (forced on by thresholds every solve exceeds)
+    out = {}
+    for hard in (None, 2):
+        prob = streamer.device_problem(msh.coords, msh.cells)
+        st = streamer.Stepper(prob)
+        st.initialise()
+        prob.setup_multigrid(nu=1, omega=0.85, hard_poly_degree=hard)
+        from fedm_amd.device import chebyshev_weights
+        prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(6), switch_above=0.5, back_below=0.1)
+        for _ in range(4):
+            st.step()
+        out[hard] = (st.newton_iterations, st.linear_iterations, prob.get_state())
+        prob.close()
+    assert out[None][0] == out[2][0] and out[2][1] <= out[None][1]
+    scale = np.abs(out[None][2]).max(axis=0)
+    assert (np.abs(out[None][2] - out[2][2]).max(axis=0) / scale).max() < 1e-6
+
+
 @pytest.mark.parametrize("three_species", [False, True])
 def test_row_at_a_time_assembly_matches_the_unrolled_element(monkeypatch, three_species):
     """F + J patches run through element_lean.hpp (one equation row at a time, rows as workgroup
