@@ -291,6 +291,9 @@ def main():
                "frac_of_measured_copy": gbs_spmv / copy_gbs if copy_gbs else None,
                "traffic": pick(tr, "spmv_kernel<3, false>", "spmv_kernel<3,false>", "spmv"),
                "algorithmic_bytes": b_spmv,
+               # SURVEY 8(d) counts every structural block whole; the kernel does not load value
+               # planes that are structurally zero for the model (d(electron row)/d(ion density))
+               "bytes_not_loaded_structural_zero_planes": sz["nnz_blocks"] * 8 * sz.get("zero_planes", 0),
                "ms_per_launch": ms_spmv, "launches": prof2["spmv"][1],
                "share_of_profiling_pass": share2["spmv"], "measured": second_pass}
     rl_asm = {"bound": "hbm", "kernel": runner.assembly_kernel_name,
@@ -299,6 +302,9 @@ def main():
               "frac_of_measured_copy": gbs_asm / copy_gbs if copy_gbs else None,
               "traffic": pick(tr, "assemble_lean2", "assemble_lean", "assemble_patch"),
               "traffic_source": tr_source, "algorithmic_bytes": b_asm,
+              # ... and the assembly neither recomputes nor rewrites planes that cannot change
+              # (potential-potential: geometry only; structurally zero species planes)
+              "bytes_not_rewritten_kept_planes": sz["stored_blocks"] * 8 * sz.get("kept_planes", 0),
               "ms_per_launch": ms_asm, "launches": prof["assembly_FJ"][1],
               "ms_residual_only": ms_res, "residual_only_algorithmic_bytes": b_res,
               "residual_only_frac": b_res / (ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_res else None,

@@ -169,6 +169,7 @@ _SIGNATURES = {
     "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
     "fedm_set_assembly": (C.c_int, [_P, C.c_int]),
     "fedm_set_preconditioner_side": (C.c_int, [_P, C.c_int]),
+    "fedm_plane_masks": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fedm_set_fieldsplit_order": (C.c_int, [_P, C.c_int]),
     "fedm_sizes": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 6),
 }

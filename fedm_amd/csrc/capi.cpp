@@ -1006,6 +1006,9 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
                         coupled = coupled || (model->net[j][s_] != 0 && model->power[j][i] > 0);
                     if (!coupled) c.const_plane_mask |= 1u << (s_ * c.neq + i);
                 }
+            c.zero_plane_mask = c.const_plane_mask & ~(1u << (c.ns * c.neq + c.ns));
+            if (const char *e = getenv("FEDM_SPMV_SKIP_ZERO_PLANES"))
+                if (e[0] == '0') c.zero_plane_mask = 0;
         }
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
         if (const char *e = getenv("FEDM_FS_ORDER")) c.fs_upper = std::string(e) == "upper";
@@ -1711,6 +1714,13 @@ int fedm_set_fieldsplit_order(fedm_ctx *h, int upper) {
         iter_graphs_clear(c);  // captured for the other order
         c.fs_upper = upper == 1;
     }
+    return 0;
+}
+
+int fedm_plane_masks(fedm_ctx *h, uint32_t *kept_planes, uint32_t *zero_planes) {
+    Ctx &c = h->c;
+    if (kept_planes) *kept_planes = (c.skip_const_planes && c.assembly_kind == 1 && c.assembly_lean == 2) ? c.const_plane_mask : 0u;
+    if (zero_planes) *zero_planes = c.neq == 3 ? (c.zero_plane_mask & 10u) : 0u;
     return 0;
 }
 

@@ -91,6 +91,7 @@ struct Ctx {
     // Planes (row, col) of the Jacobian that never change: potential-potential, and species planes that
     // are structurally zero.  bit row * neq + col; kept between assemblies once a full one has written them.
     uint32_t const_plane_mask = 0;
+    uint32_t zero_plane_mask = 0;   // the structurally zero ones among them (the SpMV skips their bytes)
     bool skip_const_planes = true, const_planes_valid = false;
     bool halo_pending = false;  // several GPUs: ghost entries of d_u are stale (kernels.hip, flush_pending_halo)
     bool assembly_overlap = true;  // ... and the next assembly hides their exchange behind its interior patches

@@ -914,7 +914,10 @@ void launch_block_inverse(Ctx &c) {
 // Matrix values and column indices stream in coalesced (lanes contiguous); x is gathered per
 // neighbour (n_eq contiguous doubles).  Optional fused block-Jacobi scaling y = Dinv (A x).
 // =============================================================================================
-template <int NEQ, bool FS>
+// ZMASK: bit (r * NEQ + c) marks a value plane that is structurally zero for this model (no reaction
+// couples the two species: d(electron row)/d(ion density) of the streamer model) -- it is neither
+// loaded nor multiplied: one ninth of the streamer matrix's bytes.
+template <int NEQ, bool FS, unsigned ZMASK = 0u>
 __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
                                                    const int *__restrict__ boff,
                                                    const int *__restrict__ colidx,
@@ -953,7 +956,8 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
 #pragma unroll
         for (int r = 0; r < NEQ; ++r)
 #pragma unroll
-            for (int cc = 0; cc < NEQ; ++cc) acc[r] += vp[(size_t)(r * NEQ + cc) * SLICE] * xj[cc];
+            for (int cc = 0; cc < NEQ; ++cc)
+                if (!((ZMASK >> (r * NEQ + cc)) & 1u)) acc[r] += vp[(size_t)(r * NEQ + cc) * SLICE] * xj[cc];
     }
     const size_t vtx = (size_t)slice * SLICE + lane;
     if ((int)vtx >= n_owned) {  // ghost / padding rows belong to someone else (or to nobody)
@@ -997,19 +1001,28 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int 
     if (n == 0) return;
     const dim3 g((n + 3) / 4), b(256);
     const double *dinv = scale_dinv ? c.d_dinv : nullptr;
-#define FEDM_SPMV(NEQ)                                                                             \
-    hipLaunchKernelGGL((spmv_kernel<NEQ, false>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
+#define FEDM_SPMV_Z(NEQ, Z)                                                                           \
+    hipLaunchKernelGGL((spmv_kernel<NEQ, false, Z>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
                        c.d_colidx, c.d_val, x, y, dinv, (double *)nullptr, (double *)nullptr, 0.0,         \
                        slice_list, 0, (c.xcd_remap && !slice_list) ? 1 : 0)
+#define FEDM_SPMV(NEQ) FEDM_SPMV_Z(NEQ, 0u)
     switch (c.neq) {
         case 1: FEDM_SPMV(1); break;
         case 2: FEDM_SPMV(2); break;
-        case 3: FEDM_SPMV(3); break;
+        case 3:  // two species + potential: the species-species planes (0,1) / (1,0) may be zero
+            switch (c.zero_plane_mask & 10u) {
+                case 2u: FEDM_SPMV_Z(3, 2u); break;
+                case 8u: FEDM_SPMV_Z(3, 8u); break;
+                case 10u: FEDM_SPMV_Z(3, 10u); break;
+                default: FEDM_SPMV(3); break;
+            }
+            break;
         case 4: FEDM_SPMV(4); break;
         case 5: FEDM_SPMV(5); break;
         case 6: FEDM_SPMV(6); break;
     }
 #undef FEDM_SPMV
+#undef FEDM_SPMV_Z
 }
 
 // t = A x together with the first field-split stage (c.d_dinv holds the species-block inverses);
@@ -1019,18 +1032,27 @@ void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, doubl
     const int n = slice_list ? n_list : c.pat.n_slices;
     if (n == 0) return;
     const dim3 g((n + 3) / 4), b(256);
-#define FEDM_SPMV(NEQ)                                                                            \
-    hipLaunchKernelGGL((spmv_kernel<NEQ, true>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
+#define FEDM_SPMV_Z(NEQ, Z)                                                                          \
+    hipLaunchKernelGGL((spmv_kernel<NEQ, true, Z>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
                        c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale, slice_list, compact32 ? 1 : 0,      \
                        (c.xcd_remap && !slice_list) ? 1 : 0)
+#define FEDM_SPMV(NEQ) FEDM_SPMV_Z(NEQ, 0u)
     switch (c.neq) {
         case 2: FEDM_SPMV(2); break;
-        case 3: FEDM_SPMV(3); break;
+        case 3:
+            switch (c.zero_plane_mask & 10u) {
+                case 2u: FEDM_SPMV_Z(3, 2u); break;
+                case 8u: FEDM_SPMV_Z(3, 8u); break;
+                case 10u: FEDM_SPMV_Z(3, 10u); break;
+                default: FEDM_SPMV(3); break;
+            }
+            break;
         case 4: FEDM_SPMV(4); break;
         case 5: FEDM_SPMV(5); break;
         case 6: FEDM_SPMV(6); break;
     }
 #undef FEDM_SPMV
+#undef FEDM_SPMV_Z
 }
 
 // y = alpha * Dinv x

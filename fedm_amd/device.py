@@ -683,6 +683,13 @@ class DeviceProblem:
         self._check(self.lib.fedm_field_error(self._h, int(component), C.byref(e)), "fedm_field_error")
         return e.value
 
+    def plane_masks(self):
+        """(kept, zero): bit masks over the n_eq x n_eq value planes of a Jacobian block that the
+        assembly keeps between assemblies / that the SpMV skips (``fedm_plane_masks``)."""
+        kept, zero = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.fedm_plane_masks(self._h, C.byref(kept), C.byref(zero)), "fedm_plane_masks")
+        return kept.value, zero.value
+
     def set_assembly(self, kind):
         """'patch' (LDS patches, default) or 'colour' (global colouring, bitwise reproducible)."""
         code = {"colour": 0, "patch": 1}[kind]
@@ -732,7 +739,10 @@ class DeviceProblem:
         v = [C.c_int64() for _ in range(6)]
         self.lib.fedm_sizes(self._h, *[C.byref(x) for x in v])
         keys = ("n_vertices", "n_cells", "n_eq", "nnz_blocks", "stored_blocks", "n_colours")
-        return dict(zip(keys, (x.value for x in v)))
+        out = dict(zip(keys, (x.value for x in v)))
+        kept, zero = self.plane_masks()
+        out["kept_planes"], out["zero_planes"] = bin(kept).count("1"), bin(zero).count("1")
+        return out
 
 
 def rccl_unique_id():

@@ -369,6 +369,11 @@ int fedm_set_preconditioner_side(fedm_ctx *ctx, int right);
  *       steps of the bench case (tools/fs_order_accuracy.py): an explicit trade, not the default.
  * Takes effect with the next Jacobian assembly.  Environment: FEDM_FS_ORDER=lower|upper. */
 int fedm_set_fieldsplit_order(fedm_ctx *ctx, int upper);
+/* value planes of the Jacobian blocks (bit r * n_eq + c = d(row r)/d(unknown c)) that the assembly
+ * keeps between assemblies (constant or structurally zero: not recomputed, not written again) and
+ * that the Jacobian SpMV skips (structurally zero: no reaction couples the two species): the bytes
+ * the roofline model must not count. */
+int fedm_plane_masks(fedm_ctx *ctx, uint32_t *kept_planes, uint32_t *zero_planes);
 /* sizes the roofline model needs */
 int fedm_sizes(fedm_ctx *ctx, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq,
                int64_t *nnz_blocks, int64_t *stored_blocks, int64_t *n_colours);

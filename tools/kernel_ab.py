@@ -6,7 +6,8 @@ read when the context is created).  Prints one JSON line per configuration.
 usage: kernel_ab.py [mesh] [KEY=VAL[,KEY=VAL...]] ...      one argument per configuration, e.g.
     kernel_ab.py 576 FEDM_PATCH_ORDER=0 FEDM_PATCH_ORDER=16,16 FEDM_SKIP_CONST_PLANES=0
 Switches: FEDM_ASSEMBLY_LEAN=0|1|2, FEDM_XCD_REMAP=0|1, FEDM_PATCH_ORDER=group,mod|0,
-FEDM_PATCH_ORDER_READS=w, FEDM_SKIP_CONST_PLANES=0|1, FEDM_HIP_LIB=<experiment build>.
+FEDM_PATCH_ORDER_READS=w, FEDM_SKIP_CONST_PLANES=0|1, FEDM_SPMV_SKIP_ZERO_PLANES=0|1,
+FEDM_HIP_LIB=<experiment build>.
 Boxes of the pool differ by up to 12 % (MI355X_MICROARCH.md, DVFS): compare within one call only.
 Round-2 results: DESIGN.md 8.1.
 """
@@ -17,7 +18,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KEYS = ("FEDM_ASSEMBLY_LEAN", "FEDM_XCD_REMAP", "FEDM_PATCH_ORDER", "FEDM_PATCH_ORDER_READS",
-        "FEDM_SKIP_CONST_PLANES", "FEDM_HIP_LIB")
+        "FEDM_SKIP_CONST_PLANES", "FEDM_SPMV_SKIP_ZERO_PLANES", "FEDM_HIP_LIB")
 
 
 def child(n):
