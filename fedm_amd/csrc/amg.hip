@@ -461,7 +461,9 @@ __global__ void fs_species_kernel(int nvp, const double *__restrict__ dinv_uu,
 // The iterate is a compact single-precision vector between the sweeps ([vertex][NS] floats: a
 // third of the bytes of the interleaved fp64 vector; accumulation in fp64); the LAST sweep writes
 // the interleaved fp64 vector that the Krylov method sees.
-template <int NS, bool LAST>
+// ZS: bit (r * NS + c) marks a plane of S that is structurally zero (the Jacobian plane is, and the
+// block diagonal is then triangular, so the scaling keeps the zero): not loaded.
+template <int NS, bool LAST, unsigned ZS = 0u>
 __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
     const _Float16 *__restrict__ s16, const float *__restrict__ g, const float *__restrict__ zin,
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
         for (int r = 0; r < NS; ++r)
 #pragma unroll
             for (int cidx = 0; cidx < NS; ++cidx)
-                acc[r] += (double)(float)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
+                if (!((ZS >> (r * NS + cidx)) & 1u)) acc[r] += (double)(float)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
     }
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
@@ -665,17 +667,28 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
         return !(e && e[0] == '0');
     }();
     const bool overlap = halo && overlap_ok && c.comm->n_interior > 0;
+    // two species: the off-diagonal planes (0,1) / (1,0) of S may be structurally zero
+    unsigned zs_mask = 0u;
+    if (NS == 2) zs_mask = ((c.zero_plane_mask >> 1) & 1u) << 1 | ((c.zero_plane_mask >> 3) & 1u) << 2;
     auto sweep = [&](bool last, const float *in_, float *out32, double zs, double w, const int *list, int n) {
         if (n == 0) return;
         const dim3 g((n + 3) / 4);
-        if (last)
-            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true>), g, dim3(256), 0, c.stream, n, c.d_slice_boff,
-                               c.d_colidx, c.d_s16, g32, in_, (float *)nullptr, z, zs, w, list,
-                               upper ? (const double *)amg.levels[0].x : (const double *)nullptr);
-        else
-            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, false>), g, dim3(256), 0, c.stream, n, c.d_slice_boff,
-                               c.d_colidx, c.d_s16, g32, in_, out32, (double *)nullptr, zs, w, list,
-                               (const double *)nullptr);
+        const double *x0 = upper ? (const double *)amg.levels[0].x : (const double *)nullptr;
+#define FEDM_SWEEP(Z)                                                                                          \
+    do {                                                                                                       \
+        if (last)                                                                                              \
+            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true, Z>), g, dim3(256), 0, c.stream, n,           \
+                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in_, (float *)nullptr, z, zs, w, list, x0); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((fs_species_sweep_kernel<NS, false, Z>), g, dim3(256), 0, c.stream, n,          \
+                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in_, out32, (double *)nullptr, zs, w, \
+                               list, (const double *)nullptr);                                                 \
+    } while (0)
+        if (NS == 2 && zs_mask == 2u) FEDM_SWEEP(2u);
+        else if (NS == 2 && zs_mask == 4u) FEDM_SWEEP(4u);
+        else if (NS == 2 && zs_mask == 6u) FEDM_SWEEP(6u);
+        else FEDM_SWEEP(0u);
+#undef FEDM_SWEEP
     };
     for (int s = 1; s <= n_sweeps; ++s) {
         const double zs = s == 1 ? c.fs_w[0] : 1.0;
