@@ -285,11 +285,11 @@ def main():
                    f"kernels launched one by one ({1e3 * elapsed2 / pass_steps:.2f} ms/step)")
     copy_gbs = measured_copy_ceiling(torch.device("cuda", local_rank)) if rank == 0 else None
     tr, tr_source = pmc_traffic() if (world == 1 and n == 576) else ({}, "not the profiled workload")
-    rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3,false> (Jacobian SpMV, sliced block-ELL)",
+    rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3,false,ZMASK> (Jacobian SpMV, sliced block-ELL; structurally zero value planes not loaded)",
                "achieved": gbs_spmv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": gbs_spmv / HBM_PEAK_GBS,
                "frac_of_measured_copy": gbs_spmv / copy_gbs if copy_gbs else None,
-               "traffic": pick(tr, "spmv_kernel<3, false>", "spmv_kernel<3,false>", "spmv"),
+               "traffic": pick(tr, "fedm::spmv_kernel<3, false", "fedm::spmv_kernel<3,false"),
                "algorithmic_bytes": b_spmv,
                # SURVEY 8(d) counts every structural block whole; the kernel does not load value
                # planes that are structurally zero for the model (d(electron row)/d(ion density))
