@@ -1058,10 +1058,11 @@ void fedm_ctx_destroy(fedm_ctx *h) {
                     c.d_patch_cells, c.d_bfacets, c.d_gd, c.d_gd_fields};
     for (void *p : ptrs)
         if (p) hipFree(p);
-    if (c.amg) {
-        c.amg->release();
-        delete c.amg;
-    }
+    for (Amg *a : {c.amg, c.amg_alt})
+        if (a) {
+            a->release();
+            delete a;
+        }
     if (c.comm) {
         c.comm->release();
         delete c.comm;
@@ -1237,7 +1238,17 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         } else {
             eval_jacobian(c, 0);
         }
-        norm2_read(c, c.d_F, 0, 3);  // |F|, and |dx|, |x| of the previous update (slots 1, 2) in one wait
+        // |F|, and |dx|, |x| of the previous update (slots 1, 2) in one publication.  After a Jacobian
+        // assembly the field split's planes are formed while those numbers travel to the host (an
+        // iteration that turns out to be the last one has formed them for nothing: the expected last
+        // one assembles no Jacobian at all).
+        norm2_publish(c, c.d_F, 0, 3);
+        bool planes_done = false;
+        if (!residual_only && right_preconditioned(c)) {
+            prepare_preconditioner_and_rhs(c);
+            planes_done = true;
+        }
+        wait_red(c);
         fnorm = std::sqrt(c.h_red[0]);
         if (it > 0) {
             snorm = std::sqrt(c.h_red[1]);
@@ -1259,7 +1270,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             break;
         }
         if (residual_only) eval_jacobian(c, 0);  // not converged after all: the Jacobian is needed
-        prepare_preconditioner_and_rhs(c);
+        if (!planes_done) prepare_preconditioner_and_rhs(c);
         int lits = 0;
         double lres = 0.0;
         const bool right = right_preconditioned(c);

@@ -227,6 +227,7 @@ void launch_set_dirichlet_state(Ctx &c);    // u[dof] = g
 void wait_red_seq(Ctx &c, unsigned long long seq);  // a particular publication (steps launched ahead)
 void read_red(Ctx &c, int k);
 void norm2_read(Ctx &c, const double *x, int slot, int k);  // launch_norm2 + read_red, one kernel fewer on one GPU               // publish d_red[0..k) to h_red and wait for it
+void norm2_publish(Ctx &c, const double *x, int slot, int k);  // the launches of norm2_read; wait_red(c) later
 void wait_red(Ctx &c);                      // wait for the publication launch_dots(finish) queued
 
 #define FEDM_HIP_CHECK(expr)                                                          \

@@ -1464,10 +1464,14 @@ __global__ __launch_bounds__(64) void reduce_slot_publish_kernel(const double *_
     }
 }
 
-void norm2_read(Ctx &c, const double *x, int slot, int k) {
+// |x|^2 into slot `slot` and d_red[0..k) into the mailbox, without the wait: the caller may queue
+// more work behind the publication before it calls wait_red (what it queues runs while the
+// numbers travel to the host)
+void norm2_publish(Ctx &c, const double *x, int slot, int k) {
     if (c.comm) {  // the all-reduce sits between the reduction and the publication
         launch_norm2(c, x, slot);
-        read_red(c, k);
+        hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_mail, c.d_mail_seq);
+        ++c.mail_seq;
         return;
     }
     const int grid = red_grid(c);
@@ -1477,6 +1481,10 @@ void norm2_read(Ctx &c, const double *x, int slot, int k) {
     hipLaunchKernelGGL(reduce_slot_publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_partials, grid, RED_K - 1,
                        c.d_red, slot, k, c.h_mail, c.d_mail_seq);
     ++c.mail_seq;
+}
+
+void norm2_read(Ctx &c, const double *x, int slot, int k) {
+    norm2_publish(c, x, slot, k);
     wait_red(c);
 }
 
