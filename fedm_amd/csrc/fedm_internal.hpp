@@ -100,6 +100,13 @@ struct Ctx {
     fedm_gd_desc *d_gd = nullptr;
     double *d_gd_fields = nullptr;  // [n_fields][nv] nodal coefficient fields
     int gd_n_fields = 0;
+    // Jacobian by element matrices + gather (gd.hip): every cell's 3 x 3 blocks, then each stored block
+    // sums its contributions (inverse of cell_slots as CSR over the stored positions): each matrix
+    // value is written once, coalesced, in a fixed summation order
+    double *d_gd_elem = nullptr;          // [9 * neq * neq][nc]
+    int *d_gd_inv_ptr = nullptr;          // [total_bc * 64 + 1]
+    int *d_gd_inv_idx = nullptr;          // cell * 9 + (a * 3 + b)
+    int gd_hand_mode = 3;                 // gd.hip, launch_assemble_gd
     GdPrep *gd_prep = nullptr;  // on-device per-step coefficient refresh (LMEA)
     Pattern pat;
     double dt = 1.0, dt_old = 1e30;

@@ -13,6 +13,9 @@
 // per (cell, local dof) for the Jacobian -- a colour alone has too few cells to fill the chip.
 #include "fedm_internal.hpp"
 
+#include <cstdlib>
+#include <vector>
+
 namespace fedm {
 
 struct Dual {
@@ -367,11 +370,492 @@ __global__ __launch_bounds__(128) void gd_assemble_kernel(
     }
 }
 
+
+// =============================================================================================
+// Hand-derived element Jacobian.
+//
+// At a point the integrand of equation row `row` is  W (S phi_a - Gx G_a,x - Gy G_a,y)  with
+// S = T - source (time term minus sources) and G the flux; S, Gx, Gy are functions of the point values
+// and gradients of the unknowns.  Their partial derivatives are written down by hand -- the
+// dual-number kernel above is the cross-check (tests: both against the oracle) -- and combined into
+// DIRECTIONAL derivatives along the basis function of one column vertex b: for column field s the
+// triple (tS, tX, tY) = d(S, Gx, Gy)/dU[b][s], so that
+//   dR[a] / dU[b][s] = W (tS phi_a - tX G_a,x - tY G_a,y).
+// The semi-implicit coefficients depend on u_0 (energy) and u_e (electrons) through the change of
+// the mean energy dme = (exp(u_0) - exp(u_e) me_old) / exp(u_e,old)  (value and gradient: three
+// "channels" c1, c2, c3); a derivative with respect to a channel reaches the columns 0 and e through
+// the channels' own directional derivatives (GdChannels::k*).
+// Work split: a workgroup takes 64 cells and one column vertex b; its waves are the equation rows
+// (wave-uniform row: scalar branches, no lane evaluates another row's integrands).  The nodal
+// coefficient fields and unknowns of the 64 cells are staged in LDS by all waves together.  One
+// evaluation of the point functions per (cell, row, b, point) instead of fifteen dual passes of the
+// whole element per cell and fifteen threads holding 512 registers each.
+// All cells in one launch (the cells of one colour do not fill the chip: a launch per colour lasts as
+// long as its slowest thread, nine times per assembly).
+// =============================================================================================
+struct N3 {
+    double v, gx, gy;
+};
+// `fl`: a cell's block of staged field values, field fi at fl[3 fi .. 3 fi + 2] (its three vertices)
+__device__ __forceinline__ N3 nodal3(const double *fl, int fi, const GdCell &c, const double phi[3]) {
+    const double a0 = fl[3 * fi], a1 = fl[3 * fi + 1], a2 = fl[3 * fi + 2];
+    return {a0 * phi[0] + a1 * phi[1] + a2 * phi[2], a0 * c.G[0][0] + a1 * c.G[1][0] + a2 * c.G[2][0],
+            a0 * c.G[0][1] + a1 * c.G[1][1] + a2 * c.G[2][1]};
+}
+__device__ __forceinline__ double nodal1(const double *fl, int fi, const double phi[3]) {
+    return fl[3 * fi] * phi[0] + fl[3 * fi + 1] * phi[1] + fl[3 * fi + 2] * phi[2];
+}
+
+// dme = (c1; c2, c3) and the derivatives of the three channels along the basis function of the
+// column vertex for the columns 0 (energy) and e (electrons)
+struct GdChannels {
+    double c1, c2, c3;
+    double k1_0, k2_0, k3_0, k1_e, k2_e, k3_e;
+};
+
+// drift-diffusion flux of one species (gd_flux above) with its partial derivatives
+struct GdFluxD {
+    double Gx, Gy;      // dG/dv_own = G itself
+    double dg;          // dGx/dgx_own = dGy/dgy_own
+    double dE;          // dGx/dEx = dGy/dEy
+    double x_c1, x_c2;  // dGx/dc1, dGx/dc2
+    double y_c1, y_c3;  // dGy/dc1, dGy/dc3
+};
+// coefficient fields f_mu, f_d (values) and f_mud, f_dd (derivatives with respect to the mean
+// energy); scale: 5/3 for the energy flux
+__device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, int f_mud, int f_d, int f_dd,
+                                                    const GdCell &c, const double phi[3], const GdChannels &ch,
+                                                    double sign, double scale, bool drift, bool grad_diffusion,
+                                                    double v, double gx, double gy, double Ex, double Ey) {
+    const N3 Da = nodal3(fl, f_d, c, phi), Db = nodal3(fl, f_dd, c, phi);
+    // D = Da + Db * dme as value + gradient (product rule of the SG type above)
+    const double Dv = scale * (Da.v + Db.v * ch.c1);
+    const double Dgx = scale * (Da.gx + Db.gx * ch.c1 + Db.v * ch.c2);
+    const double Dgy = scale * (Da.gy + Db.gy * ch.c1 + Db.v * ch.c3);
+    double muv = 0.0, mub = 0.0;
+    if (drift) {
+        mub = scale * nodal1(fl, f_mud, phi);
+        muv = scale * nodal1(fl, f_mu, phi) + mub * ch.c1;
+    }
+    const double e = exp(v);
+    GdFluxD F;
+    const double zm = sign * muv * e;
+    if (grad_diffusion) {
+        F.Gx = -(Dgx * e + Dv * e * gx) + zm * Ex;
+        F.Gy = -(Dgy * e + Dv * e * gy) + zm * Ey;
+    } else {
+        F.Gx = -(Dv * e * gx) + zm * Ex;
+        F.Gy = -(Dv * e * gy) + zm * Ey;
+    }
+    F.dg = -Dv * e;
+    F.dE = zm;
+    const double dDv = scale * Db.v;   // dDv/dc1 (= dDgx/dc2 = dDgy/dc3)
+    const double dmu = sign * mub * e;  // d(zm)/dc1
+    F.x_c1 = -e * gx * dDv + dmu * Ex;
+    F.y_c1 = -e * gy * dDv + dmu * Ey;
+    F.x_c2 = 0.0;
+    F.y_c3 = 0.0;
+    if (grad_diffusion) {
+        F.x_c1 -= e * scale * Db.gx;
+        F.y_c1 -= e * scale * Db.gy;
+        F.x_c2 = -e * dDv;
+        F.y_c3 = -e * dDv;
+    }
+    return F;
+}
+
+// STORE: 2 = the element blocks go to `val` = the element buffer [(a * 3 + b) * NEQ * NEQ + row * NEQ + s]
+// [cell] (lanes = cells: coalesced) and gd_gather_kernel sums them into the matrix -- every matrix
+// value written once, fixed summation order; 1 = fp64 atomics straight into the matrix (the fall-back
+// when the buffer cannot be allocated).  The residual is added with atomics.
+template <int NEQ, int STORE>
+__global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
+    const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields, int nv,
+    const int *__restrict__ cell_list, int n_cells, const int *__restrict__ cells,
+    const double *__restrict__ coords, const int8_t *__restrict__ ftags,
+    const uint32_t *__restrict__ cell_slots, const double *__restrict__ u,
+    const double *__restrict__ uold, const double *__restrict__ uold1, double dt, double dt_old,
+    double *__restrict__ val, double *__restrict__ F, int mode) {
+    constexpr int NEQ2 = NEQ * NEQ, ns = NEQ - 1, IPHI = NEQ - 1, ie = ns - 1;
+    const double two_pi = 6.283185307179586476925286766559;
+    const int lc = threadIdx.x & (SLICE - 1);
+    const int row = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;                      // column vertex of this workgroup
+    const int ci = blockIdx.x * SLICE + lc;
+    const int nr = md->n_reactions;
+    const int NF = 4 * ns + 2 * nr + 3;
+    extern __shared__ double gd_lds[];
+    int *lds_vtx = reinterpret_cast<int *>(gd_lds);                 // [64][3] global vertex ids (-1: no cell)
+    double *lds_f = gd_lds + (3 * SLICE + 1) / 2;                   // [64][NF][3]
+    double *lds_u = lds_f + (size_t)SLICE * NF * 3;                 // [64][3][NEQ]
+    for (int i = threadIdx.x; i < 3 * SLICE; i += blockDim.x) {
+        const int cc = blockIdx.x * SLICE + i / 3;
+        lds_vtx[i] = cc < n_cells ? cells[3 * (cell_list ? cell_list[cc] : cc) + i % 3] : -1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SLICE * NF * 3; i += blockDim.x) {
+        const int cc = i / (NF * 3), rem = i - cc * (NF * 3), fi = rem / 3, a = rem - 3 * fi;
+        const int vtx = lds_vtx[3 * cc + a];
+        lds_f[i] = vtx >= 0 ? fields[(size_t)fi * nv + vtx] : 0.0;
+    }
+    for (int i = threadIdx.x; i < SLICE * 3 * NEQ; i += blockDim.x) {
+        const int cc = i / (3 * NEQ), rem = i - cc * (3 * NEQ), a = rem / NEQ, sidx = rem - a * NEQ;
+        const int vtx = lds_vtx[3 * cc + a];
+        lds_u[i] = vtx >= 0 ? u[(size_t)vtx * NEQ + sidx] : 0.0;
+    }
+    __syncthreads();
+    if (ci >= n_cells) return;
+    if (mode == 1 && row != IPHI) return;   // Poisson-only: the other rows are identity rows
+    const int cidx = cell_list ? cell_list[ci] : ci;   // no list: the mesh's own cell order
+    const double *fl = lds_f + (size_t)lc * NF * 3;
+    const double *ul = lds_u + (size_t)lc * 3 * NEQ;   // [a][s]
+    GdCell c;
+    double Hrow[3];
+    const double tr = dt / dt_old, trp1 = 1.0 + tr, c_new = (1.0 + 2.0 * tr) / trp1;
+    {
+        double x[3][2];   // (not kept: the facet terms read the two coordinates they need again)
+        for (int a = 0; a < 3; ++a) {
+            c.v[a] = lds_vtx[3 * lc + a];
+            x[a][0] = coords[2 * c.v[a]];
+            x[a][1] = coords[2 * c.v[a] + 1];
+            c.rn[a] = md->axisymmetric ? x[a][0] : 0.5 / 3.14159265358979323846;
+            Hrow[a] = (-(trp1 * trp1) * uold[(size_t)c.v[a] * NEQ + row] + (tr * tr) * uold1[(size_t)c.v[a] * NEQ + row]) / trp1;
+        }
+        const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
+        const double d2x = x[2][0] - x[0][0], d2y = x[2][1] - x[0][1];
+        const double det = d1x * d2y - d1y * d2x;
+        c.detJ = fabs(det);
+        c.G[0][0] = (x[1][1] - x[2][1]) / det;
+        c.G[0][1] = (x[2][0] - x[1][0]) / det;
+        c.G[1][0] = (x[2][1] - x[0][1]) / det;
+        c.G[1][1] = (x[0][0] - x[2][0]) / det;
+        c.G[2][0] = (x[0][1] - x[1][1]) / det;
+        c.G[2][1] = (x[1][0] - x[0][0]) / det;
+    }
+    // gradient of the column vertex's basis function (selects, not a run-time index into registers)
+    const double w_x = b == 0 ? c.G[0][0] : b == 1 ? c.G[1][0] : c.G[2][0];
+    const double w_y = b == 0 ? c.G[0][1] : b == 1 ? c.G[1][1] : c.G[2][1];
+    const int F_MU = 0, F_D = ns, F_MUD = 2 * ns, F_DD = 3 * ns, F_K = 4 * ns, F_KD = 4 * ns + nr,
+              F_MEO = 4 * ns + 2 * nr, F_ME = F_MEO + 1, F_UEO = F_MEO + 2;
+    double Racc[3] = {0.0, 0.0, 0.0}, Jacc[3][NEQ];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) Jacc[a][s] = 0.0;
+
+    // value and gradient of unknown s at a point (s is wave-uniform or a compile-time index)
+    auto value = [&](int s, const double phi[3]) {
+        return ul[s] * phi[0] + ul[NEQ + s] * phi[1] + ul[2 * NEQ + s] * phi[2];
+    };
+    auto grad_x = [&](int s) { return ul[s] * c.G[0][0] + ul[NEQ + s] * c.G[1][0] + ul[2 * NEQ + s] * c.G[2][0]; };
+    auto grad_y = [&](int s) { return ul[s] * c.G[0][1] + ul[NEQ + s] * c.G[1][1] + ul[2 * NEQ + s] * c.G[2][1]; };
+    const double gx0 = grad_x(0), gy0 = grad_y(0), gxe = grad_x(ie), gye = grad_y(ie);
+    const double Ex = -grad_x(IPHI), Ey = -grad_y(IPHI);
+
+    auto channels = [&](const double phi[3], double w_v) {
+        const N3 meo = nodal3(fl, F_MEO, c, phi), ueo = nodal3(fl, F_UEO, c, phi);
+        const double ieo = exp(-ueo.v);
+        const double r0 = exp(value(0, phi)) * ieo, re = exp(value(ie, phi)) * ieo;
+        GdChannels ch;
+        ch.c1 = r0 - re * meo.v;
+        ch.c2 = r0 * gx0 - re * (gxe * meo.v + meo.gx) - ch.c1 * ueo.gx;
+        ch.c3 = r0 * gy0 - re * (gye * meo.v + meo.gy) - ch.c1 * ueo.gy;
+        const double rem = -re * meo.v;
+        ch.k1_0 = r0 * w_v;
+        ch.k2_0 = r0 * (gx0 - ueo.gx) * w_v + r0 * w_x;
+        ch.k3_0 = r0 * (gy0 - ueo.gy) * w_v + r0 * w_y;
+        ch.k1_e = rem * w_v;
+        ch.k2_e = -re * (gxe * meo.v + meo.gx - meo.v * ueo.gx) * w_v + rem * w_x;
+        ch.k3_e = -re * (gye * meo.v + meo.gy - meo.v * ueo.gy) * w_v + rem * w_y;
+        return ch;
+    };
+    // W (tS phi_a - tX G_a,x - tY G_a,y) into column s of the accumulators (s: wave-uniform)
+    auto add = [&](int s, double W, const double phi[3], double tS, double tX, double tY) {
+#pragma unroll
+        for (int k = 0; k < NEQ; ++k)
+            if (k == s) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) Jacc[a][k] += W * (tS * phi[a] - tX * c.G[a][0] - tY * c.G[a][1]);
+            }
+    };
+    auto species_flux = [&](int s, double scale, int own, const double phi[3], const GdChannels &ch) {
+        const int et = md->eq_type[s];
+        const bool drift = et == FEDM_EQ_DRIFT_DIFFUSION_REACTION;
+        const bool gdf = drift ? md->grad_diffusion[s] != 0 : true;   // diffusion-reaction: -grad(D exp(u))
+        return gd_flux_partials(fl, F_MU + s, F_MUD + s, F_D + s, F_DD + s, c, phi, ch, md->sign[s], scale, drift, gdf,
+                                value(own, phi), grad_x(own), grad_y(own), Ex, Ey);
+    };
+    // directional derivative of a flux (column vertex b) into the flux columns of the accumulators
+    auto flux_columns = [&](const GdFluxD &Fl, int own, const GdChannels &ch, double W, const double phi[3], double w_v) {
+        add(own, W, phi, 0.0, Fl.Gx * w_v + Fl.dg * w_x, Fl.Gy * w_v + Fl.dg * w_y);
+        add(IPHI, W, phi, 0.0, -Fl.dE * w_x, -Fl.dE * w_y);   // E = -grad Phi
+        add(0, W, phi, 0.0, Fl.x_c1 * ch.k1_0 + Fl.x_c2 * ch.k2_0, Fl.y_c1 * ch.k1_0 + Fl.y_c3 * ch.k3_0);
+        add(ie, W, phi, 0.0, Fl.x_c1 * ch.k1_e + Fl.x_c2 * ch.k2_e, Fl.y_c1 * ch.k1_e + Fl.y_c3 * ch.k3_e);
+    };
+    // ... of factor * (w . G) (Joule heating: w = E; wall flux: w = n) into the source columns
+    auto flux_dot_columns = [&](const GdFluxD &Fl, int own, const GdChannels &ch, double wx, double wy, double factor,
+                                double W, const double phi[3], double w_v) {
+        add(own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * w_v + Fl.dg * (wx * w_x + wy * w_y)), 0.0, 0.0);
+        add(IPHI, W, phi, -factor * Fl.dE * (wx * w_x + wy * w_y), 0.0, 0.0);
+        const double o1 = factor * (Fl.x_c1 * wx + Fl.y_c1 * wy), o2 = factor * Fl.x_c2 * wx, o3 = factor * Fl.y_c3 * wy;
+        add(0, W, phi, o1 * ch.k1_0 + o2 * ch.k2_0 + o3 * ch.k3_0, 0.0, 0.0);
+        add(ie, W, phi, o1 * ch.k1_e + o2 * ch.k2_e + o3 * ch.k3_e, 0.0, 0.0);
+    };
+
+    for (int q = 0; q < md->n_qp; ++q) {
+        const double phi[3] = {1.0 - md->qp_x[q] - md->qp_y[q], md->qp_x[q], md->qp_y[q]};
+        const double rq = c.rn[0] * phi[0] + c.rn[1] * phi[1] + c.rn[2] * phi[2];
+        const double W = md->qp_w[q] * c.detJ * two_pi * rq;
+        const double w_v = b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2];
+        if (row == IPHI) {
+            // 2 pi r (grad Phi . grad v - rho v): S = -rho, G = -grad Phi
+            double rho = 0.0;
+#pragma unroll
+            for (int i = 1; i < ns; ++i) {
+                const double ni = (md->sign[i] * md->charge_over_eps) * exp(value(i, phi));
+                rho += ni;
+                add(i, W, phi, -ni * w_v, 0.0, 0.0);
+            }
+            add(IPHI, W, phi, 0.0, -w_x, -w_y);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Racc[a] += W * (-rho * phi[a] - (Ex * c.G[a][0] + Ey * c.G[a][1]));
+            continue;
+        }
+        const GdChannels ch = channels(phi, w_v);
+        double n[ns];
+#pragma unroll
+        for (int i = 1; i < ns; ++i) n[i] = exp(value(i, phi));
+        // source of this row: sum_j w_j rate_j with w_j = net[j][row] (species) or -loss_j (energy)
+        double src = 0.0, src_c1 = 0.0, src_v[ns];
+#pragma unroll
+        for (int i = 0; i < ns; ++i) src_v[i] = 0.0;
+        for (int j = 0; j < nr; ++j) {
+            const double w = (row == 0) ? -md->energy_loss[j] : (double)md->net[j][row];
+            if (w == 0.0) continue;
+            const double kv = nodal1(fl, F_K + j, phi), kd = nodal1(fl, F_KD + j, phi);
+            double prod = 1.0;
+#pragma unroll
+            for (int i = 0; i < ns; ++i)
+                for (int e = 0; e < md->power[j][i]; ++e) prod *= (i == 0) ? md->N0 : n[i];
+            const double rate = (kv + kd * ch.c1) * prod;
+            src += w * rate;
+            src_c1 += w * kd * prod;
+#pragma unroll
+            for (int i = 1; i < ns; ++i) src_v[i] += w * (double)md->power[j][i] * rate;
+        }
+        // time term, fedm/functions.py:350-357
+        const double hq = Hrow[0] * phi[0] + Hrow[1] * phi[1] + Hrow[2] * phi[2];
+        const double vr = value(row, phi), er = exp(vr);
+        const double T = er * (vr * c_new + hq) / dt;
+        double S = T - src;
+        add(row, W, phi, (T + er * c_new / dt) * w_v, 0.0, 0.0);
+#pragma unroll
+        for (int i = 1; i < ns; ++i) add(i, W, phi, -src_v[i] * w_v, 0.0, 0.0);
+        add(0, W, phi, -src_c1 * ch.k1_0, 0.0, 0.0);
+        add(ie, W, phi, -src_c1 * ch.k1_e, 0.0, 0.0);
+        double Gx = 0.0, Gy = 0.0;
+        if (row == 0) {
+            // energy: 5/3 of the electron coefficients on u_0 (fedm-gd.py:354), Joule heating -Gamma_e . E
+            const GdFluxD Fw = species_flux(ie, 5.0 / 3.0, 0, phi, ch);
+            Gx = Fw.Gx;
+            Gy = Fw.Gy;
+            flux_columns(Fw, 0, ch, W, phi, w_v);
+            const GdFluxD Fe = species_flux(ie, 1.0, ie, phi, ch);
+            S += Fe.Gx * Ex + Fe.Gy * Ey;
+            flux_dot_columns(Fe, ie, ch, Ex, Ey, 1.0, W, phi, w_v);
+            add(IPHI, W, phi, -(Fe.Gx * w_x + Fe.Gy * w_y), 0.0, 0.0);   // d(G . E)/dE = G, E = -grad Phi
+        } else if (md->eq_type[row] != FEDM_EQ_REACTION) {
+            const GdFluxD Fl = species_flux(row, 1.0, row, phi, ch);
+            Gx = Fl.Gx;
+            Gy = Fl.Gy;
+            flux_columns(Fl, row, ch, W, phi, w_v);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) Racc[a] += W * (S * phi[a] - (Gx * c.G[a][0] + Gy * c.G[a][1]));
+    }
+
+    // 'flux source' boundary facets, functions.py:514-522
+    if (mode == 0 && row != IPHI) {
+        for (int i = 0; i < 3; ++i) {
+            const int tag = ftags[3 * cidx + i];
+            if (tag <= 0) continue;
+            const int sp = (row == 0) ? ie : row;
+            const int et = md->eq_type[sp];
+            if (et == FEDM_EQ_REACTION) continue;
+            const int j = (i == 0) ? 1 : 0, kk = (i == 2) ? 1 : 2;   // the facet's two vertices
+            const double Gi0 = i == 0 ? c.G[0][0] : i == 1 ? c.G[1][0] : c.G[2][0];
+            const double Gi1 = i == 0 ? c.G[0][1] : i == 1 ? c.G[1][1] : c.G[2][1];
+            const double gi = sqrt(Gi0 * Gi0 + Gi1 * Gi1);
+            const double nx = -Gi0 / gi, ny = -Gi1 / gi;
+            const int vj = j == 0 ? c.v[0] : c.v[1], vk = kk == 1 ? c.v[1] : c.v[2];
+            const double ex = coords[2 * vj] - coords[2 * vk], ey = coords[2 * vj + 1] - coords[2 * vk + 1];
+            const double L = sqrt(ex * ex + ey * ey);
+            const double ref = md->ref[tag - 1][sp], fac = (1.0 - ref) / (1.0 + ref);
+            for (int tq = 0; tq < md->n_fqp; ++tq) {
+                const double tj = 1.0 - md->fqp_t[tq], tk = md->fqp_t[tq];
+                // phi is tj at vertex j, tk at vertex kk, 0 at vertex i
+                const double phi[3] = {i == 0 ? 0.0 : (j == 0 ? tj : tk), i == 1 ? 0.0 : (j == 1 ? tj : tk),
+                                       i == 2 ? 0.0 : tk};
+                const double rq = c.rn[0] * phi[0] + c.rn[1] * phi[1] + c.rn[2] * phi[2];
+                const double W = md->fqp_w[tq] * L * two_pi * rq;
+                const double w_v = b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2];
+                const double dens = exp(value(row, phi));
+                double vth = (sp == ie) ? sqrt(md->vth_e_coef * nodal1(fl, F_ME, phi)) : md->vth[sp];
+                double mu_scale = 1.0, gam = md->gamma[tag - 1];
+                if (row == 0) {  // energy: 5/3 mu, 1.3333 vth, gamma * mean energy of secondaries
+                    vth *= 1.3333;
+                    mu_scale = 5.0 / 3.0;
+                    gam *= md->we_secondary;
+                }
+                double wall;
+                if (et == FEDM_EQ_DIFFUSION_REACTION) {
+                    wall = fac * (0.5 * vth * dens);
+                    add(row, W, phi, wall * w_v, 0.0, 0.0);
+                } else {
+                    const GdChannels ch = channels(phi, w_v);
+                    const double En = Ex * nx + Ey * ny;
+                    const double mub = nodal1(fl, F_MUD + sp, phi);
+                    const double muv = nodal1(fl, F_MU + sp, phi) + mub * ch.c1;
+                    const double zs = md->sign[sp] * mu_scale;
+                    const double qd = zs * (muv * En), sg = qd < 0.0 ? -1.0 : 1.0;
+                    wall = fac * ((0.5 * vth + sg * qd) * dens);
+                    add(row, W, phi, wall * w_v, 0.0, 0.0);
+                    const double k = fac * dens * sg * zs;
+                    add(0, W, phi, k * mub * En * ch.k1_0, 0.0, 0.0);
+                    add(ie, W, phi, k * mub * En * ch.k1_e, 0.0, 0.0);
+                    add(IPHI, W, phi, -k * muv * (nx * w_x + ny * w_y), 0.0, 0.0);
+                    if (sp == ie) {
+                        // - 2 gamma / (1 + r) * sum over ions of Max(Gamma_s . n, 0), fedm-gd.py:351
+                        const double cI = 2.0 * gam / (1.0 + ref);
+                        for (int s = 1; s < ns; ++s) {
+                            if (!md->is_ion[s]) continue;
+                            const GdFluxD Fs = species_flux(s, 1.0, s, phi, ch);
+                            const double gn = Fs.Gx * nx + Fs.Gy * ny;
+                            if (gn < 0.0) continue;
+                            wall -= cI * gn;
+                            flux_dot_columns(Fs, s, ch, nx, ny, -cI, W, phi, w_v);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) Racc[a] += W * wall * phi[a];
+            }
+        }
+    }
+
+    for (int a = 0; a < 3; ++a) {
+        if (b == 0) {   // the residual is the same for every column vertex: written once
+            unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
+        }
+        if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
+            double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_cells] = Jacc[a][s];
+            continue;
+        }
+        const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
+        double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) {
+            unsafeAtomicAdd(&dst[(size_t)(row * NEQ + s) * SLICE], Jacc[a][s]);
+        }
+    }
+}
+
+// every stored block position p = (block column, lane) of the sliced block-ELL matrix sums the
+// element blocks that land on it (inv_ptr / inv_idx: inverse of cell_slots), in the order of the
+// list, and writes its NEQ * NEQ planes: one coalesced store per matrix value, padding included
+template <int NEQ>
+__global__ __launch_bounds__(256) void gd_gather_kernel(int n_pos, const int *__restrict__ inv_ptr,
+                                                        const int *__restrict__ inv_idx,
+                                                        const double *__restrict__ elem, double *__restrict__ val,
+                                                        int row_first, int row_last, int n_cells) {
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pos) return;
+    double acc[NEQ2];
+#pragma unroll
+    for (int e = 0; e < NEQ2; ++e) acc[e] = 0.0;
+    for (int k = inv_ptr[p]; k < inv_ptr[p + 1]; ++k) {
+        const int ce = inv_idx[k], cell = ce / 9, ab = ce - 9 * cell;
+        const double *src = elem + (size_t)ab * NEQ2 * n_cells + cell;
+#pragma unroll
+        for (int e = 0; e < NEQ2; ++e) acc[e] += src[(size_t)e * n_cells];
+    }
+    double *dst = val + ((size_t)(p >> 6) * NEQ2) * SLICE + (p & 63);
+#pragma unroll
+    for (int e = 0; e < NEQ2; ++e)
+        if (e / NEQ >= row_first && e / NEQ <= row_last) dst[(size_t)e * SLICE] = acc[e];
+}
+
+// element buffer and the inverse of cell_slots, built the first time they are needed
+static int gd_elem_setup(Ctx &c) {
+    if (c.d_gd_elem) return 0;
+    const size_t n_pos = (size_t)c.pat.total_bc * SLICE, n_e = (size_t)c.nc * 9;
+    std::vector<int> ptr(n_pos + 1, 0), idx(n_e);
+    for (size_t e = 0; e < n_e; ++e) ++ptr[c.pat.cell_slots[e] + 1];
+    for (size_t p = 0; p < n_pos; ++p) ptr[p + 1] += ptr[p];
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (size_t e = 0; e < n_e; ++e) idx[fill[c.pat.cell_slots[e]]++] = (int)e;
+    if (hipMalloc((void **)&c.d_gd_inv_ptr, sizeof(int) * ptr.size()) != hipSuccess ||
+        hipMalloc((void **)&c.d_gd_inv_idx, sizeof(int) * idx.size()) != hipSuccess ||
+        hipMalloc((void **)&c.d_gd_elem, sizeof(double) * n_e * c.neq * c.neq) != hipSuccess ||
+        hipMemcpy(c.d_gd_inv_ptr, ptr.data(), sizeof(int) * ptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c.d_gd_inv_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c.d_gd_elem, 0, sizeof(double) * n_e * c.neq * c.neq) != hipSuccess) {
+        hipGetLastError();
+        for (void *q : {(void *)c.d_gd_inv_ptr, (void *)c.d_gd_inv_idx, (void *)c.d_gd_elem})
+            if (q) hipFree(q);
+        c.d_gd_inv_ptr = c.d_gd_inv_idx = nullptr;
+        c.d_gd_elem = nullptr;
+        return -1;   // the caller falls back to the atomics
+    }
+    return 0;
+}
+
 void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
     hipMemsetAsync(c.d_F, 0, sizeof(double) * c.np, c.stream);
+    const int ncol = (int)c.pat.colour_ptr.size() - 1;
+    // Ctx::gd_hand_mode (FEDM_GD_HAND when the context is created): 0 = dual numbers, a launch per
+    // colour (the cross-check of the hand-derived blocks), 2 = hand-derived blocks, fp64 atomics into the
+    // matrix, 3 (default) = hand-derived blocks, element buffer + gather
+    const int hand_mode = c.gd_hand_mode;
+    if (jacobian && hand_mode >= 2) {
+        // in Poisson-only mode the other rows keep the zeros of the memset (identity rows follow)
+        const int n = c.nc;
+        const bool gather = hand_mode == 3 && gd_elem_setup(c) == 0;
+        if (!gather || mode != 0)   // (the gather writes every value of the rows it covers)
+            hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * c.neq * c.neq, c.stream);
+        const int cpb = SLICE, nf = c.gd_n_fields;
+        const size_t lds_h = sizeof(double) * ((size_t)(3 * cpb + 1) / 2 + (size_t)cpb * nf * 3 + (size_t)cpb * 3 * c.neq);
+        const dim3 gh((unsigned)((n + cpb - 1) / cpb), 3), bh(SLICE * c.neq);
+        const int n_pos = (int)(c.pat.total_bc * SLICE);
+        const int row_first = mode == 1 ? c.neq - 1 : 0, row_last = c.neq - 1;
+#define FEDM_GD_HAND_LAUNCH(NEQ)                                                                                  \
+    do {                                                                                                          \
+        if (gather) {                                                                                             \
+            hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 2>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
+                               c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,   \
+                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode);             \
+            hipLaunchKernelGGL((gd_gather_kernel<NEQ>), dim3((n_pos + 255) / 256), dim3(256), 0, c.stream, n_pos, \
+                               c.d_gd_inv_ptr, c.d_gd_inv_idx, c.d_gd_elem, c.d_val, row_first, row_last, n);     \
+        } else {                                                                                                  \
+            hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 1>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
+                               c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,   \
+                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_val, c.d_F, mode);                 \
+        }                                                                                                         \
+    } while (0)
+        switch (c.neq) {
+            case 3: FEDM_GD_HAND_LAUNCH(3); break;
+            case 4: FEDM_GD_HAND_LAUNCH(4); break;
+            case 5: FEDM_GD_HAND_LAUNCH(5); break;
+            case 6: FEDM_GD_HAND_LAUNCH(6); break;
+        }
+#undef FEDM_GD_HAND_LAUNCH
+        return;
+    }
     if (jacobian)
         hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * c.neq * c.neq, c.stream);
-    const int ncol = (int)c.pat.colour_ptr.size() - 1;
     for (int k = 0; k < ncol; ++k) {
         const int n = c.pat.colour_ptr[k + 1] - c.pat.colour_ptr[k];
         if (n == 0) continue;

@@ -12,9 +12,14 @@ ROOT = Path(__file__).resolve().parent.parent
 DECK = ROOT / "decks" / "glow_discharge" / "file_input" / "4_particles"
 
 
-def test_gd_residual_and_jacobian_match_the_oracle():
+@pytest.mark.parametrize("variant", ["3", "2", "0"])
+def test_gd_residual_and_jacobian_match_the_oracle(variant, monkeypatch):
+    """LMEA element Jacobian against the oracle for the three device variants (csrc/gd.hip):
+    hand-derived blocks through the element buffer + gather (3, default), the same blocks added with
+    atomics (2), and the dual-number kernel (0) that cross-checks the hand derivation."""
     from oracle import gd as ogd
     from fedm_amd.cases import glow_discharge as gdc
+    monkeypatch.setenv("FEDM_GD_HAND", variant)
     case = gdc.Case(nx=10, ny=10, device_pipeline=False)
     o = ogd.GlowDischarge(DECK, 10, 10)
     nv = o.mesh.nv
