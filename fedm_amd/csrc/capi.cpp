@@ -1058,7 +1058,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
                     c.d_tmp, c.d_fs, c.d_fs_g, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
                     c.d_ext[3], c.d_patch_cell_ptr, c.d_patch_halo_ptr, c.d_patch_halo,
                     c.d_patch_cells, c.d_bfacets, c.d_gd, c.d_gd_fields, c.d_gd_elem, c.d_gd_inv_ptr,
-                    c.d_gd_inv_idx};
+                    c.d_gd_inv_idx, c.d_gd_elemF, c.d_gd_vinv_ptr, c.d_gd_vinv_idx};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (Amg *a : {c.amg, c.amg_alt})

@@ -106,6 +106,8 @@ struct Ctx {
     double *d_gd_elem = nullptr;          // [9 * neq * neq][nc]
     int *d_gd_inv_ptr = nullptr;          // [total_bc * 64 + 1]
     int *d_gd_inv_idx = nullptr;          // cell * 9 + (a * 3 + b)
+    double *d_gd_elemF = nullptr;         // element residuals [3 * neq][nc]
+    int *d_gd_vinv_ptr = nullptr, *d_gd_vinv_idx = nullptr;   // vertex -> cell * 3 + local vertex
     int gd_hand_mode = 3;                 // gd.hip, launch_assemble_gd
     GdPrep *gd_prep = nullptr;  // on-device per-step coefficient refresh (LMEA)
     Pattern pat;

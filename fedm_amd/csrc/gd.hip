@@ -468,6 +468,7 @@ __device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, 
 // [cell] (lanes = cells: coalesced) and gd_gather_kernel sums them into the matrix -- every matrix
 // value written once, fixed summation order; 1 = fp64 atomics straight into the matrix (the fall-back
 // when the buffer cannot be allocated).  The residual is added with atomics.
+// STORE 0: residual only (launched with one column vertex: gridDim.y = 1).
 template <int NEQ, int STORE>
 __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
     const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields, int nv,
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
     const double *__restrict__ coords, const int8_t *__restrict__ ftags,
     const uint32_t *__restrict__ cell_slots, const double *__restrict__ u,
     const double *__restrict__ uold, const double *__restrict__ uold1, double dt, double dt_old,
-    double *__restrict__ val, double *__restrict__ F, int mode) {
+    double *__restrict__ val, double *__restrict__ F, int mode, double *__restrict__ elemF) {
     constexpr int NEQ2 = NEQ * NEQ, ns = NEQ - 1, IPHI = NEQ - 1, ie = ns - 1;
     const double two_pi = 6.283185307179586476925286766559;
     const int lc = threadIdx.x & (SLICE - 1);
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
     };
     // W (tS phi_a - tX G_a,x - tY G_a,y) into column s of the accumulators (s: wave-uniform)
     auto add = [&](int s, double W, const double phi[3], double tS, double tX, double tY) {
+        if (STORE == 0) return;
 #pragma unroll
         for (int k = 0; k < NEQ; ++k)
             if (k == s) {
@@ -745,8 +747,10 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
 
     for (int a = 0; a < 3; ++a) {
         if (b == 0) {   // the residual is the same for every column vertex: written once
-            unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
+            if (elemF) elemF[(size_t)(a * NEQ + row) * n_cells + cidx] = Racc[a];   // summed by gd_gather_residual_kernel
+            else unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
         }
+        if (STORE == 0) continue;
         if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
             double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
 #pragma unroll
@@ -788,7 +792,29 @@ __global__ __launch_bounds__(256) void gd_gather_kernel(int n_pos, const int *__
         if (e / NEQ >= row_first && e / NEQ <= row_last) dst[(size_t)e * SLICE] = acc[e];
 }
 
-// element buffer and the inverse of cell_slots, built the first time they are needed
+// every vertex sums the element residuals of its cells (inverse of the connectivity), fixed order
+template <int NEQ>
+__global__ __launch_bounds__(256) void gd_gather_residual_kernel(int nv, const int *__restrict__ inv_ptr,
+                                                                 const int *__restrict__ inv_idx,
+                                                                 const double *__restrict__ elemF,
+                                                                 double *__restrict__ F, int row_first, int n_cells) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    double acc[NEQ];
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
+    for (int k = inv_ptr[v]; k < inv_ptr[v + 1]; ++k) {
+        const int ca = inv_idx[k], cell = ca / 3, a = ca - 3 * cell;
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r)
+            if (r >= row_first) acc[r] += elemF[(size_t)(a * NEQ + r) * n_cells + cell];
+    }
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r)
+        if (r >= row_first) F[(size_t)v * NEQ + r] = acc[r];
+}
+
+// element buffers and the inverse maps (cell_slots, connectivity), built the first time they are needed
 static int gd_elem_setup(Ctx &c) {
     if (c.d_gd_elem) return 0;
     const size_t n_pos = (size_t)c.pat.total_bc * SLICE, n_e = (size_t)c.nc * 9;
@@ -797,17 +823,36 @@ static int gd_elem_setup(Ctx &c) {
     for (size_t p = 0; p < n_pos; ++p) ptr[p + 1] += ptr[p];
     std::vector<int> fill(ptr.begin(), ptr.end() - 1);
     for (size_t e = 0; e < n_e; ++e) idx[fill[c.pat.cell_slots[e]]++] = (int)e;
-    if (hipMalloc((void **)&c.d_gd_inv_ptr, sizeof(int) * ptr.size()) != hipSuccess ||
+    // vertex -> (cell, local vertex): read back from the device copy of the connectivity
+    std::vector<int> cells_h((size_t)c.nc * 3), vptr((size_t)c.nv + 1, 0), vidx((size_t)c.nc * 3);
+    if (hipMemcpy(cells_h.data(), c.d_cells, sizeof(int) * cells_h.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+        hipGetLastError();
+        return -1;
+    }
+    for (size_t e = 0; e < cells_h.size(); ++e) ++vptr[cells_h[e] + 1];
+    for (int v = 0; v < c.nv; ++v) vptr[v + 1] += vptr[v];
+    {
+        std::vector<int> vfill(vptr.begin(), vptr.end() - 1);
+        for (size_t e = 0; e < cells_h.size(); ++e) vidx[vfill[cells_h[e]]++] = (int)e;
+    }
+    if (hipMalloc((void **)&c.d_gd_vinv_ptr, sizeof(int) * vptr.size()) != hipSuccess ||
+        hipMalloc((void **)&c.d_gd_vinv_idx, sizeof(int) * vidx.size()) != hipSuccess ||
+        hipMalloc((void **)&c.d_gd_elemF, sizeof(double) * (size_t)c.nc * 3 * c.neq) != hipSuccess ||
+        hipMemcpy(c.d_gd_vinv_ptr, vptr.data(), sizeof(int) * vptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c.d_gd_vinv_idx, vidx.data(), sizeof(int) * vidx.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c.d_gd_elemF, 0, sizeof(double) * (size_t)c.nc * 3 * c.neq) != hipSuccess ||
+        hipMalloc((void **)&c.d_gd_inv_ptr, sizeof(int) * ptr.size()) != hipSuccess ||
         hipMalloc((void **)&c.d_gd_inv_idx, sizeof(int) * idx.size()) != hipSuccess ||
         hipMalloc((void **)&c.d_gd_elem, sizeof(double) * n_e * c.neq * c.neq) != hipSuccess ||
         hipMemcpy(c.d_gd_inv_ptr, ptr.data(), sizeof(int) * ptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c.d_gd_inv_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c.d_gd_elem, 0, sizeof(double) * n_e * c.neq * c.neq) != hipSuccess) {
         hipGetLastError();
-        for (void *q : {(void *)c.d_gd_inv_ptr, (void *)c.d_gd_inv_idx, (void *)c.d_gd_elem})
+        for (void *q : {(void *)c.d_gd_inv_ptr, (void *)c.d_gd_inv_idx, (void *)c.d_gd_elem, (void *)c.d_gd_vinv_ptr,
+                        (void *)c.d_gd_vinv_idx, (void *)c.d_gd_elemF})
             if (q) hipFree(q);
-        c.d_gd_inv_ptr = c.d_gd_inv_idx = nullptr;
-        c.d_gd_elem = nullptr;
+        c.d_gd_inv_ptr = c.d_gd_inv_idx = c.d_gd_vinv_ptr = c.d_gd_vinv_idx = nullptr;
+        c.d_gd_elem = c.d_gd_elemF = nullptr;
         return -1;   // the caller falls back to the atomics
     }
     return 0;
@@ -836,13 +881,15 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         if (gather) {                                                                                             \
             hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 2>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,   \
-                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode);             \
+                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF); \
             hipLaunchKernelGGL((gd_gather_kernel<NEQ>), dim3((n_pos + 255) / 256), dim3(256), 0, c.stream, n_pos, \
                                c.d_gd_inv_ptr, c.d_gd_inv_idx, c.d_gd_elem, c.d_val, row_first, row_last, n);     \
+            hipLaunchKernelGGL((gd_gather_residual_kernel<NEQ>), dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, \
+                               c.nv, c.d_gd_vinv_ptr, c.d_gd_vinv_idx, c.d_gd_elemF, c.d_F, row_first, n);        \
         } else {                                                                                                  \
             hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 1>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,   \
-                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_val, c.d_F, mode);                 \
+                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_val, c.d_F, mode, (double *)nullptr); \
         }                                                                                                         \
     } while (0)
         switch (c.neq) {
@@ -852,6 +899,33 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
             case 6: FEDM_GD_HAND_LAUNCH(6); break;
         }
 #undef FEDM_GD_HAND_LAUNCH
+        return;
+    }
+    if (!jacobian && hand_mode >= 2) {
+        // residual only: the same point functions without the derivative columns, all cells in one
+        // launch; element residuals summed per vertex (no atomics: fixed order)
+        const int n = c.nc;
+        double *elemF = (hand_mode == 3 && gd_elem_setup(c) == 0) ? c.d_gd_elemF : nullptr;
+        const size_t lds_h = sizeof(double) * ((size_t)(3 * SLICE + 1) / 2 + (size_t)SLICE * c.gd_n_fields * 3 +
+                                               (size_t)SLICE * 3 * c.neq);
+        const dim3 gh((unsigned)((n + SLICE - 1) / SLICE), 1), bh(SLICE * c.neq);
+        const int row_first = mode == 1 ? c.neq - 1 : 0;
+#define FEDM_GD_RES_LAUNCH(NEQ)                                                                                   \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 0>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields,     \
+                           c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,       \
+                           c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, (double *)nullptr, c.d_F, mode, elemF);    \
+        if (elemF)                                                                                                \
+            hipLaunchKernelGGL((gd_gather_residual_kernel<NEQ>), dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, \
+                               c.nv, c.d_gd_vinv_ptr, c.d_gd_vinv_idx, elemF, c.d_F, row_first, n);               \
+    } while (0)
+        switch (c.neq) {
+            case 3: FEDM_GD_RES_LAUNCH(3); break;
+            case 4: FEDM_GD_RES_LAUNCH(4); break;
+            case 5: FEDM_GD_RES_LAUNCH(5); break;
+            case 6: FEDM_GD_RES_LAUNCH(6); break;
+        }
+#undef FEDM_GD_RES_LAUNCH
         return;
     }
     if (jacobian)
