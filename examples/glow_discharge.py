@@ -296,7 +296,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
     # initial potential and the coefficients that depend on it (:283-315), now that the device exists
     problem.device.setup_multigrid(nu=1)
     from fedm_amd.device import chebyshev_weights
-    problem.device.set_fieldsplit(chebyshev_weights(4))
+    problem.device.set_fieldsplit(chebyshev_weights(8, 0.3, 2.2))   # tools/gd_cycle.py
     problem.device.poisson_solve()
     assigner.assign(variable_list_new, u_new)
     Phi_old1.assign(Phi_old)
