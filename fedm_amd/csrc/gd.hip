@@ -410,7 +410,8 @@ __device__ __forceinline__ double nodal1(const double *fl, int fi, const double 
 // column vertex for the columns 0 (energy) and e (electrons)
 struct GdChannels {
     double c1, c2, c3;
-    double k1_0, k2_0, k3_0, k1_e, k2_e, k3_e;
+    // d c1 / d v_0 = d c2 / d gx_0 = d c3 / d gy_0 = r0;  d c1 / d v_e = d c2 / d gx_e = d c3 / d gy_e = rem
+    double r0, rem, c2_v0, c3_v0, c2_ve, c3_ve;
 };
 
 // drift-diffusion flux of one species (gd_flux above) with its partial derivatives
@@ -470,7 +471,7 @@ __device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, 
 // when the buffer cannot be allocated).  The residual is added with atomics.
 // STORE 0: residual only (launched with one column vertex: gridDim.y = 1).
 template <int NEQ, int STORE>
-__global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
+__global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(2, 2))) void gd_jacobian_rows_kernel(
     const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields, int nv,
     const int *__restrict__ cell_list, int n_cells, const int *__restrict__ cells,
     const double *__restrict__ coords, const int8_t *__restrict__ ftags,
@@ -480,8 +481,7 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
     constexpr int NEQ2 = NEQ * NEQ, ns = NEQ - 1, IPHI = NEQ - 1, ie = ns - 1;
     const double two_pi = 6.283185307179586476925286766559;
     const int lc = threadIdx.x & (SLICE - 1);
-    const int row = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;                      // column vertex of this workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ci = blockIdx.x * SLICE + lc;
     const int nr = md->n_reactions;
     const int NF = 4 * ns + 2 * nr + 3;
@@ -506,13 +506,10 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
     }
     __syncthreads();
     if (ci >= n_cells) return;
-    if (mode == 1 && row != IPHI) return;   // Poisson-only: the other rows are identity rows
     const int cidx = cell_list ? cell_list[ci] : ci;   // no list: the mesh's own cell order
     const double *fl = lds_f + (size_t)lc * NF * 3;
     const double *ul = lds_u + (size_t)lc * 3 * NEQ;   // [a][s]
     GdCell c;
-    double Hrow[3];
-    const double tr = dt / dt_old, trp1 = 1.0 + tr, c_new = (1.0 + 2.0 * tr) / trp1;
     {
         double x[3][2];   // (not kept: the facet terms read the two coordinates they need again)
         for (int a = 0; a < 3; ++a) {
@@ -520,7 +517,6 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
             x[a][0] = coords[2 * c.v[a]];
             x[a][1] = coords[2 * c.v[a] + 1];
             c.rn[a] = md->axisymmetric ? x[a][0] : 0.5 / 3.14159265358979323846;
-            Hrow[a] = (-(trp1 * trp1) * uold[(size_t)c.v[a] * NEQ + row] + (tr * tr) * uold1[(size_t)c.v[a] * NEQ + row]) / trp1;
         }
         const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
         const double d2x = x[2][0] - x[0][0], d2y = x[2][1] - x[0][1];
@@ -533,16 +529,26 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
         c.G[2][0] = (x[0][1] - x[1][1]) / det;
         c.G[2][1] = (x[1][0] - x[0][0]) / det;
     }
-    // gradient of the column vertex's basis function (selects, not a run-time index into registers)
-    const double w_x = b == 0 ? c.G[0][0] : b == 1 ? c.G[1][0] : c.G[2][0];
-    const double w_y = b == 0 ? c.G[0][1] : b == 1 ? c.G[1][1] : c.G[2][1];
+    const double tr = dt / dt_old, trp1 = 1.0 + tr, c_new = (1.0 + 2.0 * tr) / trp1;
     const int F_MU = 0, F_D = ns, F_MUD = 2 * ns, F_DD = 3 * ns, F_K = 4 * ns, F_KD = 4 * ns + nr,
               F_MEO = 4 * ns + 2 * nr, F_ME = F_MEO + 1, F_UEO = F_MEO + 2;
-    double Racc[3] = {0.0, 0.0, 0.0}, Jacc[3][NEQ];
-#pragma unroll
+    // One wave per species/energy row; the (cheap) Poisson row is a second pass of wave 1, so that a
+    // workgroup is NEQ - 1 waves (four for the glow-discharge model: two workgroups per CU at two waves
+    // per SIMD; five-wave workgroups left three of eight wave slots empty).
+    for (int pass = 0; pass < 2; ++pass) {
+    const int row = pass == 0 ? wave : IPHI;
+    if (pass == 1 && wave != (ns > 1 ? 1 : 0)) break;
+    if (mode == 1 && row != IPHI) continue;   // Poisson-only: the other rows are identity rows
+    double Hrow[3];
     for (int a = 0; a < 3; ++a)
+        Hrow[a] = (-(trp1 * trp1) * uold[(size_t)c.v[a] * NEQ + row] + (tr * tr) * uold1[(size_t)c.v[a] * NEQ + row]) / trp1;
+    double Racc[3] = {0.0, 0.0, 0.0}, Jacc[3][3][NEQ];   // [column vertex b][row vertex a][column field s]
 #pragma unroll
-        for (int s = 0; s < NEQ; ++s) Jacc[a][s] = 0.0;
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) Jacc[b][a][s] = 0.0;
 
     // value and gradient of unknown s at a point (s is wave-uniform or a compile-time index)
     auto value = [&](int s, const double phi[3]) {
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
     const double gx0 = grad_x(0), gy0 = grad_y(0), gxe = grad_x(ie), gye = grad_y(ie);
     const double Ex = -grad_x(IPHI), Ey = -grad_y(IPHI);
 
-    auto channels = [&](const double phi[3], double w_v) {
+    auto channels = [&](const double phi[3]) {
         const N3 meo = nodal3(fl, F_MEO, c, phi), ueo = nodal3(fl, F_UEO, c, phi);
         const double ieo = exp(-ueo.v);
         const double r0 = exp(value(0, phi)) * ieo, re = exp(value(ie, phi)) * ieo;
@@ -561,24 +567,41 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
         ch.c1 = r0 - re * meo.v;
         ch.c2 = r0 * gx0 - re * (gxe * meo.v + meo.gx) - ch.c1 * ueo.gx;
         ch.c3 = r0 * gy0 - re * (gye * meo.v + meo.gy) - ch.c1 * ueo.gy;
-        const double rem = -re * meo.v;
-        ch.k1_0 = r0 * w_v;
-        ch.k2_0 = r0 * (gx0 - ueo.gx) * w_v + r0 * w_x;
-        ch.k3_0 = r0 * (gy0 - ueo.gy) * w_v + r0 * w_y;
-        ch.k1_e = rem * w_v;
-        ch.k2_e = -re * (gxe * meo.v + meo.gx - meo.v * ueo.gx) * w_v + rem * w_x;
-        ch.k3_e = -re * (gye * meo.v + meo.gy - meo.v * ueo.gy) * w_v + rem * w_y;
+        ch.r0 = r0;
+        ch.rem = -re * meo.v;
+        ch.c2_v0 = r0 * (gx0 - ueo.gx);
+        ch.c3_v0 = r0 * (gy0 - ueo.gy);
+        ch.c2_ve = -re * (gxe * meo.v + meo.gx - meo.v * ueo.gx);
+        ch.c3_ve = -re * (gye * meo.v + meo.gy - meo.v * ueo.gy);
         return ch;
     };
     // W (tS phi_a - tX G_a,x - tY G_a,y) into column s of the accumulators (s: wave-uniform)
-    auto add = [&](int s, double W, const double phi[3], double tS, double tX, double tY) {
+    // (b is a compile-time index where add is called: the loops over the column vertex are unrolled)
+    auto add = [&](int b, int s, double W, const double phi[3], double tS, double tX, double tY) {
         if (STORE == 0) return;
 #pragma unroll
         for (int k = 0; k < NEQ; ++k)
             if (k == s) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Jacc[a][k] += W * (tS * phi[a] - tX * c.G[a][0] - tY * c.G[a][1]);
+                for (int a = 0; a < 3; ++a) Jacc[b][a][k] += W * (tS * phi[a] - tX * c.G[a][0] - tY * c.G[a][1]);
             }
+    };
+    // derivatives of the channels along the basis function of column vertex b (value w_v, gradient w_x, w_y)
+    struct Seeds {
+        double w_v, w_x, w_y, k1_0, k2_0, k3_0, k1_e, k2_e, k3_e;
+    };
+    auto seeds = [&](int b, const double phi[3], const GdChannels &ch) {
+        Seeds sd;
+        sd.w_v = phi[b];
+        sd.w_x = c.G[b][0];
+        sd.w_y = c.G[b][1];
+        sd.k1_0 = ch.r0 * sd.w_v;
+        sd.k2_0 = ch.c2_v0 * sd.w_v + ch.r0 * sd.w_x;
+        sd.k3_0 = ch.c3_v0 * sd.w_v + ch.r0 * sd.w_y;
+        sd.k1_e = ch.rem * sd.w_v;
+        sd.k2_e = ch.c2_ve * sd.w_v + ch.rem * sd.w_x;
+        sd.k3_e = ch.c3_ve * sd.w_v + ch.rem * sd.w_y;
+        return sd;
     };
     auto species_flux = [&](int s, double scale, int own, const double phi[3], const GdChannels &ch) {
         const int et = md->eq_type[s];
@@ -588,27 +611,26 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
                                 value(own, phi), grad_x(own), grad_y(own), Ex, Ey);
     };
     // directional derivative of a flux (column vertex b) into the flux columns of the accumulators
-    auto flux_columns = [&](const GdFluxD &Fl, int own, const GdChannels &ch, double W, const double phi[3], double w_v) {
-        add(own, W, phi, 0.0, Fl.Gx * w_v + Fl.dg * w_x, Fl.Gy * w_v + Fl.dg * w_y);
-        add(IPHI, W, phi, 0.0, -Fl.dE * w_x, -Fl.dE * w_y);   // E = -grad Phi
-        add(0, W, phi, 0.0, Fl.x_c1 * ch.k1_0 + Fl.x_c2 * ch.k2_0, Fl.y_c1 * ch.k1_0 + Fl.y_c3 * ch.k3_0);
-        add(ie, W, phi, 0.0, Fl.x_c1 * ch.k1_e + Fl.x_c2 * ch.k2_e, Fl.y_c1 * ch.k1_e + Fl.y_c3 * ch.k3_e);
+    auto flux_columns = [&](int b, const GdFluxD &Fl, int own, const Seeds &sd, double W, const double phi[3]) {
+        add(b, own, W, phi, 0.0, Fl.Gx * sd.w_v + Fl.dg * sd.w_x, Fl.Gy * sd.w_v + Fl.dg * sd.w_y);
+        add(b, IPHI, W, phi, 0.0, -Fl.dE * sd.w_x, -Fl.dE * sd.w_y);   // E = -grad Phi
+        add(b, 0, W, phi, 0.0, Fl.x_c1 * sd.k1_0 + Fl.x_c2 * sd.k2_0, Fl.y_c1 * sd.k1_0 + Fl.y_c3 * sd.k3_0);
+        add(b, ie, W, phi, 0.0, Fl.x_c1 * sd.k1_e + Fl.x_c2 * sd.k2_e, Fl.y_c1 * sd.k1_e + Fl.y_c3 * sd.k3_e);
     };
     // ... of factor * (w . G) (Joule heating: w = E; wall flux: w = n) into the source columns
-    auto flux_dot_columns = [&](const GdFluxD &Fl, int own, const GdChannels &ch, double wx, double wy, double factor,
-                                double W, const double phi[3], double w_v) {
-        add(own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * w_v + Fl.dg * (wx * w_x + wy * w_y)), 0.0, 0.0);
-        add(IPHI, W, phi, -factor * Fl.dE * (wx * w_x + wy * w_y), 0.0, 0.0);
+    auto flux_dot_columns = [&](int b, const GdFluxD &Fl, int own, const Seeds &sd, double wx, double wy, double factor,
+                                double W, const double phi[3]) {
+        add(b, own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * sd.w_v + Fl.dg * (wx * sd.w_x + wy * sd.w_y)), 0.0, 0.0);
+        add(b, IPHI, W, phi, -factor * Fl.dE * (wx * sd.w_x + wy * sd.w_y), 0.0, 0.0);
         const double o1 = factor * (Fl.x_c1 * wx + Fl.y_c1 * wy), o2 = factor * Fl.x_c2 * wx, o3 = factor * Fl.y_c3 * wy;
-        add(0, W, phi, o1 * ch.k1_0 + o2 * ch.k2_0 + o3 * ch.k3_0, 0.0, 0.0);
-        add(ie, W, phi, o1 * ch.k1_e + o2 * ch.k2_e + o3 * ch.k3_e, 0.0, 0.0);
+        add(b, 0, W, phi, o1 * sd.k1_0 + o2 * sd.k2_0 + o3 * sd.k3_0, 0.0, 0.0);
+        add(b, ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e, 0.0, 0.0);
     };
 
     for (int q = 0; q < md->n_qp; ++q) {
         const double phi[3] = {1.0 - md->qp_x[q] - md->qp_y[q], md->qp_x[q], md->qp_y[q]};
         const double rq = c.rn[0] * phi[0] + c.rn[1] * phi[1] + c.rn[2] * phi[2];
         const double W = md->qp_w[q] * c.detJ * two_pi * rq;
-        const double w_v = b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2];
         if (row == IPHI) {
             // 2 pi r (grad Phi . grad v - rho v): S = -rho, G = -grad Phi
             double rho = 0.0;
@@ -616,14 +638,16 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
             for (int i = 1; i < ns; ++i) {
                 const double ni = (md->sign[i] * md->charge_over_eps) * exp(value(i, phi));
                 rho += ni;
-                add(i, W, phi, -ni * w_v, 0.0, 0.0);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) add(b, i, W, phi, -ni * phi[b], 0.0, 0.0);
             }
-            add(IPHI, W, phi, 0.0, -w_x, -w_y);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) add(b, IPHI, W, phi, 0.0, -c.G[b][0], -c.G[b][1]);
 #pragma unroll
             for (int a = 0; a < 3; ++a) Racc[a] += W * (-rho * phi[a] - (Ex * c.G[a][0] + Ey * c.G[a][1]));
             continue;
         }
-        const GdChannels ch = channels(phi, w_v);
+        const GdChannels ch = channels(phi);
         double n[ns];
 #pragma unroll
         for (int i = 1; i < ns; ++i) n[i] = exp(value(i, phi));
@@ -650,27 +674,44 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
         const double vr = value(row, phi), er = exp(vr);
         const double T = er * (vr * c_new + hq) / dt;
         double S = T - src;
-        add(row, W, phi, (T + er * c_new / dt) * w_v, 0.0, 0.0);
-#pragma unroll
-        for (int i = 1; i < ns; ++i) add(i, W, phi, -src_v[i] * w_v, 0.0, 0.0);
-        add(0, W, phi, -src_c1 * ch.k1_0, 0.0, 0.0);
-        add(ie, W, phi, -src_c1 * ch.k1_e, 0.0, 0.0);
+        const double dT = T + er * c_new / dt;
         double Gx = 0.0, Gy = 0.0;
         if (row == 0) {
             // energy: 5/3 of the electron coefficients on u_0 (fedm-gd.py:354), Joule heating -Gamma_e . E
             const GdFluxD Fw = species_flux(ie, 5.0 / 3.0, 0, phi, ch);
             Gx = Fw.Gx;
             Gy = Fw.Gy;
-            flux_columns(Fw, 0, ch, W, phi, w_v);
             const GdFluxD Fe = species_flux(ie, 1.0, ie, phi, ch);
             S += Fe.Gx * Ex + Fe.Gy * Ey;
-            flux_dot_columns(Fe, ie, ch, Ex, Ey, 1.0, W, phi, w_v);
-            add(IPHI, W, phi, -(Fe.Gx * w_x + Fe.Gy * w_y), 0.0, 0.0);   // d(G . E)/dE = G, E = -grad Phi
-        } else if (md->eq_type[row] != FEDM_EQ_REACTION) {
-            const GdFluxD Fl = species_flux(row, 1.0, row, phi, ch);
-            Gx = Fl.Gx;
-            Gy = Fl.Gy;
-            flux_columns(Fl, row, ch, W, phi, w_v);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const Seeds sd = seeds(b, phi, ch);
+                add(b, 0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0, 0.0, 0.0);
+#pragma unroll
+                for (int i = 1; i < ns; ++i) add(b, i, W, phi, -src_v[i] * sd.w_v, 0.0, 0.0);
+                add(b, ie, W, phi, -src_c1 * sd.k1_e, 0.0, 0.0);
+                flux_columns(b, Fw, 0, sd, W, phi);
+                flux_dot_columns(b, Fe, ie, sd, Ex, Ey, 1.0, W, phi);
+                add(b, IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y), 0.0, 0.0);   // d(G . E)/dE = G, E = -grad Phi
+            }
+        } else {
+            const bool has_flux = md->eq_type[row] != FEDM_EQ_REACTION;
+            GdFluxD Fl = {};
+            if (has_flux) {
+                Fl = species_flux(row, 1.0, row, phi, ch);
+                Gx = Fl.Gx;
+                Gy = Fl.Gy;
+            }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const Seeds sd = seeds(b, phi, ch);
+                add(b, row, W, phi, dT * sd.w_v, 0.0, 0.0);
+#pragma unroll
+                for (int i = 1; i < ns; ++i) add(b, i, W, phi, -src_v[i] * sd.w_v, 0.0, 0.0);
+                add(b, 0, W, phi, -src_c1 * sd.k1_0, 0.0, 0.0);
+                add(b, ie, W, phi, -src_c1 * sd.k1_e, 0.0, 0.0);
+                if (has_flux) flux_columns(b, Fl, row, sd, W, phi);
+            }
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) Racc[a] += W * (S * phi[a] - (Gx * c.G[a][0] + Gy * c.G[a][1]));
@@ -700,7 +741,6 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
                                        i == 2 ? 0.0 : tk};
                 const double rq = c.rn[0] * phi[0] + c.rn[1] * phi[1] + c.rn[2] * phi[2];
                 const double W = md->fqp_w[tq] * L * two_pi * rq;
-                const double w_v = b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2];
                 const double dens = exp(value(row, phi));
                 double vth = (sp == ie) ? sqrt(md->vth_e_coef * nodal1(fl, F_ME, phi)) : md->vth[sp];
                 double mu_scale = 1.0, gam = md->gamma[tag - 1];
@@ -712,20 +752,25 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
                 double wall;
                 if (et == FEDM_EQ_DIFFUSION_REACTION) {
                     wall = fac * (0.5 * vth * dens);
-                    add(row, W, phi, wall * w_v, 0.0, 0.0);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) add(b, row, W, phi, wall * phi[b], 0.0, 0.0);
                 } else {
-                    const GdChannels ch = channels(phi, w_v);
+                    const GdChannels ch = channels(phi);
                     const double En = Ex * nx + Ey * ny;
                     const double mub = nodal1(fl, F_MUD + sp, phi);
                     const double muv = nodal1(fl, F_MU + sp, phi) + mub * ch.c1;
                     const double zs = md->sign[sp] * mu_scale;
                     const double qd = zs * (muv * En), sg = qd < 0.0 ? -1.0 : 1.0;
                     wall = fac * ((0.5 * vth + sg * qd) * dens);
-                    add(row, W, phi, wall * w_v, 0.0, 0.0);
                     const double k = fac * dens * sg * zs;
-                    add(0, W, phi, k * mub * En * ch.k1_0, 0.0, 0.0);
-                    add(ie, W, phi, k * mub * En * ch.k1_e, 0.0, 0.0);
-                    add(IPHI, W, phi, -k * muv * (nx * w_x + ny * w_y), 0.0, 0.0);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const Seeds sd = seeds(b, phi, ch);
+                        add(b, row, W, phi, wall * sd.w_v, 0.0, 0.0);
+                        add(b, 0, W, phi, k * mub * En * sd.k1_0, 0.0, 0.0);
+                        add(b, ie, W, phi, k * mub * En * sd.k1_e, 0.0, 0.0);
+                        add(b, IPHI, W, phi, -k * muv * (nx * sd.w_x + ny * sd.w_y), 0.0, 0.0);
+                    }
                     if (sp == ie) {
                         // - 2 gamma / (1 + r) * sum over ions of Max(Gamma_s . n, 0), fedm-gd.py:351
                         const double cI = 2.0 * gam / (1.0 + ref);
@@ -735,7 +780,8 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
                             const double gn = Fs.Gx * nx + Fs.Gy * ny;
                             if (gn < 0.0) continue;
                             wall -= cI * gn;
-                            flux_dot_columns(Fs, s, ch, nx, ny, -cI, W, phi, w_v);
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) flux_dot_columns(b, Fs, s, seeds(b, phi, ch), nx, ny, -cI, W, phi);
                         }
                     }
                 }
@@ -746,24 +792,24 @@ __global__ __launch_bounds__(64 * NEQ) void gd_jacobian_rows_kernel(
     }
 
     for (int a = 0; a < 3; ++a) {
-        if (b == 0) {   // the residual is the same for every column vertex: written once
-            if (elemF) elemF[(size_t)(a * NEQ + row) * n_cells + cidx] = Racc[a];   // summed by gd_gather_residual_kernel
-            else unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
-        }
+        if (elemF) elemF[(size_t)(a * NEQ + row) * n_cells + cidx] = Racc[a];   // summed by gd_gather_residual_kernel
+        else unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
         if (STORE == 0) continue;
-        if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
-            double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
 #pragma unroll
-            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_cells] = Jacc[a][s];
-            continue;
-        }
-        const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
-        double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
+        for (int b = 0; b < 3; ++b) {
+            if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
+                double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
 #pragma unroll
-        for (int s = 0; s < NEQ; ++s) {
-            unsafeAtomicAdd(&dst[(size_t)(row * NEQ + s) * SLICE], Jacc[a][s]);
+                for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_cells] = Jacc[b][a][s];
+                continue;
+            }
+            const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
+            double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) unsafeAtomicAdd(&dst[(size_t)(row * NEQ + s) * SLICE], Jacc[b][a][s]);
         }
     }
+    }   // pass
 }
 
 // every stored block position p = (block column, lane) of the sliced block-ELL matrix sums the
@@ -873,7 +919,7 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
             hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * c.neq * c.neq, c.stream);
         const int cpb = SLICE, nf = c.gd_n_fields;
         const size_t lds_h = sizeof(double) * ((size_t)(3 * cpb + 1) / 2 + (size_t)cpb * nf * 3 + (size_t)cpb * 3 * c.neq);
-        const dim3 gh((unsigned)((n + cpb - 1) / cpb), 3), bh(SLICE * c.neq);
+        const dim3 gh((unsigned)((n + cpb - 1) / cpb), 1), bh(SLICE * (c.neq - 1));
         const int n_pos = (int)(c.pat.total_bc * SLICE);
         const int row_first = mode == 1 ? c.neq - 1 : 0, row_last = c.neq - 1;
 #define FEDM_GD_HAND_LAUNCH(NEQ)                                                                                  \
@@ -908,7 +954,7 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         double *elemF = (hand_mode == 3 && gd_elem_setup(c) == 0) ? c.d_gd_elemF : nullptr;
         const size_t lds_h = sizeof(double) * ((size_t)(3 * SLICE + 1) / 2 + (size_t)SLICE * c.gd_n_fields * 3 +
                                                (size_t)SLICE * 3 * c.neq);
-        const dim3 gh((unsigned)((n + SLICE - 1) / SLICE), 1), bh(SLICE * c.neq);
+        const dim3 gh((unsigned)((n + SLICE - 1) / SLICE), 1), bh(SLICE * (c.neq - 1));
         const int row_first = mode == 1 ? c.neq - 1 : 0;
 #define FEDM_GD_RES_LAUNCH(NEQ)                                                                                   \
     do {                                                                                                          \
