@@ -494,15 +494,22 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         lds_vtx[i] = cc < n_cells ? cells[3 * (cell_list ? cell_list[cc] : cc) + i % 3] : -1;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SLICE * NF * 3; i += blockDim.x) {
-        const int cc = i / (NF * 3), rem = i - cc * (NF * 3), fi = rem / 3, a = rem - 3 * fi;
-        const int vtx = lds_vtx[3 * cc + a];
-        lds_f[i] = vtx >= 0 ? fields[(size_t)fi * nv + vtx] : 0.0;
-    }
-    for (int i = threadIdx.x; i < SLICE * 3 * NEQ; i += blockDim.x) {
-        const int cc = i / (3 * NEQ), rem = i - cc * (3 * NEQ), a = rem / NEQ, sidx = rem - a * NEQ;
-        const int vtx = lds_vtx[3 * cc + a];
-        lds_u[i] = vtx >= 0 ? u[(size_t)vtx * NEQ + sidx] : 0.0;
+    {
+        // lane = cell, the waves share the (field, vertex) pairs: no division by a run-time number
+        const int nw = blockDim.x >> 6;
+        const int vt[3] = {lds_vtx[3 * lc], lds_vtx[3 * lc + 1], lds_vtx[3 * lc + 2]};
+        double *dstf = lds_f + (size_t)lc * NF * 3;
+        for (int f = wave; f < NF * 3; f += nw) {
+            const int fi = f / 3, a = f - 3 * fi;
+            const int vtx = a == 0 ? vt[0] : a == 1 ? vt[1] : vt[2];
+            dstf[f] = vtx >= 0 ? fields[(size_t)fi * nv + vtx] : 0.0;
+        }
+        double *dstu = lds_u + (size_t)lc * 3 * NEQ;
+        for (int f = wave; f < 3 * NEQ; f += nw) {
+            const int a = f / NEQ, sidx = f - a * NEQ;
+            const int vtx = a == 0 ? vt[0] : a == 1 ? vt[1] : vt[2];
+            dstu[f] = vtx >= 0 ? u[(size_t)vtx * NEQ + sidx] : 0.0;
+        }
     }
     __syncthreads();
     if (ci >= n_cells) return;
