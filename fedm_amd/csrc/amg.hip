@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     int n_slices, const int *__restrict__ boff, const int *__restrict__ colidx,
     const _Float16 *__restrict__ s16, const float *__restrict__ g, const float *__restrict__ zin,
     float *__restrict__ zout32, double *__restrict__ zout, double zs, double omega,
-    const int *__restrict__ slice_list, const double *__restrict__ x0) {
+    const int *__restrict__ slice_list, const double *__restrict__ x0,
+    const float *__restrict__ cpl32 = nullptr, double *__restrict__ b0 = nullptr) {
     constexpr int NEQ = NS + 1, PL = NS * NS;
     const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -482,11 +483,16 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
         gv[r] = g[v * NS + r];
         zv[r] = zin[v * NS + r];
     }
-    double acc[NS];
+    double acc[NS], accp = 0.0;
 #pragma unroll
     for (int r = 0; r < NS; ++r) acc[r] = 0.0;
-    const int b0 = boff[slice], b1 = boff[slice + 1];
-    for (int bc = b0; bc < b1; ++bc) {
+    // LAST with cpl32: the coupling product of the lower-triangular split rides on this sweep's gather
+    // of the neighbours' iterate, b_phi -= J_phi,u (zs z_in) -- the iterate BEFORE this last sweep
+    // (a preconditioner may lag; the separate pass over the potential row's planes and z is saved)
+    const bool couple = LAST && cpl32 != nullptr;
+    const double own_b0 = couple ? b0[v] : 0.0;
+    const int bb0 = boff[slice], bb1 = boff[slice + 1];
+    for (int bc = bb0; bc < bb1; ++bc) {
         const int col = colidx[(size_t)bc * SLICE + lane];
         double zj[NS];
 #pragma unroll
@@ -497,7 +503,13 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
 #pragma unroll
             for (int cidx = 0; cidx < NS; ++cidx)
                 if (!((ZS >> (r * NS + cidx)) & 1u)) acc[r] += (double)(float)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
+        if (couple) {
+            const float *cp = cpl32 + (size_t)bc * NS * SLICE + lane;
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx) accp += (double)cp[(size_t)cidx * SLICE] * zj[cidx];
+        }
     }
+    if (couple) b0[v] = own_b0 - zs * accp;
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         const double zn = zs * zv[r] + omega * (gv[r] - zs * acc[r]);
@@ -667,6 +679,8 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
         return !(e && e[0] == '0');
     }();
     const bool overlap = halo && overlap_ok && c.comm->n_interior > 0;
+    // lower-triangular order with sweeps: the coupling product is part of the last sweep (lagged by it)
+    const bool lagged = !upper && c.fs_lagged_coupling && n_sweeps > 0;
     // two species: the off-diagonal planes (0,1) / (1,0) of S may be structurally zero
     unsigned zs_mask = 0u;
     if (NS == 2) zs_mask = ((c.zero_plane_mask >> 1) & 1u) << 1 | ((c.zero_plane_mask >> 3) & 1u) << 2;
@@ -678,7 +692,9 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     do {                                                                                                       \
         if (last)                                                                                              \
             hipLaunchKernelGGL((fs_species_sweep_kernel<NS, true, Z>), g, dim3(256), 0, c.stream, n,           \
-                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in_, (float *)nullptr, z, zs, w, list, x0); \
+                               c.d_slice_boff, c.d_colidx, c.d_s16, g32, in_, (float *)nullptr, z, zs, w, list, x0, \
+                               lagged ? (const float *)c.d_val32 : (const float *)nullptr,                     \
+                               lagged ? amg.levels[0].b : (double *)nullptr);                                  \
         else                                                                                                   \
             hipLaunchKernelGGL((fs_species_sweep_kernel<NS, false, Z>), g, dim3(256), 0, c.stream, n,          \
                                c.d_slice_boff, c.d_colidx, c.d_s16, g32, in_, out32, (double *)nullptr, zs, w, \
@@ -706,8 +722,9 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
         if (!last) in = out;
     }
     if (upper) return;  // the potential came first
-    hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
-                       c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
+    if (!lagged)
+        hipLaunchKernelGGL(fs_coupling_kernel<NS>, gs, dim3(256), 0, c.stream, c.pat.n_slices,
+                           c.d_slice_boff, c.d_colidx, c.d_val32, z, amg.levels[0].b);
     if (!with_cycle) return;  // the caller runs the V-cycle (collectives inside it) and scatters
     amg.run(c);
     if (scatter) hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);

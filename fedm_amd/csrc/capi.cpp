@@ -1011,6 +1011,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
                 if (e[0] == '0') c.zero_plane_mask = 0;
         }
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
+        if (const char *e = getenv("FEDM_FS_LAGGED_COUPLING")) c.fs_lagged_coupling = e[0] != '0';
         if (const char *e = getenv("FEDM_GD_HAND"))
             if (e[0] == '0' || e[0] == '2' || e[0] == '3') c.gd_hand_mode = e[0] - '0';
         if (const char *e = getenv("FEDM_FS_ORDER")) c.fs_upper = std::string(e) == "upper";

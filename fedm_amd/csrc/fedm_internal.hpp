@@ -151,6 +151,9 @@ struct Ctx {
     double fs_main_w[16] = {1}, fs_alt_w[16] = {1};
     bool fs_alt_active = false;
     bool fs_halo = true;    // several GPUs: ghost exchange of the species iterate before every sweep
+    // lower-triangular order: b_phi -= J_phi,u z_u formed inside the last species sweep from the
+    // iterate before it (FEDM_FS_LAGGED_COUPLING=0: separate kernel on the final iterate)
+    bool fs_lagged_coupling = true;
     // Order of the block-triangular split when it sits on the right of the operator
     // (fedm_set_fieldsplit_order, FEDM_FS_ORDER=lower|upper; the left-preconditioned path, whose
     // first stage is the SpMV's epilogue, is always lower).
