@@ -500,3 +500,47 @@ def test_non_logarithmic_weak_forms_compile_and_representations_may_not_be_mixed
     with pytest.raises(ValueError, match="densities must enter as exp"):
         ff.compile_forms(build(True, u[1]))
     forms.parameters["form_compiler"]["quadrature_degree"] = -1
+
+
+def test_polynomial_smoother_recurrence_and_weights():
+    """The polynomial-smoother hierarchy (fedm_amg_setup_poly) folds k Richardson sweeps from a zero
+    guess into one product x = S b with S <- S + w Dinv (I - A S), and the post-smoother's error
+    propagator into E = I - S_post A (csrc/capi.cpp builds C = R (I - A S_pre), G = E S_pre + S_post,
+    Q = E P from them).  Restated with scipy: the recurrence is the sweeps, the composite level is the
+    smoothed two-level cycle, and the weights of amg.chebyshev_smoother_weights are the reciprocals of
+    Chebyshev roots inside [lambda_max / fraction, lambda_max]."""
+    import scipy.sparse as sp
+    from fedm_amd import amg
+    rng = np.random.default_rng(3)
+    n, nc = 60, 12
+    A = sp.diags([-1.0, 2.4, -1.0], [-1, 0, 1], shape=(n, n)).tocsr() + sp.diags(rng.uniform(0, 0.3, n))
+    P = sp.csr_matrix((np.ones(n), (np.arange(n), np.arange(n) // 5)), shape=(n, nc))
+    dinv = 1.0 / A.diagonal()
+    w = amg.chebyshev_smoother_weights([(A, P), (P.T @ A @ P, None)], 3, fraction=6.0)[0]
+    lam = np.linalg.eigvals((sp.diags(dinv) @ A).toarray()).real.max()
+    assert np.all(1.0 / w > 1.04 * lam / 6.0) and np.all(1.0 / w < 1.06 * lam)
+
+    def smoother(ws):
+        S = sp.diags(ws[0] * dinv).tocsr()
+        for wk in ws[1:]:
+            S = S + sp.diags(wk * dinv) @ (sp.identity(n) - A @ S)
+        return S.tocsr()
+
+    def sweeps(ws, b, x):
+        for wk in ws:
+            x = x + wk * dinv * (b - A @ x)
+        return x
+    b = rng.normal(size=n)
+    Spre, Spost = smoother(w), smoother(w[::-1])
+    assert np.allclose(Spre @ b, sweeps(w, b, np.zeros(n)), rtol=1e-12, atol=1e-14)
+    # composite two-level cycle: b_c = C b, x = G b + Q x_c  ==  pre-smooth, correct, post-smooth
+    Ac = (P.T @ A @ P).toarray()
+    C = P.T @ (sp.identity(n) - A @ Spre)
+    E = sp.identity(n) - Spost @ A
+    G, Q = E @ Spre + Spost, E @ P
+    xc = np.linalg.solve(Ac, C @ b)
+    x_composite = G @ b + Q @ xc
+    x = sweeps(w, b, np.zeros(n))
+    x = x + P @ np.linalg.solve(Ac, P.T @ (b - A @ x))
+    x = sweeps(w[::-1], b, x)
+    assert np.allclose(x_composite, x, rtol=1e-11, atol=1e-13)
