@@ -88,7 +88,7 @@ class NewtonOpts(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("stol", C.c_double),
                 ("max_it", C.c_int32), ("ksp_restart", C.c_int32),
                 ("ksp_rtol", C.c_double), ("ksp_atol", C.c_double),
-                ("ksp_max_it", C.c_int32), ("pad_", C.c_int32)]
+                ("ksp_max_it", C.c_int32), ("watch_component", C.c_int32)]
 
 
 class NewtonReport(C.Structure):

@@ -1101,6 +1101,7 @@ static int get_vec(Ctx &c, double *dst, const double *src) {
 
 int fedm_set_state(fedm_ctx *h, const double *u_new, const double *u_old, const double *u_old1) {
     Ctx &c = h->c;
+    c.err_cache_comp = -1;   // the state changes: the kept error norm is stale
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     if (u_new) c.halo_pending = false;  // the caller's vector carries its own ghost values
     if (put_vec(c, c.d_u, u_new) || put_vec(c, c.d_uold, u_old) || put_vec(c, c.d_uold1, u_old1)) return -1;
@@ -1121,6 +1122,7 @@ int fedm_get_state_old(fedm_ctx *h, double *u_old) {
 
 int fedm_shift_state(fedm_ctx *h) {
     Ctx &c = h->c;
+    c.err_cache_comp = -1;   // the state changes: the kept error norm is stale
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     std::swap(c.d_uold1, c.d_uold);  // old1 <- old (by rotation), then old <- new
     launch_scale_copy(c, 1.0, c.d_u, c.d_uold);
@@ -1129,6 +1131,7 @@ int fedm_shift_state(fedm_ctx *h) {
 
 int fedm_reset_state(fedm_ctx *h) {
     Ctx &c = h->c;
+    c.err_cache_comp = -1;   // the state changes: the kept error norm is stale
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     launch_scale_copy(c, 1.0, c.d_uold, c.d_u);
     return 0;
@@ -1228,6 +1231,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     Ctx &c = h->c;
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     fedm_newton_report r{};
+    c.err_cache_comp = -1;
     int it = 0, lin_total = 0, rc = 0;
     double fnorm = 0.0, fnorm0 = 0.0, snorm = 0.0, xnorm = 0.0;
     while (true) {
@@ -1246,7 +1250,11 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         // assembly the field split's planes are formed while those numbers travel to the host (an
         // iteration that turns out to be the last one has formed them for nothing: the expected last
         // one assembles no Jacobian at all).
-        norm2_publish(c, c.d_F, 0, 3);
+        // at the expected last iteration the watched component's change (adaptive_solver's error norm)
+        // rides along: slots 3, 4
+        const bool with_error = residual_only && !c.comm && o->watch_component > 0 && o->watch_component <= c.neq;
+        if (with_error) launch_field_error_slots34(c, o->watch_component - 1);
+        norm2_publish(c, c.d_F, 0, with_error ? 5 : 3);
         bool planes_done = false;
         if (!residual_only && right_preconditioned(c)) {
             prepare_preconditioner_and_rhs(c);
@@ -1262,12 +1270,15 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             rc = FEDM_DIVERGED_NAN;
             break;
         }
-        if (it == 0) {
-            fnorm0 = fnorm;
-            if (fnorm < o->atol) break;
-        } else {
-            if (fnorm < o->atol || fnorm <= o->rtol * fnorm0) break;
-            if (snorm < o->stol * xnorm) break;
+        const bool done = it == 0 ? fnorm < o->atol
+                                  : (fnorm < o->atol || fnorm <= o->rtol * fnorm0 || snorm < o->stol * xnorm);
+        if (it == 0) fnorm0 = fnorm;
+        if (done) {
+            if (with_error) {   // the state is final: keep the error norm for fedm_field_error
+                c.err_cache = std::sqrt(c.h_red[3]) / std::sqrt(c.h_red[4]);
+                c.err_cache_comp = o->watch_component - 1;
+            }
+            break;
         }
         if (it >= o->max_it) {
             rc = FEDM_DIVERGED_MAX_IT;
@@ -1334,6 +1345,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
 // remainder.  Replaces assemble(a), assemble(L), solve() of fedm-streamer.py:205-215.
 int fedm_poisson_solve(fedm_ctx *h, double rtol, int max_it, int *iterations) {
     Ctx &c = h->c;
+    c.err_cache_comp = -1;
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     if (!c.poisson) {
         set_error("model has no Poisson row");
@@ -1406,6 +1418,10 @@ int fedm_field_error(fedm_ctx *h, int component, double *rel_err) {
         return -2;
     }
     FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (component == c.err_cache_comp) {   // computed with the last solve's final residual check
+        *rel_err = c.err_cache;
+        return 0;
+    }
     launch_field_error(c, component);
     read_red(c, 2);
     *rel_err = std::sqrt(c.h_red[0]) / std::sqrt(c.h_red[1]);

@@ -192,6 +192,10 @@ struct Ctx {
     bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
     bool capturing = false;
     int newton_its_hint = -1;     // Newton iterations of the previous converged solve
+    // relative change of one component, computed with the final residual check of the last Newton solve
+    // (fedm_newton_opts::watch_component); dropped by anything that touches the state
+    int err_cache_comp = -1;
+    double err_cache = 0.0;
     double *h_stage = nullptr;     // pinned staging, np doubles
 };
 
@@ -235,6 +239,7 @@ void launch_normalise_copy(Ctx &c, int slot, const double *x, double *y);   // y
 void launch_multi_axpy(Ctx &c, const double *coef_host, int k, const double *const *xs,
                        double *y, double sign);                             // y += sign*sum c_i x_i
 void launch_field_error(Ctx &c, int comp);  // d_red[0]=|new-old+eps|^2, d_red[1]=|old+eps|^2
+void launch_field_error_slots34(Ctx &c, int comp);
 void launch_set_dirichlet_state(Ctx &c);    // u[dof] = g
 void wait_red_seq(Ctx &c, unsigned long long seq);  // a particular publication (steps launched ahead)
 void read_red(Ctx &c, int k);

@@ -1635,7 +1635,7 @@ void launch_newton_update(Ctx &c, const double *coef_host, int k, const double *
 __global__ __launch_bounds__(256) void field_error_kernel(int nv, int neq, int comp,
                                                           const double *__restrict__ u,
                                                           const double *__restrict__ uold,
-                                                          double *__restrict__ partials) {
+                                                          double *__restrict__ partials, int slot0) {
     const double eps = 3.0e-16;  // DOLFIN_EPS
     double acc[2] = {0.0, 0.0};
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x) {
@@ -1644,15 +1644,23 @@ __global__ __launch_bounds__(256) void field_error_kernel(int nv, int neq, int c
         acc[0] += d * d;
         acc[1] += o * o;
     }
-    block_reduce_store<2>(acc, partials, 0);
+    block_reduce_store<2>(acc, partials, slot0);
 }
 
 void launch_field_error(Ctx &c, int comp) {
     int grid = (c.n_owned + 255) / 256;
     if (grid > RED_BLOCKS) grid = RED_BLOCKS;
-    hipLaunchKernelGGL(field_error_kernel, dim3(grid), dim3(256), 0, c.stream, c.n_owned, c.neq, comp, c.d_u, c.d_uold, c.d_partials);
+    hipLaunchKernelGGL(field_error_kernel, dim3(grid), dim3(256), 0, c.stream, c.n_owned, c.neq, comp, c.d_u, c.d_uold, c.d_partials, 0);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, 2, c.d_red);
     comm_allreduce(c, c.d_red, 2);
+}
+
+// the same two sums into d_red[3], d_red[4] (one GPU): they ride on the next publication
+void launch_field_error_slots34(Ctx &c, int comp) {
+    int grid = (c.n_owned + 255) / 256;
+    if (grid > RED_BLOCKS) grid = RED_BLOCKS;
+    hipLaunchKernelGGL(field_error_kernel, dim3(grid), dim3(256), 0, c.stream, c.n_owned, c.neq, comp, c.d_u, c.d_uold, c.d_partials, 3);
+    hipLaunchKernelGGL(reduce_partials_range_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, 3, c.d_red);
 }
 
 }  // namespace fedm

@@ -664,7 +664,11 @@ class DeviceProblem:
     # -- solves --------------------------------------------------------------
     def newton_solve(self, rtol=1e-9, max_it=50, atol=1e-10, stol=1e-16,
                      ksp_restart=30, ksp_rtol=1e-5, ksp_atol=1e-50, ksp_max_it=10000):
-        o = _lib.NewtonOpts(rtol, atol, stol, max_it, ksp_restart, ksp_rtol, ksp_atol, ksp_max_it, 0)
+        # (watch_component: the field whose relative change adaptive_solver asks for right after
+        # the solve -- its two sums then ride on the final residual check's publication)
+        watch = getattr(self, "watch_component", None)
+        o = _lib.NewtonOpts(rtol, atol, stol, max_it, ksp_restart, ksp_rtol, ksp_atol, ksp_max_it,
+                            0 if watch is None else int(watch) + 1)
         r = _lib.NewtonReport()
         rc = self.lib.fedm_newton_solve(self._h, C.byref(o), C.byref(r))
         self.last_report = NewtonReport(r.iterations, bool(r.converged), r.linear_iterations,

@@ -486,6 +486,7 @@ def adaptive_solver(nonlinear_solver, problem, t, dt, dt_old, u_new, u_old, var_
             for arg in (time_dependent_arguments or ()):
                 arg.t = t + step
             dev.set_step(step, dt_old.time_step)
+            dev.watch_component = watched.get(approximation)   # its error norm comes with the solve
             nonlinear_solver.solve(problem, u_new.vector())
             assigner.assign(var_list_new, u_new)
             error[0] = dev.field_error(watched[approximation]) if approximation in watched else dev.state_error()

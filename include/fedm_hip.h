@@ -108,7 +108,11 @@ typedef struct {
     double ksp_rtol;             /* PETSc default 1e-5, on the preconditioned residual      */
     double ksp_atol;
     int32_t ksp_max_it;          /* PETSc default 10000                                     */
-    int32_t pad_;
+    int32_t watch_component;     /* 1 + the component whose relative change fedm_field_error will be
+                                    asked for right after this solve (adaptive_solver's error norm,
+                                    fedm/functions.py:1062-1064); 0: none.  Its two sums then ride on the
+                                    publication of the final residual check: no extra round trip to the
+                                    host.  (One GPU; was padding: 0 keeps the old behaviour.)          */
 } fedm_newton_opts;
 
 typedef struct {
