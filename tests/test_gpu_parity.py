@@ -402,6 +402,30 @@ def test_fieldsplit_order_lower_and_upper_solve_the_same_systems():
         prob.set_fieldsplit_order("diagonal")
 
 
+def test_coupling_product_inside_the_last_sweep_changes_the_preconditioner_only(monkeypatch):
+    """The field split's coupling product b_phi -= J_phi,u z_u is formed inside the last species sweep
+    from the iterate before that sweep (default) or by its own kernel from the final iterate
+    (FEDM_FS_LAGGED_COUPLING=0).  Two preconditioners for the same systems: same Newton counts, Krylov
+    counts within a step or two, same trajectory within the solver tolerances."""
+    from fedm_amd.cases import streamer
+    msh = streamer.mesh(64, 4.0)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FEDM_FS_LAGGED_COUPLING", flag)
+        prob = streamer.device_problem(msh.coords, msh.cells)
+        st = streamer.Stepper(prob)
+        st.initialise()
+        for _ in range(6):
+            st.step()
+        out[flag] = (st.newton_iterations, st.linear_iterations, prob.get_state(), st.log_rows())
+        prob.close()
+    assert out["1"][0] == out["0"][0]
+    assert abs(out["1"][1] - out["0"][1]) <= 3
+    scale = np.abs(out["0"][2]).max(axis=0)
+    assert (np.abs(out["1"][2] - out["0"][2]).max(axis=0) / scale).max() < 1e-6
+    assert np.allclose(np.array(out["1"][3]), np.array(out["0"][3]), rtol=1e-3)
+
+
 def test_graft_entry_smoke():
     """The driver's smoke() entry point (one small streamer solve checked against the oracle)."""
     import __graft_entry__ as entry
