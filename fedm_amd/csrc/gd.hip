@@ -583,14 +583,26 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         return ch;
     };
     // W (tS phi_a - tX G_a,x - tY G_a,y) into column s of the accumulators (s: wave-uniform)
-    // (b is a compile-time index where add is called: the loops over the column vertex are unrolled)
-    auto add = [&](int b, int s, double W, const double phi[3], double tS, double tX, double tY) {
+    // (b is a compile-time index where these are called: the loops over the column vertex are unrolled;
+    // source-only and flux-only forms: a product with a literal zero is not folded without fast-math)
+    auto addS = [&](int b, int s, double W, const double phi[3], double tS) {
         if (STORE == 0) return;
+        const double w = W * tS;
 #pragma unroll
         for (int k = 0; k < NEQ; ++k)
             if (k == s) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Jacc[b][a][k] += W * (tS * phi[a] - tX * c.G[a][0] - tY * c.G[a][1]);
+                for (int a = 0; a < 3; ++a) Jacc[b][a][k] += w * phi[a];
+            }
+    };
+    auto addG = [&](int b, int s, double W, double tX, double tY) {
+        if (STORE == 0) return;
+        const double wx = W * tX, wy = W * tY;
+#pragma unroll
+        for (int k = 0; k < NEQ; ++k)
+            if (k == s) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) Jacc[b][a][k] -= wx * c.G[a][0] + wy * c.G[a][1];
             }
     };
     // derivatives of the channels along the basis function of column vertex b (value w_v, gradient w_x, w_y)
@@ -619,19 +631,19 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     };
     // directional derivative of a flux (column vertex b) into the flux columns of the accumulators
     auto flux_columns = [&](int b, const GdFluxD &Fl, int own, const Seeds &sd, double W, const double phi[3]) {
-        add(b, own, W, phi, 0.0, Fl.Gx * sd.w_v + Fl.dg * sd.w_x, Fl.Gy * sd.w_v + Fl.dg * sd.w_y);
-        add(b, IPHI, W, phi, 0.0, -Fl.dE * sd.w_x, -Fl.dE * sd.w_y);   // E = -grad Phi
-        add(b, 0, W, phi, 0.0, Fl.x_c1 * sd.k1_0 + Fl.x_c2 * sd.k2_0, Fl.y_c1 * sd.k1_0 + Fl.y_c3 * sd.k3_0);
-        add(b, ie, W, phi, 0.0, Fl.x_c1 * sd.k1_e + Fl.x_c2 * sd.k2_e, Fl.y_c1 * sd.k1_e + Fl.y_c3 * sd.k3_e);
+        addG(b, own, W, Fl.Gx * sd.w_v + Fl.dg * sd.w_x, Fl.Gy * sd.w_v + Fl.dg * sd.w_y);
+        addG(b, IPHI, W, -Fl.dE * sd.w_x, -Fl.dE * sd.w_y);   // E = -grad Phi
+        addG(b, 0, W, Fl.x_c1 * sd.k1_0 + Fl.x_c2 * sd.k2_0, Fl.y_c1 * sd.k1_0 + Fl.y_c3 * sd.k3_0);
+        addG(b, ie, W, Fl.x_c1 * sd.k1_e + Fl.x_c2 * sd.k2_e, Fl.y_c1 * sd.k1_e + Fl.y_c3 * sd.k3_e);
     };
     // ... of factor * (w . G) (Joule heating: w = E; wall flux: w = n) into the source columns
     auto flux_dot_columns = [&](int b, const GdFluxD &Fl, int own, const Seeds &sd, double wx, double wy, double factor,
                                 double W, const double phi[3]) {
-        add(b, own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * sd.w_v + Fl.dg * (wx * sd.w_x + wy * sd.w_y)), 0.0, 0.0);
-        add(b, IPHI, W, phi, -factor * Fl.dE * (wx * sd.w_x + wy * sd.w_y), 0.0, 0.0);
+        addS(b, own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * sd.w_v + Fl.dg * (wx * sd.w_x + wy * sd.w_y)));
+        addS(b, IPHI, W, phi, -factor * Fl.dE * (wx * sd.w_x + wy * sd.w_y));
         const double o1 = factor * (Fl.x_c1 * wx + Fl.y_c1 * wy), o2 = factor * Fl.x_c2 * wx, o3 = factor * Fl.y_c3 * wy;
-        add(b, 0, W, phi, o1 * sd.k1_0 + o2 * sd.k2_0 + o3 * sd.k3_0, 0.0, 0.0);
-        add(b, ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e, 0.0, 0.0);
+        addS(b, 0, W, phi, o1 * sd.k1_0 + o2 * sd.k2_0 + o3 * sd.k3_0);
+        addS(b, ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e);
     };
 
     for (int q = 0; q < md->n_qp; ++q) {
@@ -646,10 +658,10 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                 const double ni = (md->sign[i] * md->charge_over_eps) * exp(value(i, phi));
                 rho += ni;
 #pragma unroll
-                for (int b = 0; b < 3; ++b) add(b, i, W, phi, -ni * phi[b], 0.0, 0.0);
+                for (int b = 0; b < 3; ++b) addS(b, i, W, phi, -ni * phi[b]);
             }
 #pragma unroll
-            for (int b = 0; b < 3; ++b) add(b, IPHI, W, phi, 0.0, -c.G[b][0], -c.G[b][1]);
+            for (int b = 0; b < 3; ++b) addG(b, IPHI, W, -c.G[b][0], -c.G[b][1]);
 #pragma unroll
             for (int a = 0; a < 3; ++a) Racc[a] += W * (-rho * phi[a] - (Ex * c.G[a][0] + Ey * c.G[a][1]));
             continue;
@@ -693,13 +705,13 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const Seeds sd = seeds(b, phi, ch);
-                add(b, 0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0, 0.0, 0.0);
+                addS(b, 0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0);
 #pragma unroll
-                for (int i = 1; i < ns; ++i) add(b, i, W, phi, -src_v[i] * sd.w_v, 0.0, 0.0);
-                add(b, ie, W, phi, -src_c1 * sd.k1_e, 0.0, 0.0);
+                for (int i = 1; i < ns; ++i) addS(b, i, W, phi, -src_v[i] * sd.w_v);
+                addS(b, ie, W, phi, -src_c1 * sd.k1_e);
                 flux_columns(b, Fw, 0, sd, W, phi);
                 flux_dot_columns(b, Fe, ie, sd, Ex, Ey, 1.0, W, phi);
-                add(b, IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y), 0.0, 0.0);   // d(G . E)/dE = G, E = -grad Phi
+                addS(b, IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y));   // d(G . E)/dE = G, E = -grad Phi
             }
         } else {
             const bool has_flux = md->eq_type[row] != FEDM_EQ_REACTION;
@@ -712,11 +724,11 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const Seeds sd = seeds(b, phi, ch);
-                add(b, row, W, phi, dT * sd.w_v, 0.0, 0.0);
+                addS(b, row, W, phi, dT * sd.w_v);
 #pragma unroll
-                for (int i = 1; i < ns; ++i) add(b, i, W, phi, -src_v[i] * sd.w_v, 0.0, 0.0);
-                add(b, 0, W, phi, -src_c1 * sd.k1_0, 0.0, 0.0);
-                add(b, ie, W, phi, -src_c1 * sd.k1_e, 0.0, 0.0);
+                for (int i = 1; i < ns; ++i) addS(b, i, W, phi, -src_v[i] * sd.w_v);
+                addS(b, 0, W, phi, -src_c1 * sd.k1_0);
+                addS(b, ie, W, phi, -src_c1 * sd.k1_e);
                 if (has_flux) flux_columns(b, Fl, row, sd, W, phi);
             }
         }
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                 if (et == FEDM_EQ_DIFFUSION_REACTION) {
                     wall = fac * (0.5 * vth * dens);
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) add(b, row, W, phi, wall * phi[b], 0.0, 0.0);
+                    for (int b = 0; b < 3; ++b) addS(b, row, W, phi, wall * phi[b]);
                 } else {
                     const GdChannels ch = channels(phi);
                     const double En = Ex * nx + Ey * ny;
@@ -773,10 +785,10 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
                         const Seeds sd = seeds(b, phi, ch);
-                        add(b, row, W, phi, wall * sd.w_v, 0.0, 0.0);
-                        add(b, 0, W, phi, k * mub * En * sd.k1_0, 0.0, 0.0);
-                        add(b, ie, W, phi, k * mub * En * sd.k1_e, 0.0, 0.0);
-                        add(b, IPHI, W, phi, -k * muv * (nx * sd.w_x + ny * sd.w_y), 0.0, 0.0);
+                        addS(b, row, W, phi, wall * sd.w_v);
+                        addS(b, 0, W, phi, k * mub * En * sd.k1_0);
+                        addS(b, ie, W, phi, k * mub * En * sd.k1_e);
+                        addS(b, IPHI, W, phi, -k * muv * (nx * sd.w_x + ny * sd.w_y));
                     }
                     if (sp == ie) {
                         // - 2 gamma / (1 + r) * sum over ions of Max(Gamma_s . n, 0), fedm-gd.py:351
