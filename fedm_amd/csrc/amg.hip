@@ -381,7 +381,14 @@ void Amg::run(Ctx &c) {
     prof_begin(c, 3);
     if (global) {
         vcycle(c, 0, 1);
-        comm_allreduce(c, d_gb, n_global);
+        // (the level-1 right-hand side feeds a preconditioner: single precision on the wire halves the
+        // largest message of a Krylov step; FEDM_MG_ALLREDUCE_F32=0: double precision)
+        static const bool f32 = [] {
+            const char *e = std::getenv("FEDM_MG_ALLREDUCE_F32");
+            return !(e && e[0] == '0');
+        }();
+        if (f32) comm_allreduce_f32_payload(c, d_gb, n_global);
+        else comm_allreduce(c, d_gb, n_global);
         vcycle(c, 0, 2);
     } else if (graph_exec) {
         hipGraphLaunch(graph_exec, c.stream);

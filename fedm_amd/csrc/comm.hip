@@ -26,6 +26,7 @@ struct NcclApi {
 };
 NcclApi g_nccl;
 constexpr int kNcclDouble = 8;  // ncclFloat64
+constexpr int kNcclFloat = 7;   // ncclFloat32
 constexpr int kNcclSum = 0;
 
 int load_nccl() {
@@ -184,6 +185,9 @@ void Comm::release() {
     if (h_send) hipHostFree(h_send);
     if (h_recv) hipHostFree(h_recv);
     if (h_red) hipHostFree(h_red);
+    if (d_red32) hipFree(d_red32);
+    d_red32 = nullptr;
+    red32_cap = 0;
     d_send_idx = nullptr;
     d_sendbuf = d_recvtmp = nullptr;
     h_send = h_recv = h_red = nullptr;
@@ -301,6 +305,47 @@ void comm_allreduce(Ctx &c, double *d_buf, int n) {
     hipStreamSynchronize(c.stream);
     cm->allreduce_cb(cm->h_red, n, cm->user);
     hipMemcpyAsync(d_buf, cm->h_red, sizeof(double) * n, hipMemcpyHostToDevice, c.stream);
+}
+
+__global__ void to_f32_kernel(int n, const double *__restrict__ x, float *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
+}
+__global__ void from_f32_kernel(int n, const float *__restrict__ x, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (double)x[i];
+}
+
+// The same sum with a single-precision payload: for vectors that only a preconditioner reads (the
+// level-1 right-hand side of the replicated multigrid hierarchy: n_global values per V-cycle, the
+// largest message of a Krylov step).  RCCL: half the bytes on the links, summed in fp32.  Host-staged
+// transport: the contributions are rounded to fp32 and summed in fp64 (same quantisation, so the
+// one-GPU rehearsals see what the RCCL path sees up to the order of the sum).
+void comm_allreduce_f32_payload(Ctx &c, double *d_buf, int n) {
+    Comm *cm = c.comm;
+    if (!cm || cm->kind == 0 || cm->failed) return;
+    if (n > cm->red32_cap) {
+        if (cm->d_red32) hipFree(cm->d_red32);
+        cm->d_red32 = nullptr;
+        cm->red32_cap = 0;
+        if (hipMalloc((void **)&cm->d_red32, sizeof(float) * (size_t)n) != hipSuccess) {
+            hipGetLastError();
+            comm_allreduce(c, d_buf, n);   // no scratch: the double-precision path
+            return;
+        }
+        cm->red32_cap = n;
+    }
+    const dim3 g((n + 255) / 256), b(256);
+    hipLaunchKernelGGL(to_f32_kernel, g, b, 0, c.stream, n, d_buf, cm->d_red32);
+    if (cm->kind == 2) {
+        ++cm->n_allreduces;
+        nccl_ok(cm, g_nccl.AllReduce(cm->d_red32, cm->d_red32, (size_t)n, kNcclFloat, kNcclSum, cm->nccl, c.stream),
+                "ncclAllReduce (fp32 payload)");
+        hipLaunchKernelGGL(from_f32_kernel, g, b, 0, c.stream, n, cm->d_red32, d_buf);
+        return;
+    }
+    hipLaunchKernelGGL(from_f32_kernel, g, b, 0, c.stream, n, cm->d_red32, d_buf);   // rounded contributions
+    comm_allreduce(c, d_buf, n);
 }
 
 __global__ void halo_pack_kernel(int n_send, int neq, const int *__restrict__ idx,

@@ -23,6 +23,8 @@ struct Comm {
     double *d_sendbuf = nullptr, *d_recvtmp = nullptr;  // packed values out; staging for non-fp64 vectors
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;
     int h_red_cap = 0;  // doubles (host-staged all-reduce)
+    float *d_red32 = nullptr;   // scratch of comm_allreduce_f32_payload
+    int red32_cap = 0;
     fedm_allreduce_fn allreduce_cb = nullptr;
     fedm_exchange_fn exchange_cb = nullptr;
     void *user = nullptr;
@@ -52,6 +54,7 @@ int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const in
 int comm_init_rccl(Ctx &c, Comm &cm, const void *unique_id, int rank, int nranks);
 int comm_unique_id(void *out128);
 void comm_allreduce(Ctx &c, double *d_buf, int n);  // sum over ranks, in place, stream-ordered
+void comm_allreduce_f32_payload(Ctx &c, double *d_buf, int n);  // the same with fp32 on the wire
 int comm_reserve_reduction(Ctx &c, int n);          // host-staged transport: room for n doubles
 void comm_halo(Ctx &c, double *d_vec);              // refresh ghost vertices of a block vector
 void comm_halo_scalar(Ctx &c, double *d_vec);       // the same for one value per vertex

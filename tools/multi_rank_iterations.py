@@ -16,7 +16,7 @@ def worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         run = streamer_distributed.Runner(None, rank, world, 0, grading=4.0, transport="torch",
-                                          n_per_gpu=N_GLOBAL / np.sqrt(world))
+                                          n_per_gpu=int(round(N_GLOBAL / np.sqrt(world))))
         run.initialise()
         run.step()
         l0, n0 = run.linear_iterations, run.newton_iterations
@@ -24,6 +24,10 @@ def worker(rank, world, port, q):
             run.step()
         if rank == 0:
             q.put((world, run.global_n, run.global_n, (run.linear_iterations - l0) / 5, (run.newton_iterations - n0) / 5))
+    except Exception as exc:   # the parent waits on the queue: tell it instead of leaving it to its timeout
+        if rank == 0:
+            q.put(exc)
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -37,5 +41,8 @@ if __name__ == "__main__":
             s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
         procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
         for p in procs: p.start()
-        print("ranks %d: global mesh %dx%d, GMRES/step %.1f, Newton/step %.1f" % q.get(timeout=500), flush=True)
+        res = q.get(timeout=300)
+        if isinstance(res, Exception):
+            raise res
+        print("ranks %d: global mesh %dx%d, GMRES/step %.1f, Newton/step %.1f" % res, flush=True)
         for p in procs: p.join(timeout=60)
