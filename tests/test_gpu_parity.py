@@ -479,6 +479,12 @@ def test_bad_descriptors_are_hard_errors():
     prob = streamer.device_problem(msh.coords, msh.cells)
     rc = lib.fedm_set_fieldsplit(prob._h, 0, None)
     assert rc < 0 and b"sweeps" in lib.fedm_last_error()
+    assert lib.fedm_set_fieldsplit_order(prob._h, 2) < 0 and b"order" in lib.fedm_last_error()
+    # a polynomial-smoother hierarchy needs a degree, weights and at least two levels
+    assert lib.fedm_amg_setup_poly(prob._h, 1, None, None, None, None, 0, None, 0) < 0
+    assert b"polynomial" in lib.fedm_last_error()
+    kept, zero = prob.plane_masks()
+    assert zero == 0b1000 and kept & (1 << 8)     # d(electron row)/d(ion density); potential-potential
     prob.close()
 
 
