@@ -360,6 +360,19 @@ def _log_matrices(gain, loss, power):
     return "\n\n".join(f"{title} matrix:\n{numpy_2d_array_to_str(m)}" for title, m in blocks) + "\n"
 
 
+def mesh_statistics(mesh):
+    """fedm/file_io.py:619-631: the mesh as ``<output>/mesh/mesh.pvd`` and its element count and
+    extreme edge lengths on the terminal and in ``mesh info.txt``."""
+    from . import mesh_io
+    from .utils import _rank, mesh_info
+    mesh_dir = files.output_folder_path / "mesh"
+    info = mesh_info(mesh)
+    if _rank() == 0:
+        mesh_io.PVDFile(mesh_dir / "mesh.pvd", mesh).write(np.zeros(mesh.num_vertices()), "mesh", 0.0)
+        print(info.rstrip())
+        (mesh_dir / "mesh info.txt").write_text(info)
+
+
 _LOG_ENTRIES = {
     "properties": _log_properties,
     "conditions": _log_conditions,

@@ -118,10 +118,75 @@ def evaluate(x, env=None):
 # ---------------------------------------------------------------------------------------
 # scalars, nodal functions, device state handles
 # ---------------------------------------------------------------------------------------
+_CPP_FUNCTIONS = {"exp": np.exp, "log": np.log, "sqrt": np.sqrt, "pow": np.power, "sin": np.sin, "cos": np.cos,
+                  "tan": np.tan, "fabs": np.abs, "abs": np.abs, "tanh": np.tanh, "atan": np.arctan}
+_CPP_CONSTANTS = {"pi": math.pi, "DOLFIN_EPS": DOLFIN_EPS, "DOLFIN_PI": math.pi}
+
+
+def compile_cpp_expression(code):
+    """A DOLFIN C++ expression string (``'std::log(exp(-(pow(x[1]-w*t, 2)+pow(x[0], 2))/(4.0*D*t))...'``,
+    examples/time_of_flight/fedm-tof.py:107,116,120) as a function ``f(x, owner)`` of the point array
+    ``x[..., dim]`` and the object that carries the named parameters.  The arithmetic subset of the
+    language is parsed with Python's ``ast`` and walked by hand (never ``eval``): numbers, ``x[i]``,
+    parameters, ``+ - * /``, unary minus and the calls in ``_CPP_FUNCTIONS``."""
+    import ast
+    text = code.replace("std::", "").strip()
+    try:
+        tree = ast.parse(text, mode="eval").body
+    except SyntaxError as exc:
+        raise NotImplementedError(f"Expression string outside the supported arithmetic subset: {code!r}") from exc
+
+    def check(node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+            return
+        if isinstance(node, ast.Name):
+            return
+        if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and node.value.id == "x":
+            idx = node.slice
+            if isinstance(idx, ast.Constant) and isinstance(idx.value, int):
+                return
+        if isinstance(node, ast.BinOp) and isinstance(node.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
+            check(node.left)
+            check(node.right)
+            return
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            check(node.operand)
+            return
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in _CPP_FUNCTIONS \
+                and not node.keywords:
+            for a in node.args:
+                check(a)
+            return
+        raise NotImplementedError(f"Expression string outside the supported arithmetic subset: {code!r}")
+    check(tree)
+
+    def run(node, x, owner):
+        if isinstance(node, ast.Constant):
+            return float(node.value)
+        if isinstance(node, ast.Name):
+            if hasattr(owner, node.id) and node.id not in ("code", "degree", "python"):
+                return float(getattr(owner, node.id))
+            if node.id in _CPP_CONSTANTS:
+                return _CPP_CONSTANTS[node.id]
+            raise NameError(f"Expression parameter '{node.id}' is not set")
+        if isinstance(node, ast.Subscript):
+            return x[..., node.slice.value]
+        if isinstance(node, ast.BinOp):
+            a, b = run(node.left, x, owner), run(node.right, x, owner)
+            return a + b if isinstance(node.op, ast.Add) else a - b if isinstance(node.op, ast.Sub) \
+                else a * b if isinstance(node.op, ast.Mult) else a / b
+        if isinstance(node, ast.UnaryOp):
+            v = run(node.operand, x, owner)
+            return -v if isinstance(node.op, ast.USub) else v
+        return _CPP_FUNCTIONS[node.func.id](*[run(a, x, owner) for a in node.args])
+    return lambda x, owner: run(tree, np.asarray(x, dtype=float), owner) + np.zeros(np.shape(x)[:-1])
+
+
 class Expression:
     """``Expression("time_step", time_step=..., degree=0)`` and friends: a bag of named
     parameters (``.time_step``, ``.t`` ...), as FEDM scripts use it for scalars.  Spatial
-    expressions are given as ``python=callable(x)`` (no C++ JIT here)."""
+    expressions: ``python=callable(x)`` or a C++ string of the arithmetic subset that
+    :func:`compile_cpp_expression` understands (no JIT here)."""
 
     def __init__(self, code=None, degree=0, python=None, **params):
         self.code = code
@@ -135,7 +200,11 @@ class Expression:
             try:
                 return np.full(np.shape(x)[:-1], float(self.code))      # Expression('3.0', degree=1)
             except (TypeError, ValueError):
-                raise NotImplementedError("C++ expression strings are not compiled here; pass python=") from None
+                pass
+            compiled = self.__dict__.get("_compiled")
+            if compiled is None:
+                compiled = self.__dict__["_compiled"] = compile_cpp_expression(self.code)
+            return compiled(x, self)
         import inspect
         n_args = len(inspect.signature(self.python).parameters)
         return self.python(np.asarray(x)) if n_args == 1 else self.python(np.asarray(x), self)
@@ -157,8 +226,10 @@ class Expression:
 
 
 class Constant(_Ops):
+    """``Constant(c)`` or a vector constant ``Constant(('0', w))`` (fedm-tof.py:111)."""
+
     def __init__(self, value):
-        self.value = value
+        self.value = tuple(float(v) for v in value) if isinstance(value, (tuple, list)) else value
 
     def __float__(self):
         return float(self.value)
@@ -199,6 +270,8 @@ class Function(_Ops):
             return self.state.assign(getattr(other, "state", other))
         if isinstance(other, Expression) and self.space is not None:
             self._v = np.array(other(self.space.mesh.coords), dtype=float)
+        elif isinstance(other, Constant) and isinstance(other.value, tuple):
+            self._v = np.tile(np.asarray(other.value, dtype=float), (self.space.mesh.num_vertices(), 1))
         elif isinstance(other, (Constant, Real)):
             self._v = np.full_like(self._v, float(other))
         elif isinstance(other, Sym):
@@ -309,11 +382,58 @@ class SubSpace:
 
 class FunctionSpace:
     def __init__(self, mesh, element, degree=None):
+        if isinstance(element, str) and (element not in ("P", "Lagrange", "CG") or degree not in (None, 1)):
+            raise NotImplementedError("the device path implements P1 Lagrange elements")
         self.mesh = mesh
         self.n_eq = len(element) if isinstance(element, (list, MixedElement)) else 1
 
     def sub(self, i):
         return SubSpace(self, i)
+
+
+def Point(*xy):
+    """``Point(x, y)`` of ``RectangleMesh(Point(0, 0), Point(w, h), nx, ny)`` (fedm-tof.py:89)."""
+    return tuple(float(v) for v in xy)
+
+
+def VectorFunctionSpace(mesh, family, degree):
+    """P1 vector fields (fedm-tof.py:98: the constant drift velocity): nodal arrays [vertex][dim]."""
+    space = FunctionSpace(mesh, family, degree)
+    space.value_dim = 2
+    return space
+
+
+class _Communicator:
+    pass
+
+
+class MPI:
+    """``MPI.rank(MPI.comm_world)`` / ``MPI.max(MPI.comm_world, v)`` of the scripts: the ranks of
+    torch.distributed when a process group exists, one rank otherwise."""
+    comm_world = _Communicator()
+
+    @staticmethod
+    def rank(comm=None):
+        from .utils import _rank
+        return _rank()
+
+    @staticmethod
+    def size(comm=None):
+        try:
+            import torch.distributed as dist
+            return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        except ImportError:
+            return 1
+
+    @staticmethod
+    def max(comm, value):
+        if MPI.size() == 1:
+            return value
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
 
 class Unknown(_Ops):
@@ -537,10 +657,12 @@ class FieldSquared:
 
 
 def grad(u):
-    if isinstance(u, Function):
-        return Sym("grad", u)                    # of a nodal Function: cell-wise constant (project())
+    if isinstance(u, (Function, Sym)):
+        # of a nodal Function: cell-wise constant (project()); of a product like D*exp(u): a flux
+        # written by hand, recognised by compile_forms (fedm-tof.py:115)
+        return Sym("grad", u)
     if not isinstance(u, Unknown):
-        raise NotImplementedError("grad() of the potential unknown or of a nodal Function")
+        raise NotImplementedError("grad() of the potential unknown, of a nodal Function or of D*exp(u)")
     return GradOf(u)
 
 
@@ -575,18 +697,91 @@ def exp(x):
         return Density(x.index)
     if isinstance(x, TermSum):
         return x.exp()
-    if isinstance(x, (Sym, Function, FunctionComponent)):
+    if isinstance(x, (Sym, Function, FunctionComponent, Expression)):
         return Sym("exp", x)
     return math.exp(x)
+
+
+def _p1_mass(mesh):
+    """Consistent P1 mass matrix of the mesh and its factorisation (kept on the mesh)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    cached = getattr(mesh, "_p1_mass", None)
+    if cached is None:
+        x = mesh.coords[mesh.cells]
+        d1, d2 = x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]
+        det = np.abs(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0])
+        vals = det[:, None, None] * ((np.ones((3, 3)) + np.eye(3)) / 24.0)[None]
+        c = mesh.cells.astype(np.int64)
+        rows = np.broadcast_to(c[:, :, None], vals.shape).ravel()
+        cols = np.broadcast_to(c[:, None, :], vals.shape).ravel()
+        n = mesh.num_vertices()
+        M = sp.coo_matrix((vals.ravel(), (rows, cols)), shape=(n, n)).tocsc()
+        cached = mesh._p1_mass = (M, spla.splu(M), det)
+    return cached
+
+
+def _nodal(f):
+    """Nodal values of a P1 Function on the host; a Function bound to a device state is downloaded."""
+    if getattr(f, "state", None) is not None:
+        U = f.state.array()
+        return U[:, 0] if U.ndim == 2 and U.shape[1] == 1 else U
+    return np.asarray(f.vector(), dtype=float)
+
+
+def _project_exp(arg, space):
+    """``project(exp(w), V)`` of a nodal P1 Function or of a spatial Expression (fedm-tof.py:155-156),
+    the way FFC sets it up: an Expression of degree d is interpolated at the P_d lattice nodes of
+    every cell, and the quadrature degree is UFL's estimate (d + 2) + 1."""
+    from . import quadrature
+    mesh = space.mesh
+    M, lu, det = _p1_mass(mesh)
+    if isinstance(arg, Expression):
+        deg = int(arg.degree) + 3
+        xq, wq = quadrature.triangle(deg)
+        B, lam = quadrature.lagrange_interpolation_matrix(int(arg.degree), xq)
+        phi_nodes = np.stack([1 - lam[:, 0] - lam[:, 1], lam[:, 0], lam[:, 1]], axis=1)
+        nodes = np.einsum("na,cad->cnd", phi_nodes, mesh.coords[mesh.cells])
+        at_q = np.asarray(arg(nodes)) @ B.T
+    else:
+        xq, wq = quadrature.triangle(4)
+        phi_q = np.stack([1 - xq[:, 0] - xq[:, 1], xq[:, 0], xq[:, 1]], axis=1)
+        at_q = _nodal(arg)[mesh.cells] @ phi_q.T
+    phi = np.stack([1 - xq[:, 0] - xq[:, 1], xq[:, 0], xq[:, 1]], axis=1)
+    rhs = np.einsum("q,cq,qa->ca", wq, np.exp(at_q), phi) * det[:, None]
+    b = np.bincount(mesh.cells.ravel(), weights=rhs.ravel(), minlength=mesh.num_vertices())
+    return Function(space, values=lu.solve(b))
+
+
+def errornorm(u, uh, norm_type="l2"):
+    """L2 norm of the difference of two P1 Functions (fedm-tof.py:157)."""
+    if str(norm_type).lower() != "l2":
+        raise NotImplementedError("errornorm: L2 only")
+    M = _p1_mass(u.space.mesh)[0]
+    e = _nodal(u) - _nodal(uh)
+    return float(np.sqrt(e @ (M @ e)))
+
+
+def norm(u, norm_type="l2"):
+    """L2 norm of a P1 Function (fedm-tof.py:157)."""
+    if str(norm_type).lower() != "l2":
+        raise NotImplementedError("norm: L2 only")
+    M = _p1_mass(u.space.mesh)[0]
+    v = _nodal(u)
+    return float(np.sqrt(v @ (M @ v)))
 
 
 def project(expr, space=None, solver_type=None):
     """L2 projection onto P1 of ``c * sqrt(dot(grad(f), grad(f)))``-type expressions of nodal
     Functions (fedm-gd.py:309,432: the reduced electric field): the gradient of a P1 Function is
     constant per cell; consistent mass matrix, factorised once per mesh (host, post-processing
-    size -- the device-resident pipeline is `fedm_gd_prep_step`)."""
+    size -- the device-resident pipeline is `fedm_gd_prep_step`).  Also ``exp(w)`` of one nodal
+    Function or spatial Expression (fedm-tof.py:155-156)."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
+    if isinstance(expr, Sym) and expr.op == "exp" and isinstance(expr.args[0], (Function, Expression)) \
+            and space is not None:
+        return _project_exp(expr.args[0], space)
     funcs = [f for f in expr.leaves(Function)] if isinstance(expr, Sym) else []
     if not funcs:
         raise NotImplementedError("project() of an expression without nodal Functions")

@@ -186,6 +186,52 @@ def _axisymmetric(r):
     return True
 
 
+def _constant_nodal(x, dim=None):
+    """The value of a coefficient that is the same at every node: a number, a Constant, or a Function
+    interpolated from one (fedm-tof.py:111-113).  None when it varies."""
+    from . import forms
+    if isinstance(x, (int, float)):
+        return float(x)
+    if isinstance(x, forms.Constant):
+        return np.asarray(x.value, dtype=float) if isinstance(x.value, tuple) else float(x.value)
+    if isinstance(x, forms.Function):
+        v = np.asarray(x.vector(), dtype=float)
+        first = v[0]
+        if np.all(v == first):
+            return np.asarray(first, dtype=float) if v.ndim == 2 else float(first)
+    return None
+
+
+def _match_manual_flux(gamma, index):
+    """``Gamma = -grad(D*exp(u)) + w*exp(u)`` written out by hand (fedm-tof.py:115): (D, (w_r, w_z))
+    when D and the drift velocity w are the same at every node, else None."""
+    from . import forms
+
+    def density_factor(node):
+        # coefficient c of  c * exp(u_index)  (either order)
+        if isinstance(node, forms.Sym) and node.op == "mul":
+            a, b = node.args
+            for coef, dens in ((a, b), (b, a)):
+                if isinstance(dens, forms.Density) and dens.index == index:
+                    return coef
+        return None
+    if not (isinstance(gamma, forms.Sym) and gamma.op == "add"):
+        return None
+    diffusion = drift = None
+    for term in gamma.args:
+        if isinstance(term, forms.Sym) and term.op == "neg" and isinstance(term.args[0], forms.Sym) \
+                and term.args[0].op == "grad":
+            diffusion = density_factor(term.args[0].args[0])
+        else:
+            drift = density_factor(term)
+    if diffusion is None or drift is None:
+        return None
+    D, w = _constant_nodal(diffusion), _constant_nodal(drift)
+    if D is None or w is None or np.ndim(D) != 0 or np.shape(w) != (2,):
+        return None
+    return float(D), (float(w[0]), float(w[1]))
+
+
 def compile_forms(F, quadrature_degree=None):
     """FormSum -> (device Model, mesh, facet tags).  The compiler of this façade: what
     FFC does for the reference, restricted to the model family of the device kernels."""
@@ -231,7 +277,21 @@ def compile_forms(F, quadrature_degree=None):
             if wrong:
                 raise ValueError(f"{where}: densities must enter as " + ("exp(u[i])" if log else "u[i]")
                                  + f" in the {'logarithmic' if log else 'non-logarithmic'} representation")
+    drift_w, ext_sources = [None] * ns, []
     for s, p in enumerate(balances):
+        if isinstance(p.f, forms.Expression):
+            # a source given as a spatial Expression of degree d (fedm-tof.py:116): interpolated at the
+            # P_d lattice nodes of every cell and refreshed before each solve (Problem.before_solve)
+            ext_sources.append((s, p.f))
+        if p.equation_type == "drift-diffusion-reaction" and not isinstance(p.Gamma, FluxDesc):
+            manual = _match_manual_flux(p.Gamma, p.u.index)
+            if manual is None:
+                raise ValueError("drift-diffusion-reaction needs Gamma = Flux(...) or "
+                                 "-grad(D*exp(u)) + w*exp(u) with constant D and w")
+            if not log:
+                raise ValueError("a flux written with exp(u) belongs to the logarithmic representation")
+            D[s], drift_w[s], Z[s] = TermSum.const(manual[0]), manual[1], -1.0
+            continue
         if p.equation_type == "drift-diffusion-reaction":
             g = p.Gamma
             if not isinstance(g, FluxDesc):
@@ -241,6 +301,8 @@ def compile_forms(F, quadrature_degree=None):
             mu[s], D[s], Z[s] = TermSum.coerce(g.mu), TermSum.coerce(g.D), float(g.sign)
         elif p.equation_type == "diffusion-reaction":
             D[s] = TermSum.coerce(p.D)
+        if isinstance(p.f, forms.Expression):
+            continue
         check_densities(forms.RateSum.coerce(p.f).terms, f"source term of species {s}")
         for term in forms.RateSum.coerce(p.f).terms:
             power = [int(term.powers.get(i, 0)) for i in range(ns)]
@@ -279,13 +341,28 @@ def compile_forms(F, quadrature_degree=None):
     qd = quadrature_degree
     if qd is None:
         qd = forms.parameters["form_compiler"]["quadrature_degree"]
+    if (qd is None or qd < 0) and ns == 1 and not poissons and ext_sources and drift_w[0] is not None:
+        # the time-of-flight forms set no degree (fedm-tof.py): UFL's estimate for them, pinned on the
+        # reference's golden of that case
+        qd = 8
     if qd is None or qd < 0:
         raise NotImplementedError(
             "set parameters['form_compiler']['quadrature_degree'] (UFL's automatic degree "
             "estimation is reproduced only for the time-of-flight case, see DESIGN.md)")
+    extra = {}
+    if any(w is not None for w in drift_w):
+        extra["drift_w"] = drift_w
+    if ext_sources:
+        degrees = [0] * ns
+        for s, e in ext_sources:
+            if int(e.degree) not in (1, 2):
+                raise NotImplementedError("Expression sources of degree 1 or 2")
+            degrees[s] = int(e.degree)
+        extra["ext_source_degree"] = degrees
     model = Model(n_species=ns, poisson=bool(poissons), eq_type=eq_type, Z=Z, mu=mu, D=D,
                   reactions=reactions, bc_kind=bc_kind, quadrature_degree=int(qd),
-                  axisymmetric=axis, log_representation=log)
+                  axisymmetric=axis, log_representation=log, **extra)
+    model.expression_sources = ext_sources
     return model, mesh, tags_mf
 
 
@@ -328,26 +405,47 @@ class Problem:
                 for which, comp in (("old", getattr(p, "u_old", None)), ("old1", getattr(p, "u_old1", None))):
                     if isinstance(comp, forms.FunctionComponent):
                         owners[which] = comp.function
+                    elif isinstance(comp, forms.Function) and model.n_eq == 1:
+                        owners[which] = comp          # one equation on a plain space (fedm-tof.py:102-104)
             initial = {}
             for which, fn in owners.items():
                 if isinstance(fn, forms.Function):
                     fn.state = forms.DeviceState(device_problem, which)
                     if getattr(fn, "parts", None):
                         initial["u_" + which] = np.stack([np.asarray(f.vector(), dtype=float) for f in fn.parts], axis=1)
+                    elif model.n_eq == 1 and getattr(fn, "_v", None) is not None:
+                        initial["u_" + which] = np.asarray(fn._v, dtype=float)   # interpolated before Problem()
             if initial:
                 device_problem.set_state(**initial)
             binding = getattr(model, "field_binding", None)
             timed = [bc for bc in (bcs or []) if isinstance(bc.value, forms.Expression)]
+            sources = getattr(model, "expression_sources", [])
+            source_nodes = {}
+            for s_, e in sources:
+                lam = np.array([(i / e.degree, j / e.degree) for j in range(e.degree + 1)
+                                for i in range(e.degree + 1 - j)])
+                phi = np.stack([1 - lam[:, 0] - lam[:, 1], lam[:, 0], lam[:, 1]], axis=1)
+                source_nodes[s_] = np.einsum("na,cad->cnd", phi, mesh.coords[mesh.cells])
+
+            # a script that calls the nonlinear solver itself (fedm-tof.py:149) has the step sizes in the
+            # dt / dt_old Expressions of its balance equations; adaptive_solver sets the same values
+            steps = next(((p.dt, p.dt_old) for p in pieces
+                          if hasattr(getattr(p, "dt", None), "time_step")
+                          and hasattr(getattr(p, "dt_old", None), "time_step")), None)
 
             def refresh():
                 # time-dependent Dirichlet values (functions.py:1042-1044 advances their `t`) and the
                 # nodal coefficient Functions the script has just interpolated on the host
+                if steps is not None and sources:
+                    device_problem.set_step(steps[0].time_step, steps[1].time_step)
                 if timed:
                     device_problem.set_dirichlet_values(
                         np.concatenate([bc.rows(mesh, model.n_eq)[1] for bc in bcs]))
                 if binding is not None:
                     device_problem.set_gd_fields(binding.stack(mesh.num_vertices()))
-            if timed or binding is not None:
+                for s_, e in sources:       # the script has advanced the Expression's parameters (f.t = t)
+                    device_problem.set_ext_source(s_, np.asarray(e(source_nodes[s_]), dtype=float))
+            if timed or binding is not None or sources:
                 self.before_solve = refresh
         self.device = device_problem if device_problem is not None else getattr(F, "device", None)
         if self.device is None:

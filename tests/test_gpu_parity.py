@@ -5,6 +5,8 @@ SpMV) 1e-11 relative to the row/vector scale -- the kernel sums the same terms
 in a different association; solver-level quantities are bounded by the
 solvers' own stopping tolerances and stated per test.
 """
+from pathlib import Path
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -141,6 +143,27 @@ def test_tof_golden(golden_dir):
     assert np.mean(np.abs(err)) < 1e-5
     assert np.sqrt(np.mean(err ** 2)) < 1e-5
     assert np.max(np.abs(err)) < 1e-3
+
+
+def test_tof_example_script_reproduces_the_golden(golden_dir, tmp_path):
+    """examples/time_of_flight.py -- fedm-tof.py call for call (C++ Expression strings, the flux
+    written by hand, PETScSNESSolver driven by the script) -- with the harness's sizes
+    (tests/integrated_tests/time_of_flight/fedm_tof.py: 40x40, 100 steps) against the same golden."""
+    import importlib.util
+    from fedm_amd.cases import time_of_flight as tof
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("tof_example", root / "examples" / "time_of_flight.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(golden_dir / "tof_golden.npz")
+    n_num, n_exact, rel = mod.main(nx=40, ny=40, box_width=2.5e-4, box_height=5e-4, t0=2.5e-9,
+                                   T_final=2.6e-9, t_output=2.6e-9, output_dir=tmp_path, quiet=True)
+    assert np.isclose(rel, float(gold["relative_error"]))
+    err = (n_num - gold["n_e"]) / gold["n_e"]
+    assert np.mean(np.abs(err)) < 1e-5 and np.sqrt(np.mean(err ** 2)) < 1e-5 and np.max(np.abs(err)) < 1e-3
+    direct = tof.run_harness()                       # the case module, without the facade
+    assert np.abs(n_num - direct["n_num"]).max() <= 1e-9 * np.abs(direct["n_num"]).max()
+    assert np.abs(n_exact - direct["n_exact"]).max() <= 1e-12 * np.abs(direct["n_exact"]).max()
 
 
 def test_streamer_multigrid_fieldsplit(streamer_setup):

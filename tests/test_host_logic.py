@@ -544,3 +544,93 @@ def test_polynomial_smoother_recurrence_and_weights():
     x = x + P @ np.linalg.solve(Ac, P.T @ (b - A @ x))
     x = sweeps(w[::-1], b, x)
     assert np.allclose(x_composite, x, rtol=1e-11, atol=1e-13)
+
+
+def test_cpp_expression_subset_evaluates_the_reference_strings_and_refuses_the_rest():
+    """The C++ strings of fedm-tof.py:107,116,120 evaluate to the closed forms of
+    cases/time_of_flight; anything outside the arithmetic subset is refused, never executed."""
+    from fedm_amd import forms
+    from fedm_amd.cases import time_of_flight as tof
+    x = np.random.default_rng(3).uniform(0.0, 5e-4, (50, 2))
+    kw = dict(D=tof.DE, w=tof.WEZ, alpha=tof.ALPHA_E, t=2.6e-9, pi=np.pi)
+    u = forms.Expression('std::log(exp(-(pow(x[1]-w*t, 2)+pow(x[0], 2))/(4.0*D*t)+alpha*w*t)/pow(4*D*t*pi,1.5))',
+                         degree=3, **kw)
+    f = forms.Expression('exp(-(pow(x[1]-w*t, 2)+pow(x[0], 2))/(4.0*D*t)+alpha*w*t)*(w*alpha)'
+                         '/(8*pow(pi,1.5)*pow(D*t, 1.5))', degree=2, **kw)
+    np.testing.assert_allclose(u(x), tof.analytic_log_density(x, 2.6e-9), rtol=1e-14)
+    np.testing.assert_allclose(f(x), tof.source(x, 2.6e-9), rtol=1e-14)
+    f.t = 2.7e-9                                       # parameters are looked up at call time
+    np.testing.assert_allclose(f(x), tof.source(x, 2.7e-9), rtol=1e-14)
+    assert forms.Expression('x[0] > 1e-4 ? 1.0 : 0.0', degree=1).code      # construction is free ...
+    for bad in ('__import__("os").system("true")', 'x[0] > 1e-4 ? 1.0 : 0.0', 'x.shape', 'q*x[0]',
+                'x[0]; x[1]', '(lambda: 1)()'):
+        with pytest.raises((NotImplementedError, SyntaxError, NameError)): # ... evaluation is not
+            forms.Expression(bad, degree=1)(x)
+
+
+def test_time_of_flight_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):
+    """examples/time_of_flight.py follows fedm-tof.py call for call.  With the device replaced by
+    a recorder: the forms lower to the model of cases/time_of_flight, the states are the script's
+    interpolated Functions, and every solve sees the script's step sizes and its source Expression
+    at the advanced time, interpolated at the P2 lattice nodes."""
+    import importlib.util
+    import fedm_amd.device as fdev
+    from fedm_amd.cases import time_of_flight as tof
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("tof_example_cpu", root / "examples" / "time_of_flight.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    calls = []
+
+    class Recorder:
+        def __init__(self, coords, cells, model, facet_tags=None, dirichlet_dofs=None, dirichlet_vals=None,
+                     device=0):
+            self.coords, self.cells, self.model, self.t = coords, cells, model, 2.5e-9
+            self.state = {}
+            assert dirichlet_dofs.size == 0
+            calls.append(("create", model))
+
+        def set_state(self, **kw):
+            self.state.update({k: np.array(v) for k, v in kw.items()})
+            calls.append(("set_state", sorted(kw)))
+
+        def shift_state(self):
+            self.state["u_old1"], self.state["u_old"] = self.state["u_old"], self.state["u_new"]
+            calls.append(("shift",))
+
+        def set_step(self, dt, dt_old):
+            calls.append(("step", dt, dt_old))
+
+        def set_ext_source(self, s, nodal):
+            calls.append(("source", s, np.array(nodal)))
+
+        def newton_solve(self, **kw):
+            self.t += 1e-12
+            self.state["u_new"] = tof.analytic_log_density(self.coords, self.t)   # "the solver is exact"
+            calls.append(("solve", kw["rtol"], kw["max_it"]))
+
+        def get_state(self):
+            return self.state["u_new"].reshape(-1, 1)
+
+    monkeypatch.setattr(fdev, "DeviceProblem", Recorder)
+    n_num, n_exact, rel = mod.main(nx=8, ny=8, box_width=2.5e-4, box_height=5e-4, T_final=2.503e-9,
+                                   t_output=2.503e-9, output_dir=tmp_path, quiet=True)
+    model = calls[0][1]
+    assert bytes(model.to_c()) == bytes(tof.model().to_c())          # the same descriptor, byte for byte
+    assert (model.n_species, model.poisson, list(model.eq_type)) == (1, False, ["drift-diffusion-reaction"])
+    assert list(model.drift_w) == [(0.0, tof.WEZ)] and model.D[0].const_value() == tof.DE
+    assert model.quadrature_degree == 8 and list(model.ext_source_degree) == [2] and model.axisymmetric
+    assert calls[1] == ("set_state", ["u_new", "u_old", "u_old1"])
+    mesh = mod.RectangleMesh((0.0, 0.0), (2.5e-4, 5e-4), 8, 8)
+    nodes = tof.p2_nodes(mesh.coords, mesh.cells)
+    per_step = [c for c in calls[2:] if c[0] != "set_state"]
+    assert [c[0] for c in per_step] == ["shift", "step", "source", "solve"] * 3
+    assert per_step[1] == ("step", 1e-12, 1e30) and per_step[5] == ("step", 1e-12, 1e30) \
+        and per_step[9] == ("step", 1e-12, 1e-12)                 # fedm-tof.py:166-167: BDF2 from the third step
+    for k in range(3):
+        np.testing.assert_allclose(per_step[4 * k + 2][2], tof.source(nodes, 2.5e-9 + (k + 1) * 1e-12), rtol=1e-13)
+        assert per_step[4 * k + 3] == ("solve", 1e-10, 50)
+    assert 0.0 < rel < 1.0 and n_num.shape == n_exact.shape == (81,)     # 8x8 cells across a 35 um pulse
+    assert (tmp_path / "mesh" / "mesh info.txt").exists()
+    assert "relative_error" in (tmp_path / "relative error.log").read_text()
+    assert len(list((tmp_path / "number density" / "electrons").glob("*.vtu"))) == 1
