@@ -549,13 +549,22 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     double Hrow[3];
     for (int a = 0; a < 3; ++a)
         Hrow[a] = (-(trp1 * trp1) * uold[(size_t)c.v[a] * NEQ + row] + (tr * tr) * uold1[(size_t)c.v[a] * NEQ + row]) / trp1;
-    double Racc[3] = {0.0, 0.0, 0.0}, Jacc[3][3][NEQ];   // [column vertex b][row vertex a][column field s]
+    // One column vertex b at a time (a rolled loop around the quadrature loop): 15 accumulators instead
+    // of 45.  The point functions are evaluated once per column vertex -- more arithmetic, but the 45
+    // accumulators next to the live coefficients did not fit the register file: 92 spilled dwords per
+    // lane, re-read and re-written at every quadrature point, were what the kernel's time went into.
+#pragma unroll 1
+    for (int b = 0; b < (STORE == 0 ? 1 : 3); ++b) {
+    const double Gb0 = b == 0 ? c.G[0][0] : b == 1 ? c.G[1][0] : c.G[2][0];
+    const double Gb1 = b == 0 ? c.G[0][1] : b == 1 ? c.G[1][1] : c.G[2][1];
+    // The columns a row writes are known at compile time (energy 0, electrons ie, potential, the
+    // species of the sources) except its OWN column: that one has accumulators of its own, added to
+    // Jacc[.][row] after the loops -- no run-time register selection inside them.
+    double Racc[3] = {0.0, 0.0, 0.0}, Jacc[3][NEQ], Jown[3] = {0.0, 0.0, 0.0};   // [row vertex a][column field s]
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int s = 0; s < NEQ; ++s) Jacc[b][a][s] = 0.0;
+        for (int s = 0; s < NEQ; ++s) Jacc[a][s] = 0.0;
 
     // value and gradient of unknown s at a point (s is wave-uniform or a compile-time index)
     auto value = [&](int s, const double phi[3]) {
@@ -583,37 +592,48 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         return ch;
     };
     // W (tS phi_a - tX G_a,x - tY G_a,y) into column s of the accumulators (s: wave-uniform)
-    // (b is a compile-time index where these are called: the loops over the column vertex are unrolled;
-    // source-only and flux-only forms: a product with a literal zero is not folded without fast-math)
-    auto addS = [&](int b, int s, double W, const double phi[3], double tS) {
+    // (source-only and flux-only forms: a product with a literal zero is not folded without fast-math)
+    // s: a compile-time column where these are called (after inlining and unrolling), or OWN
+    constexpr int OWN = -1;
+    auto addS = [&](int s, double W, const double phi[3], double tS) {
         if (STORE == 0) return;
         const double w = W * tS;
+        if (s == OWN) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Jown[a] += w * phi[a];
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NEQ; ++k)
             if (k == s) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Jacc[b][a][k] += w * phi[a];
+                for (int a = 0; a < 3; ++a) Jacc[a][k] += w * phi[a];
             }
     };
-    auto addG = [&](int b, int s, double W, double tX, double tY) {
+    auto addG = [&](int s, double W, double tX, double tY) {
         if (STORE == 0) return;
         const double wx = W * tX, wy = W * tY;
+        if (s == OWN) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Jown[a] -= wx * c.G[a][0] + wy * c.G[a][1];
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NEQ; ++k)
             if (k == s) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Jacc[b][a][k] -= wx * c.G[a][0] + wy * c.G[a][1];
+                for (int a = 0; a < 3; ++a) Jacc[a][k] -= wx * c.G[a][0] + wy * c.G[a][1];
             }
     };
     // derivatives of the channels along the basis function of column vertex b (value w_v, gradient w_x, w_y)
     struct Seeds {
         double w_v, w_x, w_y, k1_0, k2_0, k3_0, k1_e, k2_e, k3_e;
     };
-    auto seeds = [&](int b, const double phi[3], const GdChannels &ch) {
+    auto seeds = [&](const double phi[3], const GdChannels &ch) {
         Seeds sd;
-        sd.w_v = phi[b];
-        sd.w_x = c.G[b][0];
-        sd.w_y = c.G[b][1];
+        sd.w_v = b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2];
+        sd.w_x = Gb0;
+        sd.w_y = Gb1;
         sd.k1_0 = ch.r0 * sd.w_v;
         sd.k2_0 = ch.c2_v0 * sd.w_v + ch.r0 * sd.w_x;
         sd.k3_0 = ch.c3_v0 * sd.w_v + ch.r0 * sd.w_y;
@@ -630,20 +650,20 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                                 value(own, phi), grad_x(own), grad_y(own), Ex, Ey);
     };
     // directional derivative of a flux (column vertex b) into the flux columns of the accumulators
-    auto flux_columns = [&](int b, const GdFluxD &Fl, int own, const Seeds &sd, double W, const double phi[3]) {
-        addG(b, own, W, Fl.Gx * sd.w_v + Fl.dg * sd.w_x, Fl.Gy * sd.w_v + Fl.dg * sd.w_y);
-        addG(b, IPHI, W, -Fl.dE * sd.w_x, -Fl.dE * sd.w_y);   // E = -grad Phi
-        addG(b, 0, W, Fl.x_c1 * sd.k1_0 + Fl.x_c2 * sd.k2_0, Fl.y_c1 * sd.k1_0 + Fl.y_c3 * sd.k3_0);
-        addG(b, ie, W, Fl.x_c1 * sd.k1_e + Fl.x_c2 * sd.k2_e, Fl.y_c1 * sd.k1_e + Fl.y_c3 * sd.k3_e);
+    auto flux_columns = [&](const GdFluxD &Fl, int own, const Seeds &sd, double W, const double phi[3]) {
+        addG(own, W, Fl.Gx * sd.w_v + Fl.dg * sd.w_x, Fl.Gy * sd.w_v + Fl.dg * sd.w_y);
+        addG(IPHI, W, -Fl.dE * sd.w_x, -Fl.dE * sd.w_y);   // E = -grad Phi
+        addG(0, W, Fl.x_c1 * sd.k1_0 + Fl.x_c2 * sd.k2_0, Fl.y_c1 * sd.k1_0 + Fl.y_c3 * sd.k3_0);
+        addG(ie, W, Fl.x_c1 * sd.k1_e + Fl.x_c2 * sd.k2_e, Fl.y_c1 * sd.k1_e + Fl.y_c3 * sd.k3_e);
     };
     // ... of factor * (w . G) (Joule heating: w = E; wall flux: w = n) into the source columns
-    auto flux_dot_columns = [&](int b, const GdFluxD &Fl, int own, const Seeds &sd, double wx, double wy, double factor,
+    auto flux_dot_columns = [&](const GdFluxD &Fl, int own, const Seeds &sd, double wx, double wy, double factor,
                                 double W, const double phi[3]) {
-        addS(b, own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * sd.w_v + Fl.dg * (wx * sd.w_x + wy * sd.w_y)));
-        addS(b, IPHI, W, phi, -factor * Fl.dE * (wx * sd.w_x + wy * sd.w_y));
+        addS(own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * sd.w_v + Fl.dg * (wx * sd.w_x + wy * sd.w_y)));
+        addS(IPHI, W, phi, -factor * Fl.dE * (wx * sd.w_x + wy * sd.w_y));
         const double o1 = factor * (Fl.x_c1 * wx + Fl.y_c1 * wy), o2 = factor * Fl.x_c2 * wx, o3 = factor * Fl.y_c3 * wy;
-        addS(b, 0, W, phi, o1 * sd.k1_0 + o2 * sd.k2_0 + o3 * sd.k3_0);
-        addS(b, ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e);
+        addS(0, W, phi, o1 * sd.k1_0 + o2 * sd.k2_0 + o3 * sd.k3_0);
+        addS(ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e);
     };
 
     for (int q = 0; q < md->n_qp; ++q) {
@@ -657,13 +677,13 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             for (int i = 1; i < ns; ++i) {
                 const double ni = (md->sign[i] * md->charge_over_eps) * exp(value(i, phi));
                 rho += ni;
-#pragma unroll
-                for (int b = 0; b < 3; ++b) addS(b, i, W, phi, -ni * phi[b]);
+                addS(i, W, phi, -ni * (b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2]));
             }
+            addG(IPHI, W, -Gb0, -Gb1);
+            if (b == 0) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) addG(b, IPHI, W, -c.G[b][0], -c.G[b][1]);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) Racc[a] += W * (-rho * phi[a] - (Ex * c.G[a][0] + Ey * c.G[a][1]));
+                for (int a = 0; a < 3; ++a) Racc[a] += W * (-rho * phi[a] - (Ex * c.G[a][0] + Ey * c.G[a][1]));
+            }
             continue;
         }
         const GdChannels ch = channels(phi);
@@ -702,16 +722,15 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             Gy = Fw.Gy;
             const GdFluxD Fe = species_flux(ie, 1.0, ie, phi, ch);
             S += Fe.Gx * Ex + Fe.Gy * Ey;
+            {
+                const Seeds sd = seeds(phi, ch);
+                addS(0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const Seeds sd = seeds(b, phi, ch);
-                addS(b, 0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0);
-#pragma unroll
-                for (int i = 1; i < ns; ++i) addS(b, i, W, phi, -src_v[i] * sd.w_v);
-                addS(b, ie, W, phi, -src_c1 * sd.k1_e);
-                flux_columns(b, Fw, 0, sd, W, phi);
-                flux_dot_columns(b, Fe, ie, sd, Ex, Ey, 1.0, W, phi);
-                addS(b, IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y));   // d(G . E)/dE = G, E = -grad Phi
+                for (int i = 1; i < ns; ++i) addS(i, W, phi, -src_v[i] * sd.w_v);
+                addS(ie, W, phi, -src_c1 * sd.k1_e);
+                flux_columns(Fw, 0, sd, W, phi);
+                flux_dot_columns(Fe, ie, sd, Ex, Ey, 1.0, W, phi);
+                addS(IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y));   // d(G . E)/dE = G, E = -grad Phi
             }
         } else {
             const bool has_flux = md->eq_type[row] != FEDM_EQ_REACTION;
@@ -721,19 +740,20 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                 Gx = Fl.Gx;
                 Gy = Fl.Gy;
             }
+            {
+                const Seeds sd = seeds(phi, ch);
+                addS(OWN, W, phi, dT * sd.w_v);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const Seeds sd = seeds(b, phi, ch);
-                addS(b, row, W, phi, dT * sd.w_v);
-#pragma unroll
-                for (int i = 1; i < ns; ++i) addS(b, i, W, phi, -src_v[i] * sd.w_v);
-                addS(b, 0, W, phi, -src_c1 * sd.k1_0);
-                addS(b, ie, W, phi, -src_c1 * sd.k1_e);
-                if (has_flux) flux_columns(b, Fl, row, sd, W, phi);
+                for (int i = 1; i < ns; ++i) addS(i, W, phi, -src_v[i] * sd.w_v);
+                addS(0, W, phi, -src_c1 * sd.k1_0);
+                addS(ie, W, phi, -src_c1 * sd.k1_e);
+                if (has_flux) flux_columns(Fl, OWN, sd, W, phi);
             }
         }
+        if (b == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) Racc[a] += W * (S * phi[a] - (Gx * c.G[a][0] + Gy * c.G[a][1]));
+            for (int a = 0; a < 3; ++a) Racc[a] += W * (S * phi[a] - (Gx * c.G[a][0] + Gy * c.G[a][1]));
+        }
     }
 
     // 'flux source' boundary facets, functions.py:514-522
@@ -771,8 +791,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                 double wall;
                 if (et == FEDM_EQ_DIFFUSION_REACTION) {
                     wall = fac * (0.5 * vth * dens);
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) addS(b, row, W, phi, wall * phi[b]);
+                    addS(OWN, W, phi, wall * (b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2]));
                 } else {
                     const GdChannels ch = channels(phi);
                     const double En = Ex * nx + Ey * ny;
@@ -782,13 +801,12 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                     const double qd = zs * (muv * En), sg = qd < 0.0 ? -1.0 : 1.0;
                     wall = fac * ((0.5 * vth + sg * qd) * dens);
                     const double k = fac * dens * sg * zs;
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const Seeds sd = seeds(b, phi, ch);
-                        addS(b, row, W, phi, wall * sd.w_v);
-                        addS(b, 0, W, phi, k * mub * En * sd.k1_0);
-                        addS(b, ie, W, phi, k * mub * En * sd.k1_e);
-                        addS(b, IPHI, W, phi, -k * muv * (nx * sd.w_x + ny * sd.w_y));
+                    {
+                        const Seeds sd = seeds(phi, ch);
+                        addS(OWN, W, phi, wall * sd.w_v);
+                        addS(0, W, phi, k * mub * En * sd.k1_0);
+                        addS(ie, W, phi, k * mub * En * sd.k1_e);
+                        addS(IPHI, W, phi, -k * muv * (nx * sd.w_x + ny * sd.w_y));
                     }
                     if (sp == ie) {
                         // - 2 gamma / (1 + r) * sum over ions of Max(Gamma_s . n, 0), fedm-gd.py:351
@@ -799,35 +817,41 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                             const double gn = Fs.Gx * nx + Fs.Gy * ny;
                             if (gn < 0.0) continue;
                             wall -= cI * gn;
-#pragma unroll
-                            for (int b = 0; b < 3; ++b) flux_dot_columns(b, Fs, s, seeds(b, phi, ch), nx, ny, -cI, W, phi);
+                            flux_dot_columns(Fs, s, seeds(phi, ch), nx, ny, -cI, W, phi);
                         }
                     }
                 }
+                if (b == 0) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Racc[a] += W * wall * phi[a];
+                    for (int a = 0; a < 3; ++a) Racc[a] += W * wall * phi[a];
+                }
             }
         }
     }
 
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < NEQ; ++k) Jacc[a][k] += (k == row) ? Jown[a] : 0.0;
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
-        if (elemF) elemF[(size_t)(a * NEQ + row) * n_cells + cidx] = Racc[a];   // summed by gd_gather_residual_kernel
-        else unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
-        if (STORE == 0) continue;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
-                double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
-#pragma unroll
-                for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_cells] = Jacc[b][a][s];
-                continue;
-            }
-            const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
-            double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
-#pragma unroll
-            for (int s = 0; s < NEQ; ++s) unsafeAtomicAdd(&dst[(size_t)(row * NEQ + s) * SLICE], Jacc[b][a][s]);
+        if (b == 0) {
+            if (elemF) elemF[(size_t)(a * NEQ + row) * n_cells + cidx] = Racc[a];   // summed by gd_gather_residual_kernel
+            else unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
         }
+        if (STORE == 0) continue;
+        if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
+            double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_cells] = Jacc[a][s];
+            continue;
+        }
+        const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
+        double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) unsafeAtomicAdd(&dst[(size_t)(row * NEQ + s) * SLICE], Jacc[a][s]);
     }
+    }   // column vertex b
     }   // pass
 }
 
