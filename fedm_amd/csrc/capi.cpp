@@ -801,6 +801,12 @@ int fedm_ctx_create_gd(const fedm_mesh_desc *mesh, const fedm_gd_desc *gd, int d
         set_error("unsupported LMEA model descriptor");
         return -2;
     }
+    for (int j = 0; j < gd->n_reactions; ++j)
+        for (int i = 0; i < gd->n_species; ++i)
+            if (gd->power[j][i] < 0 || gd->power[j][i] > 15) {   // the kernels pack them 4 bits each
+                set_error("LMEA reaction powers must be between 0 and 15");
+                return -2;
+            }
     return ctx_create_guarded(mesh, nullptr, gd, device, out);
 }
 

@@ -396,14 +396,15 @@ __global__ __launch_bounds__(128) void gd_assemble_kernel(
 struct N3 {
     double v, gx, gy;
 };
-// `fl`: a cell's block of staged field values, field fi at fl[3 fi .. 3 fi + 2] (its three vertices)
+// `fl`: the cell's column of the staged field values [field][vertex][cell]: field fi at vertex a is
+// fl[(3 fi + a) * SLICE] (lanes = cells: consecutive LDS words, no bank conflicts)
 __device__ __forceinline__ N3 nodal3(const double *fl, int fi, const GdCell &c, const double phi[3]) {
-    const double a0 = fl[3 * fi], a1 = fl[3 * fi + 1], a2 = fl[3 * fi + 2];
+    const double a0 = fl[(3 * fi) * SLICE], a1 = fl[(3 * fi + 1) * SLICE], a2 = fl[(3 * fi + 2) * SLICE];
     return {a0 * phi[0] + a1 * phi[1] + a2 * phi[2], a0 * c.G[0][0] + a1 * c.G[1][0] + a2 * c.G[2][0],
             a0 * c.G[0][1] + a1 * c.G[1][1] + a2 * c.G[2][1]};
 }
 __device__ __forceinline__ double nodal1(const double *fl, int fi, const double phi[3]) {
-    return fl[3 * fi] * phi[0] + fl[3 * fi + 1] * phi[1] + fl[3 * fi + 2] * phi[2];
+    return fl[(3 * fi) * SLICE] * phi[0] + fl[(3 * fi + 1) * SLICE] * phi[1] + fl[(3 * fi + 2) * SLICE] * phi[2];
 }
 
 // dme = (c1; c2, c3) and the derivatives of the three channels along the basis function of the
@@ -427,7 +428,8 @@ struct GdFluxD {
 __device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, int f_mud, int f_d, int f_dd,
                                                     const GdCell &c, const double phi[3], const GdChannels &ch,
                                                     double sign, double scale, bool drift, bool grad_diffusion,
-                                                    double v, double gx, double gy, double Ex, double Ey) {
+                                                    double v, double gx, double gy, double Ex, double Ey,
+                                                    double e_known = -1.0) {
     const N3 Da = nodal3(fl, f_d, c, phi), Db = nodal3(fl, f_dd, c, phi);
     // D = Da + Db * dme as value + gradient (product rule of the SG type above)
     const double Dv = scale * (Da.v + Db.v * ch.c1);
@@ -438,7 +440,7 @@ __device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, 
         mub = scale * nodal1(fl, f_mud, phi);
         muv = scale * nodal1(fl, f_mu, phi) + mub * ch.c1;
     }
-    const double e = exp(v);
+    const double e = e_known >= 0.0 ? e_known : exp(v);   // exp(v) of the workgroup's table, when it has one
     GdFluxD F;
     const double zm = sign * muv * e;
     if (grad_diffusion) {
@@ -470,25 +472,29 @@ __device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, 
 // value written once, fixed summation order; 1 = fp64 atomics straight into the matrix (the fall-back
 // when the buffer cannot be allocated).  The residual is added with atomics.
 // STORE 0: residual only (launched with one column vertex: gridDim.y = 1).
-template <int NEQ, int STORE>
+// NRC, NQC > 0: the numbers of reactions and of quadrature points at compile time (the loops over them
+// unroll, the model's scalars -- weights, powers, points -- are loaded once instead of by a dependent
+// scalar load and a wait in every pass of the innermost loops); 0: taken from the descriptor.
+template <int NEQ, int STORE, int NRC = 0, int NQC = 0>
 __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(2, 2))) void gd_jacobian_rows_kernel(
     const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields, int nv,
     const int *__restrict__ cell_list, int n_cells, const int *__restrict__ cells,
     const double *__restrict__ coords, const int8_t *__restrict__ ftags,
     const uint32_t *__restrict__ cell_slots, const double *__restrict__ u,
     const double *__restrict__ uold, const double *__restrict__ uold1, double dt, double dt_old,
-    double *__restrict__ val, double *__restrict__ F, int mode, double *__restrict__ elemF) {
+    double *__restrict__ val, double *__restrict__ F, int mode, double *__restrict__ elemF, int exp_table) {
     constexpr int NEQ2 = NEQ * NEQ, ns = NEQ - 1, IPHI = NEQ - 1, ie = ns - 1;
     const double two_pi = 6.283185307179586476925286766559;
     const int lc = threadIdx.x & (SLICE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ci = blockIdx.x * SLICE + lc;
-    const int nr = md->n_reactions;
+    const int nr = NRC > 0 ? NRC : md->n_reactions;
+    const int nqp = NQC > 0 ? NQC : md->n_qp;
     const int NF = 4 * ns + 2 * nr + 3;
     extern __shared__ double gd_lds[];
     int *lds_vtx = reinterpret_cast<int *>(gd_lds);                 // [64][3] global vertex ids (-1: no cell)
     double *lds_f = gd_lds + (3 * SLICE + 1) / 2;                   // [64][NF][3]
-    double *lds_u = lds_f + (size_t)SLICE * NF * 3;                 // [64][3][NEQ]
+    double *lds_u = lds_f + (size_t)SLICE * NF * 3;                 // [3][NEQ][64]
     for (int i = threadIdx.x; i < 3 * SLICE; i += blockDim.x) {
         const int cc = blockIdx.x * SLICE + i / 3;
         lds_vtx[i] = cc < n_cells ? cells[3 * (cell_list ? cell_list[cc] : cc) + i % 3] : -1;
@@ -498,24 +504,54 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         // lane = cell, the waves share the (field, vertex) pairs: no division by a run-time number
         const int nw = blockDim.x >> 6;
         const int vt[3] = {lds_vtx[3 * lc], lds_vtx[3 * lc + 1], lds_vtx[3 * lc + 2]};
-        double *dstf = lds_f + (size_t)lc * NF * 3;
+        double *dstf = lds_f + lc;
         for (int f = wave; f < NF * 3; f += nw) {
             const int fi = f / 3, a = f - 3 * fi;
             const int vtx = a == 0 ? vt[0] : a == 1 ? vt[1] : vt[2];
-            dstf[f] = vtx >= 0 ? fields[(size_t)fi * nv + vtx] : 0.0;
+            dstf[(size_t)f * SLICE] = vtx >= 0 ? fields[(size_t)fi * nv + vtx] : 0.0;
         }
-        double *dstu = lds_u + (size_t)lc * 3 * NEQ;
+        double *dstu = lds_u + lc;
         for (int f = wave; f < 3 * NEQ; f += nw) {
             const int a = f / NEQ, sidx = f - a * NEQ;
             const int vtx = a == 0 ? vt[0] : a == 1 ? vt[1] : vt[2];
-            dstu[f] = vtx >= 0 ? u[(size_t)vtx * NEQ + sidx] : 0.0;
+            dstu[(size_t)f * SLICE] = vtx >= 0 ? u[(size_t)vtx * NEQ + sidx] : 0.0;
         }
     }
     __syncthreads();
+    // exp(u_s) of the species/energy unknowns and exp(-u_e,old) at the quadrature points depend on the
+    // cell only: every row and every column-vertex pass needs them (eight exponentials per point and
+    // pass, half of the kernel's vector instructions).  Wave s tabulates unknown s for its 64 cells
+    // once: [point][unknown | NEQ-1: exp(-u_e,old)][cell].  exp_table = 0: no room in LDS, evaluate.
+    double *lds_e = lds_u + (size_t)SLICE * 3 * NEQ;
+    // per row: weight of reaction j (net gain of the species, minus the energy loss for row 0) and its
+    // powers packed 4 bits per species (-1: the reaction does not enter the row)
+    double *lds_rw = lds_e + (exp_table ? (size_t)nqp * NEQ * SLICE : 0);
+    int *lds_rp = reinterpret_cast<int *>(lds_rw + ns * FEDM_GD_MAX_REACTIONS);
+    if (lc < nr) {
+        const double w = (wave == 0) ? -md->energy_loss[lc] : (double)md->net[lc][wave];
+        int pk = 0;
+        for (int i = 0; i < ns; ++i) pk |= (md->power[lc][i] & 15) << (4 * i);
+        lds_rw[wave * FEDM_GD_MAX_REACTIONS + lc] = w;
+        lds_rp[wave * FEDM_GD_MAX_REACTIONS + lc] = w == 0.0 ? -1 : pk;
+    }
+    if (!exp_table) __syncthreads();
+    if (exp_table) {
+        const double *flw = lds_f + lc, *ulw = lds_u + lc;
+        const int f_ueo = 4 * ns + 2 * nr + 2;
+#pragma unroll
+        for (int q = 0; q < nqp; ++q) {
+            const double p0 = 1.0 - md->qp_x[q] - md->qp_y[q], p1 = md->qp_x[q], p2 = md->qp_y[q];
+            lds_e[((size_t)q * NEQ + wave) * SLICE + lc] = exp(ulw[wave * SLICE] * p0 + ulw[(NEQ + wave) * SLICE] * p1 + ulw[(2 * NEQ + wave) * SLICE] * p2);
+            if (wave == 0)
+                lds_e[((size_t)q * NEQ + ns) * SLICE + lc] =
+                    exp(-(flw[(3 * f_ueo) * SLICE] * p0 + flw[(3 * f_ueo + 1) * SLICE] * p1 + flw[(3 * f_ueo + 2) * SLICE] * p2));
+        }
+        __syncthreads();
+    }
     if (ci >= n_cells) return;
     const int cidx = cell_list ? cell_list[ci] : ci;   // no list: the mesh's own cell order
-    const double *fl = lds_f + (size_t)lc * NF * 3;
-    const double *ul = lds_u + (size_t)lc * 3 * NEQ;   // [a][s]
+    const double *fl = lds_f + lc;   // (re-based at every quadrature point, see there)
+    const double *ul = lds_u + lc;   // [a][s][cell]
     GdCell c;
     {
         double x[3][2];   // (not kept: the facet terms read the two coordinates they need again)
@@ -568,17 +604,21 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
 
     // value and gradient of unknown s at a point (s is wave-uniform or a compile-time index)
     auto value = [&](int s, const double phi[3]) {
-        return ul[s] * phi[0] + ul[NEQ + s] * phi[1] + ul[2 * NEQ + s] * phi[2];
+        return ul[s * SLICE] * phi[0] + ul[(NEQ + s) * SLICE] * phi[1] + ul[(2 * NEQ + s) * SLICE] * phi[2];
     };
-    auto grad_x = [&](int s) { return ul[s] * c.G[0][0] + ul[NEQ + s] * c.G[1][0] + ul[2 * NEQ + s] * c.G[2][0]; };
-    auto grad_y = [&](int s) { return ul[s] * c.G[0][1] + ul[NEQ + s] * c.G[1][1] + ul[2 * NEQ + s] * c.G[2][1]; };
+    auto grad_x = [&](int s) { return ul[s * SLICE] * c.G[0][0] + ul[(NEQ + s) * SLICE] * c.G[1][0] + ul[(2 * NEQ + s) * SLICE] * c.G[2][0]; };
+    auto grad_y = [&](int s) { return ul[s * SLICE] * c.G[0][1] + ul[(NEQ + s) * SLICE] * c.G[1][1] + ul[(2 * NEQ + s) * SLICE] * c.G[2][1]; };
     const double gx0 = grad_x(0), gy0 = grad_y(0), gxe = grad_x(ie), gye = grad_y(ie);
     const double Ex = -grad_x(IPHI), Ey = -grad_y(IPHI);
 
-    auto channels = [&](const double phi[3]) {
+    // exp(u_s) at volume quadrature point q from the table (q < 0: a facet point, evaluated)
+    auto expu = [&](int s, int q, const double phi[3]) {
+        return (exp_table && q >= 0) ? lds_e[((size_t)q * NEQ + s) * SLICE + lc] : exp(value(s, phi));
+    };
+    auto channels = [&](const double phi[3], int q) {
         const N3 meo = nodal3(fl, F_MEO, c, phi), ueo = nodal3(fl, F_UEO, c, phi);
-        const double ieo = exp(-ueo.v);
-        const double r0 = exp(value(0, phi)) * ieo, re = exp(value(ie, phi)) * ieo;
+        const double ieo = (exp_table && q >= 0) ? lds_e[((size_t)q * NEQ + ns) * SLICE + lc] : exp(-ueo.v);
+        const double r0 = expu(0, q, phi) * ieo, re = expu(ie, q, phi) * ieo;
         GdChannels ch;
         ch.c1 = r0 - re * meo.v;
         ch.c2 = r0 * gx0 - re * (gxe * meo.v + meo.gx) - ch.c1 * ueo.gx;
@@ -642,12 +682,13 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         sd.k3_e = ch.c3_ve * sd.w_v + ch.rem * sd.w_y;
         return sd;
     };
-    auto species_flux = [&](int s, double scale, int own, const double phi[3], const GdChannels &ch) {
+    auto species_flux = [&](int s, double scale, int own, const double phi[3], const GdChannels &ch, int q) {
         const int et = md->eq_type[s];
         const bool drift = et == FEDM_EQ_DRIFT_DIFFUSION_REACTION;
         const bool gdf = drift ? md->grad_diffusion[s] != 0 : true;   // diffusion-reaction: -grad(D exp(u))
         return gd_flux_partials(fl, F_MU + s, F_MUD + s, F_D + s, F_DD + s, c, phi, ch, md->sign[s], scale, drift, gdf,
-                                value(own, phi), grad_x(own), grad_y(own), Ex, Ey);
+                                value(own, phi), grad_x(own), grad_y(own), Ex, Ey,
+                                (exp_table && q >= 0) ? lds_e[((size_t)q * NEQ + own) * SLICE + lc] : -1.0);
     };
     // directional derivative of a flux (column vertex b) into the flux columns of the accumulators
     auto flux_columns = [&](const GdFluxD &Fl, int own, const Seeds &sd, double W, const double phi[3]) {
@@ -666,7 +707,16 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         addS(ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e);
     };
 
-    for (int q = 0; q < md->n_qp; ++q) {
+    for (int q = 0; q < nqp; ++q) {
+        // The staged nodal values do not depend on q or b: left alone, the compiler hoists their ~100
+        // LDS reads out of both loops and spills them.  An opaque lane offset per point keeps every read
+        // where it is used.
+        {
+            int lcq = lc;
+            asm volatile("" : "+v"(lcq));
+            fl = lds_f + lcq;
+            ul = lds_u + lcq;
+        }
         const double phi[3] = {1.0 - md->qp_x[q] - md->qp_y[q], md->qp_x[q], md->qp_y[q]};
         const double rq = c.rn[0] * phi[0] + c.rn[1] * phi[1] + c.rn[2] * phi[2];
         const double W = md->qp_w[q] * c.detJ * two_pi * rq;
@@ -675,7 +725,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             double rho = 0.0;
 #pragma unroll
             for (int i = 1; i < ns; ++i) {
-                const double ni = (md->sign[i] * md->charge_over_eps) * exp(value(i, phi));
+                const double ni = (md->sign[i] * md->charge_over_eps) * expu(i, q, phi);
                 rho += ni;
                 addS(i, W, phi, -ni * (b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2]));
             }
@@ -686,41 +736,51 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             }
             continue;
         }
-        const GdChannels ch = channels(phi);
+        const GdChannels ch = channels(phi, q);
         double n[ns];
 #pragma unroll
-        for (int i = 1; i < ns; ++i) n[i] = exp(value(i, phi));
+        for (int i = 1; i < ns; ++i) n[i] = expu(i, q, phi);
         // source of this row: sum_j w_j rate_j with w_j = net[j][row] (species) or -loss_j (energy)
         double src = 0.0, src_c1 = 0.0, src_v[ns];
 #pragma unroll
         for (int i = 0; i < ns; ++i) src_v[i] = 0.0;
+#pragma unroll
         for (int j = 0; j < nr; ++j) {
-            const double w = (row == 0) ? -md->energy_loss[j] : (double)md->net[j][row];
-            if (w == 0.0) continue;
+            // (weight, packed powers) of reaction j for this row: one broadcast LDS read, returned with
+            // the rate-coefficient reads that follow, instead of dependent scalar loads from the descriptor
+            const int pk = __builtin_amdgcn_readfirstlane(lds_rp[row * FEDM_GD_MAX_REACTIONS + j]);
+            if (pk < 0) continue;   // the reaction does not enter this row
+            const double w = lds_rw[row * FEDM_GD_MAX_REACTIONS + j];
             const double kv = nodal1(fl, F_K + j, phi), kd = nodal1(fl, F_KD + j, phi);
             double prod = 1.0;
 #pragma unroll
-            for (int i = 0; i < ns; ++i)
-                for (int e = 0; e < md->power[j][i]; ++e) prod *= (i == 0) ? md->N0 : n[i];
+            for (int i = 0; i < ns; ++i) {
+                // x^p for the small integer powers of a reaction scheme without a loop over p
+                const int pw = (pk >> (4 * i)) & 15;
+                const double x = (i == 0) ? md->N0 : n[i];
+                if (pw <= 3) prod *= pw == 0 ? 1.0 : pw == 1 ? x : pw == 2 ? x * x : x * x * x;
+                else
+                    for (int e = 0; e < pw; ++e) prod *= x;
+            }
             const double rate = (kv + kd * ch.c1) * prod;
             src += w * rate;
             src_c1 += w * kd * prod;
 #pragma unroll
-            for (int i = 1; i < ns; ++i) src_v[i] += w * (double)md->power[j][i] * rate;
+            for (int i = 1; i < ns; ++i) src_v[i] += w * (double)((pk >> (4 * i)) & 15) * rate;
         }
         // time term, fedm/functions.py:350-357
         const double hq = Hrow[0] * phi[0] + Hrow[1] * phi[1] + Hrow[2] * phi[2];
-        const double vr = value(row, phi), er = exp(vr);
+        const double vr = value(row, phi), er = expu(row, q, phi);
         const double T = er * (vr * c_new + hq) / dt;
         double S = T - src;
         const double dT = T + er * c_new / dt;
         double Gx = 0.0, Gy = 0.0;
         if (row == 0) {
             // energy: 5/3 of the electron coefficients on u_0 (fedm-gd.py:354), Joule heating -Gamma_e . E
-            const GdFluxD Fw = species_flux(ie, 5.0 / 3.0, 0, phi, ch);
+            const GdFluxD Fw = species_flux(ie, 5.0 / 3.0, 0, phi, ch, q);
             Gx = Fw.Gx;
             Gy = Fw.Gy;
-            const GdFluxD Fe = species_flux(ie, 1.0, ie, phi, ch);
+            const GdFluxD Fe = species_flux(ie, 1.0, ie, phi, ch, q);
             S += Fe.Gx * Ex + Fe.Gy * Ey;
             {
                 const Seeds sd = seeds(phi, ch);
@@ -736,7 +796,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             const bool has_flux = md->eq_type[row] != FEDM_EQ_REACTION;
             GdFluxD Fl = {};
             if (has_flux) {
-                Fl = species_flux(row, 1.0, row, phi, ch);
+                Fl = species_flux(row, 1.0, row, phi, ch, q);
                 Gx = Fl.Gx;
                 Gy = Fl.Gy;
             }
@@ -793,7 +853,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                     wall = fac * (0.5 * vth * dens);
                     addS(OWN, W, phi, wall * (b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2]));
                 } else {
-                    const GdChannels ch = channels(phi);
+                    const GdChannels ch = channels(phi, -1);
                     const double En = Ex * nx + Ey * ny;
                     const double mub = nodal1(fl, F_MUD + sp, phi);
                     const double muv = nodal1(fl, F_MU + sp, phi) + mub * ch.c1;
@@ -813,7 +873,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                         const double cI = 2.0 * gam / (1.0 + ref);
                         for (int s = 1; s < ns; ++s) {
                             if (!md->is_ion[s]) continue;
-                            const GdFluxD Fs = species_flux(s, 1.0, s, phi, ch);
+                            const GdFluxD Fs = species_flux(s, 1.0, s, phi, ch, -1);
                             const double gn = Fs.Gx * nx + Fs.Gy * ny;
                             if (gn < 0.0) continue;
                             wall -= cI * gn;
@@ -961,31 +1021,46 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         if (!gather || mode != 0)   // (the gather writes every value of the rows it covers)
             hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * c.neq * c.neq, c.stream);
         const int cpb = SLICE, nf = c.gd_n_fields;
-        const size_t lds_h = sizeof(double) * ((size_t)(3 * cpb + 1) / 2 + (size_t)cpb * nf * 3 + (size_t)cpb * 3 * c.neq);
+        size_t lds_h = sizeof(double) * ((size_t)(3 * cpb + 1) / 2 + (size_t)cpb * nf * 3 + (size_t)cpb * 3 * c.neq);
+        // table of exp(u) at the quadrature points, while two workgroups still fit a CU's 160 KB
+        const size_t lds_table = sizeof(double) * (size_t)c.gd.n_qp * c.neq * cpb;
+        const int exp_table = lds_h + lds_table <= 80 * 1024 ? 1 : 0;
+        if (exp_table) lds_h += lds_table;
+        lds_h += (size_t)(c.neq - 1) * FEDM_GD_MAX_REACTIONS * 12 + 8;   // the rows' reaction weights and powers
         const dim3 gh((unsigned)((n + cpb - 1) / cpb), 1), bh(SLICE * (c.neq - 1));
         const int n_pos = (int)(c.pat.total_bc * SLICE);
         const int row_first = mode == 1 ? c.neq - 1 : 0, row_last = c.neq - 1;
-#define FEDM_GD_HAND_LAUNCH(NEQ)                                                                                  \
+#define FEDM_GD_HAND_LAUNCH(NEQ, NRC, NQC)                                                                               \
     do {                                                                                                          \
+        static bool lds_attr_set = false;   /* per instantiation: a property of these kernels */            \
+        if (lds_h > 64 * 1024 && !lds_attr_set) {   /* more dynamic LDS than the default limit */               \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 2, NRC, NQC>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 1, NRC, NQC>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 0, NRC, NQC>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
+            lds_attr_set = true;                                                                                  \
+        }                                                                                                         \
         if (gather) {                                                                                             \
-            hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 2>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
+            hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 2, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,   \
-                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF); \
+                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \
             hipLaunchKernelGGL((gd_gather_kernel<NEQ>), dim3((n_pos + 255) / 256), dim3(256), 0, c.stream, n_pos, \
                                c.d_gd_inv_ptr, c.d_gd_inv_idx, c.d_gd_elem, c.d_val, row_first, row_last, n);     \
             hipLaunchKernelGGL((gd_gather_residual_kernel<NEQ>), dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, \
                                c.nv, c.d_gd_vinv_ptr, c.d_gd_vinv_idx, c.d_gd_elemF, c.d_F, row_first, n);        \
         } else {                                                                                                  \
-            hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 1>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
+            hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 1, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,   \
-                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_val, c.d_F, mode, (double *)nullptr); \
+                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_val, c.d_F, mode, (double *)nullptr, exp_table); \
         }                                                                                                         \
     } while (0)
         switch (c.neq) {
-            case 3: FEDM_GD_HAND_LAUNCH(3); break;
-            case 4: FEDM_GD_HAND_LAUNCH(4); break;
-            case 5: FEDM_GD_HAND_LAUNCH(5); break;
-            case 6: FEDM_GD_HAND_LAUNCH(6); break;
+            case 3: FEDM_GD_HAND_LAUNCH(3, 0, 0); break;
+            case 4: FEDM_GD_HAND_LAUNCH(4, 0, 0); break;
+            case 5: FEDM_GD_HAND_LAUNCH(5, 0, 0); break;
+            case 6: FEDM_GD_HAND_LAUNCH(6, 0, 0); break;
         }
 #undef FEDM_GD_HAND_LAUNCH
         return;
@@ -995,24 +1070,38 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         // launch; element residuals summed per vertex (no atomics: fixed order)
         const int n = c.nc;
         double *elemF = (hand_mode == 3 && gd_elem_setup(c) == 0) ? c.d_gd_elemF : nullptr;
-        const size_t lds_h = sizeof(double) * ((size_t)(3 * SLICE + 1) / 2 + (size_t)SLICE * c.gd_n_fields * 3 +
-                                               (size_t)SLICE * 3 * c.neq);
+        size_t lds_h = sizeof(double) * ((size_t)(3 * SLICE + 1) / 2 + (size_t)SLICE * c.gd_n_fields * 3 +
+                                         (size_t)SLICE * 3 * c.neq);
+        const size_t lds_table = sizeof(double) * (size_t)c.gd.n_qp * c.neq * SLICE;
+        const int exp_table = lds_h + lds_table <= 80 * 1024 ? 1 : 0;
+        if (exp_table) lds_h += lds_table;
+        lds_h += (size_t)(c.neq - 1) * FEDM_GD_MAX_REACTIONS * 12 + 8;
         const dim3 gh((unsigned)((n + SLICE - 1) / SLICE), 1), bh(SLICE * (c.neq - 1));
         const int row_first = mode == 1 ? c.neq - 1 : 0;
-#define FEDM_GD_RES_LAUNCH(NEQ)                                                                                   \
+#define FEDM_GD_RES_LAUNCH(NEQ, NRC, NQC)                                                                                \
     do {                                                                                                          \
-        hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 0>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields,     \
+        static bool lds_attr_set = false;                                                                         \
+        if (lds_h > 64 * 1024 && !lds_attr_set) {                                                                 \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 2, NRC, NQC>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 1, NRC, NQC>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 0, NRC, NQC>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
+            lds_attr_set = true;                                                                                  \
+        }                                                                                                         \
+        hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 0, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields,     \
                            c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,       \
-                           c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, (double *)nullptr, c.d_F, mode, elemF);    \
+                           c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, (double *)nullptr, c.d_F, mode, elemF, exp_table); \
         if (elemF)                                                                                                \
             hipLaunchKernelGGL((gd_gather_residual_kernel<NEQ>), dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, \
                                c.nv, c.d_gd_vinv_ptr, c.d_gd_vinv_idx, elemF, c.d_F, row_first, n);               \
     } while (0)
         switch (c.neq) {
-            case 3: FEDM_GD_RES_LAUNCH(3); break;
-            case 4: FEDM_GD_RES_LAUNCH(4); break;
-            case 5: FEDM_GD_RES_LAUNCH(5); break;
-            case 6: FEDM_GD_RES_LAUNCH(6); break;
+            case 3: FEDM_GD_RES_LAUNCH(3, 0, 0); break;
+            case 4: FEDM_GD_RES_LAUNCH(4, 0, 0); break;
+            case 5: FEDM_GD_RES_LAUNCH(5, 0, 0); break;
+            case 6: FEDM_GD_RES_LAUNCH(6, 0, 0); break;
         }
 #undef FEDM_GD_RES_LAUNCH
         return;
