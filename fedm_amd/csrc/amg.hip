@@ -71,10 +71,16 @@ int EllMat::from_csr(const fedm_csr &m, bool want_dinv, int l2s) {
         }
     if (hipMalloc((void **)&boff, sizeof(int) * boff_h.size()) != hipSuccess) return -1;
     if (hipMalloc((void **)&col, sizeof(int) * std::max<size_t>(col_h.size(), 1)) != hipSuccess) return -1;
-    if (hipMalloc((void **)&val, sizeof(double) * std::max<size_t>(val_h.size(), 1)) != hipSuccess) return -1;
     hipMemcpy(boff, boff_h.data(), sizeof(int) * boff_h.size(), hipMemcpyHostToDevice);
     hipMemcpy(col, col_h.data(), sizeof(int) * col_h.size(), hipMemcpyHostToDevice);
-    hipMemcpy(val, val_h.data(), sizeof(double) * val_h.size(), hipMemcpyHostToDevice);
+    if (single) {
+        std::vector<float> v32(val_h.begin(), val_h.end());
+        if (hipMalloc((void **)&val32, sizeof(float) * std::max<size_t>(v32.size(), 1)) != hipSuccess) return -1;
+        hipMemcpy(val32, v32.data(), sizeof(float) * v32.size(), hipMemcpyHostToDevice);
+    } else {
+        if (hipMalloc((void **)&val, sizeof(double) * std::max<size_t>(val_h.size(), 1)) != hipSuccess) return -1;
+        hipMemcpy(val, val_h.data(), sizeof(double) * val_h.size(), hipMemcpyHostToDevice);
+    }
     if (want_dinv) {
         if (hipMalloc((void **)&dinv, sizeof(double) * n_rows_p) != hipSuccess) return -1;
         hipMemcpy(dinv, dinv_h.data(), sizeof(double) * n_rows_p, hipMemcpyHostToDevice);
@@ -86,9 +92,11 @@ void EllMat::release() {
     if (boff) hipFree(boff);
     if (col) hipFree(col);
     if (val) hipFree(val);
+    if (val32) hipFree(val32);
     if (dinv) hipFree(dinv);
     boff = col = nullptr;
     val = dinv = nullptr;
+    val32 = nullptr;
 }
 
 // MODE 0: y = A x      1: y = b - A x      2: y = x + omega*dinv*(b - A x)     3: y += A x
@@ -98,11 +106,11 @@ void EllMat::release() {
 // (~1 us each).  So: no slice-offset lookup when the matrix has a uniform width (`width` > 0),
 // the row's own operands (b, dinv, x, y of the epilogue) are requested before the gather loop,
 // and four independent gather chains are in flight.
-template <int MODE>
+template <int MODE, typename VT>
 __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows, int log2_split, int width,
                                                        const int *__restrict__ boff,
                                                        const int *__restrict__ col,
-                                                       const double *__restrict__ val,
+                                                       const VT *__restrict__ val,
                                                        const double *__restrict__ dinv,
                                                        const double *__restrict__ x,
                                                        const double *__restrict__ b,
@@ -174,9 +182,17 @@ static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const
     if (n == 0) return;
     const dim3 g((n + 3) / 4), bl(256);
     if (!dinv) dinv = A.dinv;
-#define FEDM_ELL(M)                                                                                  \
-    hipLaunchKernelGGL(ell_spmv_kernel<M>, g, bl, 0, c.stream, n, A.n_rows, A.log2_split,            \
-                       A.width, A.boff, A.col, A.val, dinv, x, b, y, omega, aux, ystride, yoff, slice_list)
+#define FEDM_ELL(M)                                                                                          \
+    do {                                                                                                     \
+        if (A.val32)                                                                                         \
+            hipLaunchKernelGGL((ell_spmv_kernel<M, float>), g, bl, 0, c.stream, n, A.n_rows, A.log2_split,   \
+                               A.width, A.boff, A.col, A.val32, dinv, x, b, y, omega, aux, ystride, yoff,    \
+                               slice_list);                                                                  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((ell_spmv_kernel<M, double>), g, bl, 0, c.stream, n, A.n_rows, A.log2_split,  \
+                               A.width, A.boff, A.col, A.val, dinv, x, b, y, omega, aux, ystride, yoff,      \
+                               slice_list);                                                                  \
+    } while (0)
     switch (mode) {
         case 0: FEDM_ELL(0); break;
         case 1: FEDM_ELL(1); break;

@@ -16,6 +16,11 @@ struct EllMat {
     int64_t total_bc = 0;
     int *boff = nullptr, *col = nullptr;
     double *val = nullptr, *dinv = nullptr;
+    // single = true (set before from_csr): the values are stored in single precision (val32; val stays
+    // null) -- the multigrid hierarchy is a preconditioner, a third of its bytes are not needed;
+    // vectors, the diagonal's reciprocals and all sums stay double
+    bool single = false;
+    float *val32 = nullptr;
     int from_csr(const fedm_csr &m, bool want_dinv, int log2_split = -1);  // -1: choose
     void release();
 };

@@ -1840,6 +1840,11 @@ int fedm_amg_clear(fedm_ctx *h) {
 static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, const fedm_csr *P,
                      const fedm_csr *R, const double *coarse_inverse, int nu, double omega, Amg **out,
                      int composite_from, const double *poly_w = nullptr /* [n_levels - 1][nu] */) {
+    // the hierarchy's matrices in single precision (FEDM_MG_F32=0: double); see EllMat::single
+    static const bool mg_single = [] {
+        const char *e = std::getenv("FEDM_MG_F32");
+        return !(e && e[0] == '0');
+    }();
     if (n_levels < 1 || !A || (n_levels > 1 && (!P || !R)) || nu == 0) {
         set_error("bad multigrid description");
         return -2;
@@ -1899,6 +1904,7 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
             const HostCsr ASp = csr_product(A[l], nullptr, Spre.view(), 1.0);
             const HostCsr Tpre = csr_combine(Iv, 1.0, ASp.view(), -1.0, 0, n, nullptr);         // I - A S_pre
             const HostCsr Cm = csr_product(R[l], nullptr, Tpre.view(), 1.0);                     // R (I - A S_pre)
+            L.C.single = mg_single;
             rc |= L.C.from_csr(Cm.view(), false);
             if (L.composite) {
                 const HostCsr Spost = smoother(std::vector<double>(L.w.rbegin(), L.w.rend()));
@@ -1908,14 +1914,17 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
                 const HostCsr G = csr_combine(ES.view(), 1.0, Spost.view(), 1.0, 0, n, nullptr);  // E S_pre + S_post
                 const HostCsr Q = csr_product(E.view(), nullptr, P[l], 1.0);                       // E P
                 const HostCsr GQ = csr_combine(G.view(), 1.0, Q.view(), 1.0, np, np + P[l].n_cols, nullptr);
-                rc |= L.GQ.from_csr(GQ.view(), false);
+                L.GQ.single = mg_single;
+            rc |= L.GQ.from_csr(GQ.view(), false);
                 L.A.n_rows = n;
                 L.A.n_rows_p = np;
             } else {
                 // leg up as one product on the concatenated vector [b ; x_c]: x = S b + P x_c
                 const HostCsr SP = csr_combine(Spre.view(), 1.0, P[l], 1.0, np, np + P[l].n_cols, nullptr);
-                rc |= L.A.from_csr(A[l], true);
-                rc |= L.S.from_csr(SP.view(), false);
+                L.A.single = mg_single;
+            rc |= L.A.from_csr(A[l], true);
+                L.S.single = mg_single;
+            rc |= L.S.from_csr(SP.view(), false);
                 L.down_composite = true;
             }
         } else if (L.composite) {
@@ -1935,12 +1944,16 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
                 for (int64_t k = WAP.indptr[i]; k < WAP.indptr[i + 1]; ++k) WAP.values[k] *= wd[i];
             const HostCsr Q = csr_combine(P[l], 1.0, WAP.view(), -1.0, 0, P[l].n_cols, nullptr);  // (I - w Dinv A) P
             const HostCsr GQ = csr_combine(G.view(), 1.0, Q.view(), 1.0, np, np + P[l].n_cols, nullptr);
+            L.C.single = mg_single;
             rc |= L.C.from_csr(Cm.view(), false);
+            L.GQ.single = mg_single;
             rc |= L.GQ.from_csr(GQ.view(), false);
             L.A.n_rows = n;
             L.A.n_rows_p = np;
         } else if (l + 1 < n_levels) {
+            L.A.single = mg_single;
             rc |= L.A.from_csr(A[l], true);
+            L.P.single = mg_single;
             rc |= L.P.from_csr(P[l], false);
             // single-GPU hierarchy (its coarsest level is solved here): the finest level's leg down
             // as one product; across GPUs that level is a distributed operator with halo exchanges
@@ -1955,9 +1968,11 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
                 const HostCsr M1 = csr_product(A[l], wd.data(), I.view(), 1.0);
                 const HostCsr T = csr_combine(I.view(), 1.0, M1.view(), -1.0, 0, n, nullptr);
                 const HostCsr Cm = csr_product(R[l], nullptr, T.view(), 1.0);
-                rc |= L.C.from_csr(Cm.view(), false);
+                L.C.single = mg_single;
+            rc |= L.C.from_csr(Cm.view(), false);
             } else {
-                rc |= L.R.from_csr(R[l], false);
+                L.R.single = mg_single;
+            rc |= L.R.from_csr(R[l], false);
             }
         } else {
             L.A.n_rows = A[l].n_rows;
