@@ -3,6 +3,8 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <string>
+#include <vector>
 
 namespace fedm {
 
@@ -31,9 +33,24 @@ constexpr int kNcclSum = 0;
 
 int load_nccl() {
     if (g_nccl.lib) return 0;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        g_nccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    // RCCL must sit on the HIP/HSA runtime this library itself runs on.  A process may hold two ROCm
+    // installations (PyTorch's wheel carries its own libamdhip64 / libhsa-runtime64 / librccl next to
+    // /opt/rocm's): a bare dlopen("librccl.so.1") returns whichever RCCL was loaded first, and an RCCL
+    // that opens the *other* installation's HSA finds it uninitialised ("no ROCm-capable device is
+    // detected").  So: first the RCCL in the directory of the HIP runtime in use, then the search path.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        const std::string hip_path = info.dli_fname;
+        const size_t slash = hip_path.rfind('/');
+        if (slash != std::string::npos) {
+            names.push_back(hip_path.substr(0, slash) + "/librccl.so.1");
+            names.push_back(hip_path.substr(0, slash) + "/librccl.so");
+        }
+    }
+    names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+    for (const std::string &n : names) {
+        g_nccl.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (g_nccl.lib) break;
     }
     if (!g_nccl.lib) {
