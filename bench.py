@@ -28,6 +28,10 @@ from pathlib import Path
 
 import numpy as np
 
+# multi-process GPU work on this pool needs dmabuf IPC (already exported by the launcher; kept here so a
+# bare `python -m torch.distributed.run ... bench.py` from a clean shell behaves the same)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
