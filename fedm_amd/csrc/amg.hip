@@ -857,7 +857,9 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
                                                              const uint32_t *__restrict__ diag_slot,
                                                              double *__restrict__ dinv_uu,
                                                              _Float16 *__restrict__ s16, float *__restrict__ val32,
-                                                             int upper) {
+                                                             int upper, unsigned zs) {
+    // zs: bit (r * NS + c) marks a species plane of the Jacobian that is structurally zero (the sweeps'
+    // ZS): neither read here nor written to the half-precision copy, which nobody reads there
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
     const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -883,11 +885,13 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
 #pragma unroll
         for (int r = 0; r < NS; ++r)
 #pragma unroll
-            for (int cidx = 0; cidx < NS; ++cidx) J[r][cidx] = vp[(size_t)(r * NEQ + cidx) * SLICE];
+            for (int cidx = 0; cidx < NS; ++cidx)
+                J[r][cidx] = ((zs >> (r * NS + cidx)) & 1u) ? 0.0 : vp[(size_t)(r * NEQ + cidx) * SLICE];
 #pragma unroll
         for (int r = 0; r < NS; ++r)
 #pragma unroll
             for (int cidx = 0; cidx < NS; ++cidx) {
+                if ((zs >> (r * NS + cidx)) & 1u) continue;   // (wave-uniform)
                 double acc = 0.0;
 #pragma unroll
                 for (int m = 0; m < NS; ++m) acc += d[r][m] * J[m][cidx];
@@ -913,9 +917,12 @@ void fieldsplit_setup(Ctx &c) {
         return;
     }
     const dim3 gs((c.pat.n_slices + 3) / 4);
+    // the same mask the sweeps are compiled for (fs_finish_t): two species, a zero off-diagonal plane
+    unsigned zs = 0u;
+    if (c.ns == 2) zs = ((c.zero_plane_mask >> 1) & 1u) << 1 | ((c.zero_plane_mask >> 3) & 1u) << 2;
 #define FEDM_PLANES(NS_)                                                                                   \
     hipLaunchKernelGGL(species_planes_kernel<NS_>, gs, b, 0, c.stream, c.pat.n_slices, c.d_slice_boff, c.d_val, \
-                       c.d_diag_slot, c.d_dinv, c.d_s16, c.d_val32, fieldsplit_upper(c) ? 1 : 0)
+                       c.d_diag_slot, c.d_dinv, c.d_s16, c.d_val32, fieldsplit_upper(c) ? 1 : 0, zs)
     switch (c.ns) {
         case 1: FEDM_PLANES(1); break;
         case 2: FEDM_PLANES(2); break;
