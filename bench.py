@@ -212,6 +212,11 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # one rank per GPU: LOCAL_RANK is the device index when a rank sees every GPU of the node (the usual
+    # torch.distributed.run set-up); a launcher that shows each rank only its own GPU leaves index 0
+    n_visible = torch.cuda.device_count()
+    if n_visible and local_rank >= n_visible:
+        local_rank %= n_visible
     import __graft_entry__ as entry
     if not entry.LIB.exists():
         entry.build()

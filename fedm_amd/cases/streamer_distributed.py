@@ -55,7 +55,12 @@ class Runner(streamer.Stepper):
             try:
                 import torch
                 props = torch.cuda.get_device_properties(local_rank)
-                ident = (os.uname().nodename, str(getattr(props, "uuid", "")) or f"{props.pci_bus_id}")
+                # physical identity of the GPU: everything the runtime reports (a field that is missing or
+                # the same on every GPU must not make distinct GPUs look like one); nothing at all
+                # reported: the device index
+                fields = tuple(str(getattr(props, a, "")) for a in
+                               ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"))
+                ident = (os.uname().nodename, fields if any(fields) else ("index", local_rank))
                 uid = rccl_unique_id() if rank == 0 else None
                 mine = (ident, None)
             except Exception as exc:                     # noqa: BLE001 - reported below, by every rank
