@@ -1841,10 +1841,8 @@ static int build_amg(Ctx &c, int n_first_rows, int n_levels, const fedm_csr *A, 
                      const fedm_csr *R, const double *coarse_inverse, int nu, double omega, Amg **out,
                      int composite_from, const double *poly_w = nullptr /* [n_levels - 1][nu] */) {
     // the hierarchy's matrices in single precision (FEDM_MG_F32=0: double); see EllMat::single
-    static const bool mg_single = [] {
-        const char *e = std::getenv("FEDM_MG_F32");
-        return !(e && e[0] == '0');
-    }();
+    const char *mg_env = std::getenv("FEDM_MG_F32");
+    const bool mg_single = !(mg_env && mg_env[0] == '0');
     if (n_levels < 1 || !A || (n_levels > 1 && (!P || !R)) || nu == 0) {
         set_error("bad multigrid description");
         return -2;
