@@ -131,6 +131,8 @@ _SIGNATURES = {
     "fedm_set_step": (C.c_int, [_P, C.c_double, C.c_double]),
     "fedm_set_dirichlet_values": (C.c_int, [_P, _D]),
     "fedm_set_ext_source": (C.c_int, [_P, C.c_int, _D]),
+    "fedm_ext_source_program": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, _D, C.c_int]),
+    "fedm_ext_source_eval": (C.c_int, [_P, C.c_int, _D]),
     "fedm_residual": (C.c_int, [_P, _D, _D]),
     "fedm_jacobian": (C.c_int, [_P]),
     "fedm_jacobian_nnz": (C.c_int64, [_P]),
@@ -175,6 +177,13 @@ _SIGNATURES = {
 }
 
 _lib = None
+
+
+# opcodes of the expression programs (include/fedm_hip.h, FEDM_OP_*)
+EXPR_OPS = {"const": 0, "x": 1, "param": 2, "add": 3, "sub": 4, "mul": 5, "div": 6, "pow": 7, "neg": 8,
+            "exp": 9, "log": 10, "sqrt": 11, "sin": 12, "cos": 13, "tan": 14, "fabs": 15, "abs": 15,
+            "tanh": 16, "atan": 17}
+EXPR_MAX_OPS, EXPR_MAX_PARAMS, EXPR_STACK = 256, 16, 24
 
 
 def exported_symbols():

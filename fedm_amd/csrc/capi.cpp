@@ -1086,6 +1086,10 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (c.d_s16) hipFree(c.d_s16);
     if (c.d_Z) hipFree(c.d_Z);
     if (c.h_stage) hipHostFree(c.h_stage);
+    for (int s_ = 0; s_ < FEDM_MAX_SPECIES; ++s_) {
+        if (c.d_expr_ops[s_]) hipFree(c.d_expr_ops[s_]);
+        if (c.d_expr_consts[s_]) hipFree(c.d_expr_consts[s_]);
+    }
     if (c.stream) hipStreamDestroy(c.stream);
     delete h;
 }
@@ -1168,6 +1172,76 @@ int fedm_set_ext_source(fedm_ctx *h, int species, const double *nodal) {
                                   sizeof(double) * (size_t)c.nc * c.model.ext_nodes[species],
                                   hipMemcpyHostToDevice, c.stream));
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+// the program is checked here once (stack discipline, index ranges): the kernel trusts it
+int fedm_ext_source_program(fedm_ctx *h, int species, int n_ops, const int32_t *ops, int n_consts,
+                            const double *consts, int n_params) {
+    Ctx &c = h->c;
+    if (species < 0 || species >= c.ns || !c.d_ext[species]) {
+        set_error("species has no Expression source");
+        return -2;
+    }
+    const int nodes = c.model.ext_nodes[species];
+    if (nodes != 3 && nodes != 6 && nodes != 10) {
+        set_error("device evaluation of Expression sources: degree 1, 2 or 3");
+        return -2;
+    }
+    if (!ops || n_ops < 1 || n_ops > FEDM_EXPR_MAX_OPS || n_consts < 0 || (n_consts > 0 && !consts) ||
+        n_params < 0 || n_params > FEDM_EXPR_MAX_PARAMS) {
+        set_error("bad expression program");
+        return -2;
+    }
+    int depth = 0;
+    for (int k = 0; k < n_ops; ++k) {
+        const int op = ops[2 * k], arg = ops[2 * k + 1];
+        bool ok = true;
+        if (op == FEDM_OP_CONST) ok = arg >= 0 && arg < n_consts, ++depth;
+        else if (op == FEDM_OP_X) ok = arg == 0 || arg == 1, ++depth;
+        else if (op == FEDM_OP_PARAM) ok = arg >= 0 && arg < n_params, ++depth;
+        else if (op >= FEDM_OP_ADD && op <= FEDM_OP_POW) ok = depth >= 2, --depth;
+        else if (op >= FEDM_OP_NEG && op <= FEDM_OP_ATAN) ok = depth >= 1;
+        else ok = false;
+        if (!ok || depth > FEDM_EXPR_STACK) {
+            set_error("bad expression program (opcode, operand index or stack depth)");
+            return -2;
+        }
+    }
+    if (depth != 1) {
+        set_error("bad expression program (it must leave one value)");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    if (c.d_expr_ops[species]) hipFree(c.d_expr_ops[species]);
+    if (c.d_expr_consts[species]) hipFree(c.d_expr_consts[species]);
+    c.d_expr_ops[species] = nullptr;
+    c.d_expr_consts[species] = nullptr;
+    c.expr_n_ops[species] = 0;
+    FEDM_HIP_CHECK(hipMalloc((void **)&c.d_expr_ops[species], sizeof(int) * 2 * n_ops));
+    FEDM_HIP_CHECK(hipMalloc((void **)&c.d_expr_consts[species], sizeof(double) * (n_consts > 0 ? n_consts : 1)));
+    FEDM_HIP_CHECK(hipMemcpy(c.d_expr_ops[species], ops, sizeof(int) * 2 * n_ops, hipMemcpyHostToDevice));
+    if (n_consts > 0)
+        FEDM_HIP_CHECK(hipMemcpy(c.d_expr_consts[species], consts, sizeof(double) * n_consts, hipMemcpyHostToDevice));
+    c.expr_n_ops[species] = n_ops;
+    c.expr_n_params[species] = n_params;
+    return 0;
+}
+
+int fedm_ext_source_eval(fedm_ctx *h, int species, const double *params) {
+    Ctx &c = h->c;
+    if (species < 0 || species >= c.ns || !c.d_ext[species] || c.expr_n_ops[species] == 0) {
+        set_error("species has no expression program");
+        return -2;
+    }
+    if (c.expr_n_params[species] > 0 && !params) {
+        set_error("null argument");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    launch_ext_source_eval(c, species, params);
+    FEDM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

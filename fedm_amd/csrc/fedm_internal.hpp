@@ -126,6 +126,10 @@ struct Ctx {
     std::vector<int> bfacet_colour_ptr;  // facets grouped by colour
     fedm_model_desc *d_model = nullptr;
     double *d_ext[FEDM_MAX_SPECIES] = {nullptr, nullptr, nullptr, nullptr};
+    // postfix programs of Expression sources evaluated on the device (fedm_ext_source_program)
+    int *d_expr_ops[FEDM_MAX_SPECIES] = {nullptr, nullptr, nullptr, nullptr};
+    double *d_expr_consts[FEDM_MAX_SPECIES] = {nullptr, nullptr, nullptr, nullptr};
+    int expr_n_ops[FEDM_MAX_SPECIES] = {0, 0, 0, 0}, expr_n_params[FEDM_MAX_SPECIES] = {0, 0, 0, 0};
     // matrix
     int *d_slice_boff = nullptr;
     int *d_colidx = nullptr;
@@ -221,6 +225,7 @@ void launch_finalize(Ctx &c, bool jacobian, int mode);          // Dirichlet + p
 void launch_block_inverse(Ctx &c);                              // d_dinv from diagonal blocks
 void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int *slice_list = nullptr,
                  int n_list = 0);
+void launch_ext_source_eval(Ctx &c, int species, const double *params);   // gdprep.hip
 void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, double *b0, double scale,
                             const int *slice_list = nullptr, int n_list = 0, bool compact32 = false);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);

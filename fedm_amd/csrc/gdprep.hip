@@ -249,4 +249,73 @@ void gd_update_mean_energy(Ctx &c) {
                        c.d_u, row_me, c.d_gd_fields);
 }
 
+
+// ---- Expression sources on the device (fedm_ext_source_program / fedm_ext_source_eval) -----------
+// One thread per (cell, lattice node): the node's coordinates from the cell's vertices, then the
+// postfix program.  The node order is the lattice order of the host path: (i / d, j / d) for
+// j = 0..d, i = 0..d - j, barycentric weights (1 - l1 - l2, l1, l2).
+struct ExprParams {
+    double p[FEDM_EXPR_MAX_PARAMS];
+};
+
+__global__ __launch_bounds__(256) void ext_source_eval_kernel(int nc, int nodes, int degree,
+                                                              const int *__restrict__ cells,
+                                                              const double *__restrict__ coords,
+                                                              const int *__restrict__ ops, int n_ops,
+                                                              const double *__restrict__ consts, ExprParams P,
+                                                              double *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc * nodes) return;
+    const int cell = t / nodes;
+    int m = t - cell * nodes, j = 0;
+    while (m > degree - j) {   // row j of the lattice holds degree + 1 - j nodes
+        m -= degree + 1 - j;
+        ++j;
+    }
+    const double l1 = (double)m / degree, l2 = (double)j / degree, l0 = 1.0 - l1 - l2;
+    const int v0 = cells[3 * cell], v1 = cells[3 * cell + 1], v2 = cells[3 * cell + 2];
+    const double x[2] = {l0 * coords[2 * v0] + l1 * coords[2 * v1] + l2 * coords[2 * v2],
+                         l0 * coords[2 * v0 + 1] + l1 * coords[2 * v1 + 1] + l2 * coords[2 * v2 + 1]};
+    double st[FEDM_EXPR_STACK];
+    int sp = 0;
+    for (int k = 0; k < n_ops; ++k) {
+        const int op = ops[2 * k], arg = ops[2 * k + 1];
+        if (op <= FEDM_OP_PARAM) {
+            st[sp++] = op == FEDM_OP_CONST ? consts[arg] : op == FEDM_OP_X ? x[arg] : P.p[arg];
+        } else if (op <= FEDM_OP_POW) {
+            const double b = st[--sp], a = st[sp - 1];
+            st[sp - 1] = op == FEDM_OP_ADD ? a + b : op == FEDM_OP_SUB ? a - b : op == FEDM_OP_MUL ? a * b
+                       : op == FEDM_OP_DIV ? a / b : pow(a, b);
+        } else {
+            const double a = st[sp - 1];
+            double r;
+            switch (op) {
+                case FEDM_OP_NEG: r = -a; break;
+                case FEDM_OP_EXP: r = exp(a); break;
+                case FEDM_OP_LOG: r = log(a); break;
+                case FEDM_OP_SQRT: r = sqrt(a); break;
+                case FEDM_OP_SIN: r = sin(a); break;
+                case FEDM_OP_COS: r = cos(a); break;
+                case FEDM_OP_TAN: r = tan(a); break;
+                case FEDM_OP_FABS: r = fabs(a); break;
+                case FEDM_OP_TANH: r = tanh(a); break;
+                default: r = atan(a); break;
+            }
+            st[sp - 1] = r;
+        }
+    }
+    out[t] = st[0];
+}
+
+void launch_ext_source_eval(Ctx &c, int species, const double *params) {
+    const int nodes = c.model.ext_nodes[species];
+    const int degree = nodes == 3 ? 1 : nodes == 6 ? 2 : 3;
+    ExprParams P;
+    for (int i = 0; i < FEDM_EXPR_MAX_PARAMS; ++i) P.p[i] = i < c.expr_n_params[species] ? params[i] : 0.0;
+    const int n = c.nc * nodes;
+    hipLaunchKernelGGL(ext_source_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.nc, nodes, degree,
+                       c.d_cells, c.d_coords, c.d_expr_ops[species], c.expr_n_ops[species],
+                       c.d_expr_consts[species], P, c.d_ext[species]);
+}
+
 }  // namespace fedm

@@ -407,6 +407,20 @@ class DeviceProblem:
         self._check(self.lib.fedm_get_state_old(self._h, _dp(out)), "fedm_get_state_old")
         return self._back(out).reshape(self.nv, self.n_eq)
 
+    def set_ext_source_program(self, species, ops, consts, n_params):
+        """Expression source evaluated on the device: the postfix program of
+        :func:`fedm_amd.forms.expression_program` (``fedm_ext_source_program``)."""
+        ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 2)
+        consts = np.ascontiguousarray(consts, dtype=np.float64)
+        self._check(self.lib.fedm_ext_source_program(
+            self._h, int(species), int(ops.shape[0]), ops.ctypes.data_as(C.POINTER(C.c_int32)),
+            int(consts.size), _dp(consts if consts.size else np.zeros(1)), int(n_params)), "fedm_ext_source_program")
+
+    def eval_ext_source(self, species, params):
+        """Fill the species' source table with the program's values for these parameter values."""
+        p = np.ascontiguousarray(params if len(params) else [0.0], dtype=np.float64)
+        self._check(self.lib.fedm_ext_source_eval(self._h, int(species), _dp(p)), "fedm_ext_source_eval")
+
     def set_ext_source(self, species, nodal):
         v = np.ascontiguousarray(nodal, dtype=np.float64)
         self._check(self.lib.fedm_set_ext_source(self._h, int(species), _dp(v)), "fedm_set_ext_source")

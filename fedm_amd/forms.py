@@ -123,12 +123,9 @@ _CPP_FUNCTIONS = {"exp": np.exp, "log": np.log, "sqrt": np.sqrt, "pow": np.power
 _CPP_CONSTANTS = {"pi": math.pi, "DOLFIN_EPS": DOLFIN_EPS, "DOLFIN_PI": math.pi}
 
 
-def compile_cpp_expression(code):
-    """A DOLFIN C++ expression string (``'std::log(exp(-(pow(x[1]-w*t, 2)+pow(x[0], 2))/(4.0*D*t))...'``,
-    examples/time_of_flight/fedm-tof.py:107,116,120) as a function ``f(x, owner)`` of the point array
-    ``x[..., dim]`` and the object that carries the named parameters.  The arithmetic subset of the
-    language is parsed with Python's ``ast`` and walked by hand (never ``eval``): numbers, ``x[i]``,
-    parameters, ``+ - * /``, unary minus and the calls in ``_CPP_FUNCTIONS``."""
+def _parse_cpp_expression(code):
+    """The checked syntax tree of a C++ expression string of the arithmetic subset (see
+    compile_cpp_expression); NotImplementedError for anything else."""
     import ast
     text = code.replace("std::", "").strip()
     try:
@@ -137,7 +134,7 @@ def compile_cpp_expression(code):
         raise NotImplementedError(f"Expression string outside the supported arithmetic subset: {code!r}") from exc
 
     def check(node):
-        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)) and not isinstance(node.value, bool):
             return
         if isinstance(node, ast.Name):
             return
@@ -153,12 +150,104 @@ def compile_cpp_expression(code):
             check(node.operand)
             return
         if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in _CPP_FUNCTIONS \
-                and not node.keywords:
+                and not node.keywords and len(node.args) == (2 if node.func.id == "pow" else 1):
             for a in node.args:
                 check(a)
             return
         raise NotImplementedError(f"Expression string outside the supported arithmetic subset: {code!r}")
     check(tree)
+    return tree
+
+
+def expression_program(expr):
+    """The postfix program of a spatial Expression for the device (``fedm_ext_source_program``):
+    ``(ops int32[n][2], consts float64[], parameter names)``.  Names that the Expression carries as
+    attributes are parameters (their values are read when the program runs, so ``f.t = t`` works),
+    ``pi`` / ``DOLFIN_EPS`` otherwise constants."""
+    import ast
+    from ._lib import EXPR_OPS as OP, EXPR_MAX_OPS, EXPR_MAX_PARAMS, EXPR_STACK
+    if expr.python is not None or not isinstance(expr.code, str):
+        raise NotImplementedError("only Expression strings have a device program")
+    tree = _parse_cpp_expression(expr.code)
+    ops, consts, params = [], [], []
+
+    def const(v):
+        v = float(v)
+        if v not in consts:
+            consts.append(v)
+        ops.append((OP["const"], consts.index(v)))
+
+    def emit(node):
+        if isinstance(node, ast.Constant):
+            const(node.value)
+        elif isinstance(node, ast.Name):
+            if hasattr(expr, node.id) and node.id not in ("code", "degree", "python"):
+                if node.id not in params:
+                    params.append(node.id)
+                ops.append((OP["param"], params.index(node.id)))
+            elif node.id in _CPP_CONSTANTS:
+                const(_CPP_CONSTANTS[node.id])
+            else:
+                raise NameError(f"Expression parameter '{node.id}' is not set")
+        elif isinstance(node, ast.Subscript):
+            if node.slice.value not in (0, 1):
+                raise NotImplementedError("x[i] with i = 0, 1")
+            ops.append((OP["x"], int(node.slice.value)))
+        elif isinstance(node, ast.BinOp):
+            emit(node.left)
+            emit(node.right)
+            ops.append((OP[{ast.Add: "add", ast.Sub: "sub", ast.Mult: "mul", ast.Div: "div"}[type(node.op)]], 0))
+        elif isinstance(node, ast.UnaryOp):
+            emit(node.operand)
+            if isinstance(node.op, ast.USub):
+                ops.append((OP["neg"], 0))
+        else:
+            for a in node.args:
+                emit(a)
+            ops.append((OP[node.func.id], 0))
+    emit(tree)
+    depth = peak = 0
+    for op, _ in ops:
+        depth += 1 if op <= OP["param"] else -1 if op <= OP["pow"] else 0
+        peak = max(peak, depth)
+    if len(ops) > EXPR_MAX_OPS or len(params) > EXPR_MAX_PARAMS or peak > EXPR_STACK:
+        raise NotImplementedError("Expression too long for the device evaluator")
+    return np.array(ops, dtype=np.int32).reshape(-1, 2), np.array(consts, dtype=np.float64), params
+
+
+def run_expression_program(ops, consts, params, x):
+    """Host interpreter of a device expression program (for tests): the value at points x[..., 2]."""
+    from ._lib import EXPR_OPS as OP
+    unary = {OP["neg"]: np.negative, OP["exp"]: np.exp, OP["log"]: np.log, OP["sqrt"]: np.sqrt, OP["sin"]: np.sin,
+             OP["cos"]: np.cos, OP["tan"]: np.tan, OP["fabs"]: np.abs, OP["tanh"]: np.tanh, OP["atan"]: np.arctan}
+    binary = {OP["add"]: np.add, OP["sub"]: np.subtract, OP["mul"]: np.multiply, OP["div"]: np.divide,
+              OP["pow"]: np.power}
+    x = np.asarray(x, dtype=float)
+    stack = []
+    for op, arg in np.asarray(ops).reshape(-1, 2):
+        if op == OP["const"]:
+            stack.append(float(consts[arg]))        # (scalars stay scalars: numpy's x**2.0 fast path as in the AST walk)
+        elif op == OP["x"]:
+            stack.append(x[..., arg])
+        elif op == OP["param"]:
+            stack.append(float(params[arg]))
+        elif op in binary:
+            b = stack.pop()
+            stack[-1] = binary[op](stack[-1], b)
+        else:
+            stack[-1] = unary[op](stack[-1])
+    (value,) = stack
+    return value + np.zeros(x.shape[:-1])
+
+
+def compile_cpp_expression(code):
+    """A DOLFIN C++ expression string (``'std::log(exp(-(pow(x[1]-w*t, 2)+pow(x[0], 2))/(4.0*D*t))...'``,
+    examples/time_of_flight/fedm-tof.py:107,116,120) as a function ``f(x, owner)`` of the point array
+    ``x[..., dim]`` and the object that carries the named parameters.  The arithmetic subset of the
+    language is parsed with Python's ``ast`` and walked by hand (never ``eval``): numbers, ``x[i]``,
+    parameters, ``+ - * /``, unary minus and the calls in ``_CPP_FUNCTIONS``."""
+    import ast
+    tree = _parse_cpp_expression(code)
 
     def run(node, x, owner):
         if isinstance(node, ast.Constant):

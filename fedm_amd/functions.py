@@ -420,8 +420,15 @@ class Problem:
             binding = getattr(model, "field_binding", None)
             timed = [bc for bc in (bcs or []) if isinstance(bc.value, forms.Expression)]
             sources = getattr(model, "expression_sources", [])
-            source_nodes = {}
+            source_nodes, source_programs = {}, {}
             for s_, e in sources:
+                try:    # Expression strings run on the device; Python callables are evaluated here
+                    ops, consts, names = forms.expression_program(e)
+                    device_problem.set_ext_source_program(s_, ops, consts, len(names))
+                    source_programs[s_] = names
+                    continue
+                except NotImplementedError:
+                    pass
                 lam = np.array([(i / e.degree, j / e.degree) for j in range(e.degree + 1)
                                 for i in range(e.degree + 1 - j)])
                 phi = np.stack([1 - lam[:, 0] - lam[:, 1], lam[:, 0], lam[:, 1]], axis=1)
@@ -444,7 +451,10 @@ class Problem:
                 if binding is not None:
                     device_problem.set_gd_fields(binding.stack(mesh.num_vertices()))
                 for s_, e in sources:       # the script has advanced the Expression's parameters (f.t = t)
-                    device_problem.set_ext_source(s_, np.asarray(e(source_nodes[s_]), dtype=float))
+                    if s_ in source_programs:
+                        device_problem.eval_ext_source(s_, [float(getattr(e, n)) for n in source_programs[s_]])
+                    else:
+                        device_problem.set_ext_source(s_, np.asarray(e(source_nodes[s_]), dtype=float))
             if timed or binding is not None or sources:
                 self.before_solve = refresh
         self.device = device_problem if device_problem is not None else getattr(F, "device", None)

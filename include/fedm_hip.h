@@ -221,6 +221,27 @@ int fedm_set_step(fedm_ctx *ctx, double dt, double dt_old);
 int fedm_set_dirichlet_values(fedm_ctx *ctx, const double *vals);
 /* Expression source of one species for this step: [n_cells][ext_nodes] */
 int fedm_set_ext_source(fedm_ctx *ctx, int species, const double *nodal);
+/* The same source evaluated on the device.  A DOLFIN Expression string of the arithmetic subset
+ * (examples/time_of_flight/fedm-tof.py:116: f = Expression('exp(-(pow(x[1]-w*t, 2)+...)...', D=..., w=...,
+ * t=t, degree=2); the script advances f.t before every solve, :145) is handed over once as a postfix
+ * program over x[0], x[1], constants and named parameters; fedm_ext_source_eval then fills the
+ * species' [n_cells][ext_nodes] table at the P_degree lattice nodes of every cell with the current
+ * parameter values -- what fedm_set_ext_source does with a host array, without the host evaluation and
+ * the upload.  ops: n_ops pairs (opcode, argument). */
+#define FEDM_EXPR_MAX_OPS 256
+#define FEDM_EXPR_MAX_PARAMS 16
+#define FEDM_EXPR_STACK 24
+enum {
+    FEDM_OP_CONST = 0, /* push consts[arg]   */
+    FEDM_OP_X = 1,     /* push x[arg]        */
+    FEDM_OP_PARAM = 2, /* push params[arg]   */
+    FEDM_OP_ADD = 3, FEDM_OP_SUB = 4, FEDM_OP_MUL = 5, FEDM_OP_DIV = 6, FEDM_OP_POW = 7, /* binary */
+    FEDM_OP_NEG = 8, FEDM_OP_EXP = 9, FEDM_OP_LOG = 10, FEDM_OP_SQRT = 11, FEDM_OP_SIN = 12, FEDM_OP_COS = 13,
+    FEDM_OP_TAN = 14, FEDM_OP_FABS = 15, FEDM_OP_TANH = 16, FEDM_OP_ATAN = 17 /* unary */
+};
+int fedm_ext_source_program(fedm_ctx *ctx, int species, int n_ops, const int32_t *ops /* [n_ops][2] */,
+                            int n_consts, const double *consts, int n_params);
+int fedm_ext_source_eval(fedm_ctx *ctx, int species, const double *params /* [n_params] */);
 
 /* Problem.F: assemble(F) then bc.apply(b, x)              fedm/functions.py:188-194 */
 int fedm_residual(fedm_ctx *ctx, double *F_out /* N or NULL */, double *fnorm /* or NULL */);

@@ -166,6 +166,38 @@ def test_tof_example_script_reproduces_the_golden(golden_dir, tmp_path):
     assert np.abs(n_exact - direct["n_exact"]).max() <= 1e-12 * np.abs(direct["n_exact"]).max()
 
 
+def test_expression_source_evaluated_on_the_device_matches_the_host():
+    """fedm_ext_source_program / fedm_ext_source_eval: the postfix program of the ToF source string, run
+    by the device at the P2 lattice nodes of every cell, against the host evaluation of the same string
+    uploaded with fedm_set_ext_source -- through the residual, which is where the table is used."""
+    from fedm_amd import forms
+    from fedm_amd.cases import time_of_flight as tof
+    prob, mesh = tof.device_problem(24, 32, 2.5e-4, 5e-4)
+    f = forms.Expression('exp(-(pow(x[1]-w*t, 2)+pow(x[0], 2))/(4.0*D*t)+alpha*w*t)*(w*alpha)'
+                         '/(8*pow(pi,1.5)*pow(D*t, 1.5))', D=tof.DE, w=tof.WEZ, alpha=tof.ALPHA_E, t=2.5e-9,
+                         pi=np.pi, degree=2)
+    ops, consts, names = forms.expression_program(f)
+    prob.set_ext_source_program(0, ops, consts, len(names))
+    u = tof.analytic_log_density(mesh.coords, 2.5e-9)
+    prob.set_state(u, u, u)
+    prob.set_step(1e-12, 1e30)
+    nodes = tof.p2_nodes(mesh.coords, mesh.cells)
+    for t in (2.5e-9, 2.6e-9):
+        f.t = t
+        prob.set_ext_source(0, np.asarray(f(nodes)))
+        F_host, _ = prob.residual()
+        prob.set_ext_source(0, np.zeros(nodes.shape[:2]))
+        F_none, _ = prob.residual()
+        prob.eval_ext_source(0, [getattr(f, n) for n in names])
+        F_dev, _ = prob.residual()
+        scale = np.abs(F_host - F_none).max()
+        assert scale > 0 and np.abs(F_dev - F_host).max() <= 1e-12 * scale      # exp / pow differ by ulps
+    with pytest.raises(RuntimeError, match="bad expression program"):
+        prob.set_ext_source_program(0, [[3, 0]], [], 0)                         # an operator on an empty stack
+    with pytest.raises(RuntimeError, match="bad expression program"):
+        prob.set_ext_source_program(0, [[0, 2]], [1.0], 0)                      # constant index out of range
+
+
 def test_streamer_multigrid_fieldsplit(streamer_setup):
     """Field-split + V-cycle preconditioning changes the Krylov path, not the answer."""
     from oracle.newton import newton_solve

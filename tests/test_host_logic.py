@@ -561,6 +561,20 @@ def test_cpp_expression_subset_evaluates_the_reference_strings_and_refuses_the_r
     np.testing.assert_allclose(f(x), tof.source(x, 2.6e-9), rtol=1e-14)
     f.t = 2.7e-9                                       # parameters are looked up at call time
     np.testing.assert_allclose(f(x), tof.source(x, 2.7e-9), rtol=1e-14)
+    # the same strings as postfix programs for the device (fedm_ext_source_program): parameters stay
+    # symbolic, pi is one here because the script passes it (pi=pi)
+    ops, consts, names = forms.expression_program(f)
+    assert set(names) == {"w", "t", "D", "alpha", "pi"} and ops.shape[1] == 2 and ops.dtype == np.int32
+    for t in (2.6e-9, 2.9e-9):
+        f.t = t
+        values = forms.run_expression_program(ops, consts, [getattr(f, n) for n in names], x)
+        np.testing.assert_array_equal(values, f(x))                 # the same operations in the same order
+        np.testing.assert_allclose(values, tof.source(x, t), rtol=1e-12)
+    ops_u, consts_u, names_u = forms.expression_program(u)
+    np.testing.assert_allclose(forms.run_expression_program(ops_u, consts_u, [getattr(u, n) for n in names_u], x),
+                               tof.analytic_log_density(x, 2.6e-9), rtol=1e-14)
+    with pytest.raises(NotImplementedError):
+        forms.expression_program(forms.Expression(degree=1, python=lambda x: x[..., 0]))
     assert forms.Expression('x[0] > 1e-4 ? 1.0 : 0.0', degree=1).code      # construction is free ...
     for bad in ('__import__("os").system("true")', 'x[0] > 1e-4 ? 1.0 : 0.0', 'x.shape', 'q*x[0]',
                 'x[0]; x[1]', '(lambda: 1)()'):
@@ -603,6 +617,15 @@ def test_time_of_flight_script_is_lowered_onto_the_device_model(tmp_path, monkey
 
         def set_ext_source(self, s, nodal):
             calls.append(("source", s, np.array(nodal)))
+
+        def set_ext_source_program(self, s, ops, consts, n_params):     # the C++ string as a device program
+            self.program = (np.array(ops), np.array(consts), n_params)
+
+        def eval_ext_source(self, s, params):                           # what the device kernel computes
+            from fedm_amd import forms
+            assert len(params) == self.program[2]
+            nodes = tof.p2_nodes(self.coords, self.cells)
+            calls.append(("source", s, forms.run_expression_program(self.program[0], self.program[1], params, nodes)))
 
         def newton_solve(self, **kw):
             self.t += 1e-12
