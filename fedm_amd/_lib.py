@@ -166,6 +166,7 @@ _SIGNATURES = {
     "fedm_comm_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fedm_time_comm": (C.c_int, [_P, C.c_int, C.c_int, _D]),
     "fedm_debug_comm_fault": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
+    "fedm_debug_comm_roundtrip": (C.c_int, [_P, _D, _D, C.c_int]),
     "fedm_pattern_stats": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_int64)]),
     "fedm_profile": (C.c_int, [_P, C.c_int]),
     "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),

@@ -1655,6 +1655,32 @@ int fedm_comm_stats(fedm_ctx *h, int64_t out[8]) {
 
 int fedm_debug_comm_fault(int fail_at, int64_t out[4]) { return comm_fault_selftest(fail_at, out); }
 
+int fedm_debug_comm_roundtrip(fedm_ctx *h, double *vec, double *red, int k) {
+    Ctx &c = h->c;
+    if (!c.comm || !vec || k < 0 || k > RED_K || (k > 0 && !red)) {
+        set_error("no transport on this context, or bad arguments");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipMemsetAsync(c.d_tmp, 0, sizeof(double) * c.np, c.stream));
+    if (put_vec(c, c.d_tmp, vec)) return -1;
+    comm_halo(c, c.d_tmp);          // on the compute stream ...
+    comm_halo_begin(c);             // ... and once more the way the Krylov loop overlaps it: on the
+    comm_halo_exchange(c, c.d_tmp); // communication stream, fenced by events (same values)
+    if (k > 0) {
+        FEDM_HIP_CHECK(hipMemcpyAsync(c.d_red, red, sizeof(double) * k, hipMemcpyHostToDevice, c.stream));
+        comm_allreduce(c, c.d_red, k);
+        comm_allreduce_f32_payload(c, c.d_red, k);   // the multigrid's single-precision payload (rounds to fp32)
+        FEDM_HIP_CHECK(hipMemcpyAsync(red, c.d_red, sizeof(double) * k, hipMemcpyDeviceToHost, c.stream));
+    }
+    if (get_vec(c, vec, c.d_tmp)) return -1;
+    if (comm_failed(c)) {
+        set_error(c.comm->error);
+        return -1;
+    }
+    return 0;
+}
+
 int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[8]) {
     if (!mesh || !out || mesh->n_vertices < 3 || mesh->n_cells < 1) {
         set_error("null or empty mesh");

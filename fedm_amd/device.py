@@ -455,6 +455,15 @@ class DeviceProblem:
         self._check(self.lib.fedm_spmv(self._h, _dp(x), _dp(y)), "fedm_spmv")
         return self._back(y)
 
+    def comm_roundtrip(self, vec, red=()):
+        """One halo exchange of a DOF vector and one all-reduce through the context's transport
+        (``fedm_debug_comm_roundtrip``): returns (vector with the ghost entries received, sums)."""
+        x = self._vec(vec).copy()
+        r = np.ascontiguousarray(red if len(red) else [0.0], dtype=np.float64).copy()
+        self._check(self.lib.fedm_debug_comm_roundtrip(self._h, _dp(x), _dp(r), int(len(red))),
+                    "fedm_debug_comm_roundtrip")
+        return self._back(x), r[:len(red)]
+
     # -- multi-GPU transport ---------------------------------------------------------
     def _plan_arrays(self, lm):
         nb = np.ascontiguousarray(lm.neighbours, dtype=np.int32)

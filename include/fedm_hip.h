@@ -351,6 +351,12 @@ int fedm_time_comm(fedm_ctx *ctx, int kind, int repeats, double *ms_per_op);
  * `fail_at`-th call fails.  out = {failed flag latched, transport calls made, calls made after
  * the failing one, comm_failed()}; returns 1 when a failure was latched. */
 int fedm_debug_comm_fault(int fail_at, int64_t out[4]);
+/* One halo exchange of the DOF vector `vec` (N values in the caller's order, ghost entries replaced by
+ * what the neighbours sent) and one sum over the ranks of `red[0..k)`, through whatever transport the
+ * context has: lets a test drive the transport's data path by itself (e.g. RCCL on one rank that is
+ * its own neighbour).  The exchange runs twice (compute stream; communication stream fenced by events),
+ * the sum twice (double; single-precision payload, so red comes back rounded to fp32).  red may be NULL. */
+int fedm_debug_comm_roundtrip(fedm_ctx *ctx, double *vec, double *red, int k);
 /* Host-side preprocessing alone (no GPU needed): what DOLFIN builds with the FunctionSpace /
  * sparsity pattern (fedm/functions.py:192,200).  out = {matrix slices (= assembly patches),
  * max cells per patch, max block columns per slice, max staged vertices per patch, cell visits

@@ -101,6 +101,43 @@ def test_rccl_transport_single_rank():
     assert np.allclose(out[0], out[1], rtol=1e-9, atol=1e-9)
 
 
+def test_rccl_point_to_point_path_on_one_rank_that_is_its_own_neighbour():
+    """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd and ncclAllReduce as the halo code issues them,
+    on real RCCL with ONE rank: the sub-mesh of rank 0 of a two-way partition, with the exchange plan
+    rewired so that the rank sends the values of some owned vertices to itself and receives them into
+    its ghost segment (RCCL allows a send to self inside a group).  Not a meaningful solve -- the data
+    path of the transport by itself, which two ranks on one GPU cannot exercise (RCCL refuses them)."""
+    import dataclasses
+    from fedm_amd import partition
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import DeviceProblem, rccl_unique_id
+    msh = streamer.mesh(24, 2.0)
+    part = partition.partition_rcb(msh.coords, 2)
+    lm = partition.local_mesh(msh.coords, msh.cells, part, 0)
+    n_ghost = lm.n_ghost
+    assert n_ghost > 0 and n_ghost <= lm.n_owned
+    rng = np.random.default_rng(5)
+    send = np.sort(rng.choice(lm.n_owned, size=n_ghost, replace=False))
+    me = dataclasses.replace(lm, neighbours=np.array([0]), send_ptr=np.array([0, n_ghost]), send_idx=send,
+                             recv_ptr=np.array([0, n_ghost]))
+    tags = np.zeros((lm.cells.shape[0], 3), dtype=np.int8)
+    prob = DeviceProblem(lm.coords, lm.cells, streamer.model(), facet_tags=tags, n_owned=lm.n_owned)
+    try:
+        prob.init_comm_rccl(me, rccl_unique_id(), 0, 1)
+        neq = prob.n_eq
+        v = rng.standard_normal((prob.nv, neq))
+        v[lm.n_owned:] = 0.0
+        out, red = prob.comm_roundtrip(v.ravel(), red=[1.5, -2.0, 3.25])
+        out = out.reshape(prob.nv, neq)
+        assert np.array_equal(out[:lm.n_owned], v[:lm.n_owned])          # owned entries untouched
+        assert np.array_equal(out[lm.n_owned:], v[send])                 # ghosts = what was "sent"
+        assert np.array_equal(red, [1.5, -2.0, 3.25])                    # a sum over one rank
+        stats = prob.comm_stats()
+        assert stats["transport"] == "rccl" and not stats["failed"] and stats["halo_exchanges"] >= 1
+    finally:
+        prob.close()
+
+
 def _worker_rccl(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, str(ROOT))
