@@ -25,7 +25,7 @@ class Runner(streamer.Stepper):
     fallback_reason = None
 
     def __init__(self, per_gpu_mesh, rank, world, local_rank, grading=4.0, transport="rccl",
-                 group=None, n_per_gpu=None, global_n=None, **kw):
+                 group=None, n_per_gpu=None, global_n=None, distributed_multigrid=None, **kw):
         """Mesh size: ``global_n`` cells per side of the whole mesh (strong scaling, e.g. BASELINE
         configs[4]), else ``n_per_gpu`` (or the size of ``per_gpu_mesh``) cells per side PER GPU."""
         import torch.distributed as dist
@@ -37,6 +37,9 @@ class Runner(streamer.Stepper):
         part = partition.partition_rcb(gmesh.coords, world)
         lm = partition.local_mesh(gmesh.coords, gmesh.cells, part, rank)
         self.lm, self.world, self.rank = lm, world, rank
+        # (True with one rank: the several-GPU solver -- distributed finest level, replicated coarse
+        # levels, their all-reduces -- on a single rank: how the tests reach that code with RCCL)
+        self.distributed_multigrid = world > 1 if distributed_multigrid is None else bool(distributed_multigrid)
         self.global_n = n
         # boundary tags and Dirichlet rows from the global mesh, restricted to the local cells
         gtags = Marking_boundaries(gmesh, streamer.BOUNDARIES)
@@ -111,7 +114,7 @@ class Runner(streamer.Stepper):
         U = np.zeros((prob.nv, 3))
         U[:, 0], U[:, 1] = streamer.initial_log_densities(prob.coords)
         prob.set_state(U, U, U)
-        if self.world_size > 1:
+        if self.distributed_multigrid:
             # (the distributed finest level keeps the V(1,1) cycle: no alternative for hard systems)
             prob.setup_multigrid_distributed(self.lm, self._group, nu=streamer.MULTIGRID["nu"],
                                              omega=streamer.MULTIGRID["omega"])

@@ -274,7 +274,7 @@ def _worker_rccl_two_devices(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         run = streamer_distributed.Runner(None, rank, world, rank, grading=2.0, transport="rccl",
-                                          n_per_gpu=N_PER_GPU, **TOL)
+                                          n_per_gpu=N_PER_GPU, distributed_multigrid=True, **TOL)
         run.solver.parameters["krylov_relative_tolerance"] = 1e-11
         run.initialise()
         for _ in range(STEPS):
@@ -284,6 +284,34 @@ def _worker_rccl_two_devices(rank, world, port, q):
                run.prob.comm_stats()))
     finally:
         dist.destroy_process_group()
+
+
+def test_several_gpu_solver_on_one_rank_over_rccl_matches_single_gpu():
+    """The whole several-GPU solver on real RCCL with ONE rank: distributed finest multigrid level,
+    replicated coarse levels with their (single-precision payload) all-reduce, the Krylov loop with its
+    halo / all-reduce / finish sequence and split graphs -- everything but a second process.  Same
+    time steps as the plain single-GPU solver."""
+    import torch.multiprocessing as mp
+    from fedm_amd.cases import streamer
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl_two_devices, args=(0, 1, _free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert res[5] == "rccl" and res[6]["transport"] == "rccl" and not res[6]["failed"] and res[6]["allreduces"] > 0
+    msh = streamer.mesh(res[4], 2.0)
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    st = streamer.Stepper(prob, **TOL)
+    st.solver.parameters["krylov_relative_tolerance"] = 1e-11
+    st.initialise()
+    for _ in range(STEPS):
+        st.step()
+    U_ref = prob.get_state()
+    U = np.zeros_like(U_ref)
+    U[res[1]] = res[2]
+    assert (np.abs(U - U_ref) / np.abs(U_ref).max(axis=0)).max() < 1e-8
 
 
 def test_two_ranks_over_rccl_match_single_gpu():
