@@ -697,9 +697,13 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     // ... and the exchange overlaps with the sweep's interior slices (those without ghost columns):
     // mark the iterate complete, sweep the interior, exchange on the communication stream, wait,
     // sweep the boundary slices -- as the Krylov halo does with the Jacobian product
+    // Off by default: a sweep's interior slices take 7 us, the two event-fenced hops between the streams
+    // cost 20 us (measured with the several-GPU solver on one rank over RCCL, tools/one_rank_rccl_overhead.py:
+    // 2.49 -> 1.88 ms per step without them) -- more than the exchange they could hide behind those 7 us.
+    // FEDM_FS_HALO_OVERLAP=1 switches the overlap on.
     static const bool overlap_ok = [] {
         const char *e = std::getenv("FEDM_FS_HALO_OVERLAP");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     const bool overlap = halo && overlap_ok && c.comm->n_interior > 0;
     // lower-triangular order with sweeps: the coupling product is part of the last sweep (lagged by it)
