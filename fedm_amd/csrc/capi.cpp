@@ -1332,9 +1332,14 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
         // one assembles no Jacobian at all).
         // at the expected last iteration the watched component's change (adaptive_solver's error norm)
         // rides along: slots 3, 4
-        const bool with_error = residual_only && !c.comm && o->watch_component > 0 && o->watch_component <= c.neq;
+        // several GPUs: the update's sums and the error sums are rank-local until this publication's
+        // all-reduce carries them with |F|^2 (one collective instead of three)
+        const bool sums_local = c.comm && it > 0 && c.red12_local;
+        const bool with_error = residual_only && (!c.comm || sums_local) && o->watch_component > 0 &&
+                                o->watch_component <= c.neq;
         if (with_error) launch_field_error_slots34(c, o->watch_component - 1);
-        norm2_publish(c, c.d_F, 0, with_error ? 5 : 3);
+        norm2_publish(c, c.d_F, 0, with_error ? 5 : 3, sums_local ? (with_error ? 5 : 3) : 1);
+        c.red12_local = false;
         bool planes_done = false;
         if (!residual_only && right_preconditioned(c)) {
             prepare_preconditioner_and_rhs(c);
@@ -1382,6 +1387,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             launch_axpy(c, 1.0, c.d_delta, c.d_u);
             launch_norm2(c, c.d_delta, 1);
             launch_norm2(c, c.d_u, 2);
+            c.red12_local = false;   // (all-reduced by launch_norm2)
         }
         // ghost entries of the new state: exchanged by the next assembly, behind its interior patches
         if (c.comm && c.assembly_overlap) c.halo_pending = true;

@@ -158,6 +158,7 @@ struct Ctx {
     // lower-triangular order: b_phi -= J_phi,u z_u formed inside the last species sweep from the
     // iterate before it (FEDM_FS_LAGGED_COUPLING=0: separate kernel on the final iterate)
     bool fs_lagged_coupling = true;
+    bool red12_local = false;   // several GPUs: d_red[1..2] of the last Newton update are rank-local sums
     // Order of the block-triangular split when it sits on the right of the operator
     // (fedm_set_fieldsplit_order, FEDM_FS_ORDER=lower|upper; the left-preconditioned path, whose
     // first stage is the SpMV's epilogue, is always lower).
@@ -249,7 +250,7 @@ void launch_set_dirichlet_state(Ctx &c);    // u[dof] = g
 void wait_red_seq(Ctx &c, unsigned long long seq);  // a particular publication (steps launched ahead)
 void read_red(Ctx &c, int k);
 void norm2_read(Ctx &c, const double *x, int slot, int k);  // launch_norm2 + read_red, one kernel fewer on one GPU               // publish d_red[0..k) to h_red and wait for it
-void norm2_publish(Ctx &c, const double *x, int slot, int k);  // the launches of norm2_read; wait_red(c) later
+void norm2_publish(Ctx &c, const double *x, int slot, int k, int k_sum = 1);  // the launches of norm2_read; wait_red(c) later
 void wait_red(Ctx &c);                      // wait for the publication launch_dots(finish) queued
 
 #define FEDM_HIP_CHECK(expr)                                                          \

@@ -1467,9 +1467,21 @@ __global__ __launch_bounds__(64) void reduce_slot_publish_kernel(const double *_
 // |x|^2 into slot `slot` and d_red[0..k) into the mailbox, without the wait: the caller may queue
 // more work behind the publication before it calls wait_red (what it queues runs while the
 // numbers travel to the host)
-void norm2_publish(Ctx &c, const double *x, int slot, int k) {
+void norm2_publish(Ctx &c, const double *x, int slot, int k, int k_sum) {
     if (c.comm) {  // the all-reduce sits between the reduction and the publication
-        launch_norm2(c, x, slot);
+        // k_sum > 1 (slot 0): d_red[1 .. k_sum) hold rank-local sums that have not been all-reduced yet
+        // (|dx|^2, |x|^2 of the Newton update, the watched component's error sums): ONE all-reduce
+        // carries them together with |x|^2 instead of one each
+        if (slot == 0 && k_sum > 1) {
+            const int grid = red_grid(c);
+            PtrPack8 pk;
+            for (int i = 0; i < 8; ++i) pk.p[i] = x;
+            hipLaunchKernelGGL(dots_kernel<1>, dim3(grid), dim3(256), 0, c.stream, pk, x, (size_t)c.n_dot, c.d_partials, RED_K - 1);
+            hipLaunchKernelGGL(reduce_partials_slot_kernel, dim3(1), dim3(64), 0, c.stream, c.d_partials, grid, RED_K - 1, c.d_red, 0);
+            comm_allreduce(c, c.d_red, k_sum);
+        } else {
+            launch_norm2(c, x, slot);
+        }
         hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_mail, c.d_mail_seq);
         ++c.mail_seq;
         return;
@@ -1484,7 +1496,7 @@ void norm2_publish(Ctx &c, const double *x, int slot, int k) {
 }
 
 void norm2_read(Ctx &c, const double *x, int slot, int k) {
-    norm2_publish(c, x, slot, k);
+    norm2_publish(c, x, slot, k, 1);
     wait_red(c);
 }
 
@@ -1628,7 +1640,9 @@ void launch_newton_update(Ctx &c, const double *coef_host, int k, const double *
     }
 #undef FEDM_NU
     hipLaunchKernelGGL(reduce_partials_range_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, 1, c.d_red);
-    comm_allreduce(c, c.d_red + 1, 2);
+    // several GPUs: d_red[1], d_red[2] stay rank-local; they are all-reduced together with the next |F|^2
+    // (norm2_publish, k_sum = 3): Ctx::red12_local tells the Newton loop
+    c.red12_local = c.comm != nullptr;
 }
 
 // |new - old + eps|^2 and |old + eps|^2 over one component (fedm/functions.py:1062-1064)
@@ -1655,7 +1669,8 @@ void launch_field_error(Ctx &c, int comp) {
     comm_allreduce(c, c.d_red, 2);
 }
 
-// the same two sums into d_red[3], d_red[4] (one GPU): they ride on the next publication
+// the same two sums into d_red[3], d_red[4]: they ride on the next publication (several GPUs: rank-local
+// until norm2_publish all-reduces them with |F|^2)
 void launch_field_error_slots34(Ctx &c, int comp) {
     int grid = (c.n_owned + 255) / 256;
     if (grid > RED_BLOCKS) grid = RED_BLOCKS;
