@@ -538,7 +538,6 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     if (exp_table) {
         const double *flw = lds_f + lc, *ulw = lds_u + lc;
         const int f_ueo = 4 * ns + 2 * nr + 2;
-#pragma unroll
         for (int q = 0; q < nqp; ++q) {
             const double p0 = 1.0 - md->qp_x[q] - md->qp_y[q], p1 = md->qp_x[q], p2 = md->qp_y[q];
             lds_e[((size_t)q * NEQ + wave) * SLICE + lc] = exp(ulw[wave * SLICE] * p0 + ulw[(NEQ + wave) * SLICE] * p1 + ulw[(2 * NEQ + wave) * SLICE] * p2);
@@ -744,7 +743,6 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         double src = 0.0, src_c1 = 0.0, src_v[ns];
 #pragma unroll
         for (int i = 0; i < ns; ++i) src_v[i] = 0.0;
-#pragma unroll
         for (int j = 0; j < nr; ++j) {
             // (weight, packed powers) of reaction j for this row: one broadcast LDS read, returned with
             // the rate-coefficient reads that follow, instead of dependent scalar loads from the descriptor
