@@ -427,8 +427,11 @@ def main():
             "partition": r4.partition_name}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n, args.grading, args.cpu_steps or args.steps,
-                                           args.cpu_threads)
+        try:    # (a reported baseline: its failure must not take the measured record with it)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n, args.grading, args.cpu_steps or args.steps,
+                                               args.cpu_threads)
+        except Exception as exc:                          # noqa: BLE001 - reported in the record
+            out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
