@@ -657,3 +657,63 @@ def test_time_of_flight_script_is_lowered_onto_the_device_model(tmp_path, monkey
     assert (tmp_path / "mesh" / "mesh info.txt").exists()
     assert "relative_error" in (tmp_path / "relative error.log").read_text()
     assert len(list((tmp_path / "number density" / "electrons").glob("*.vtu"))) == 1
+
+
+def test_python_callable_expression_source_keeps_the_host_path(monkeypatch):
+    """An Expression source given as a Python callable has no device program: `Problem` evaluates it
+    on the host at the lattice nodes of its degree and uploads the table before every solve."""
+    import fedm_amd.device as fdev
+    from fedm_amd import forms, functions as ff
+    from fedm_amd.mesh import RectangleMesh
+    calls = []
+
+    class Recorder:
+        def __init__(self, coords, cells, model, **kw):
+            self.model = model
+
+        def set_state(self, **kw):
+            pass
+
+        def set_step(self, dt, dt_old):
+            calls.append(("step", dt, dt_old))
+
+        def set_ext_source(self, s, nodal):
+            calls.append(("host", s, np.array(nodal)))
+
+        def set_ext_source_program(self, *a):
+            calls.append(("program",))
+
+        def eval_ext_source(self, *a):
+            calls.append(("device",))
+
+        def newton_solve(self, **kw):
+            calls.append(("solve",))
+
+    monkeypatch.setattr(fdev, "DeviceProblem", Recorder)
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 2.0), 3, 4)
+    V = forms.FunctionSpace(mesh, "P", 1)
+    u, v = forms.TrialFunction(V), forms.TestFunction(V)
+    u_old, u_old1, u_new = forms.Function(V), forms.Function(V), forms.Function(V)
+    dt = forms.Expression("time_step", time_step=1e-3, degree=0)
+    dt_old = forms.Expression("time_step", time_step=1e30, degree=0)
+    r = forms.Expression("x[0]", degree=1)
+    w = forms.interpolate(forms.Constant(("0", 2.0)), forms.VectorFunctionSpace(mesh, "P", 1))
+    D = forms.interpolate(forms.Constant(0.5), V)
+    f = forms.Expression(degree=1, python=lambda x, e: e.t * (x[..., 0] + 2.0 * x[..., 1]), t=3.0)
+    Gamma = -forms.grad(D * forms.exp(u)) + w * forms.exp(u)
+    F = ff.weak_form_balance_equation_log_representation("drift-diffusion-reaction", dt, dt_old, forms.dx, u, u_old,
+                                                         u_old1, v, f, Gamma, r)
+    forms.parameters["form_compiler"]["quadrature_degree"] = 4
+    problem = ff.Problem(forms.derivative(forms.action(F, u_new), u_new, u), forms.action(F, u_new), [])
+    assert list(problem.device.model.ext_source_degree) == [1] and problem.device.model.quadrature_degree == 4
+    solver = ff.PETScSNESSolver()
+    solver.solve(problem, None)
+    f.t = 5.0
+    solver.solve(problem, None)
+    kinds = [c[0] for c in calls]
+    assert "program" not in kinds and "device" not in kinds and kinds.count("host") == 2
+    vertices = mesh.coords[mesh.cells]                                   # degree 1: the lattice nodes are the vertices
+    expected = vertices[..., 0] + 2.0 * vertices[..., 1]
+    host = [c for c in calls if c[0] == "host"]
+    np.testing.assert_allclose(host[0][2], 3.0 * expected)
+    np.testing.assert_allclose(host[1][2], 5.0 * expected)
