@@ -25,7 +25,7 @@ from fedm_amd.physical_constants import *         # noqa: F401,F403
 from fedm_amd.file_io import *                    # noqa: F401,F403
 from fedm_amd.functions import *                  # noqa: F401,F403
 from fedm_amd.mesh import RectangleMesh
-from fedm_amd.mesh_io import XDMFFile, file_output
+from fedm_amd.mesh_io import XDMFFile            # (dolfin's; file_output comes with fedm.file_io as in the reference)
 
 
 def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", quiet=True, ttol=2e-3):

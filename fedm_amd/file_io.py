@@ -360,6 +360,13 @@ def _log_matrices(gain, loss, power):
     return "\n\n".join(f"{title} matrix:\n{numpy_2d_array_to_str(m)}" for title, m in blocks) + "\n"
 
 
+def file_output(*args, **kwargs):
+    """fedm/file_io.py:527-616, under the name and in the module the scripts import it from
+    (``from fedm.file_io import *``); the writers live in :mod:`fedm_amd.mesh_io`."""
+    from .mesh_io import file_output as write
+    return write(*args, **kwargs)
+
+
 def mesh_statistics(mesh):
     """fedm/file_io.py:619-631: the mesh as ``<output>/mesh/mesh.pvd`` and its element count and
     extreme edge lengths on the terminal and in ``mesh info.txt``."""

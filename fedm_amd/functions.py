@@ -12,7 +12,7 @@ from typing import Any, List, Optional, Tuple
 
 import numpy as np
 
-from .mesh import Marking_boundaries  # noqa: F401  (fedm/functions.py:86)
+from .mesh import CircleSubDomain, LineSubDomain, Marking_boundaries  # noqa: F401  (fedm/functions.py:49-124)
 from .physical_constants import elementary_charge, kB, kB_eV
 from .utils import comma_separated, print_rank_0
 

@@ -101,6 +101,43 @@ def geometric_lines(length, n, ratio):
     return length * h / h[-1]
 
 
+class SubDomain:
+    """Point predicate of a boundary part (DOLFIN's SubDomain as the two classes below use it):
+    ``inside(x, on_boundary)`` for one point ``x = (r, z)``."""
+
+    def inside(self, x, on_boundary):
+        raise NotImplementedError
+
+
+class LineSubDomain(SubDomain):
+    """Axis-parallel boundary segment, fedm/functions.py:73-84: the closed box ``r_range x z_range``
+    widened by DOLFIN_EPS (``df.between``), on the boundary only."""
+
+    def __init__(self, r_range, z_range):
+        self._r_range, self._z_range = tuple(r_range), tuple(z_range)
+
+    def inside(self, x, on_boundary):
+        within = all(lo - DOLFIN_EPS <= c <= hi + DOLFIN_EPS
+                     for c, (lo, hi) in zip((x[0], x[1]), (self._r_range, self._z_range)))
+        return bool(within and on_boundary)
+
+
+class CircleSubDomain(SubDomain):
+    """Circular electrode tip, fedm/functions.py:49-70.  As in the reference the constructor does not
+    keep ``gap_length``, so ``inside`` fails with the same AttributeError for a tip at z > 0 -- the
+    reason no reference example uses the 'circle' boundary type."""
+
+    def __init__(self, center_z, center_r, radius, gap_length, submesh=False, tol=1e-8):
+        self._center_z, self._center_r, self._radius = float(center_z), float(center_r), float(radius)
+        self._submesh, self._tol = bool(submesh), float(tol)
+
+    def inside(self, x, on_boundary):
+        d2 = (x[0] - self._center_r) ** 2 + (x[1] - self._center_z) ** 2
+        on_circle = abs(d2 - self._radius ** 2) <= self._tol
+        side = x[1] <= 0 if self._center_z <= 0 else x[1] >= self._gap_length
+        return bool(on_circle and side and (on_boundary or self._submesh))
+
+
 def Marking_boundaries(mesh, boundaries, submesh=False, gap_length=0.01):
     """Facet tags (n_cells, 3), int8; tag idx+1 for ``boundaries[idx]``.
 

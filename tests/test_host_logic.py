@@ -717,3 +717,26 @@ def test_python_callable_expression_source_keeps_the_host_path(monkeypatch):
     host = [c for c in calls if c[0] == "host"]
     np.testing.assert_allclose(host[0][2], 3.0 * expected)
     np.testing.assert_allclose(host[1][2], 5.0 * expected)
+
+
+def test_subdomain_predicates_are_what_marking_boundaries_tags():
+    """LineSubDomain / CircleSubDomain (fedm/functions.py:49-84) as point predicates: the line one
+    agrees with the facet tags of Marking_boundaries, the circle one carries the reference's defect."""
+    from fedm_amd import functions as ff
+    from fedm_amd.mesh import RectangleMesh
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 2.0), 4, 6)
+    boundaries = [['line', 0.0, 0.0, 0.0, 1.0], ['line', 2.0, 2.0, 0.0, 1.0]]
+    tags = ff.Marking_boundaries(mesh, boundaries)
+    cell, local = mesh.exterior_facets()
+    ends = (np.array([1, 0, 0])[local], np.array([2, 2, 1])[local])
+    for idx, (_, z1, z2, r1, r2) in enumerate(boundaries):
+        sub = ff.LineSubDomain((r1, r2), (z1, z2))
+        for c, l, a, b in zip(cell, local, *ends):
+            pa, pb = mesh.coords[mesh.cells[c, a]], mesh.coords[mesh.cells[c, b]]
+            inside = all(sub.inside(p, True) for p in (pa, pb, 0.5 * (pa + pb)))
+            assert inside == (tags[c, l] == idx + 1)
+        assert not sub.inside((0.5, z1), False)                          # not on the boundary
+    tip = ff.CircleSubDomain(-0.5, 0.0, 0.5, 0.01)
+    assert tip.inside((0.0, 0.0), True) and not tip.inside((0.0, 0.0), False) and not tip.inside((0.3, 0.3), True)
+    with pytest.raises(AttributeError, match="_gap_length"):
+        ff.CircleSubDomain(2.5, 0.0, 0.5, 2.0).inside((0.0, 2.0), True)
