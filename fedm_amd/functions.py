@@ -503,6 +503,40 @@ class PETScSNESSolver:
                                 ksp_max_it=p["krylov_maximum_iterations"])
 
 
+def Normal_vector(mesh):
+    """Outward unit normal projected onto P1, fedm/functions.py:1133-1151: the solution of
+    ``inner(u, v)*ds = inner(n, v)*ds`` over the exterior facets, interior vertices (zero rows made
+    identity rows by ``ident_zeros``) zero.  Host post-processing: a boundary mass matrix of the
+    boundary vertices, solved once per component.  Returns a vector Function (nodal array [vertex][2])."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from . import forms
+    cell, local = mesh.exterior_facets()
+    a = mesh.cells[cell, np.array([1, 0, 0])[local]].astype(np.int64)
+    b = mesh.cells[cell, np.array([2, 2, 1])[local]].astype(np.int64)
+    opposite = mesh.coords[mesh.cells[cell, local]]
+    pa, pb = mesh.coords[a], mesh.coords[b]
+    edge = pb - pa
+    length = np.hypot(edge[:, 0], edge[:, 1])
+    normal = np.stack([edge[:, 1], -edge[:, 0]], axis=1) / length[:, None]
+    outward = np.einsum("fd,fd->f", normal, 0.5 * (pa + pb) - opposite) > 0.0
+    normal[~outward] *= -1.0
+    nv = mesh.num_vertices()
+    rows = np.concatenate([a, a, b, b])
+    cols = np.concatenate([a, b, a, b])
+    vals = np.concatenate([length / 3.0, length / 6.0, length / 6.0, length / 3.0])     # P1 mass of an edge
+    M = sp.coo_matrix((vals, (rows, cols)), shape=(nv, nv)).tocsr()
+    on_boundary = np.zeros(nv, dtype=bool)
+    on_boundary[a] = on_boundary[b] = True
+    M = (M + sp.diags((~on_boundary).astype(float))).tocsc()                               # ident_zeros()
+    lu = spla.splu(M)
+    out = np.zeros((nv, 2))
+    for d in range(2):
+        rhs = np.bincount(np.concatenate([a, b]), weights=np.tile(0.5 * length * normal[:, d], 2), minlength=nv)
+        out[:, d] = lu.solve(rhs)
+    return forms.Function(forms.VectorFunctionSpace(mesh, "CG", 1), values=out)
+
+
 def Max(a, b):
     """(a + b + |a - b|)/2, fedm/functions.py:205-209; symbolic operands: the wall flux of an ion
     species, Max(dot(Gamma, normal), 0) (fedm-gd.py:351)."""

@@ -740,3 +740,23 @@ def test_subdomain_predicates_are_what_marking_boundaries_tags():
     assert tip.inside((0.0, 0.0), True) and not tip.inside((0.0, 0.0), False) and not tip.inside((0.3, 0.3), True)
     with pytest.raises(AttributeError, match="_gap_length"):
         ff.CircleSubDomain(2.5, 0.0, 0.5, 2.0).inside((0.0, 2.0), True)
+
+
+def test_normal_vector_is_the_projected_outward_normal():
+    """Normal_vector (fedm/functions.py:1133-1151): interior vertices zero, the exact normal along a
+    straight side away from the corners, the boundary mass system satisfied."""
+    from fedm_amd import functions as ff
+    from fedm_amd.mesh import RectangleMesh
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 2.0), 16, 32)
+    n = np.asarray(ff.Normal_vector(mesh).vector())
+    x = mesh.coords
+    interior = (x[:, 0] > 1e-12) & (x[:, 0] < 1 - 1e-12) & (x[:, 1] > 1e-12) & (x[:, 1] < 2 - 1e-12)
+    assert n.shape == (mesh.num_vertices(), 2) and np.all(n[interior] == 0.0)
+    mid = lambda m: m & ~interior
+    bottom = mid((np.abs(x[:, 1]) < 1e-12) & (np.abs(x[:, 0] - 0.5) < 0.2))
+    right = mid((np.abs(x[:, 0] - 1.0) < 1e-12) & (np.abs(x[:, 1] - 1.0) < 0.4))
+    assert bottom.sum() >= 5 and right.sum() >= 5
+    np.testing.assert_allclose(n[bottom], np.tile([0.0, -1.0], (bottom.sum(), 1)), atol=1e-3)
+    np.testing.assert_allclose(n[right], np.tile([1.0, 0.0], (right.sum(), 1)), atol=1e-3)
+    corner = np.argmin(np.abs(x[:, 0]) + np.abs(x[:, 1]))                 # (0, 0): both sides meet
+    assert n[corner, 0] < -0.3 and n[corner, 1] < -0.3
