@@ -2,9 +2,10 @@
 """Positive streamer in air (Bagheri et al. 2018) -- the reference's
 examples/streamer_discharge/fedm-streamer.py with the same sequence of calls, on the
 MI355X device path.  Differences forced by the platform: no DOLFIN (so `from fedm_amd.forms
-import *` stands for `from dolfin import *`), spatial Expressions are Python callables, the
-mesh is generated (the reference's mesh.xml is not distributed), results are returned
-instead of written as PVD files.
+import *` stands for `from dolfin import *`), the mesh is generated (the reference's mesh.xml is not
+distributed), results are returned instead of written as PVD files.  The initial conditions are the
+reference's C++ Expression strings, the potential of the initial time step is assembled and solved as
+the script does it (lhs / rhs / assemble / bc.apply / solve, on the host).
 """
 import sys
 from pathlib import Path
@@ -51,7 +52,7 @@ def main(n=64, T_final=1e-10, input_dir=None, output_dir=None, quiet=False):
     error = [0.0] * number_of_species
     max_error = [1] * 3
 
-    r = Expression('x[0]', degree=1, python=lambda x: x[..., 0])
+    r = Expression('x[0]', degree=1)
     box_width = box_height = 0.0125
     boundaries = [['line', 0.0, 0.0, 0.0, box_width],
                   ['line', box_height, box_height, 0.0, box_width],
@@ -82,6 +83,19 @@ def main(n=64, T_final=1e-10, input_dir=None, output_dir=None, quiet=False):
     Gamma = Function_definition(V, 'Function', number_of_equations)
     f = Function_definition(V, 'Function', number_of_equations)
 
+    # variables of the initial Poisson problem and of the post-processing (fedm-streamer.py:150-163)
+    PhiV = TrialFunction(V)
+    vp = TestFunction(V)
+    Phi = Function(V)
+    u_newV = Function_definition(V, 'Function', number_of_equations)
+    u_oldV = Function_definition(V, 'Function', number_of_equations)
+
+    # initial conditions (:168-171): the reference's C++ strings
+    u_oldV[0] = interpolate(Expression('std::log(1e13+5e18*exp(-(pow(x[0], 2)+pow(x[1]-1e-2, 2))/pow(0.4e-3, 2)))', degree=1), V)
+    u_oldV[1] = interpolate(Expression('std::log(1e13)', degree=1), V)
+    u_newV[0] = interpolate(Expression('std::log(1e13+5e18*exp(-(pow(x[0], 2)+pow(x[1]-1e-2, 2))/pow(0.4e-3, 2)))', degree=1), V)
+    u_newV[1] = interpolate(Expression('std::log(1e13)', degree=1), V)
+
     Phi_cathode, Phi_anode = Constant(0.0), Constant(U_w)
 
     def Cathode(x, on_boundary):
@@ -89,6 +103,21 @@ def main(n=64, T_final=1e-10, input_dir=None, output_dir=None, quiet=False):
 
     def Anode(x, on_boundary):
         return near(x[1], box_height) and on_boundary
+
+    # the potential of the initial time step (:196-215): assembled and solved on the host
+    potential_Cathode_bc = DirichletBC(V, Phi_cathode, Cathode)
+    potential_Anode_bc = DirichletBC(V, Phi_anode, Anode)
+    bcs_potential = [potential_Cathode_bc, potential_Anode_bc]
+    potential_f = (exp(u_oldV[0]) - exp(u_oldV[1])) * elementary_charge / epsilon_0
+    Fp = weak_form_Poisson_equation(dx_, PhiV, vp, potential_f, r)
+    a, L = lhs(Fp), rhs(Fp)
+    potential_A = assemble(a)
+    [bc_.apply(potential_A) for bc_ in bcs_potential]
+    potential_b = assemble(L)
+    [bc_.apply(potential_b) for bc_ in bcs_potential]
+    solve(potential_A, Phi.vector(), potential_b)
+    u_oldV[2].assign(Phi)                                                                  # :224-225
+    u_newV[2].assign(Phi)
 
     E = -grad(u[2])
     E_m = sqrt(inner(-grad(u[2]), -grad(u[2])))
@@ -135,17 +164,12 @@ def main(n=64, T_final=1e-10, input_dir=None, output_dir=None, quiet=False):
     J = derivative(F, None, u)
     problem = Problem(J, F, bc)
 
-    # initial conditions and the initial Poisson solve (fedm-streamer.py:169-225)
+    # the device states start from the script's per-field Functions (what the reference's assigner does
+    # with u_oldV / u_newV, :287-290)
     dev = problem.device
-    x = mesh.coords
-    U0 = np.zeros((mesh.num_vertices(), 3))
-    U0[:, 0] = np.log(1e13 + 5e18 * np.exp(-(x[:, 0]**2 + (x[:, 1] - 1e-2)**2) / (0.4e-3)**2))
-    U0[:, 1] = np.log(1e13)
+    U0 = np.stack([np.asarray(fn.vector(), dtype=float) for fn in u_oldV], axis=1)
     dev.set_state(U0, U0, U0)
     dev.setup_multigrid(nu=1)
-    dev.poisson_solve(rtol=1e-12)
-    U0 = dev.get_state()
-    dev.set_state(U0, U0, U0)
     u_new, u_old, u_old1 = DeviceState(dev, "new"), DeviceState(dev, "old"), DeviceState(dev, "old1")
 
     nonlinear_solver = PETScSNESSolver()

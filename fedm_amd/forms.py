@@ -575,6 +575,14 @@ class DirichletBC:
         self.space = space.space if isinstance(space, SubSpace) else space
         self.value, self.inside = value, inside
 
+    def apply(self, tensor):
+        """``bc.apply(A)`` (unit rows) / ``bc.apply(b)`` (boundary values) on host-assembled tensors."""
+        dofs, vals = self.rows(tensor.mesh, 1)
+        if isinstance(tensor, HostMatrix):
+            tensor.identity_rows(dofs)
+        else:
+            tensor[dofs] = vals
+
     def rows(self, mesh, n_eq):
         cell, local = mesh.exterior_facets()
         ends = np.array([[1, 2], [0, 2], [0, 1]])[local]
@@ -907,6 +915,112 @@ def project(expr, space=None, solver_type=None):
         lu = mesh._p1_mass_lu = spla.splu(sp.coo_matrix((vals.ravel(), (rows, cols)), shape=(n, n)).tocsc())
     rhs = np.bincount(mesh.cells.ravel(), weights=np.repeat(f * np.abs(det) / 6.0, 3), minlength=n)
     return Function(space or funcs[0].space, values=lu.solve(rhs))
+
+
+# ---------------------------------------------------------------------------------------
+# lhs / rhs / assemble / bc.apply / solve for the scalar Poisson problem the scripts solve once
+# before the time loop (fedm-streamer.py:203-215, fedm-gd.py:287-300): host side, scipy -- a
+# one-off solve of post-processing size; the Newton systems of the time loop are the device's.
+# ---------------------------------------------------------------------------------------
+class _FormSide:
+    def __init__(self, piece, side):
+        self.piece, self.side = piece, side
+
+
+def lhs(form):
+    return _FormSide(form, "lhs")
+
+
+def rhs(form):
+    return _FormSide(form, "rhs")
+
+
+class HostMatrix:
+    """Assembled P1 matrix (scipy CSR) with DOLFIN's ``bc.apply(A)`` semantics."""
+
+    def __init__(self, csr, mesh):
+        self.csr, self.mesh = csr.tolil(), mesh
+
+    def identity_rows(self, dofs):
+        for d in dofs:
+            self.csr.rows[d], self.csr.data[d] = [int(d)], [1.0]
+
+
+class HostVector(np.ndarray):
+    """Assembled P1 vector; carries its mesh for ``bc.apply(b)``."""
+    mesh = None
+
+
+def _at_quadrature(expr, mesh, phi_q):
+    """Values [cell][point] of an expression of nodal P1 Functions, Constants, numbers and parameter
+    Expressions at the quadrature points of every cell (the Functions interpolated first, then the
+    arithmetic: what FFC generates for exp(u_old) in a form)."""
+    if isinstance(expr, Real):
+        return float(expr)
+    if isinstance(expr, Constant):
+        return float(expr.value)
+    if isinstance(expr, Function):
+        return np.asarray(expr.vector(), dtype=float)[mesh.cells] @ phi_q.T
+    if isinstance(expr, Expression):
+        return expr.value()
+    if isinstance(expr, Sym):
+        if expr.op == "pow":
+            return _at_quadrature(expr.args[0], mesh, phi_q) ** expr.args[1]
+        a = [_at_quadrature(v, mesh, phi_q) for v in expr.args]
+        ops = {"add": lambda: a[0] + a[1], "sub": lambda: a[0] - a[1], "mul": lambda: a[0] * a[1],
+               "div": lambda: a[0] / a[1], "neg": lambda: -a[0], "abs": lambda: np.abs(a[0]),
+               "exp": lambda: np.exp(a[0]), "sqrt": lambda: np.sqrt(a[0]), "log": lambda: np.log(a[0])}
+        if expr.op in ops:
+            return ops[expr.op]()
+    raise NotImplementedError(f"assemble(): {type(expr).__name__} in a host-assembled source term")
+
+
+def assemble(form, tensor=None):
+    """``assemble(lhs(F))`` / ``assemble(rhs(F))`` of a ``weak_form_Poisson_equation`` on a scalar P1
+    space: ``2 pi r grad(u).grad(v) dx`` and ``2 pi r f v dx`` (``r`` the coordinate Expression, or the
+    default ``0.5/pi`` of plane problems), the source at the points of the degree set in
+    ``parameters["form_compiler"]["quadrature_degree"]`` (2 if unset)."""
+    import scipy.sparse as sp
+    from . import quadrature
+    from .functions import PoissonEq, _axisymmetric
+    if not isinstance(form, _FormSide) or not isinstance(form.piece, PoissonEq):
+        raise NotImplementedError("assemble(): lhs/rhs of weak_form_Poisson_equation on a scalar space")
+    piece = form.piece
+    mesh = piece.u.space.mesh
+    x = mesh.coords[mesh.cells]
+    d1, d2 = x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]
+    det = d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]
+    axis = _axisymmetric(piece.r)
+    two_pi_r = 2.0 * np.pi * x[:, :, 0] if axis else np.ones(x.shape[:2])      # at the vertices, [cell][a]
+    n = mesh.num_vertices()
+    c = mesh.cells.astype(np.int64)
+    if form.side == "lhs":
+        G = np.stack([np.stack([x[:, 1, 1] - x[:, 2, 1], x[:, 2, 0] - x[:, 1, 0]], axis=1),
+                      np.stack([x[:, 2, 1] - x[:, 0, 1], x[:, 0, 0] - x[:, 2, 0]], axis=1),
+                      np.stack([x[:, 0, 1] - x[:, 1, 1], x[:, 1, 0] - x[:, 0, 0]], axis=1)], axis=1) / det[:, None, None]
+        weight = 0.5 * np.abs(det) * two_pi_r.mean(axis=1)                       # r is linear: exact
+        vals = np.einsum("cad,cbd->cab", G, G) * weight[:, None, None]
+        rows = np.broadcast_to(c[:, :, None], vals.shape).ravel()
+        cols = np.broadcast_to(c[:, None, :], vals.shape).ravel()
+        return HostMatrix(sp.coo_matrix((vals.ravel(), (rows, cols)), shape=(n, n)).tocsr(), mesh)
+    degree = parameters["form_compiler"]["quadrature_degree"]
+    xq, wq = quadrature.triangle(degree if degree and degree > 0 else 2)
+    phi_q = np.stack([1 - xq[:, 0] - xq[:, 1], xq[:, 0], xq[:, 1]], axis=1)       # [point][a]
+    f_q = np.broadcast_to(_at_quadrature(piece.f, mesh, phi_q), (c.shape[0], len(wq)))
+    r_q = two_pi_r @ phi_q.T
+    elem = np.einsum("q,cq,cq,qa->ca", wq, f_q, r_q, phi_q) * np.abs(det)[:, None]
+    b = np.bincount(c.ravel(), weights=elem.ravel(), minlength=n).view(HostVector)
+    b.mesh = mesh
+    return b
+
+
+def solve(A, x, b, *solver_arguments):
+    """``solve(A, Phi.vector(), b[, 'mumps'])``: sparse direct solve on the host, into ``x``."""
+    import scipy.sparse.linalg as spla
+    if not isinstance(A, HostMatrix):
+        raise NotImplementedError("solve(): a matrix from assemble(lhs(...))")
+    x[...] = spla.spsolve(A.csr.tocsc(), np.asarray(b, dtype=float))
+    return x
 
 
 def action(form, u):

@@ -760,3 +760,37 @@ def test_normal_vector_is_the_projected_outward_normal():
     np.testing.assert_allclose(n[right], np.tile([1.0, 0.0], (right.sum(), 1)), atol=1e-3)
     corner = np.argmin(np.abs(x[:, 0]) + np.abs(x[:, 1]))                 # (0, 0): both sides meet
     assert n[corner, 0] < -0.3 and n[corner, 1] < -0.3
+
+
+def test_host_poisson_assemble_and_solve_like_the_scripts_initial_solve():
+    """lhs / rhs / assemble / bc.apply / solve as fedm-streamer.py:203-215 uses them, on the host: a
+    manufactured axisymmetric problem (Phi = z^2 + r^2 has -(1/r)(r Phi_r)_r - Phi_zz = -6) and the plane
+    default r = 0.5/pi with a linear solution."""
+    from fedm_amd import forms, functions as ff
+    from fedm_amd.mesh import RectangleMesh
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 2.0), 24, 48)
+    V = forms.FunctionSpace(mesh, "P", 1)
+    u, v, Phi = forms.TrialFunction(V), forms.TestFunction(V), forms.Function(V)
+    x = mesh.coords
+    forms.parameters["form_compiler"]["quadrature_degree"] = 2
+    exact = lambda p: p[..., 1] ** 2 + p[..., 0] ** 2
+    every = lambda p, on_boundary: on_boundary
+    r = forms.Expression("x[0]", degree=1)
+    n0 = forms.interpolate(forms.Constant(np.log(6.0)), V)
+    Fp = ff.weak_form_Poisson_equation(forms.dx, u, v, -forms.exp(n0), r)      # f = -6 through exp(Function)
+    A, b = forms.assemble(forms.lhs(Fp)), forms.assemble(forms.rhs(Fp))
+    bcs = [forms.DirichletBC(V, exact, every)]
+    [bc.apply(A) for bc in bcs]
+    [bc.apply(b) for bc in bcs]
+    forms.solve(A, Phi.vector(), b, "mumps")
+    assert np.abs(Phi.vector() - exact(x)).max() < 2e-3 * np.abs(exact(x)).max()   # second order, h = 1/24
+    # plane problem, Laplace: Phi = 3 z between Phi(0) = 0 and Phi(2) = 6, exact in P1
+    Fp = ff.weak_form_Poisson_equation(forms.dx, u, v, forms.Constant(0.0))
+    A, b = forms.assemble(forms.lhs(Fp)), forms.assemble(forms.rhs(Fp))
+    bottom = lambda p, on_boundary: forms.near(p[1], 0.0) and on_boundary
+    top = lambda p, on_boundary: forms.near(p[1], 2.0) and on_boundary
+    for bc in (forms.DirichletBC(V, forms.Constant(0.0), bottom), forms.DirichletBC(V, forms.Constant(6.0), top)):
+        bc.apply(A)
+        bc.apply(b)
+    forms.solve(A, Phi.vector(), b)
+    np.testing.assert_allclose(Phi.vector(), 3.0 * x[:, 1], atol=1e-12)
