@@ -5,9 +5,8 @@ cited on the right), on the MI355X device path.
 
 Differences forced by the platform, as in examples/streamer_discharge.py: no DOLFIN
 (`from fedm_amd.forms import *` stands for `from dolfin import *`); spatial / parameter
-Expressions with C++ strings carry a `python=` callable; the initial Poisson solve
-(fedm-gd.py:283-297) runs on the device right after `Problem(...)` exists instead of through
-assemble()/solve() before it (same result: zero voltage and equal charges give Phi = 0).
+Expressions with C++ strings carry a `python=` callable.  The initial Poisson solve
+(fedm-gd.py:283-300) is the script's own lhs / rhs / assemble / bc.apply / solve, on the host.
 
 What the script does per time step is what the reference does: it refreshes the nodal transport
 and rate coefficients ON THE HOST with `Transport_coefficient_interpolation` & co. (numpy), and
@@ -140,6 +139,9 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
     Phi = Function(V)
     Phi_old = Function(V)
     Phi_old1 = Function(V)
+    u_phi = TrialFunction(V)                                                               # :196-202
+    v_phi = TestFunction(V)
+    rho_poisson = 0
     rho_poisson_C = 0
     redE = Function(V)
     redE_old = Function(V)
@@ -185,6 +187,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
         u_newV[i].assign(n_init[i])
         u_oldV[i].assign(n_init[i])
         u_old1V[i].assign(Constant(0.0))
+        rho_poisson += elementary_charge * sign[i] * exp(u_oldV[i])
         rho_poisson_C += elementary_charge * sign[i] * exp(u[i])
         i += 1
     log_energy_density = Expression('std::log(a) + b', a=mean_energy, b=u_oldV[number_of_species - 1], degree=1,
@@ -210,6 +213,31 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
 
     def Grounded_electrode(x, on_boundary):
         return near(x[1], gap_length, DOLFIN_EPS) and on_boundary
+
+    Powered_Electrode_bc = DirichletBC(V, Phi_powered, Powered_electrode)                  # :280-300
+    Grounded_bc = DirichletBC(V, Phi_grounded, Grounded_electrode)
+    Voltage_bcs = [Powered_Electrode_bc, Grounded_bc]
+    f_potential = rho_poisson / epsilon
+    F_potential = weak_form_Poisson_equation(dx, u_phi, v_phi, f_potential, r)
+    a_potential, L_potential = lhs(F_potential), rhs(F_potential)
+    A_potential = None
+    A_potential = assemble(a_potential, tensor=A_potential)
+    [bc_.apply(A_potential) for bc_ in Voltage_bcs]
+    b_potential = None
+    b_potential = assemble(L_potential, tensor=b_potential)
+    [bc_.apply(b_potential) for bc_ in Voltage_bcs]
+    solve(A_potential, Phi.vector(), b_potential, 'mumps')
+
+    Phi_old1.assign(Phi_old)                                                               # :302-315
+    Phi_old.assign(Phi)
+    temp_output_variable.assign(Phi)
+    temp_output_variable.rename('Phi', str(0))
+    vtkfile_Phi[0] << (temp_output_variable, t)
+    redE.assign(project(1e21 * sqrt(dot(-grad(Phi), -grad(Phi))) / N0, solver_type='mumps'))
+    redE_old.assign(redE)
+    Transport_coefficient_interpolation('initial', mobility_dependence, N0, Tgas, mu, mu_x, mu_y, mean_energy, redE, mu)
+    Transport_coefficient_interpolation('initial', Diffusion_dependence, N0, Tgas, D, D_x, D_y, mean_energy, redE, mu)
+    Rate_coefficient_interpolation('initial', k_dependence, rate_coefficient, k_x, k_y, mean_energy, redE, Te=0, Tgas=0)
 
     if semi_implicit:                                                                      # :317-333
         rate_coefficient_si = semi_implicit_coefficients(k_dependence, mean_energy_e, mean_energy_old,
@@ -293,22 +321,10 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
 
     problem = Problem(J, F, Voltage_bcs_C)                                                 # :408
 
-    # initial potential and the coefficients that depend on it (:283-315), now that the device exists
+    # the device's linear solver (no counterpart in the script: PETSc's defaults there)
     problem.device.setup_multigrid(nu=1)
     from fedm_amd.device import chebyshev_weights
     problem.device.set_fieldsplit(chebyshev_weights(8, 0.3, 2.2))   # tools/gd_cycle.py
-    problem.device.poisson_solve()
-    assigner.assign(variable_list_new, u_new)
-    Phi_old1.assign(Phi_old)
-    Phi_old.assign(Phi)
-    temp_output_variable.assign(Phi)
-    temp_output_variable.rename('Phi', str(0))
-    vtkfile_Phi[0] << (temp_output_variable, t)
-    redE.assign(project(1e21 * sqrt(dot(-grad(Phi), -grad(Phi))) / N0, solver_type='mumps'))
-    redE_old.assign(redE)
-    Transport_coefficient_interpolation('initial', mobility_dependence, N0, Tgas, mu, mu_x, mu_y, mean_energy, redE, mu)
-    Transport_coefficient_interpolation('initial', Diffusion_dependence, N0, Tgas, D, D_x, D_y, mean_energy, redE, mu)
-    Rate_coefficient_interpolation('initial', k_dependence, rate_coefficient, k_x, k_y, mean_energy, redE, Te=0, Tgas=0)
 
     nonlinear_solver = PETScSNESSolver()                                                   # :411-414
     nonlinear_solver.parameters['relative_tolerance'] = relative_tolerance
