@@ -794,3 +794,47 @@ def test_host_poisson_assemble_and_solve_like_the_scripts_initial_solve():
         bc.apply(b)
     forms.solve(A, Phi.vector(), b)
     np.testing.assert_allclose(Phi.vector(), 3.0 * x[:, 1], atol=1e-12)
+
+
+def test_streamer_script_runs_up_to_the_device_and_lowers_to_the_case_model(tmp_path, monkeypatch):
+    """examples/streamer_discharge.py follows fedm-streamer.py:19-299 line by line.  Up to the point
+    where the device context would be created (no GPU here): the initial conditions from the C++
+    strings, the host-side initial Poisson solve, the forms lowered to the model of cases/streamer, the
+    initial values of the mixed Functions collected by the reverse assigner."""
+    import importlib.util
+    import fedm_amd.functions as ff
+    from fedm_amd.cases import streamer
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("streamer_example_cpu", root / "examples" / "streamer_discharge.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def capture(J, F, bcs):
+        seen.update(F=F, bcs=bcs)
+        raise Stop
+    monkeypatch.setattr(mod, "Problem", capture)
+    with pytest.raises(Stop):
+        mod.main(n=12, output_dir=tmp_path, quiet=True)
+    model, mesh, tags = ff.compile_forms(seen["F"])
+    ref = streamer.model()
+    assert (model.n_species, model.poisson, list(model.eq_type), list(model.Z)) == (2, True, list(ref.eq_type), [1.0, -1.0])
+    assert model.bc_kind == ref.bc_kind and model.quadrature_degree == 2 and model.axisymmetric
+    for E in (1e5, 3e7):
+        assert model.reactions[0].k(E) == pytest.approx(ref.reactions[0].k(E), rel=1e-14)
+    assert len(seen["bcs"]) == 2
+    # what Problem() would upload: the parts the reverse assigner collected for u_new / u_old
+    parts = seen["F"].u_new.parts
+    assert len(parts) == 3
+    x = mesh.coords
+    ions, electrons = streamer.initial_log_densities(x)
+    np.testing.assert_allclose(parts[0].vector(), ions, rtol=1e-14)
+    np.testing.assert_allclose(parts[1].vector(), electrons, rtol=1e-14)
+    phi = np.asarray(parts[2].vector())
+    assert abs(phi[np.argmin(x[:, 1])]) < 1e-9 and phi[np.argmax(x[:, 1])] == pytest.approx(18750.0)
+    assert np.all(np.diff(phi[np.argsort(x[:, 1], kind="stable")][::13]) >= -1e-6)      # rises from cathode to anode
+    assert (tmp_path / "potential" / "Phi" / "Phi000000.vtu").exists()
+    assert (tmp_path / "number density" / "electrons" / "electrons000000.vtu").exists()
