@@ -23,8 +23,6 @@ from fedm_amd.forms import *                      # noqa: F401,F403  (stands for
 from fedm_amd.physical_constants import *         # noqa: F401,F403
 from fedm_amd.file_io import *                    # noqa: F401,F403
 from fedm_amd.functions import *                  # noqa: F401,F403
-from fedm_amd.mesh import RectangleMesh
-from fedm_amd.mesh_io import XDMFFile            # (dolfin's; file_output comes with fedm.file_io as in the reference)
 
 
 def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", quiet=True, ttol=2e-3):
@@ -119,7 +117,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
     log('matrices', files.model_log, gain_matrix, loss_matrix, power_matrix)
     log('initial time', files.model_log, t)
 
-    P1 = FiniteElement("Lagrange", None, 1)                                                # :178-201
+    P1 = FiniteElement("Lagrange", mesh_plasma.ufl_cell(), 1)                              # :178-201
     elements_list = Mixed_element_list(number_of_equations, P1)
     Element = MixedElement(elements_list)
     ME = FunctionSpace(mesh_plasma, Element)

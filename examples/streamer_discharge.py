@@ -21,7 +21,7 @@ from fedm_amd.forms import *                      # noqa: F401,F403,E402  (stand
 from fedm_amd.physical_constants import *         # noqa: F401,F403,E402
 from fedm_amd.file_io import *                    # noqa: F401,F403,E402
 from fedm_amd.functions import *                  # noqa: F401,F403,E402
-from fedm_amd.mesh import RectangleMesh, geometric_lines   # noqa: E402
+from fedm_amd.mesh import geometric_lines                  # noqa: E402  (grading of the generated mesh)
 from fedm_amd.termsum import parse as parse_coefficient    # noqa: E402
 
 
@@ -104,11 +104,12 @@ def main(n=64, T_final=1e-10, input_dir=None, output_dir=None, quiet=False):
         mesh_statistics(mesh)
     boundary_mesh_function = Marking_boundaries(mesh, boundaries)
     normal = FacetNormal(mesh)
+    File(str(files.output_folder_path / 'mesh' / 'boundary_mesh_function.pvd')) << boundary_mesh_function
     dx = Measure('dx', domain=mesh)
     ds = Measure('ds', domain=mesh, subdomain_data=boundary_mesh_function)
     log('initial time', files.model_log, t)
 
-    P1 = FiniteElement("Lagrange", None, 1)                                                # :132-163
+    P1 = FiniteElement("Lagrange", mesh.ufl_cell(), 1)                                     # :132-163
     Element_list = Mixed_element_list(number_of_equations, P1)
     ME = FunctionSpace(mesh, MixedElement(Element_list))
     V = FunctionSpace(mesh, P1)

@@ -15,7 +15,6 @@ from fedm_amd.forms import *                      # noqa: F401,F403,E402  (stand
 from fedm_amd.physical_constants import *         # noqa: F401,F403,E402
 from fedm_amd.file_io import *                    # noqa: F401,F403,E402
 from fedm_amd.functions import *                  # noqa: F401,F403,E402
-from fedm_amd.mesh import RectangleMesh           # noqa: E402
 
 
 def main(nx=160, ny=320, box_width=5e-4, box_height=1e-3, t0=2.5e-9, T_final=3e-9, t_output=3e-9,

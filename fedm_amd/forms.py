@@ -480,6 +480,55 @@ class FunctionSpace:
         return SubSpace(self, i)
 
 
+def RectangleMesh(*args, **kwargs):
+    """``RectangleMesh(Point(0, 0), Point(w, h), nx, ny[, diagonal])``: DOLFIN's numbering
+    (:func:`fedm_amd.mesh.RectangleMesh`; ``x_lines`` / ``y_lines`` grade it)."""
+    from .mesh import RectangleMesh as build
+    return build(*args, **kwargs)
+
+
+def Mesh(path):
+    """``Mesh('mesh.xml')``: a DOLFIN XML mesh file (fedm-streamer.py:117)."""
+    from .mesh_io import read_dolfin_xml
+    return read_dolfin_xml(path)
+
+
+def XDMFFile(*args, **kwargs):
+    """``XDMFFile(path)`` with ``write_checkpoint`` (fedm-gd.py:265-270; ``XDMFFile.Encoding.HDF5``)."""
+    from .mesh_io import XDMFFile as writer
+    return writer(*args, **kwargs)
+
+
+class _XdmfEncoding:
+    HDF5, ASCII = "HDF5", "ASCII"
+
+
+XDMFFile.Encoding = _XdmfEncoding
+
+
+class File:
+    """``File('x.pvd') << (function, t)`` (VTU series) and ``File('x.pvd') << boundary_mesh_function``
+    (fedm-streamer.py:122: the facet tags, written as a text table next to the name -- a facet
+    MeshFunction has no VTU representation here)."""
+
+    def __init__(self, path):
+        from pathlib import Path
+        self.path = Path(path)
+        self._pvd = None
+
+    def __lshift__(self, item):
+        if isinstance(item, np.ndarray):
+            self.path.parent.mkdir(parents=True, exist_ok=True)
+            np.savetxt(self.path.with_suffix(".txt"), np.asarray(item).reshape(item.shape[0], -1), fmt="%d",
+                       header="facet tags [cell][local facet]")
+            return self
+        if self._pvd is None:
+            from .mesh_io import PVDFile
+            self._pvd = PVDFile(self.path)
+        self._pvd << item
+        return self
+
+
 def Point(*xy):
     """``Point(x, y)`` of ``RectangleMesh(Point(0, 0), Point(w, h), nx, ny)`` (fedm-tof.py:89)."""
     return tuple(float(v) for v in xy)

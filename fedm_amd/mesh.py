@@ -38,6 +38,10 @@ class Mesh:
     def hmin(self):
         return float(self._edge_lengths().min())
 
+    def ufl_cell(self):
+        """``FiniteElement("Lagrange", mesh.ufl_cell(), 1)`` (fedm-streamer.py:132)."""
+        return "triangle"
+
     def exterior_facets(self):
         """(cell, local facet) of every boundary edge; facet i is opposite vertex i."""
         c = self.cells.astype(np.int64)

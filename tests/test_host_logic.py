@@ -838,3 +838,25 @@ def test_streamer_script_runs_up_to_the_device_and_lowers_to_the_case_model(tmp_
     assert np.all(np.diff(phi[np.argsort(x[:, 1], kind="stable")][::13]) >= -1e-6)      # rises from cathode to anode
     assert (tmp_path / "potential" / "Phi" / "Phi000000.vtu").exists()
     assert (tmp_path / "number density" / "electrons" / "electrons000000.vtu").exists()
+
+
+def test_dolfin_like_names_of_the_star_import(tmp_path):
+    """`from fedm_amd.forms import *` stands for `from dolfin import *` in the example scripts: the mesh
+    constructors and file objects they use come with it (fedm-streamer.py:117-122,132; fedm-gd.py:163,265;
+    fedm-tof.py:89)."""
+    from fedm_amd import forms, mesh_io
+    mesh = forms.RectangleMesh(forms.Point(0, 0), forms.Point(1.0, 2.0), 3, 4)
+    assert mesh.num_cells() == 24 and mesh.ufl_cell() == "triangle"
+    assert forms.RectangleMesh((0, 0), (1, 1), 2, 2, "crossed").num_cells() == 16
+    mesh_io.write_dolfin_xml(mesh, tmp_path / "mesh.xml")
+    again = forms.Mesh(str(tmp_path / "mesh.xml"))
+    assert np.array_equal(again.cells, mesh.cells) and np.allclose(again.coords, mesh.coords)
+    tags = np.arange(72, dtype=np.int8).reshape(24, 3) % 5
+    forms.File(str(tmp_path / "mesh" / "boundary_mesh_function.pvd")) << tags
+    assert np.array_equal(np.loadtxt(tmp_path / "mesh" / "boundary_mesh_function.txt", dtype=int), tags)
+    f = forms.Function(forms.FunctionSpace(mesh, "P", 1))
+    out = forms.File(str(tmp_path / "f.pvd"))
+    out << (f, 0.5)
+    out << (f, 1.0)
+    assert sorted(p.name for p in tmp_path.glob("f*")) == ["f.pvd", "f000000.vtu", "f000001.vtu"]
+    assert forms.XDMFFile.Encoding.HDF5 == "HDF5"
