@@ -4,8 +4,8 @@ reference's examples/glow_discharge/fedm-gd.py with the same sequence of calls (
 cited on the right), on the MI355X device path.
 
 Differences forced by the platform, as in examples/streamer_discharge.py: no DOLFIN
-(`from fedm_amd.forms import *` stands for `from dolfin import *`); spatial / parameter
-Expressions with C++ strings carry a `python=` callable.  The initial Poisson solve
+(`from fedm_amd.forms import *` stands for `from dolfin import *`); the C++ Expression strings are the
+reference's (arithmetic subset, evaluated without a JIT).  The initial Poisson solve
 (fedm-gd.py:283-300) is the script's own lhs / rhs / assemble / bc.apply / solve, on the host.
 
 What the script does per time step is what the reference does: it refreshes the nodal transport
@@ -94,7 +94,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
     error = [0.0] * (number_of_species + 1)
     max_error = [1] * 3
 
-    r = Expression('x[0]', degree=1, python=lambda x: x[..., 0])                           # :133-155
+    r = Expression('x[0]', degree=1)                                                       # :133-155
     gap_length = 0.01
     wall = 0.01
     boundaries = [['line', 0.0, 0.0, 0.0, wall], ['line', gap_length, gap_length, 0.0, wall],
@@ -173,8 +173,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
     n_init = [0] * number_of_species                                                       # :237-262
     i = 0
     while i < number_of_species:
-        n_init[i] = Expression('std::log(ic)', ic=n_ic[i], degree=1,
-                               python=lambda x, e: np.full(x.shape[:-1], np.log(e.ic)))
+        n_init[i] = Expression('std::log(ic)', ic=n_ic[i], degree=1)
         i += 1
     mean_energy_init = interpolate(Expression('3.0', degree=1), V)
     mean_energy.assign(mean_energy_init)
@@ -188,8 +187,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
         rho_poisson += elementary_charge * sign[i] * exp(u_oldV[i])
         rho_poisson_C += elementary_charge * sign[i] * exp(u[i])
         i += 1
-    log_energy_density = Expression('std::log(a) + b', a=mean_energy, b=u_oldV[number_of_species - 1], degree=1,
-                                    python=lambda x, e: np.log(e.a.vector()) + e.b.vector())
+    log_energy_density = Expression('std::log(a) + b', a=mean_energy, b=u_oldV[number_of_species - 1], degree=1)
     we_newV = interpolate(log_energy_density, V)
     we_oldV = interpolate(log_energy_density, V)
     we_old1V = interpolate(Constant(0.0), V)
@@ -203,8 +201,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
         i += 1
 
     Phi_grounded = Constant(0.0)                                                           # :276-290
-    Phi_powered = Expression('U0*(1-exp(-t/1e-9))', U0=U_w, t=t, pi=pi, degree=0,
-                             python=lambda x, e: e.U0 * (1.0 - np.exp(-e.t / 1e-9)))
+    Phi_powered = Expression('U0*(1-exp(-t/1e-9))', U0=U_w, t=t, pi=pi, degree=0)
 
     def Powered_electrode(x, on_boundary):
         return near(x[1], 0, DOLFIN_EPS) and on_boundary

@@ -254,7 +254,16 @@ def compile_cpp_expression(code):
             return float(node.value)
         if isinstance(node, ast.Name):
             if hasattr(owner, node.id) and node.id not in ("code", "degree", "python"):
-                return float(getattr(owner, node.id))
+                value = getattr(owner, node.id)
+                if isinstance(value, Function):
+                    # a Function as parameter (fedm-gd.py:258: Expression('std::log(a) + b', a=mean_energy,
+                    # b=u_oldV[...])): its nodal values, i.e. the expression is evaluated at the vertices
+                    nodal = np.asarray(value.vector(), dtype=float)
+                    if nodal.shape != np.shape(x)[:-1]:
+                        raise NotImplementedError("an Expression with Function parameters is evaluated at the "
+                                                  "mesh vertices only (interpolate)")
+                    return nodal
+                return float(value)
             if node.id in _CPP_CONSTANTS:
                 return _CPP_CONSTANTS[node.id]
             raise NameError(f"Expression parameter '{node.id}' is not set")
@@ -305,7 +314,10 @@ class Expression:
             return float(np.asarray(self(np.zeros((1, 2)))).ravel()[0])
         if self.code in self.__dict__:
             return float(self.__dict__[self.code])
-        return float(self.code)
+        try:
+            return float(self.code)
+        except (TypeError, ValueError):      # an arithmetic string of the parameters: 'U0*(1-exp(-t/1e-9))'
+            return float(np.asarray(self(np.zeros((1, 2)))).ravel()[0])
 
     def __mul__(self, o):
         return Sym("mul", self, o)

@@ -575,6 +575,20 @@ def test_cpp_expression_subset_evaluates_the_reference_strings_and_refuses_the_r
                                tof.analytic_log_density(x, 2.6e-9), rtol=1e-14)
     with pytest.raises(NotImplementedError):
         forms.expression_program(forms.Expression(degree=1, python=lambda x: x[..., 0]))
+    # parameters that are nodal Functions (fedm-gd.py:258) and parameter-only arithmetic (:272)
+    from fedm_amd.mesh import RectangleMesh
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 1.0), 3, 3)
+    V = forms.FunctionSpace(mesh, "P", 1)
+    a = forms.interpolate(forms.Expression("2.0 + x[0]", degree=1), V)
+    b = forms.interpolate(forms.Expression("x[1]", degree=1), V)
+    we = forms.interpolate(forms.Expression("std::log(a) + b", a=a, b=b, degree=1), V)
+    np.testing.assert_allclose(we.vector(), np.log(2.0 + mesh.coords[:, 0]) + mesh.coords[:, 1], rtol=1e-15)
+    with pytest.raises(NotImplementedError, match="mesh vertices"):
+        forms.Expression("std::log(a) + b", a=a, b=b, degree=1)(x)            # other points than the vertices
+    powered = forms.Expression("U0*(1-exp(-t/1e-9))", U0=250.0, t=2e-9, pi=np.pi, degree=0)
+    assert powered.value() == pytest.approx(250.0 * (1.0 - np.exp(-2.0)), rel=1e-15)
+    powered.t = 0.0
+    assert powered.value() == 0.0
     assert forms.Expression('x[0] > 1e-4 ? 1.0 : 0.0', degree=1).code      # construction is free ...
     for bad in ('__import__("os").system("true")', 'x[0] > 1e-4 ? 1.0 : 0.0', 'x.shape', 'q*x[0]',
                 'x[0]; x[1]', '(lambda: 1)()'):
