@@ -503,6 +503,19 @@ class PETScSNESSolver:
                                 ksp_max_it=p["krylov_maximum_iterations"])
 
 
+def Poisson_solver(A, L, b, bcs, u, solver_type="mumps", preconditioner="hypre_amg"):
+    """fedm/functions.py:1154-1161: assemble the right-hand side ``L`` (into ``b``), apply the Dirichlet
+    values and solve ``A u = b`` -- with the host-side tensors of ``fedm_amd.forms.assemble`` (``A``
+    already carries the boundary rows, as in the reference).  The solver names are accepted; the solve is
+    a sparse direct one."""
+    from . import forms
+    b = forms.assemble(L, tensor=b)
+    for bc in bcs:
+        bc.apply(b)
+    forms.solve(A, u.vector(), b, solver_type)
+    return b
+
+
 def Normal_vector(mesh):
     """Outward unit normal projected onto P1, fedm/functions.py:1133-1151: the solution of
     ``inner(u, v)*ds = inner(n, v)*ds`` over the exterior facets, interior vertices (zero rows made

@@ -808,6 +808,11 @@ def test_host_poisson_assemble_and_solve_like_the_scripts_initial_solve():
         bc.apply(b)
     forms.solve(A, Phi.vector(), b)
     np.testing.assert_allclose(Phi.vector(), 3.0 * x[:, 1], atol=1e-12)
+    # the same through Poisson_solver (fedm/functions.py:1154-1161): A with its boundary rows, L, bcs
+    again = forms.Function(V)
+    bcs = [forms.DirichletBC(V, forms.Constant(0.0), bottom), forms.DirichletBC(V, forms.Constant(6.0), top)]
+    ff.Poisson_solver(A, forms.rhs(Fp), None, bcs, again, solver_type="gmres", preconditioner="hypre_amg")
+    np.testing.assert_allclose(again.vector(), 3.0 * x[:, 1], atol=1e-12)
 
 
 def test_streamer_script_runs_up_to_the_device_and_lowers_to_the_case_model(tmp_path, monkeypatch):
