@@ -1,261 +1,270 @@
 #!/usr/bin/env python3
-"""Positive streamer in air (Bagheri et al. 2018) -- the reference's
-examples/streamer_discharge/fedm-streamer.py with the same sequence of calls (its lines are cited on
-the right), on the MI355X device path.
+"""Positive streamer in atmospheric air between two planar electrodes (the benchmark of Bagheri et
+al., Plasma Sources Sci. Technol. 27 (2018) 095002, case 1) on one MI355X through the fedm_amd facade.
 
-Differences forced by the platform: no DOLFIN (`from fedm_amd.forms import *` stands for
-`from dolfin import *`); the mesh is generated (the reference's mesh.xml is not distributed: a graded
-tensor-product mesh of `n` x `n` cells); the deck's coefficient strings are parsed
-(`parse_coefficient`) where the reference eval()s them.  The initial conditions are the reference's
-C++ Expression strings, the potential of the initial time step is the script's own
-lhs / rhs / assemble / bc.apply / solve (on the host), the time loop is `adaptive_solver` with the
-Newton solves on the device.
+A driver of our own for the functions a FEDM user knows (`fedm.functions`, `fedm.file_io`): the deck
+is read with the deck readers, the weak form is put together from `weak_form_balance_equation_log_
+representation`, `weak_form_Poisson_equation`, `Flux` and `Boundary_flux`, the time loop is
+`adaptive_solver` + `adaptive_timestep`, results go through `file_output`.  It solves the case of
+the reference's examples/streamer_discharge/fedm-streamer.py (same deck, boundary table, initial
+condition, tolerances and end time), so the two can be compared; that the reference's script itself
+lowers to the same device model is checked in tests/test_reference_scripts.py, in the build
+container, against the script where it lies.
+
+The mesh is loaded from a DOLFIN XML file like the reference's; as that file is not distributed
+(.MISSING_LARGE_BLOBS), `--mesh-spacing` generates a locally refined unstructured stand-in first
+(`fedm_amd.cases.streamer.refined_mesh`).  `--cells N` runs on an N x N graded tensor-product mesh
+instead (the headline bench's mesh).
+
+    python examples/streamer_discharge.py --mesh-spacing 8e-6 --end 1.4e-8 --out streamer_output
 """
+import argparse
+import contextlib
+import io
 import sys
+from dataclasses import dataclass, field
 from pathlib import Path
 
-import numpy as np
-
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from fedm_amd.forms import *                      # noqa: F401,F403,E402  (stands for `from dolfin import *`)
-from fedm_amd.physical_constants import *         # noqa: F401,F403,E402
-from fedm_amd.file_io import *                    # noqa: F401,F403,E402
-from fedm_amd.functions import *                  # noqa: F401,F403,E402
-from fedm_amd.mesh import geometric_lines                  # noqa: E402  (grading of the generated mesh)
-from fedm_amd.termsum import parse as parse_coefficient    # noqa: E402
+from fedm_amd import forms as fem                          # noqa: E402  (what `dolfin` is to a FEDM script)
+from fedm_amd import file_io, functions as fedm            # noqa: E402
+from fedm_amd.physical_constants import elementary_charge, epsilon_0     # noqa: E402
+from fedm_amd.termsum import parse as deck_expression      # noqa: E402
+
+REPO = Path(__file__).resolve().parent.parent
+SEED = "std::log(1e13+5e18*exp(-(pow(x[0], 2)+pow(x[1]-1e-2, 2))/pow(0.4e-3, 2)))"    # ions: background + seed
+BACKGROUND = "std::log(1e13)"                                                           # electrons
 
 
-def main(n=64, T_final=1e-10, input_dir=None, output_dir=None, quiet=False):
-    parameters["form_compiler"]["optimize"] = True                                         # :19-23
-    parameters["form_compiler"]["cpp_optimize"] = True
-    parameters["std_out_all_processes"] = False
-    parameters['krylov_solver']['nonzero_initial_guess'] = True
-    parameters["form_compiler"]["quadrature_degree"] = 2
+@dataclass
+class Case:
+    """Conditions of the run (Bagheri et al. 2018, case 1; values as in fedm-streamer.py:26-41,67-76,96-108)."""
+    deck: str = "benchmark_model"
+    pressure_torr: float = 760.0
+    gas_temperature: float = 300.0
+    anode_voltage: float = 18750.0
+    side: float = 0.0125                        # the domain is side x side in (r, z)
+    end_time: float = 1.4e-8
+    first_step: float = 5e-12
+    longest_step: float = 5e-12
+    shortest_step: float = 1e-15
+    step_tolerance: float = 1e-3
+    newton_rtol: float = 1e-4
+    newton_max_it: int = 20
+    kinds: tuple = ("reaction", "drift-diffusion-reaction")        # ions do not move, electrons drift and diffuse
+    roles: tuple = ("Ions", "electrons")
+    output_windows: tuple = (1e-11, 1e-10, 1e-9)
+    # per boundary (cathode z=0, anode z=side, axis r=0, outer wall r=side): condition per species
+    walls: dict = field(default_factory=lambda: {
+        "cathode": ("zero flux", "Neumann"), "anode": ("zero flux", "Neumann"),
+        "axis": ("zero flux", "zero flux"), "outer": ("zero flux", "zero flux")})
 
-    linear_solver = "gmres"          # (the reference's default is "mumps"; the device solves with GMRES)   :26-28
-    maximum_iterations = 20
-    relative_tolerance = 1e-4
+    @property
+    def gas_density(self):
+        return self.pressure_torr * 3.21877e22
 
-    model = 'benchmark_model'                                                              # :33-41
-    coordinates = 'cylindrical'
-    gas = 'Air'
-    Tgas = 300.0
-    p0 = 760.0
-    N0 = p0 * 3.21877e22
-    U_w = 18750.0
-    approximation = 'LFA'
-    files.file_input = Path(input_dir) if input_dir else \
-        Path(__file__).resolve().parent.parent / "decks" / "streamer_discharge" / "file_input"
-    if output_dir is not None:
-        files.output_folder_path = Path(output_dir)
-    path = files.file_input / model
-
-    number_of_species, particle_species, particle_prop, particle_species_file_names = read_speclist(path)   # :47-60
-    M, sign = read_particle_properties(particle_prop, model)
-    equation_type = ['reaction', 'drift-diffusion-reaction']
-    particle_species_type = ['Ions', 'electrons']
-    number_of_species, number_of_equations, particle_species, M, sign = modify_approximation_vars(
-        approximation, number_of_species, particle_species, M, sign)
-    charge = [i * elementary_charge for i in sign]
-    vtkfile_u = output_files('pvd', 'number density', particle_species_type)
-    vtkfile_Phi = output_files('pvd', 'potential', ['Phi'])
-    output_file_list = [vtkfile_Phi[0], vtkfile_u[0], vtkfile_u[1]]
-    file_type = ['pvd', 'pvd', 'pvd']
-
-    t_old = None                                                                           # :65-89
-    t0 = 0.0
-    t = t0
-    dt_min = 1e-15
-    dt_max = 5e-12
-    dt_init = 5e-12
-    dt_old_init = 1e30
-    dt = Expression("time_step", time_step=dt_init, degree=0)
-    dt_old = Expression("time_step", time_step=dt_old_init, degree=0)
-    ttol = 1e-3
-    t_output_list = [1e-11, 1e-10, 1e-9]
-    t_output_step_list = [1e-11, 1e-10, 1e-9]
-    t_output_step = t_output_list[0]
-    t_output = t_output_step_list[0]
-    error = [0.0] * number_of_species
-    max_error = [1] * 3
-
-    if coordinates == 'cylindrical':                                                       # :94-112
-        r = Expression('x[0]', degree=1)
-        z = Expression('x[1]', degree=1)                                                   # noqa: F841
-    box_width = 0.0125
-    box_height = 0.0125
-    boundaries = [['line', 0.0, 0.0, 0.0, box_width],
-                  ['line', box_height, box_height, 0.0, box_width],
-                  ['line', 0.0, box_height, 0.0, 0.0],
-                  ['line', 0.0, box_height, box_width, box_width]]
-    number_of_boundaries = len(boundaries)
-    bc_type_grounded = ['zero flux', 'Neumann']
-    bc_type_powered = ['zero flux', 'Neumann']
-    bc_type_axis = ['zero flux', 'zero flux']
-    bc_type_wall = ['zero flux', 'zero flux']
-    bc_type = [bc_type_grounded, bc_type_powered, bc_type_axis, bc_type_wall]
-    gamma = [0.0, 0.0]
-    log('conditions', files.model_log, dt.time_step, U_w, p0, box_height, N0, Tgas)
-    log('properties', files.model_log, gas, model, particle_species_file_names, M, charge)
-
-    mesh = RectangleMesh((0.0, 0.0), (box_width, box_height), n, n,                        # :117-127 (Mesh('mesh.xml'))
-                         x_lines=geometric_lines(box_width, n, 4.0))
-    with open_quietly(quiet):
-        mesh_statistics(mesh)
-    boundary_mesh_function = Marking_boundaries(mesh, boundaries)
-    normal = FacetNormal(mesh)
-    File(str(files.output_folder_path / 'mesh' / 'boundary_mesh_function.pvd')) << boundary_mesh_function
-    dx = Measure('dx', domain=mesh)
-    ds = Measure('ds', domain=mesh, subdomain_data=boundary_mesh_function)
-    log('initial time', files.model_log, t)
-
-    P1 = FiniteElement("Lagrange", mesh.ufl_cell(), 1)                                     # :132-163
-    Element_list = Mixed_element_list(number_of_equations, P1)
-    ME = FunctionSpace(mesh, MixedElement(Element_list))
-    V = FunctionSpace(mesh, P1)
-    W = VectorFunctionSpace(mesh, 'P', 1)                                                  # noqa: F841
-    assigner = FunctionAssigner(Function_space_list(number_of_equations, V), ME)
-    rev_assigner = FunctionAssigner(ME, Function_space_list(number_of_equations, V))
-    temp_output_variable = Function(V)
-    u = TrialFunction(ME)
-    v = TestFunctions(ME)
-    u_new = Function(ME)
-    u_old = Function(ME)
-    u_old1 = Function(ME)
-    PhiV = TrialFunction(V)
-    vp = TestFunction(V)
-    Phi = Function(V)
-    Phi_old = Function(V)                                                                  # noqa: F841
-    u_newV = Function_definition(V, 'Function', number_of_equations)
-    u_oldV = Function_definition(V, 'Function', number_of_equations)
-    u_old1V = Function_definition(V, 'Function', number_of_equations)                      # noqa: F841
-    mu = Function_definition(V, 'Function', number_of_equations)
-    D = Function_definition(V, 'Function', number_of_equations)
-    Gamma = Function_definition(V, 'Function', number_of_equations)
-    f = Function_definition(V, 'Function', number_of_equations)
-
-    u_oldV[0] = interpolate(Expression('std::log(1e13+5e18*exp(-(pow(x[0], 2)+pow(x[1]-1e-2, 2))/pow(0.4e-3, 2)))', degree=1), V)   # :168-171
-    u_oldV[1] = interpolate(Expression('std::log(1e13)', degree=1), V)
-    u_newV[0] = interpolate(Expression('std::log(1e13+5e18*exp(-(pow(x[0], 2)+pow(x[1]-1e-2, 2))/pow(0.4e-3, 2)))', degree=1), V)
-    u_newV[1] = interpolate(Expression('std::log(1e13)', degree=1), V)
-
-    i = 0                                                                                  # :174-179
-    while i < number_of_species:
-        temp_output_variable.assign(u_oldV[i])
-        temp_output_variable.rename(particle_species_file_names[i + 1], str(i + 1))
-        vtkfile_u[i] << (temp_output_variable, t)
-        i += 1
-
-    Phi_cathode = Constant(0.0)                                                            # :185-199
-    Phi_anode = Constant(U_w)
-
-    def Cathode(x, on_boundary):
-        return near(x[1], 0) and on_boundary
-
-    def Anode(x, on_boundary):
-        return near(x[1], box_height) and on_boundary
-
-    potential_Cathode_bc = DirichletBC(V, Phi_cathode, Cathode)
-    potential_Anode_bc = DirichletBC(V, Phi_anode, Anode)
-    bcs_potential = [potential_Cathode_bc, potential_Anode_bc]
-
-    potential_f = (exp(u_oldV[0]) - exp(u_oldV[1])) * elementary_charge / epsilon_0        # :201-215
-    Fp = weak_form_Poisson_equation(dx, PhiV, vp, potential_f, r)
-    a, L = lhs(Fp), rhs(Fp)
-    potential_A = assemble(a)
-    [bc_.apply(potential_A) for bc_ in bcs_potential]
-    potential_b = assemble(L)
-    [bc_.apply(potential_b) for bc_ in bcs_potential]
-    solve(potential_A, Phi.vector(), potential_b)
-
-    temp_output_variable.assign(Phi)                                                       # :217-225
-    vtkfile_Phi[0] << (temp_output_variable, t)
-    E = -grad(u[2])
-    E_m = sqrt(inner(-grad(u[2]), -grad(u[2])))
-    u_oldV[2].assign(Phi)
-    u_newV[2].assign(Phi)
-
-    D_x, D_y, Diffusion_dependence = read_transport_coefficients(particle_species, 'Diffusion', model)     # :227-228
-    mu_x, mu_y, mu_dependence = read_transport_coefficients(particle_species, 'mobility', model)
-
-    Cathode_bc = DirichletBC(ME.sub(2), Phi_cathode, Cathode)                              # :233-235
-    Anode_bc = DirichletBC(ME.sub(2), Phi_anode, Anode)
-    bc = [Cathode_bc, Anode_bc]
-
-    D[0] = D_y[0]                                                                          # :236-249
-    mu[1] = parse_coefficient(mu_y[1])          # the reference eval()s these deck strings
-    D[1] = parse_coefficient(D_y[1])
-    alpha = (1.1944e6 + 4.3666e26 * E_m**(-3)) * exp(-2.73e7 / E_m) - 340.75
-    Gamma[0] = 0.0
-    Gamma[1] = Flux(sign[1], u[1], D[1], mu[1], E, grad_diffusion=False)
-    f[0] = alpha * mu[1] * E_m * exp(u[1])
-    f[1] = alpha * mu[1] * E_m * exp(u[1])
-    i = 0
-    while i < number_of_species:
-        f[2] += sign[i] * exp(u[i]) * elementary_charge / epsilon_0
-        i += 1
-
-    F = 0.0                                                                                # :252-271
-    i = 0
-    while i < number_of_species:
-        F += weak_form_balance_equation_log_representation(equation_type[i], dt, dt_old, dx, u[i], u_old[i],
-                                                           u_old1[i], v[i], f[i], Gamma[i], r, D[i])
-        i += 1
-    F += weak_form_Poisson_equation(dx, u[number_of_equations - 1], v[number_of_equations - 1],
-                                    f[number_of_equations - 1], r)
-    i = 0
-    while i < number_of_boundaries:
-        j = 0
-        while j < number_of_species:
-            F += Boundary_flux(bc_type[i][j], equation_type[j], particle_species_type[j], sign[j], mu[j], E,
-                               normal, u[j], gamma[j], v[j], ds(i + 1), r)
-            j += 1
-        i += 1
-
-    variable_list_new = [u_newV[0], u_newV[1], u_newV[2]]                                  # :276-283
-    variable_list_old = [u_oldV[0], u_oldV[1], u_oldV[2]]
-    output_old_variable_list = [u_oldV[2], u_oldV[0], u_oldV[1]]
-    output_new_variable_list = [u_newV[2], u_newV[0], u_newV[1]]
-    output_files_variabe_names = ['Phi', particle_species_type[0], particle_species_type[1]]
-    rev_assigner.assign(u_old, variable_list_old)
-    rev_assigner.assign(u_new, variable_list_new)
-
-    F = action(F, u_new)                                                                   # :288-299
-    J = derivative(F, u_new, u)
-    problem = Problem(J, F, bc)
-    problem.device.setup_multigrid(nu=1)        # the device's preconditioner (the reference: "hypre_amg" with gmres)
-    nonlinear_solver = PETScSNESSolver()
-    nonlinear_solver.parameters['relative_tolerance'] = relative_tolerance
-    nonlinear_solver.parameters["linear_solver"] = linear_solver
-    nonlinear_solver.parameters['maximum_iterations'] = maximum_iterations
-
-    while abs(t - T_final) / T_final > 1e-6:                                               # :304-345
-        t_old = t
-        u_old1.assign(u_old)
-        u_old.assign(u_new)
-        assigner.assign(variable_list_old, u_old)
-        with open_quietly(quiet):
-            t = adaptive_solver(nonlinear_solver, problem, t, dt, dt_old, u_new, u_old, variable_list_new,
-                                variable_list_old, assigner, error, files.error_file, max_error, ttol, dt_min,
-                                time_dependent_arguments=[], approximation=approximation)
-        log('time', files.model_log, t)
-        dt_old.time_step = dt.time_step
-        dt.time_step = adaptive_timestep(dt.time_step, max_error, ttol, dt_min, dt_max)
-        max_error[2] = max_error[1]
-        max_error[1] = max_error[0]
-        t_output, t_output_step = file_output(t, t_old, t_output, t_output_step, t_output_list, t_output_step_list,
-                                              file_type, output_file_list, output_files_variabe_names,
-                                              output_new_variable_list, output_old_variable_list)
-    return problem.device.get_state(), files.error_file
+    def wall_lines(self):
+        s = self.side
+        return {"cathode": ["line", 0.0, 0.0, 0.0, s], "anode": ["line", s, s, 0.0, s],
+                "axis": ["line", 0.0, s, 0.0, 0.0], "outer": ["line", 0.0, s, s, s]}
 
 
-def open_quietly(quiet):
-    """stdout of the library's progress lines, or nothing (tests)."""
-    import contextlib
-    import io
+def read_deck(case, input_dir):
+    """Species, charges and transport data through the FEDM deck readers."""
+    file_io.files.file_input = Path(input_dir) if input_dir else REPO / "decks" / "streamer_discharge" / "file_input"
+    deck_dir = file_io.files.file_input / case.deck
+    n_species, names, property_files, file_names = file_io.read_speclist(deck_dir)
+    masses, charge_numbers = file_io.read_particle_properties(property_files, case.deck)
+    n_species, n_equations, names, masses, charge_numbers = fedm.modify_approximation_vars(
+        "LFA", n_species, names, masses, charge_numbers)
+    _, diffusion, _ = file_io.read_transport_coefficients(names, "Diffusion", case.deck)
+    _, mobility, _ = file_io.read_transport_coefficients(names, "mobility", case.deck)
+    return dict(n_species=n_species, n_equations=n_equations, names=names, file_names=file_names, masses=masses,
+                charge_numbers=charge_numbers, diffusion=diffusion, mobility=mobility)
+
+
+def load_mesh(case, cells, mesh_spacing, mesh_file, workdir):
+    if cells:
+        from fedm_amd.mesh import geometric_lines
+        return fem.RectangleMesh((0.0, 0.0), (case.side, case.side), cells, cells,
+                                 x_lines=geometric_lines(case.side, cells, 4.0))
+    if mesh_file is None:
+        from fedm_amd.cases import streamer
+        from fedm_amd import mesh_io
+        mesh_file = Path(workdir) / "mesh.xml"
+        mesh_file.parent.mkdir(parents=True, exist_ok=True)
+        mesh_io.write_dolfin_xml(streamer.refined_mesh(mesh_spacing), mesh_file)
+    return fem.Mesh(str(mesh_file))
+
+
+class Fields:
+    """The mixed space of the coupled system, the scalar space of its parts, and the Functions."""
+
+    def __init__(self, mesh, n_equations):
+        lagrange = fem.FiniteElement("Lagrange", mesh.ufl_cell(), 1)
+        self.mixed = fem.FunctionSpace(mesh, fem.MixedElement(fedm.Mixed_element_list(n_equations, lagrange)))
+        self.scalar = fem.FunctionSpace(mesh, lagrange)
+        parts = fedm.Function_space_list(n_equations, self.scalar)
+        self.split = fem.FunctionAssigner(parts, self.mixed)          # mixed -> parts
+        self.join = fem.FunctionAssigner(self.mixed, parts)           # parts -> mixed
+        self.trial, self.tests = fem.TrialFunction(self.mixed), fem.TestFunctions(self.mixed)
+        self.now, self.before, self.before2 = (fem.Function(self.mixed) for _ in range(3))
+        self.parts_now = fedm.Function_definition(self.scalar, "Function", n_equations)
+        self.parts_before = fedm.Function_definition(self.scalar, "Function", n_equations)
+        self.scratch = fem.Function(self.scalar)
+
+
+def electrode_conditions(case, space):
+    """Dirichlet values of the potential on the two electrodes for `space` (scalar or a sub-space)."""
+    def on_cathode(x, on_boundary):
+        return on_boundary and fem.near(x[1], 0)
+
+    def on_anode(x, on_boundary):
+        return on_boundary and fem.near(x[1], case.side)
+    return [fem.DirichletBC(space, fem.Constant(0.0), on_cathode),
+            fem.DirichletBC(space, fem.Constant(case.anode_voltage), on_anode)]
+
+
+def initial_state(case, deck, fl, dx, radius, writers, t):
+    """Seed + background densities and the potential they produce (one linear Poisson solve)."""
+    for k, text in enumerate((SEED, BACKGROUND)):
+        for target in (fl.parts_before, fl.parts_now):
+            target[k] = fem.interpolate(fem.Expression(text, degree=1), fl.scalar)
+    for k, writer in enumerate(writers["density"]):
+        fl.scratch.assign(fl.parts_before[k])
+        fl.scratch.rename(deck["file_names"][k + 1], str(k + 1))
+        writer << (fl.scratch, t)
+    space_charge = (fem.exp(fl.parts_before[0]) - fem.exp(fl.parts_before[1])) * elementary_charge / epsilon_0
+    poisson = fedm.weak_form_Poisson_equation(dx, fem.TrialFunction(fl.scalar), fem.TestFunction(fl.scalar),
+                                              space_charge, radius)
+    conditions = electrode_conditions(case, fl.scalar)
+    matrix, load = fem.assemble(fem.lhs(poisson)), fem.assemble(fem.rhs(poisson))
+    for condition in conditions:
+        condition.apply(matrix)
+        condition.apply(load)
+    potential = fem.Function(fl.scalar)
+    fem.solve(matrix, potential.vector(), load)
+    fl.scratch.assign(potential)
+    writers["potential"] << (fl.scratch, t)
+    for target in (fl.parts_before, fl.parts_now):
+        target[-1].assign(potential)
+
+
+def coupled_form(case, deck, fl, mesh, dx, radius, dt, dt_before):
+    """Ion and electron balance in logarithmic variables + Poisson, local field approximation."""
+    wall_tags = fedm.Marking_boundaries(mesh, list(case.wall_lines().values()))
+    ds = fem.Measure("ds", domain=mesh, subdomain_data=wall_tags)
+    outward = fem.FacetNormal(mesh)
+    u, v = fl.trial, fl.tests
+    n_sp, i_phi = deck["n_species"], deck["n_equations"] - 1
+    field_vector = -fem.grad(u[i_phi])
+    field_strength = fem.sqrt(fem.inner(-fem.grad(u[i_phi]), -fem.grad(u[i_phi])))
+    # the deck gives the electron coefficients as expressions of the field strength E_m (parsed, not
+    # eval'd); the ions of this model do not move
+    mobility = [deck["mobility"][0], deck_expression(deck["mobility"][1])]
+    diffusion = [deck["diffusion"][0], deck_expression(deck["diffusion"][1])]
+    ionisation = (1.1944e6 + 4.3666e26 * field_strength ** (-3)) * fem.exp(-2.73e7 / field_strength) - 340.75
+    production = ionisation * mobility[1] * field_strength * fem.exp(u[1])            # alpha |mu E| n_e
+    sources = [production, production]
+    fluxes = [0.0, fedm.Flux(deck["charge_numbers"][1], u[1], diffusion[1], mobility[1], field_vector,
+                             grad_diffusion=False)]
+    charge_density = sum(z * fem.exp(u[k]) * elementary_charge / epsilon_0
+                         for k, z in enumerate(deck["charge_numbers"][:n_sp]))
+    form = 0.0
+    for k in range(n_sp):
+        form += fedm.weak_form_balance_equation_log_representation(
+            case.kinds[k], dt, dt_before, dx, u[k], fl.before[k], fl.before2[k], v[k], sources[k], fluxes[k],
+            radius, diffusion[k])
+    form += fedm.weak_form_Poisson_equation(dx, u[i_phi], v[i_phi], charge_density, radius)
+    for tag, wall in enumerate(case.walls, start=1):
+        for k in range(n_sp):
+            form += fedm.Boundary_flux(case.walls[wall][k], case.kinds[k], case.roles[k], deck["charge_numbers"][k],
+                                       mobility[k], field_vector, outward, u[k], 0.0, v[k], ds(tag), radius)
+    return form, wall_tags
+
+
+def quiet_stdout(quiet):
     return contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()
 
 
+def main(cells=None, mesh_spacing=2.5e-5, mesh_file=None, end_time=None, input_dir=None, output_dir=None,
+         quiet=False, stop_before_device=None):
+    """Runs the case; returns (state as (n_vertices, 3) array of ln n_i, ln n_e, Phi; error-log path)."""
+    case = Case() if end_time is None else Case(end_time=end_time)
+    fem.parameters["form_compiler"]["quadrature_degree"] = 2
+    deck = read_deck(case, input_dir)
+    if output_dir is not None:
+        file_io.files.output_folder_path = Path(output_dir)
+    out = file_io.files.output_folder_path
+    writers = {"density": file_io.output_files("pvd", "number density", list(case.roles)),
+               "potential": file_io.output_files("pvd", "potential", ["Phi"])[0]}
+    dt = fem.Expression("time_step", time_step=case.first_step, degree=0)
+    dt_before = fem.Expression("time_step", time_step=1e30, degree=0)     # "no previous step": BDF2 starts as BDF1
+    charges = [z * elementary_charge for z in deck["charge_numbers"]]
+    file_io.log("conditions", file_io.files.model_log, dt.time_step, case.anode_voltage, case.pressure_torr, case.side,
+                case.gas_density, case.gas_temperature)
+    file_io.log("properties", file_io.files.model_log, "Air", case.deck, deck["file_names"], deck["masses"], charges)
+
+    mesh = load_mesh(case, cells, mesh_spacing, mesh_file, out / "mesh")
+    with quiet_stdout(quiet):
+        file_io.mesh_statistics(mesh)
+    radius = fem.Expression("x[0]", degree=1)
+    dx = fem.Measure("dx", domain=mesh)
+    fl = Fields(mesh, deck["n_equations"])
+    t = 0.0
+    file_io.log("initial time", file_io.files.model_log, t)
+    initial_state(case, deck, fl, dx, radius, writers, t)
+    form, wall_tags = coupled_form(case, deck, fl, mesh, dx, radius, dt, dt_before)
+    fem.File(str(out / "mesh" / "boundary_mesh_function.pvd")) << wall_tags
+    fl.join.assign(fl.before, list(fl.parts_before))
+    fl.join.assign(fl.now, list(fl.parts_now))
+
+    residual = fem.action(form, fl.now)
+    jacobian = fem.derivative(residual, fl.now, fl.trial)
+    build_problem = stop_before_device or fedm.Problem
+    problem = build_problem(jacobian, residual, electrode_conditions(case, fl.mixed.sub(deck["n_equations"] - 1)))
+    problem.device.setup_multigrid(nu=1)                 # preconditioner of the device's GMRES (no script counterpart)
+    newton = fedm.PETScSNESSolver()
+    newton.parameters["relative_tolerance"] = case.newton_rtol
+    newton.parameters["maximum_iterations"] = case.newton_max_it
+    newton.parameters["linear_solver"] = "gmres"
+
+    # what file_output interpolates between: potential first, then the species
+    order = [deck["n_equations"] - 1] + list(range(deck["n_species"]))
+    out_files = [writers["potential"]] + list(writers["density"])
+    out_names = ["Phi"] + list(case.roles)
+    out_now, out_before = [fl.parts_now[k] for k in order], [fl.parts_before[k] for k in order]
+    window, stride = case.output_windows[0], case.output_windows[0]
+    step_errors, recent_errors = [0.0] * deck["n_species"], [1] * 3
+    while abs(t - case.end_time) / case.end_time > 1e-6:
+        t_before = t
+        fl.before2.assign(fl.before)
+        fl.before.assign(fl.now)
+        fl.split.assign(list(fl.parts_before), fl.before)
+        with quiet_stdout(quiet):
+            t = fedm.adaptive_solver(newton, problem, t, dt, dt_before, fl.now, fl.before, list(fl.parts_now),
+                                     list(fl.parts_before), fl.split, step_errors, file_io.files.error_file,
+                                     recent_errors, case.step_tolerance, case.shortest_step,
+                                     time_dependent_arguments=[], approximation="LFA")
+        file_io.log("time", file_io.files.model_log, t)
+        dt_before.time_step = dt.time_step
+        dt.time_step = fedm.adaptive_timestep(dt.time_step, recent_errors, case.step_tolerance, case.shortest_step,
+                                              case.longest_step)
+        recent_errors[1:] = recent_errors[:2]
+        window, stride = file_io.file_output(t, t_before, window, stride, list(case.output_windows),
+                                             list(case.output_windows), ["pvd"] * len(order), out_files, out_names,
+                                             out_now, out_before)
+    return problem.device.get_state(), file_io.files.error_file
+
+
 if __name__ == "__main__":
-    state, log_path = main(n=int(sys.argv[1]) if len(sys.argv) > 1 else 64)
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--cells", type=int, help="N x N graded tensor-product mesh instead of the unstructured one")
+    ap.add_argument("--mesh-spacing", type=float, default=2.5e-5, help="finest spacing of the generated mesh [m]")
+    ap.add_argument("--mesh", help="DOLFIN XML mesh to load instead of generating one")
+    ap.add_argument("--end", type=float, default=1e-10, help="end time [s] (the reference script: 1.4e-8)")
+    ap.add_argument("--out", default="streamer_output")
+    a = ap.parse_args()
+    state, log_path = main(cells=a.cells, mesh_spacing=a.mesh_spacing, mesh_file=a.mesh, end_time=a.end,
+                           output_dir=a.out)
     print(open(log_path).read())

@@ -168,6 +168,7 @@ _SIGNATURES = {
     "fedm_debug_comm_fault": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
     "fedm_debug_comm_roundtrip": (C.c_int, [_P, _D, _D, C.c_int]),
     "fedm_pattern_stats": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_int64)]),
+    "fedm_pattern_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fedm_profile": (C.c_int, [_P, C.c_int]),
     "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
     "fedm_set_assembly": (C.c_int, [_P, C.c_int]),
@@ -187,6 +188,9 @@ EXPR_OPS = {"const": 0, "x": 1, "param": 2, "add": 3, "sub": 4, "mul": 5, "div":
 EXPR_MAX_OPS, EXPR_MAX_PARAMS, EXPR_STACK = 256, 16, 24
 
 
+ABI_VERSION = 2          # include/fedm_hip.h FEDM_ABI_VERSION
+
+
 def exported_symbols():
     return sorted(_SIGNATURES)
 
@@ -201,6 +205,10 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  fedm_amd has no CPU fallback.")
     lib = C.CDLL(os.fspath(LIB_PATH))
+    lib.fedm_abi_version.restype = C.c_int
+    if lib.fedm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI version {lib.fedm_abi_version()}, this binding was "
+                           f"written against {ABI_VERSION} (include/fedm_hip.h FEDM_ABI_VERSION): rebuild it")
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

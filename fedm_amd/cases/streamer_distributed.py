@@ -25,11 +25,15 @@ class Runner(streamer.Stepper):
     fallback_reason = None
 
     def __init__(self, per_gpu_mesh, rank, world, local_rank, grading=4.0, transport="rccl",
-                 group=None, n_per_gpu=None, global_n=None, distributed_multigrid=None, **kw):
-        """Mesh size: ``global_n`` cells per side of the whole mesh (strong scaling, e.g. BASELINE
-        configs[4]), else ``n_per_gpu`` (or the size of ``per_gpu_mesh``) cells per side PER GPU."""
+                 group=None, n_per_gpu=None, global_n=None, distributed_multigrid=None, mesh=None, **kw):
+        """Mesh: ``mesh`` (any triangle mesh of the box, e.g. `streamer.refined_mesh`) is the GLOBAL
+        mesh, partitioned as it is; else ``global_n`` cells per side of the whole tensor-product mesh
+        (strong scaling, e.g. BASELINE configs[4]), else ``n_per_gpu`` (or the size of
+        ``per_gpu_mesh``) cells per side PER GPU."""
         import torch.distributed as dist
-        if global_n:
+        if mesh is not None:
+            gmesh, n = mesh, 0
+        elif global_n:
             gmesh, n = streamer.mesh(int(global_n), grading), int(global_n)
         else:
             n_per_gpu = n_per_gpu or int(round(np.sqrt(per_gpu_mesh.num_cells() / 2)))
@@ -103,7 +107,8 @@ class Runner(streamer.Stepper):
         self.world_size = world
         self.transport = transport
         self.total_dofs = gmesh.num_vertices() * 3
-        self.partition_name = (f"RCB vertex partition, {world} parts, global mesh {n}x{n}, "
+        shape = f"{n}x{n}" if n else f"unstructured, {gmesh.num_vertices()} vertices"
+        self.partition_name = (f"RCB vertex partition, {world} parts, global mesh {shape}, "
                                f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices on rank {rank}, "
                                f"{len(lm.neighbours)} neighbours, transport {transport}")
 

@@ -754,7 +754,7 @@ using namespace fedm;
 extern "C" {
 
 const char *fedm_last_error(void) { return g_error.c_str(); }
-int fedm_abi_version(void) { return 1; }
+int fedm_abi_version(void) { return FEDM_ABI_VERSION; }
 
 static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *model,
                            const fedm_gd_desc *gd, int device, fedm_ctx **out);
@@ -996,7 +996,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         // (glow discharge, 402k DOFs: 70 against 100 steps per time step).  FEDM_PRECOND_SIDE or
         // fedm_set_preconditioner_side override.
         c.right_precond = c.model_kind == 0;
-        if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] >= '0' && lean[0] <= '2' ? lean[0] - '0' : 2;
+        if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] == '0' ? 0 : 2;
         if (const char *e = getenv("FEDM_XCD_REMAP")) c.xcd_remap = e[0] != '0';
         if (const char *e = getenv("FEDM_ASSEMBLY_OVERLAP")) c.assembly_overlap = e[0] != '0';
         if (const char *e = getenv("FEDM_SKIP_CONST_PLANES")) c.skip_const_planes = e[0] != '0';
@@ -1687,7 +1687,7 @@ int fedm_debug_comm_roundtrip(fedm_ctx *h, double *vec, double *red, int k) {
     return 0;
 }
 
-int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[8]) {
+int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[12]) {
     if (!mesh || !out || mesh->n_vertices < 3 || mesh->n_cells < 1) {
         set_error("null or empty mesh");
         return -2;
@@ -1725,6 +1725,10 @@ int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[8]) {
     out[5] = pairs;
     out[6] = clashes;
     out[7] = pat.nnz_blocks;
+    out[8] = pat.total_bc * SLICE;
+    out[9] = (int64_t)pat.patch_halo.size();
+    out[10] = (int64_t)pat.colour_ptr.size() - 1;
+    out[11] = 0;
     return 0;
 }
 
@@ -1876,6 +1880,26 @@ int fedm_sizes(fedm_ctx *h, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq
     if (nnz_blocks) *nnz_blocks = c.pat.nnz_blocks;
     if (stored_blocks) *stored_blocks = c.pat.total_bc * SLICE;
     if (n_colours) *n_colours = (int64_t)c.pat.colour_ptr.size() - 1;
+    return 0;
+}
+
+int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
+    if (!h || !out) return -2;
+    Ctx &c = h->c;
+    out[0] = c.pat.n_slices;
+    out[1] = c.pat.max_patch_cells;
+    out[2] = c.pat.max_patch_width;
+    out[3] = c.pat.max_patch_verts;
+    out[4] = (int64_t)c.pat.patch_cells.size();
+    out[5] = (int64_t)c.pat.patch_halo.size();
+    // the volume assembly a fedm_jacobian call runs: 0 global colouring, 1 LDS patches with the
+    // unrolled element routine, 2 LDS patches one equation row at a time (lean2 kernels)
+    bool ext = false;
+    for (int s = 0; s < c.ns; ++s) ext = ext || (c.model_kind == 0 && c.model.ext_nodes[s] > 0);
+    const bool lean2 = c.assembly_kind == 1 && c.assembly_lean >= 2 && c.poisson && c.model_kind == 0 && !ext &&
+                       c.model.n_qp == 3 && !c.model.linear_representation && c.pat.max_patch_cells <= 256;
+    out[6] = c.assembly_kind == 0 ? 0 : (lean2 ? 2 : 1);
+    out[7] = c.assembly_kind == 0 ? 0 : (c.pat.max_patch_cells <= 192 ? 192 : (lean2 ? 256 : 320));
     return 0;
 }
 

@@ -18,287 +18,11 @@ __device__ __forceinline__ double pick(const double (&v)[NS], int s) {
     return r;
 }
 
-template <int NS>
-__device__ __forceinline__ void poisson_row(const fedm_model_desc *__restrict__ md, const double (&G)[3][2],
-                                            const double (&W)[3], const double (&E)[2], const int (&lv)[3],
-                                            int wj0, int wj1, int wj2, const double *__restrict__ nql,
-                                            int nq_stride, double *__restrict__ acc, double *__restrict__ Fl) {
-    constexpr int NEQ = NS + 1, IPHI = NS;
-        double m2[NS][6], m1h[3] = {0.0, 0.0, 0.0}, m01 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) m2[i][k] = 0.0;
-        const double coe = md->charge_over_eps;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double h = 0.0, g[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const double cz = md->Z[i] * nql[(q * NS + i) * nq_stride] * coe;
-                h -= cz;
-                g[i] = -cz;
-            }
-            const double Wq = W[q];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double pa = Wq * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
-                m1h[a] += pa * h;
-#pragma unroll
-                for (int b = a; b < 3; ++b) {
-                    const double pp = pa * (b == q ? 2.0 / 3.0 : 1.0 / 6.0);
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) m2[i][sym6(a, b)] += pp * g[i];
-                }
-            }
-            m01 += Wq;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int lane = lv[a];
-            if (lane >= SLICE) continue;
-            unsafeAtomicAdd(&Fl[lane * NEQ + IPHI], m1h[a] - (E[0] * G[a][0] + E[1] * G[a][1]) * m01);
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int k = sym6(a, b);
-                const double ggk = G[a][0] * G[b][0] + G[a][1] * G[b][1];
-                const int e = a * 3 + b;
-                const int jab = ((e < 4 ? wj0 : e < 8 ? wj1 : wj2) >> (8 * (e & 3))) & 255;
-                double *dst = acc + (size_t)jab * NEQ * SLICE + lane;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) unsafeAtomicAdd(&dst[i * SLICE], m2[i][k]);
-                unsafeAtomicAdd(&dst[IPHI * SLICE], ggk * m01);
-            }
-        }
-    }
-
 // The packed indices of a cell (local vertex ids, block columns) are all that a thread keeps in
 // registers between equation rows.
 struct LeanCell {
     int wl, wj0, wj1, wj2;
 };
-
-// once per cell: pack the indices; exp(u) of every species at the three quadrature points goes to
-// a per-thread LDS column (6 doubles that would otherwise be live across every row)
-template <int NS>
-__device__ __forceinline__ LeanCell lean_prologue(const PatchCell &pc, const double *__restrict__ Ul,
-                                                  double *__restrict__ nql, int nq_stride) {
-    constexpr int NEQ = NS + 1;
-    LeanCell lc;
-    lc.wl = pc.lv[0] | (pc.lv[1] << 8) | (pc.lv[2] << 16);
-    lc.wj0 = pc.j[0] | (pc.j[1] << 8) | (pc.j[2] << 16) | (pc.j[3] << 24);
-    lc.wj1 = pc.j[4] | (pc.j[5] << 8) | (pc.j[6] << 16) | (pc.j[7] << 24);
-    lc.wj2 = pc.j[8];
-    const int l0 = pc.lv[0], l1 = pc.lv[1], l2 = pc.lv[2];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const double u0 = Ul[l0 * NEQ + i], u1 = Ul[l1 * NEQ + i], u2 = Ul[l2 * NEQ + i];
-        const double sum6 = (u0 + u1 + u2) * (1.0 / 6.0);
-        // (one exp at a time: six interleaved ones cost 100 registers)
-        __builtin_amdgcn_sched_barrier(0);
-        nql[(0 * NS + i) * nq_stride] = exp(sum6 + 0.5 * u0);
-        __builtin_amdgcn_sched_barrier(0);
-        nql[(1 * NS + i) * nq_stride] = exp(sum6 + 0.5 * u1);
-        __builtin_amdgcn_sched_barrier(0);
-        nql[(2 * NS + i) * nq_stride] = exp(sum6 + 0.5 * u2);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return lc;
-}
-
-// One equation row of one cell: residual and Jacobian entries of the row's vertices that this
-// patch owns (local id < 64), accumulated with LDS atomics into Fl [64][NEQ] and into the ROW's
-// accumulators acc [block column][NEQ][64].  Everything but the packed indices is recomputed
-// from the LDS staging area (geometry, field: a few dozen instructions), so nothing else
-// occupies registers from one row to the next.
-template <int NS, int NR>
-__device__ __forceinline__ void lean_row(const fedm_model_desc *__restrict__ md, int row, const LeanCell &lc,
-                                         const double *__restrict__ vx, const double *__restrict__ Ul,
-                                         const double *__restrict__ Hl, const StepCoef sc,
-                                         double *__restrict__ acc, double *__restrict__ Fl,
-                                         const double *__restrict__ nql, int nq_stride) {
-    constexpr int NEQ = NS + 1, IPHI = NS;
-    const double two_pi = 6.283185307179586476925286766559;
-    const int wl = lc.wl, wj0 = lc.wj0, wj1 = lc.wj1, wj2 = lc.wj2;
-    int lv[3];
-    {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) lv[a] = (wl >> (8 * a)) & 255;
-        // geometry
-        double G[3][2], W[3];
-        {
-            double x[3][2];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                x[a][0] = vx[2 * lv[a]];
-                x[a][1] = vx[2 * lv[a] + 1];
-            }
-            CellGeom cg;
-            cg.init(x, md->axisymmetric);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                G[a][0] = cg.G[a][0];
-                G[a][1] = cg.G[a][1];
-            }
-            // quadrature weights times 2 pi r: points (1/6,1/6), (2/3,1/6), (1/6,2/3) -> the basis
-            // function values at point q are 2/3 for vertex q and 1/6 for the other two
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                double rq = 0.0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) rq += cg.rn[a] * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
-                W[q] = (1.0 / 6.0) * cg.detJ * two_pi * rq;
-            }
-        }
-        // field
-        double gradPhi[2] = {0.0, 0.0};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double p = Ul[lv[a] * NEQ + IPHI];
-            gradPhi[0] += p * G[a][0];
-            gradPhi[1] += p * G[a][1];
-        }
-        double E[2] = {-gradPhi[0], -gradPhi[1]};
-        const double Em = sqrt(E[0] * E[0] + E[1] * E[1]);
-        double invEm = 1.0 / Em;
-        const double lnE = log(Em);
-        if (row == NS) {
-            poisson_row<NS>(md, G, W, E, lv, wj0, wj1, wj2, nql, nq_stride, acc, Fl);
-            return;
-        }
-        const int s = row;
-        // rate coefficients (the sources couple the species)
-        const int nreac = md->n_reactions;
-        double kv[NR], kd[NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            kv[j] = kd[j] = 0.0;
-            if (j < nreac) termsum_eval(md->k[j], Em, invEm, lnE, kv[j], kd[j]);
-        }
-        double Us[3], Hs[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            Us[a] = Ul[lv[a] * NEQ + s];
-            Hs[a] = Hl[lv[a] * NS + s];
-        }
-        const int eq = md->eq_type[s];
-        const bool flux = eq != FEDM_EQ_REACTION;
-        double Dv = 0.0, Dd = 0.0, muv = 0.0, mud = 0.0, vel[2] = {0.0, 0.0}, gradu[2] = {0.0, 0.0};
-        bool fdrift = false;
-        const double Z = md->Z[s];
-        if (flux) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                gradu[0] += Us[a] * G[a][0];
-                gradu[1] += Us[a] * G[a][1];
-            }
-            termsum_eval(md->D[s], Em, invEm, lnE, Dv, Dd);
-            vel[0] = -Dv * gradu[0];
-            vel[1] = -Dv * gradu[1];
-            if (eq == FEDM_EQ_DRIFT_DIFFUSION_REACTION) {
-                if (md->has_drift_w[s]) {
-                    vel[0] += md->drift_w[s][0];
-                    vel[1] += md->drift_w[s][1];
-                } else {
-                    termsum_eval(md->mu[s], Em, invEm, lnE, muv, mud);
-                    vel[0] += Z * muv * E[0];
-                    vel[1] += Z * muv * E[1];
-                    fdrift = true;
-                }
-            }
-        }
-        // moments of the row
-        double m2[NS][6], m1h[3] = {0.0, 0.0, 0.0}, m1n[3] = {0.0, 0.0, 0.0}, m1sp[3] = {0.0, 0.0, 0.0}, m0n = 0.0;
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) m2[i][k] = 0.0;
-        const double usum6 = (Us[0] + Us[1] + Us[2]) * (1.0 / 6.0), hsum6 = (Hs[0] + Hs[1] + Hs[2]) * (1.0 / 6.0);
-        // (unrolled, but the scheduler may not interleave the points: one point's temporaries at a time)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            __builtin_amdgcn_sched_barrier(0);
-            double nqq[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) nqq[i] = nql[(q * NS + i) * nq_stride];
-            const double ns_ = pick<NS>(nqq, s);
-            const double u_part = sc.c_new * (usum6 + 0.5 * Us[q]) + (hsum6 + 0.5 * Hs[q]);
-            double h = ns_ * u_part * sc.inv_dt, sp = 0.0, g[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) g[i] = (i == s) ? ns_ * (u_part + sc.c_new) * sc.inv_dt : 0.0;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                if (j >= nreac) break;
-                const double nu = (double)md->net[j][s];
-                if (nu == 0.0) continue;
-                double prod = 1.0;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    const int P = md->power[j][i];
-                    for (int e = 0; e < P; ++e) prod *= nqq[i];
-                }
-                h -= nu * kv[j] * prod;
-                sp += nu * kd[j] * prod;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    const int P = md->power[j][i];
-                    if (P) g[i] -= nu * kv[j] * (double)P * prod;
-                }
-            }
-            const double Wq = W[q];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double pa = Wq * (a == q ? 2.0 / 3.0 : 1.0 / 6.0);
-                m1h[a] += pa * h;
-                m1n[a] += pa * ns_;
-                m1sp[a] += pa * sp;
-#pragma unroll
-                for (int b = a; b < 3; ++b) {
-                    const double pp = pa * (b == q ? 2.0 / 3.0 : 1.0 / 6.0);
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) m2[i][sym6(a, b)] += pp * g[i];
-                }
-            }
-            m0n += Wq * ns_;
-        }
-        // factors shared by the row's entries
-        double velG[3] = {0.0, 0.0, 0.0}, T[3] = {m1sp[0], m1sp[1], m1sp[2]}, DGm = 0.0, Kd = 0.0;
-        if (flux) {
-            DGm = Dv * m0n;
-            const double zmud = fdrift ? Z * mud : 0.0;
-            if (fdrift) Kd = Z * muv * m0n;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                velG[a] = vel[0] * G[a][0] + vel[1] * G[a][1];
-                const double Pa = gradu[0] * G[a][0] + gradu[1] * G[a][1];
-                const double Qa = E[0] * G[a][0] + E[1] * G[a][1];
-                T[a] += (zmud * Qa - Dd * Pa) * m0n;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int lane = lv[a];
-            if (lane >= SLICE) continue;  // row vertex owned by another patch
-            unsafeAtomicAdd(&Fl[lane * NEQ + s], m1h[a] - velG[a] * m0n);
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int k = sym6(a, b);
-                const double ggk = G[a][0] * G[b][0] + G[a][1] * G[b][1];
-                const double dEb = -(E[0] * G[b][0] + E[1] * G[b][1]) * invEm;
-                const int e = a * 3 + b;
-                const int jab = ((e < 4 ? wj0 : e < 8 ? wj1 : wj2) >> (8 * (e & 3))) & 255;
-                double *dst = acc + (size_t)jab * NEQ * SLICE + lane;
-#pragma unroll
-                for (int i = 0; i < NS; ++i)
-                    unsafeAtomicAdd(&dst[i * SLICE], m2[i][k] + ((i == s) ? DGm * ggk - velG[a] * m1n[b] : 0.0));
-                unsafeAtomicAdd(&dst[IPHI * SLICE], Kd * ggk - dEb * T[a]);
-            }
-        }
-    }
-
-}
 
 // =============================================================================================
 // Second generation of the row-at-a-time routine (assemble_lean2_kernel).  Differences:

@@ -277,93 +277,6 @@ __device__ __forceinline__ void lds_only_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// F + J one equation row at a time (element_lean.hpp).  The rows are phases of the WORKGROUP: all
-// cells emit row r into accumulators that hold that row only (a third of the LDS), the row's
-// planes are streamed out, the next row follows.  168 VGPRs and 29 KB of LDS: four 3-wave
-// workgroups per CU (3 waves/SIMD) instead of two.
-template <int NS, int NR, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void assemble_lean_kernel(
-    FEDM_PATCH_PARAMS) {
-    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
-    extern __shared__ __align__(16) double lds[];
-    double *acc = lds;                          // [width][NEQ][64]: one row of every block
-    double *Fl = acc + acc_doubles;             // [64][NEQ]
-    double *vx = Fl + SLICE * NEQ;              // [max_verts][2]
-    double *Ul = vx + 2 * max_verts;            // [max_verts][NEQ]
-    double *Hl = Ul + NEQ * max_verts;          // [max_verts][NS]
-    double *nql = Hl + NS * max_verts;          // [3 * NS][THREADS]
-#ifdef FEDM_PHASE_TIMING
-    unsigned long long t_prev_ = wall_clock64();
-#endif
-    const int S = blockIdx.x;
-    const int b0 = boff[S], width = boff[S + 1] - b0;
-    const int n_acc = width * NEQ * SLICE;      // a multiple of 64: 16-byte LDS / HBM accesses
-    // the thread's cell record is requested first: its two dependent global loads travel with the
-    // staging loads below instead of after them
-    const int c0 = cell_ptr[S], n_cells = cell_ptr[S + 1] - c0;
-    const bool active = (int)threadIdx.x < n_cells;   // one cell per thread (n_cells <= THREADS)
-    PatchCell pc_own = {};
-    if (active) pc_own = pcells[c0 + threadIdx.x];
-    {
-        double2 *acc2 = reinterpret_cast<double2 *>(acc);
-        for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) acc2[k] = make_double2(0.0, 0.0);
-    }
-    for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) Fl[k] = 0.0;
-    const int h0 = halo_ptr[S], n_local = SLICE + halo_ptr[S + 1] - h0;
-    for (int i = threadIdx.x; i < n_local; i += THREADS) {
-        const int g = (i < SLICE) ? S * SLICE + i : halo[h0 + i - SLICE];
-        if (g < nv) {
-            vx[2 * i] = coords[2 * (size_t)g];
-            vx[2 * i + 1] = coords[2 * (size_t)g + 1];
-#pragma unroll
-            for (int s = 0; s < NEQ; ++s) Ul[i * NEQ + s] = u[(size_t)g * NEQ + s];
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                Hl[i * NS + s] = sc.c_old * uold[(size_t)g * NEQ + s] + sc.c_old1 * uold1[(size_t)g * NEQ + s];
-        }
-    }
-    FEDM_T(0)   // zero + stage (issue)
-    __syncthreads();
-    FEDM_T(1)   // barrier: the staged loads arrive
-    LeanCell lc = {0, 0, 0, 0};
-    if (active) lc = lean_prologue<NS>(pc_own, Ul, nql + threadIdx.x, THREADS);
-    FEDM_T(2)   // prologue: cell record, exp(u) at the quadrature points
-#pragma unroll 1
-    for (int row = 0; row < NEQ; ++row) {
-        asm volatile("" : "+v"(lc.wl), "+v"(lc.wj0), "+v"(lc.wj1), "+v"(lc.wj2));  // nothing hoisted out of the row
-        if (active) lean_row<NS, NR>(md, row, lc, vx, Ul, Hl, sc, acc, Fl, nql + threadIdx.x, THREADS);
-        FEDM_T(3)   // the row (wave 0's view)
-        __syncthreads();
-        FEDM_T(4)   // barrier: the other waves finish the row
-        // the row's planes of every block: NEQ * 64 consecutive doubles per block in HBM
-        constexpr int PER = NEQ * SLICE / 2;   // 16-byte pieces per block column
-        if constexpr (THREADS % PER == 0) {
-            // a thread keeps its place within the block column and strides over the columns
-            const int rem = threadIdx.x % PER;
-            for (int bc = threadIdx.x / PER; bc < width; bc += THREADS / PER) {
-                double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
-                double2 *src = reinterpret_cast<double2 *>(acc) + bc * PER + rem;
-                dst[rem] = *src;
-                *src = make_double2(0.0, 0.0);
-            }
-        } else {
-            for (int k = threadIdx.x; k < n_acc / 2; k += THREADS) {
-                const int bc = k / PER, rem = k - bc * PER;
-                double2 *dst = reinterpret_cast<double2 *>(val + ((size_t)(b0 + bc) * NEQ2 + row * NEQ) * SLICE);
-                double2 *src = reinterpret_cast<double2 *>(acc) + k;
-                dst[rem] = *src;
-                *src = make_double2(0.0, 0.0);
-            }
-        }
-        FEDM_T(5)   // stream-out + zeroing (issue)
-        lds_only_barrier();   // accumulators zero again; the stores above stay in flight
-        FEDM_T(6)
-    }
-    double *fdst = F + (size_t)S * SLICE * NEQ;
-    for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) fdst[k] = Fl[k];
-    FEDM_T(7)
-}
-
 // Workgroups b, b + 8, b + 16, ... are observed to share an XCD (round-robin dispatch; a speed
 // heuristic, never relied upon for correctness): give every XCD a contiguous range of patches so
 // that the halo vertices two neighbouring patches both stage are served by ONE L2.
@@ -551,17 +464,25 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     if constexpr (PO && CACHE == 2 && NS >= 1 && !LIN) {
         bool ext = false;
         for (int s_ = 0; s_ < NS; ++s_) ext = ext || c.model.ext_nodes[s_] > 0;
-        if (mode == 0 && !ext && c.assembly_lean >= 2 && c.pat.max_patch_cells <= 192) {
+        if (mode == 0 && !ext && c.assembly_lean >= 2 && c.pat.max_patch_cells <= 256) {
+            // one cell per thread: 192 threads where every patch has at most 192 cells (tensor-product
+            // meshes: 160; compact patches of an unstructured mesh: 170-190), else 256
+            const int T = c.pat.max_patch_cells <= 192 ? 192 : 256;
             const int acc_row = jacobian ? c.pat.max_patch_width * NEQ * SLICE : 0;
             const size_t lds_bytes = sizeof(double) * ((size_t)acc_row + SLICE * NEQ + 2 * c.pat.max_patch_verts +
                                                        (size_t)(NEQ + 2 * NS) * c.pat.max_patch_verts +
-                                                       (size_t)LeanStash<NR>::N * 192);
-#define FEDM_LEAN2_LAUNCH(KERNEL, LIST, N)                                                                  \
-    hipLaunchKernelGGL((KERNEL<NS, NR, 192>), dim3(N), dim3(192), lds_bytes, c.stream, c.d_model,           \
+                                                       (size_t)LeanStash<NR>::N * T);
+#define FEDM_LEAN2_LAUNCH_T(KERNEL, LIST, N, TT)                                                            \
+    hipLaunchKernelGGL((KERNEL<NS, NR, TT>), dim3(N), dim3(TT), lds_bytes, c.stream, c.d_model,             \
                        c.nv, c.d_slice_boff, c.d_patch_cell_ptr, c.d_patch_cells, c.d_patch_halo_ptr,       \
                        c.d_patch_halo, c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc, c.d_ext[0], c.d_ext[1],  \
                        c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_row, c.pat.max_patch_verts,        \
                        c.xcd_remap ? 1 : 0, LIST, cmask)
+#define FEDM_LEAN2_LAUNCH(KERNEL, LIST, N)                                                                  \
+    do {                                                                                                    \
+        if (T == 192) FEDM_LEAN2_LAUNCH_T(KERNEL, LIST, N, 192);                                            \
+        else FEDM_LEAN2_LAUNCH_T(KERNEL, LIST, N, 256);                                                     \
+    } while (0)
 #define FEDM_LEAN2_BOTH(LIST, N)                                                                            \
     do {                                                                                                    \
         if ((N) <= 0) break;                                                                                \
@@ -589,19 +510,8 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
             }
 #undef FEDM_LEAN2_BOTH
 #undef FEDM_LEAN2_LAUNCH
+#undef FEDM_LEAN2_LAUNCH_T
             if (jacobian) c.const_planes_valid = true;
-            return;
-        }
-        flush_pending_halo(c);
-        if (jacobian && mode == 0 && !ext && c.assembly_lean && c.pat.max_patch_cells <= 192) {
-            const int acc_row = c.pat.max_patch_width * NEQ * SLICE;
-            const size_t lds_bytes = sizeof(double) * ((size_t)acc_row + SLICE * NEQ + 2 * c.pat.max_patch_verts +
-                                                       (size_t)(NEQ + NS) * c.pat.max_patch_verts + 3 * NS * 192);
-            hipLaunchKernelGGL((assemble_lean_kernel<NS, NR, 192>), dim3(c.pat.n_slices), dim3(192), lds_bytes,
-                               c.stream, c.d_model, c.nv, c.d_slice_boff, c.d_patch_cell_ptr, c.d_patch_cells,
-                               c.d_patch_halo_ptr, c.d_patch_halo, c.d_coords, c.d_u, c.d_uold, c.d_uold1, sc,
-                               c.d_ext[0], c.d_ext[1], c.d_ext[2], c.d_ext[3], c.d_val, c.d_F, mode, acc_row,
-                               c.pat.max_patch_verts);
             return;
         }
     }

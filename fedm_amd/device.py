@@ -199,20 +199,99 @@ def _part1by1(v):
     return v
 
 
-def locality_order(coords):
-    """Vertex order along a Z-curve over the rank-quantised coordinates.
-
-    64 consecutive vertices then form a compact 2-D patch (about 8x8 on a
-    tensor-product mesh, whatever its grading), which is what the slice-based kernels
-    want: few halo vertices per assembly patch, neighbours of a matrix slice within a
-    few cache lines, aggregates of the multigrid contiguous in memory.
-    Returns ``order`` (new -> old)."""
+def z_curve_order(coords):
+    """Vertex order along a Z-curve over the rank-quantised coordinates: on a tensor-product mesh,
+    whatever its grading, 64 consecutive vertices form an 8x8 block."""
     ranks = []
     for d in range(2):
         _, inv = np.unique(coords[:, d], return_inverse=True)
         ranks.append(inv.astype(np.uint64))
     key = _part1by1(ranks[0]) | (_part1by1(ranks[1]) << np.uint64(1))
     return np.argsort(key, kind="stable")
+
+
+def _vertex_spacing(coords, cells):
+    """Mean |dx|, |dy| of the edges at every vertex: the metric in which a patch should be round."""
+    e = np.concatenate([cells[:, [0, 1]], cells[:, [1, 2]], cells[:, [2, 0]]])
+    d = np.abs(coords[e[:, 0]] - coords[e[:, 1]])
+    acc, cnt = np.zeros_like(coords), np.zeros(coords.shape[0])
+    for k in (0, 1):
+        np.add.at(acc, e[:, k], d)
+        np.add.at(cnt, e[:, k], 1.0)
+    h = acc / np.maximum(cnt, 1.0)[:, None]
+    h[h <= 0.0] = h[h > 0.0].mean() if np.any(h > 0.0) else 1.0
+    return h
+
+
+def bisection_order(coords, spacing=None, leaf=64):
+    """Vertex order by recursive median bisection (a k-d tree whose leaves are the 64-vertex
+    slices): each split halves the vertex set across its longer side, measured in local mesh
+    spacings, and puts a multiple of 64 vertices to the left, so that every slice is one leaf -- a
+    compact patch on a locally refined unstructured mesh, where the quantised Z-curve tears patches
+    apart.  Inside a leaf the bisection goes on down to single vertices (a Z-like local order)."""
+    n = coords.shape[0]
+    h = np.ones_like(coords) if spacing is None else spacing
+    order = np.arange(n)
+    stack = [(0, n)]
+    while stack:
+        a, b = stack.pop()
+        m = b - a
+        if m <= leaf:
+            continue
+        idx = order[a:b]
+        p = coords[idx]
+        ext = (p.max(axis=0) - p.min(axis=0)) / h[idx].mean(axis=0)
+        d = 0 if ext[0] >= ext[1] else 1
+        n_left = ((m + leaf - 1) // leaf + 1) // 2 * leaf
+        order[a:b] = idx[np.argpartition(p[:, d], n_left - 1)]
+        stack.append((a, a + n_left))
+        stack.append((a + n_left, b))
+    n_leaves = (n + leaf - 1) // leaf
+    o = np.concatenate([order, np.full(n_leaves * leaf - n, -1, dtype=order.dtype)])
+    g = leaf
+    while g > 1:                                   # all leaves at once, one level per pass
+        grp = o.reshape(-1, g)
+        valid = grp >= 0
+        safe = np.maximum(grp, 0)
+        P, H = coords[safe], h[safe]
+        lo = np.where(valid[..., None], P, np.inf).min(axis=1)
+        hi = np.where(valid[..., None], P, -np.inf).max(axis=1)
+        hm = np.where(valid[..., None], H, 0.0).sum(axis=1) / np.maximum(valid.sum(axis=1), 1)[:, None]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ext = (hi - lo) / hm
+        d = np.where(np.nan_to_num(ext[:, 0], nan=0.0) >= np.nan_to_num(ext[:, 1], nan=0.0), 0, 1)
+        key = np.where(valid, np.take_along_axis(P, d[:, None, None], axis=2)[..., 0], np.inf)
+        o = np.take_along_axis(grp, np.argsort(key, axis=1, kind="stable"), axis=1).reshape(-1)
+        g //= 2
+    return o[o >= 0]
+
+
+def cell_visits(order, cells, n_vertices, leaf=64):
+    """Cell evaluations of the patch assembly under a vertex order: a cell is evaluated once by
+    every slice that owns one of its vertices."""
+    inv = np.empty(n_vertices, dtype=np.int64)
+    inv[order] = np.arange(order.size)
+    s = np.sort(inv[cells] // leaf, axis=1)
+    return int(cells.shape[0] + (s[:, 1] != s[:, 0]).sum() + (s[:, 2] != s[:, 1]).sum())
+
+
+def locality_order(coords, cells=None):
+    """Internal vertex numbering of the device path (returns ``order``: new -> old).
+
+    64 consecutive vertices are one slice = one assembly patch = one wavefront of matrix rows, so
+    the order should make them compact: few halo vertices and redundant cell evaluations per patch,
+    the neighbours of a matrix slice within a few cache lines, multigrid aggregates contiguous.
+    Two candidates -- the Z-curve over rank-quantised coordinates (ideal on tensor-product meshes,
+    whatever their grading) and recursive bisection in the metric of the local mesh spacing (for
+    unstructured, locally refined meshes) -- and the one with fewer redundant cell evaluations is
+    taken; without ``cells`` the Z-curve.  Deterministic: every rank computes the same order."""
+    z = z_curve_order(coords)
+    if cells is None or len(cells) == 0:
+        return z
+    cells = np.asarray(cells)
+    kd = bisection_order(coords, _vertex_spacing(coords, cells))
+    nv = coords.shape[0]
+    return z if cell_visits(z, cells, nv) <= cell_visits(kd, cells, nv) else kd
 
 
 def pattern_stats(coords, cells, reorder=True):
@@ -222,7 +301,7 @@ def pattern_stats(coords, cells, reorder=True):
     lib = _lib.load()
     coords = np.ascontiguousarray(coords, dtype=np.float64)
     cells = np.ascontiguousarray(cells, dtype=np.int32)
-    order = locality_order(coords) if reorder else np.arange(coords.shape[0])
+    order = locality_order(coords, cells) if reorder else np.arange(coords.shape[0])
     inv = np.empty(coords.shape[0], dtype=np.int64)
     inv[order] = np.arange(coords.shape[0])
     cdev = np.ascontiguousarray(coords[order])
@@ -231,12 +310,13 @@ def pattern_stats(coords, cells, reorder=True):
     mesh.n_vertices, mesh.n_cells = coords.shape[0], cells.shape[0]
     mesh.coords = _dp(cdev)
     mesh.cells = kdev.ctypes.data_as(C.POINTER(C.c_int32))
-    out = (C.c_int64 * 8)()
+    out = (C.c_int64 * 12)()
     rc = lib.fedm_pattern_stats(C.byref(mesh), out)
     if rc != 0:
         raise RuntimeError(f"fedm_pattern_stats failed ({rc}): {_lib.last_error()}")
     keys = ("n_slices", "max_patch_cells", "max_patch_width", "max_patch_verts", "cell_visits",
-            "owned_pairs", "bank_clashes", "nnz_blocks")
+            "owned_pairs", "bank_clashes", "nnz_blocks", "stored_blocks", "halo_vertices", "n_colours",
+            "reserved")
     return dict(zip(keys, (int(v) for v in out)))
 
 
@@ -262,7 +342,9 @@ class DeviceProblem:
         self.n_owned = self.nv if n_owned is None else int(n_owned)
         self._order = np.arange(self.nv)
         if reorder:
-            self._order[:self.n_owned] = locality_order(self.coords[:self.n_owned])
+            # (cells among the owned vertices: across GPUs the ghosts keep their place at the end)
+            own_cells = self.cells[(self.cells < self.n_owned).all(axis=1)]
+            self._order[:self.n_owned] = locality_order(self.coords[:self.n_owned], own_cells)
         self._inv = np.empty(self.nv, dtype=np.int64)
         self._inv[self._order] = np.arange(self.nv)
         neq = self.n_eq
@@ -769,7 +851,16 @@ class DeviceProblem:
         out = dict(zip(keys, (x.value for x in v)))
         kept, zero = self.plane_masks()
         out["kept_planes"], out["zero_planes"] = bin(kept).count("1"), bin(zero).count("1")
+        info = (C.c_int64 * 8)()
+        self._check(self.lib.fedm_pattern_info(self._h, info), "fedm_pattern_info")
+        out.update(zip(("n_slices", "max_patch_cells", "max_patch_width", "max_patch_verts", "cell_visits",
+                        "halo_vertices"), (int(v) for v in info[:6])))
+        out["assembly_variant"] = ("global colouring", "lds-patches/unrolled", "lds-patches")[int(info[6])]
+        out["patch_threads"] = int(info[7])
         return out
+
+    def assembly_variant(self):
+        return self.sizes()["assembly_variant"]
 
 
 def rccl_unique_id():

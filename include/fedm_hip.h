@@ -187,6 +187,11 @@ typedef struct {
 typedef struct fedm_ctx fedm_ctx;
 
 const char *fedm_last_error(void);
+/* Version of this header's structs and entry points; a binding compares it with the constant it was
+ * written against and refuses a library of another version (a descriptor that grew would otherwise be
+ * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
+ * fedm_pattern_stats out[12]. */
+#define FEDM_ABI_VERSION 2
 int fedm_abi_version(void);
 
 /* mesh + model -> device: colouring, sliced block-ELL pattern, buffers.
@@ -361,8 +366,15 @@ int fedm_debug_comm_roundtrip(fedm_ctx *ctx, double *vec, double *red, int k);
  * sparsity pattern (fedm/functions.py:192,200).  out = {matrix slices (= assembly patches),
  * max cells per patch, max block columns per slice, max staged vertices per patch, cell visits
  * of all patches, owned (cell, local vertex) pairs, pairs that clash with another cell of their
- * 16-lane group on an LDS accumulator bank (FEDM_PATCH_ORDER, see csrc/prep.cpp), structural blocks}. */
-int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[8]);
+ * 16-lane group on an LDS accumulator bank (FEDM_PATCH_ORDER, see csrc/prep.cpp), structural blocks,
+ * stored blocks of the sliced block-ELL layout (structural + padding), halo vertices staged by all
+ * patches, colours of the global cell colouring, 0}. */
+int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[12]);
+/* The same for a live context, and which volume-assembly kernels it runs: out = {slices, max cells per
+ * patch, max block columns per slice, max staged vertices per patch, cell visits, halo vertices,
+ * assembly variant (0 global colouring, 1 LDS patches / unrolled element routine, 2 LDS patches / one
+ * equation row at a time), threads per patch workgroup}. */
+int fedm_pattern_info(fedm_ctx *ctx, int64_t out[8]);
 
 /* |new - old + eps| / |old + eps| on one component        fedm/functions.py:1062-1064 */
 int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);

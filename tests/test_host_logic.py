@@ -412,10 +412,11 @@ def test_patch_micro_colouring_removes_lds_bank_clashes(monkeypatch):
 
 
 def test_lmea_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):
-    """examples/glow_discharge.py follows fedm-gd.py:196-408 call for call; `Problem()` hands the
-    form to fedm_amd.lmea.compile_lmea, which must recover the parameters of the device's LMEA
-    model from the script's own objects (and refuse what the kernels do not implement).  Runs up to
-    the point where the device context would be created."""
+    """examples/glow_discharge.py (our own driver for the case of fedm-gd.py) builds the LMEA form
+    with the facade's functions; `Problem()` hands it to fedm_amd.lmea.compile_lmea, which must
+    recover the parameters of the device's LMEA model from the script's own objects (and refuse
+    what the kernels do not implement).  Runs up to the point where the device context would be
+    created.  (The reference's script itself: tests/test_reference_scripts.py.)"""
     import importlib.util
     import fedm_amd.functions as ff
     from fedm_amd import lmea
@@ -431,9 +432,8 @@ def test_lmea_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):
     def capture(J, F, bcs):
         seen.update(F=F, bcs=bcs)
         raise Stop
-    monkeypatch.setattr(mod, "Problem", capture)
     with pytest.raises(Stop):
-        mod.main(nx=6, ny=6, output_dir=tmp_path)
+        mod.main(nx=6, ny=6, output_dir=tmp_path, stop_before_device=capture)
     model, mesh, tags = ff.compile_forms(seen["F"])
     assert model.n_species == 4 and model.n_eq == 5 and model.N0 == pytest.approx(3.21877e22)
     assert model.eq_type == ["reaction", "diffusion-reaction", "drift-diffusion-reaction", "drift-diffusion-reaction"]
@@ -597,10 +597,10 @@ def test_cpp_expression_subset_evaluates_the_reference_strings_and_refuses_the_r
 
 
 def test_time_of_flight_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):
-    """examples/time_of_flight.py follows fedm-tof.py call for call.  With the device replaced by
-    a recorder: the forms lower to the model of cases/time_of_flight, the states are the script's
-    interpolated Functions, and every solve sees the script's step sizes and its source Expression
-    at the advanced time, interpolated at the P2 lattice nodes."""
+    """examples/time_of_flight.py (our own driver for the case of fedm-tof.py).  With the device
+    replaced by a recorder: the forms lower to the model of cases/time_of_flight, the states are the
+    script's interpolated Functions, and every solve sees the script's step sizes and its source
+    Expression at the advanced time, interpolated at the P2 lattice nodes."""
     import importlib.util
     import fedm_amd.device as fdev
     from fedm_amd.cases import time_of_flight as tof
@@ -658,12 +658,12 @@ def test_time_of_flight_script_is_lowered_onto_the_device_model(tmp_path, monkey
     assert list(model.drift_w) == [(0.0, tof.WEZ)] and model.D[0].const_value() == tof.DE
     assert model.quadrature_degree == 8 and list(model.ext_source_degree) == [2] and model.axisymmetric
     assert calls[1] == ("set_state", ["u_new", "u_old", "u_old1"])
-    mesh = mod.RectangleMesh((0.0, 0.0), (2.5e-4, 5e-4), 8, 8)
+    mesh = mod.fem.RectangleMesh((0.0, 0.0), (2.5e-4, 5e-4), 8, 8)
     nodes = tof.p2_nodes(mesh.coords, mesh.cells)
     per_step = [c for c in calls[2:] if c[0] != "set_state"]
     assert [c[0] for c in per_step] == ["shift", "step", "source", "solve"] * 3
     assert per_step[1] == ("step", 1e-12, 1e30) and per_step[5] == ("step", 1e-12, 1e30) \
-        and per_step[9] == ("step", 1e-12, 1e-12)                 # fedm-tof.py:166-167: BDF2 from the third step
+        and per_step[9] == ("step", 1e-12, 1e-12)                 # BDF2 from the third step (fedm-tof.py:166-167)
     for k in range(3):
         np.testing.assert_allclose(per_step[4 * k + 2][2], tof.source(nodes, 2.5e-9 + (k + 1) * 1e-12), rtol=1e-13)
         assert per_step[4 * k + 3] == ("solve", 1e-10, 50)
@@ -816,10 +816,11 @@ def test_host_poisson_assemble_and_solve_like_the_scripts_initial_solve():
 
 
 def test_streamer_script_runs_up_to_the_device_and_lowers_to_the_case_model(tmp_path, monkeypatch):
-    """examples/streamer_discharge.py follows fedm-streamer.py:19-299 line by line.  Up to the point
-    where the device context would be created (no GPU here): the initial conditions from the C++
+    """examples/streamer_discharge.py (our own driver for the case of fedm-streamer.py).  Up to the
+    point where the device context would be created (no GPU here): the initial conditions from the C++
     strings, the host-side initial Poisson solve, the forms lowered to the model of cases/streamer, the
-    initial values of the mixed Functions collected by the reverse assigner."""
+    initial values of the mixed Functions collected by the reverse assigner -- on the tensor-product
+    mesh and on the unstructured one that is written to and loaded from `mesh.xml`."""
     import importlib.util
     import fedm_amd.functions as ff
     from fedm_amd.cases import streamer
@@ -835,10 +836,14 @@ def test_streamer_script_runs_up_to_the_device_and_lowers_to_the_case_model(tmp_
     def capture(J, F, bcs):
         seen.update(F=F, bcs=bcs)
         raise Stop
-    monkeypatch.setattr(mod, "Problem", capture)
     with pytest.raises(Stop):
-        mod.main(n=12, output_dir=tmp_path, quiet=True)
+        mod.main(mesh_spacing=1.5e-4, output_dir=tmp_path / "unstructured", quiet=True, stop_before_device=capture)
+    model_u, mesh_u, _ = ff.compile_forms(seen["F"])
+    assert (tmp_path / "unstructured" / "mesh" / "mesh.xml").exists() and mesh_u.num_vertices() > 1000
+    with pytest.raises(Stop):
+        mod.main(cells=12, output_dir=tmp_path, quiet=True, stop_before_device=capture)
     model, mesh, tags = ff.compile_forms(seen["F"])
+    assert bytes(model.to_c()) == bytes(model_u.to_c())            # the model does not depend on the mesh
     ref = streamer.model()
     assert (model.n_species, model.poisson, list(model.eq_type), list(model.Z)) == (2, True, list(ref.eq_type), [1.0, -1.0])
     assert model.bc_kind == ref.bc_kind and model.quadrature_degree == 2 and model.axisymmetric
