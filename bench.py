@@ -16,6 +16,13 @@ Records in the line, besides the driver's contract:
 * ``late_window``: the same K steps timed again from the developed streamer (step 200, t ~ 1 ns),
   where a step needs several times the Krylov iterations of the first steps;
 * ``multi_gpu`` (N > 1): transport, ranks, halo exchanges / all-reduces per step and their latency;
+* ``unstructured`` (N = 1): the same K steps on the locally refined UNSTRUCTURED mesh (Delaunay, written
+  to and read back from DOLFIN XML like the reference's ``Mesh('mesh.xml')``, ~1 M DOFs) with its own
+  roofline block -- the mesh kind the reference's streamer case runs on;
+* ``roofline_beyond_infinity_cache`` (N = 1): assembly and SpMV fractions on the 1152x1152 mesh (4 M
+  DOFs, Jacobian 670 MB > the 256 MiB Infinity Cache): rates that cannot come from the last-level cache;
+* ``glow_discharge`` (N = 1): BASELINE configs[2] (LMEA, 141x141 crossed, 200 225 DOFs) with the roofline
+  of its assembly kernels;
 * ``cpu_baseline`` (N = 1): the C/OpenMP restatement under oracle/ on the same mesh.
 """
 import argparse
@@ -36,7 +43,24 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md, chip-level parameters (spec)
-PMC_PROFILE = ROOT / "profiles" / "r02_pmc_traffic.json"
+PMC_PROFILE = ROOT / "profiles" / "r03_pmc_traffic.json"
+
+
+def library_ready():
+    """The HIP library is built (or rebuilt when a source is newer) BEFORE torch is imported or the GPU
+    is touched: the compiler driver exec()s its tools, which a process that has initialised the GPU --
+    or any child of one running under rocprofv3, whose preloaded tool initialises it -- must not do on
+    this pool.  Under a profiler a missing or stale library is an error, not a reason to compile."""
+    import __graft_entry__ as entry
+    if not entry._stale(entry.LIB):
+        return entry
+    profiled = any(k in os.environ for k in ("ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARIES",
+                                             "ROCPROF_OUTPUT_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if profiled:
+        raise SystemExit(f"{entry.LIB} is missing or older than its sources: build it first, unprofiled "
+                         "(python3 -c 'import __graft_entry__ as g; g.build()')")
+    entry.build()
+    return entry
 KERNEL_SOURCES = ["kernels.hip", "element.hpp", "element_lean.hpp", "prep.cpp", "fedm_internal.hpp"]
 
 
@@ -56,6 +80,13 @@ def parse_args():
     ap.add_argument("--configs4", choices=["auto", "on", "off"], default="auto",
                     help="second record on the ~4 M-DOF mesh of BASELINE configs[4] (auto: at 8 GPUs)")
     ap.add_argument("--configs4-mesh", type=int, default=1152, help="global cells per side of that record")
+    ap.add_argument("--unstructured", choices=["auto", "on", "off"], default="auto",
+                    help="second record on the locally refined unstructured mesh (auto: on one GPU)")
+    ap.add_argument("--mesh-spacing", type=float, default=4e-6,
+                    help="finest spacing of that mesh [m] (4e-6: 341 280 vertices, 1 023 840 DOFs)")
+    ap.add_argument("--big-mesh", type=int, default=1152,
+                    help="cells per side of the single-GPU mesh beyond the Infinity Cache (0 disables the record)")
+    ap.add_argument("--no-glow-discharge", action="store_true", help="skip the configs[2] record")
     # The data path across GPUs is RCCL.  When its set-up fails, every rank agrees on a host-staged
     # transport (gloo), which is correct but measures the host, not xGMI: the run then stops with a
     # non-zero exit code unless this flag says that such a number is wanted.
@@ -121,27 +152,15 @@ def pick(tr, *needles):
     return None
 
 
-def measured_copy_ceiling(device):
-    """Device copy bandwidth on this box (read + write bytes / time, 1 GiB buffers, HIP events):
-    the practical ceiling next to the 8 TB/s specification."""
-    import torch
-    n = 1 << 27                                           # 1 GiB of fp64
-    a = torch.empty(n, dtype=torch.float64, device=device)
-    b = torch.empty_like(a)
-    a.fill_(1.0)
-    b.copy_(a)
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    reps = 10
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize(device)
-    ms = e0.elapsed_time(e1) / reps
-    del a, b
-    torch.cuda.empty_cache()
-    return 2 * n * 8 / (ms * 1e-3) / 1e9
+def measured_copy_ceiling(device_index):
+    """Device copy rate on this box (read + write bytes / time): the library's own 16-byte-per-lane
+    grid-stride copy between two 1 GiB buffers, timed with HIP events (`fedm_copy_bandwidth`) -- the
+    practical ceiling next to the 8 TB/s specification (the guide measures 6.29 TB/s this way)."""
+    import ctypes as C
+    from fedm_amd import _lib
+    gbs = C.c_double()
+    rc = _lib.load().fedm_copy_bandwidth(int(device_index), 1 << 30, 10, C.byref(gbs))
+    return gbs.value if rc == 0 else None
 
 
 def cpu_baseline(n, grading, steps, threads):
@@ -210,6 +229,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    entry = library_ready()          # before torch: nothing may exec once the GPU is initialised
     import torch
     import torch.distributed as dist
     # one rank per GPU: LOCAL_RANK is the device index when a rank sees every GPU of the node (the usual
@@ -217,9 +237,6 @@ def main():
     n_visible = torch.cuda.device_count()
     if n_visible and local_rank >= n_visible:
         local_rank %= n_visible
-    import __graft_entry__ as entry
-    if not entry.LIB.exists():
-        entry.build()
     from fedm_amd.cases import streamer
 
     placement = pin_to_gpu_numa_node(torch, local_rank)
@@ -254,88 +271,107 @@ def main():
         msh = streamer.mesh(n_per_gpu, args.grading)
         return streamer.Stepper(streamer.device_problem(msh.coords, msh.cells, device=local_rank))
 
+    copy_gbs = measured_copy_ceiling(local_rank) if rank == 0 else None
+
+    def hot_path(runner, steps, warmup, tr, tr_source):
+        """W warm-up steps, K timed steps (HIP events around the assembly kernels, on the library's stream),
+        then a second, untimed pass with plain launches for the kernels inside the Krylov iterations
+        (events cannot sit inside the replayed per-iteration graphs).  Returns the record pieces."""
+        for _ in range(warmup):
+            runner.step()
+        elapsed, newton, gmres, prof = timed_steps(runner, steps, barrier, torch, dist, distributed)
+        comm0 = runner.prob.comm_stats() if distributed else None
+        pass_steps = max(1, min(steps, 5))
+        runner.profile(2)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(pass_steps):
+            runner.step()
+        barrier()
+        elapsed2 = time.perf_counter() - t1
+        prof2 = runner.profile_read()
+        runner.profile(False)
+        sz = runner.sizes()
+        # average launch duration of the hot kernels inside the timed region
+        ms_asm = prof["assembly_FJ"][0] / max(prof["assembly_FJ"][1], 1)
+        ms_spmv = prof2["spmv"][0] / max(prof2["spmv"][1], 1)
+        ms_res = prof["assembly_F"][0] / max(prof["assembly_F"][1], 1)
+        b_spmv, b_asm, b_res = spmv_bytes(sz), assembly_bytes(sz), residual_bytes(sz)
+        gbs_spmv = b_spmv / (ms_spmv * 1e-3) / 1e9
+        gbs_asm = b_asm / (ms_asm * 1e-3) / 1e9
+        share = {k: v[0] / (elapsed * 1e3) for k, v in prof.items()}
+        share2 = {k: v[0] / (elapsed2 * 1e3) for k, v in prof2.items()}
+        second_pass = (f"separate profiling pass of {pass_steps} steps right after the timed region, "
+                       f"kernels launched one by one ({1e3 * elapsed2 / pass_steps:.2f} ms/step)")
+
+        def moved(traffic, ms):          # HBM bytes the counters saw, over the kernel's time
+            return traffic / (ms * 1e-3) / 1e9 if traffic and ms else None
+        t_spmv = pick(tr, "fedm::spmv_kernel<3, false", "fedm::spmv_kernel<3,false")
+        t_asm = pick(tr, "assemble_lean2", "assemble_patch")
+        rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3,false,ZMASK> (Jacobian SpMV, sliced block-ELL; structurally zero value planes not loaded)",
+                   "achieved": gbs_spmv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": gbs_spmv / HBM_PEAK_GBS,
+                   "frac_of_measured_copy": gbs_spmv / copy_gbs if copy_gbs else None,
+                   "traffic": t_spmv, "achieved_traffic_GBs": moved(t_spmv, ms_spmv),
+                   "algorithmic_bytes": b_spmv,
+                   # SURVEY 8(d) counts every structural block whole; the kernel does not load value
+                   # planes that are structurally zero for the model (d(electron row)/d(ion density))
+                   "bytes_not_loaded_structural_zero_planes": sz["nnz_blocks"] * 8 * sz.get("zero_planes", 0),
+                   "ms_per_launch": ms_spmv, "launches": prof2["spmv"][1],
+                   "share_of_profiling_pass": share2["spmv"], "measured": second_pass,
+                   "infinity_cache_note": ("the Jacobian of this mesh (%.0f MB) fits the 256 MiB Infinity Cache and the "
+                                           "counters include its hits: the cache-free rates are in "
+                                           "'roofline_beyond_infinity_cache'" % (sz["stored_blocks"] * 72 / 1e6))
+                                          if sz["stored_blocks"] * 72 < 256 * 2 ** 20 else
+                                          "the Jacobian of this mesh does not fit the 256 MiB Infinity Cache"}
+        rl_asm = {"bound": "hbm", "kernel": runner.assembly_kernel_name,
+                  "achieved": gbs_asm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": gbs_asm / HBM_PEAK_GBS,
+                  "frac_of_measured_copy": gbs_asm / copy_gbs if copy_gbs else None,
+                  "traffic": t_asm, "achieved_traffic_GBs": moved(t_asm, ms_asm),
+                  "traffic_source": tr_source, "algorithmic_bytes": b_asm,
+                  # ... and the assembly neither recomputes nor rewrites planes that cannot change
+                  # (potential-potential: geometry only; structurally zero species planes)
+                  "bytes_not_rewritten_kept_planes": sz["stored_blocks"] * 8 * sz.get("kept_planes", 0),
+                  "ms_per_launch": ms_asm, "launches": prof["assembly_FJ"][1],
+                  "ms_residual_only": ms_res, "residual_only_algorithmic_bytes": b_res,
+                  "residual_only_frac": b_res / (ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_res else None,
+                  "share_of_timed_region": share["assembly_FJ"]}
+
+        # BASELINE.json's target is quoted on the assembly + SpMV path together: algorithmic bytes of
+        # all assemblies and Krylov SpMVs of a step over the time their kernels take
+        def path_record(prof_w, gmres_w, steps_w):
+            n_asm = prof_w["assembly_FJ"][1] / steps_w
+            n_res = prof_w["assembly_F"][1] / steps_w        # residual-only assemblies (final Newton checks)
+            n_spmv = gmres_w / steps_w                       # one Jacobian SpMV per GMRES iteration
+            m_asm = prof_w["assembly_FJ"][0] / max(prof_w["assembly_FJ"][1], 1)
+            m_res = prof_w["assembly_F"][0] / max(prof_w["assembly_F"][1], 1)
+            path_bytes = n_asm * b_asm + n_res * b_res + n_spmv * b_spmv
+            path_ms = n_asm * m_asm + n_res * m_res + n_spmv * ms_spmv
+            path_gbs = path_bytes / (path_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": path_gbs / HBM_PEAK_GBS, "assemblies_per_step": n_asm,
+                    "residual_only_assemblies_per_step": n_res, "spmv_per_step": n_spmv,
+                    "algorithmic_bytes_per_step": path_bytes, "kernel_ms_per_step": path_ms,
+                    "measured_copy_ceiling_GBs": copy_gbs,
+                    "frac_of_measured_copy": (path_gbs / copy_gbs) if copy_gbs else None}
+        vcycle = {"ms_per_cycle": prof2["vcycle"][0] / max(prof2["vcycle"][1], 1),
+                  "cycles": prof2["vcycle"][1], "share_of_profiling_pass": share2["vcycle"],
+                  "levels": runner.multigrid_levels, "measured": second_pass}
+        return dict(elapsed=elapsed, newton=newton, gmres=gmres, prof=prof, sz=sz, comm0=comm0, rl_asm=rl_asm,
+                    rl_spmv=rl_spmv, path=path_record(prof, gmres, steps), path_record=path_record, vcycle=vcycle)
+
     n = args.mesh
     t_setup = time.perf_counter()
     runner = make_runner(n_per_gpu=n)
     runner.initialise()
     setup_s = time.perf_counter() - t_setup
-    for _ in range(args.warmup):
-        runner.step()
-
-    # ---- the timed region: K steps right after the warm-up (SURVEY 8(d)'s window) -------------
-    elapsed, newton, gmres, prof = timed_steps(runner, args.steps, barrier, torch, dist, distributed)
-    comm0 = runner.prob.comm_stats() if distributed else None
-
-    # Second, untimed pass for the kernels inside the Krylov iterations: timing them needs plain
-    # launches (HIP events cannot sit inside the replayed per-iteration graphs).
-    pass_steps = max(1, min(args.steps, 5))
-    runner.profile(2)
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(pass_steps):
-        runner.step()
-    barrier()
-    elapsed2 = time.perf_counter() - t1
-    prof2 = runner.profile_read()
-    runner.profile(False)
-
-    total_dofs = runner.total_dofs
-    sz = runner.sizes()
-    # average launch duration of the hot kernels inside the timed region
-    ms_asm = prof["assembly_FJ"][0] / max(prof["assembly_FJ"][1], 1)
-    ms_spmv = prof2["spmv"][0] / max(prof2["spmv"][1], 1)
-    ms_res = prof["assembly_F"][0] / max(prof["assembly_F"][1], 1)
-    b_spmv, b_asm, b_res = spmv_bytes(sz), assembly_bytes(sz), residual_bytes(sz)
-    gbs_spmv = b_spmv / (ms_spmv * 1e-3) / 1e9
-    gbs_asm = b_asm / (ms_asm * 1e-3) / 1e9
-    share = {k: v[0] / (elapsed * 1e3) for k, v in prof.items()}
-    share2 = {k: v[0] / (elapsed2 * 1e3) for k, v in prof2.items()}
-    second_pass = (f"separate profiling pass of {pass_steps} steps right after the timed region, "
-                   f"kernels launched one by one ({1e3 * elapsed2 / pass_steps:.2f} ms/step)")
-    copy_gbs = measured_copy_ceiling(torch.device("cuda", local_rank)) if rank == 0 else None
     tr, tr_source = pmc_traffic() if (world == 1 and n == 576) else ({}, "not the profiled workload")
-    rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3,false,ZMASK> (Jacobian SpMV, sliced block-ELL; structurally zero value planes not loaded)",
-               "achieved": gbs_spmv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": gbs_spmv / HBM_PEAK_GBS,
-               "frac_of_measured_copy": gbs_spmv / copy_gbs if copy_gbs else None,
-               "traffic": pick(tr, "fedm::spmv_kernel<3, false", "fedm::spmv_kernel<3,false"),
-               "algorithmic_bytes": b_spmv,
-               # SURVEY 8(d) counts every structural block whole; the kernel does not load value
-               # planes that are structurally zero for the model (d(electron row)/d(ion density))
-               "bytes_not_loaded_structural_zero_planes": sz["nnz_blocks"] * 8 * sz.get("zero_planes", 0),
-               "ms_per_launch": ms_spmv, "launches": prof2["spmv"][1],
-               "share_of_profiling_pass": share2["spmv"], "measured": second_pass}
-    rl_asm = {"bound": "hbm", "kernel": runner.assembly_kernel_name,
-              "achieved": gbs_asm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-              "frac": gbs_asm / HBM_PEAK_GBS,
-              "frac_of_measured_copy": gbs_asm / copy_gbs if copy_gbs else None,
-              "traffic": pick(tr, "assemble_lean2", "assemble_lean", "assemble_patch"),
-              "traffic_source": tr_source, "algorithmic_bytes": b_asm,
-              # ... and the assembly neither recomputes nor rewrites planes that cannot change
-              # (potential-potential: geometry only; structurally zero species planes)
-              "bytes_not_rewritten_kept_planes": sz["stored_blocks"] * 8 * sz.get("kept_planes", 0),
-              "ms_per_launch": ms_asm, "launches": prof["assembly_FJ"][1],
-              "ms_residual_only": ms_res, "residual_only_algorithmic_bytes": b_res,
-              "residual_only_frac": b_res / (ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_res else None,
-              "share_of_timed_region": share["assembly_FJ"]}
-    # BASELINE.json's target is quoted on the assembly + SpMV path together: algorithmic bytes of
-    # all assemblies and Krylov SpMVs of a step over the time their kernels take
-
-    def path_record(prof_w, gmres_w, steps_w):
-        n_asm = prof_w["assembly_FJ"][1] / steps_w
-        n_res = prof_w["assembly_F"][1] / steps_w        # residual-only assemblies (final Newton checks)
-        n_spmv = gmres_w / steps_w                       # one Jacobian SpMV per GMRES iteration
-        m_asm = prof_w["assembly_FJ"][0] / max(prof_w["assembly_FJ"][1], 1)
-        m_res = prof_w["assembly_F"][0] / max(prof_w["assembly_F"][1], 1)
-        path_bytes = n_asm * b_asm + n_res * b_res + n_spmv * b_spmv
-        path_ms = n_asm * m_asm + n_res * m_res + n_spmv * ms_spmv
-        path_gbs = path_bytes / (path_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": path_gbs / HBM_PEAK_GBS, "assemblies_per_step": n_asm,
-                "residual_only_assemblies_per_step": n_res, "spmv_per_step": n_spmv,
-                "algorithmic_bytes_per_step": path_bytes, "kernel_ms_per_step": path_ms,
-                "measured_copy_ceiling_GBs": copy_gbs,
-                "frac_of_measured_copy": (path_gbs / copy_gbs) if copy_gbs else None}
+    # ---- the timed region: K steps right after the warm-up (SURVEY 8(d)'s window) -------------
+    hp = hot_path(runner, args.steps, args.warmup, tr, tr_source)
+    elapsed, newton, gmres, sz, comm0 = hp["elapsed"], hp["newton"], hp["gmres"], hp["sz"], hp["comm0"]
+    rl_asm, rl_spmv, path_record = hp["rl_asm"], hp["rl_spmv"], hp["path_record"]
+    total_dofs = runner.total_dofs
 
     gmres_text = ("flexible, restart 30, rtol 1e-5 on the true residual, right-preconditioned: field split, "
                   "Chebyshev(6) block Jacobi on species (degree 4 once a Newton system needs >= 5 Krylov "
@@ -366,10 +402,10 @@ def main():
         "gmres_iterations_per_step": gmres / args.steps,
         "roofline": rl_asm,
         "roofline_other": rl_spmv,
-        "assembly_plus_spmv": path_record(prof, gmres, args.steps),
-        "vcycle": {"ms_per_cycle": prof2["vcycle"][0] / max(prof2["vcycle"][1], 1),
-                   "cycles": prof2["vcycle"][1], "share_of_profiling_pass": share2["vcycle"],
-                   "levels": runner.multigrid_levels, "measured": second_pass},
+        "assembly_plus_spmv": hp["path"],
+        "vcycle": hp["vcycle"],
+        "measured_copy_ceiling_GBs": copy_gbs,
+        "copy_ceiling_how": "fedm_copy_bandwidth: 16-byte-per-lane grid-stride copy kernel, 2 x 1 GiB, HIP events",
     }
 
     # ---- the developed streamer: the same K steps from step `late_start` on ---------------------
@@ -387,6 +423,110 @@ def main():
             "gmres_iterations_per_step": l_gmres / args.steps,
             "assembly_plus_spmv": path_record(l_prof, l_gmres, args.steps)}
         out["sustained_timesteps_per_sec"] = args.steps / l_elapsed
+
+    # ---- the same K steps on the locally refined UNSTRUCTURED mesh (what the reference's case runs on) ----
+    if world == 1 and args.unstructured != "off":
+        import tempfile
+        del runner
+        t_u = time.perf_counter()
+        with tempfile.TemporaryDirectory(prefix="fedm_mesh_") as tmp:
+            umesh = streamer.refined_mesh(args.mesh_spacing, growth=0.1, xml_path=Path(tmp) / "mesh.xml",
+                                          channel=(0.0, 100.0 * args.mesh_spacing) + streamer.CHANNEL[2:])
+        t_mesh = time.perf_counter() - t_u
+        urun = streamer.Stepper(streamer.device_problem(umesh.coords, umesh.cells, device=local_rank))
+        urun.initialise()
+        u_setup = time.perf_counter() - t_u - t_mesh
+        uh = hot_path(urun, args.steps, args.warmup, {}, "no PMC pass on this mesh")
+        usz = uh["sz"]
+        out["unstructured"] = {
+            "workload": "the same streamer case on a locally refined unstructured mesh: Delaunay triangulation of "
+                        f"nested hexagonal lattices, spacing {args.mesh_spacing:g} m in the streamer channel "
+                        f"(r < {100.0 * args.mesh_spacing:g} m), growing 0.1 per unit distance outside; written to "
+                        "DOLFIN XML and read back through the mesh reader (the way of the reference's Mesh('mesh.xml'))",
+            "vertices": usz["n_vertices"], "cells": usz["n_cells"], "dofs_total": urun.total_dofs,
+            "hmin": umesh.hmin(), "hmax": umesh.hmax(),
+            "value": urun.total_dofs * args.steps / uh["elapsed"], "unit": "DOF-updates/s",
+            "timesteps_per_sec": args.steps / uh["elapsed"], "ms_per_step": 1e3 * uh["elapsed"] / args.steps,
+            "newton_iterations_per_step": uh["newton"] / args.steps,
+            "gmres_iterations_per_step": uh["gmres"] / args.steps,
+            "roofline": uh["rl_asm"], "roofline_other": uh["rl_spmv"], "assembly_plus_spmv": uh["path"],
+            "vcycle": uh["vcycle"],
+            "pattern": {"stored_blocks_over_nnz_blocks": usz["stored_blocks"] / usz["nnz_blocks"],
+                        "max_block_columns_per_slice": usz["max_patch_width"],
+                        "max_cells_per_patch": usz["max_patch_cells"], "max_staged_vertices_per_patch": usz["max_patch_verts"],
+                        "cell_visits_over_cells": usz["cell_visits"] / usz["n_cells"],
+                        "patch_workgroup_threads": usz["patch_threads"], "assembly_variant": usz["assembly_variant"],
+                        "vertex_order": "recursive bisection in the metric of the local spacing (device.locality_order)"},
+            "mesh_seconds": t_mesh, "setup_seconds": u_setup,
+            "run_to_reference_end_time": "profiles/r03_refined_run_*.json: this mesh carries the streamer to the "
+                                         "reference's T_final = 1.4e-8 s (2801 accepted steps, none rejected)"}
+        runner = urun
+
+    # ---- rates that cannot come from the Infinity Cache: the 4 M-DOF mesh on ONE GPU ------------------
+    if world == 1 and args.big_mesh > 0:
+        del runner
+        t_b = time.perf_counter()
+        bmesh = streamer.mesh(args.big_mesh, args.grading)
+        brun = streamer.Stepper(streamer.device_problem(bmesh.coords, bmesh.cells, device=local_rank))
+        brun.initialise()
+        b_setup = time.perf_counter() - t_b
+        bsteps = max(2, min(args.steps, 5))
+        bh = hot_path(brun, bsteps, 1, {}, "no PMC pass on this mesh")
+        keep = ("achieved", "frac", "frac_of_measured_copy", "algorithmic_bytes", "ms_per_launch", "launches")
+        out["roofline_beyond_infinity_cache"] = {
+            "workload": f"{args.big_mesh}x{args.big_mesh} graded mesh on one GPU ({brun.total_dofs} DOFs; Jacobian values "
+                        f"{bh['sz']['stored_blocks'] * 72 / 1e6:.0f} MB, more than twice the 256 MiB Infinity Cache)",
+            "assembly_FJ": {k: bh["rl_asm"][k] for k in keep},
+            "spmv": {k: bh["rl_spmv"][k] for k in keep},
+            "assembly_plus_spmv_frac": bh["path"]["frac"],
+            "timesteps_per_sec": bsteps / bh["elapsed"], "ms_per_step": 1e3 * bh["elapsed"] / bsteps,
+            "gmres_iterations_per_step": bh["gmres"] / bsteps, "setup_seconds": b_setup,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm"}
+        runner = brun
+
+    # ---- BASELINE configs[2]: glow discharge (LMEA), 141 x 141 crossed = 200 225 DOFs ------------------
+    if world == 1 and not args.no_glow_discharge:
+        import contextlib
+        import io
+        from fedm_amd.cases import glow_discharge as gdc
+        del runner
+        runner = None
+        with contextlib.redirect_stdout(io.StringIO()):
+            case = gdc.Case(nx=141, ny=141, T_final=1.0, device=local_rank)
+        case.step()
+        case.prob.profile(1)
+        n0, l0 = case.newton_iterations, case.linear_iterations
+        torch.cuda.synchronize()
+        t_g = time.perf_counter()
+        gsteps = 10
+        for _ in range(gsteps):
+            case.step()
+        torch.cuda.synchronize()
+        g_el = time.perf_counter() - t_g
+        gp = case.prob.profile_read()
+        case.prob.profile(False)
+        gsz = case.prob.sizes()
+        nv, nc, neq, nnzb = gsz["n_vertices"], gsz["n_cells"], gsz["n_eq"], gsz["nnz_blocks"]
+        n_fields = case.prob.model.n_fields
+        # SURVEY 8(d) with the LMEA's nodal coefficient fields: + n_fields * Nv * 8
+        g_bytes = nv * (16 + 24 * neq) + nc * (12 + 36) + nnzb * neq * neq * 8 + nv * neq * 8 + n_fields * nv * 8
+        g_ms = gp["assembly_FJ"][0] / max(gp["assembly_FJ"][1], 1)
+        g_gbs = g_bytes / (g_ms * 1e-3) / 1e9
+        out["glow_discharge"] = {
+            "workload": "BASELINE configs[2]: argon glow discharge, LMEA (energy + 3 particle balances + Poisson), "
+                        "141x141 crossed mesh, device-resident per-step pipeline (fedm_amd.cases.glow_discharge)",
+            "dofs_total": case.prob.n, "timesteps_per_sec": gsteps / g_el, "ms_per_step": 1e3 * g_el / gsteps,
+            "value": case.prob.n * gsteps / g_el, "unit": "DOF-updates/s",
+            "newton_iterations_per_step": (case.newton_iterations - n0) / gsteps,
+            "gmres_iterations_per_step": (case.linear_iterations - l0) / gsteps,
+            "roofline": {"bound": "hbm", "kernel": "gd_jacobian_rows_kernel + gd_gather_kernel (element blocks of all cells, "
+                                                   "summed per stored matrix position; F + J)",
+                         "achieved": g_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes": g_bytes, "ms_per_launch": g_ms, "launches": gp["assembly_FJ"][1],
+                         "traffic": None,
+                         "note": "compute/latency-bound (two waves per SIMD, 9.6 k vector instructions per wave), "
+                                 "not bandwidth-bound: DESIGN.md 8.3"}}
+        case.prob.close()
 
     # ---- multi-GPU plumbing: what travelled, and what one exchange / reduction costs ------------
     if distributed:

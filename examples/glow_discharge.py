@@ -267,7 +267,7 @@ def main(nx=100, ny=100, T_final=1e-11, input_dir=None, output_dir="gd_output", 
     problem.device.setup_multigrid(nu=1)
     problem.device.set_fieldsplit(chebyshev_weights(8, 0.3, 2.2))
     newton = fedm.PETScSNESSolver()
-    newton.parameters.update(relative_tolerance=1e-4, maximum_iterations=20, linear_solver="mumps")
+    newton.parameters.update(relative_tolerance=1e-4, linear_solver="mumps")     # iteration limit: the solver's default
 
     out_files = [writers["potential"]] + writers["density"][1:]
     out_names = ["Phi"] + deck["file_names"][1:]

@@ -157,6 +157,7 @@ _SIGNATURES = {
                                      C.POINTER(C.c_int32)]),
     "fedm_field_error": (C.c_int, [_P, C.c_int, _D]),
     "fedm_time_kernel": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "fedm_copy_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.c_int, _D]),
     "fedm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fedm_comm_init_rccl": (C.c_int, [_P, C.c_int] + [C.POINTER(C.c_int32)] * 4
                             + [C.c_void_p, C.c_int, C.c_int]),

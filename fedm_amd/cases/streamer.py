@@ -149,8 +149,14 @@ class Stepper:
     """The script-level time loop of fedm-streamer.py:304-340 around one device problem."""
 
     partition_name = "single GPU"
-    assembly_kernel_name = ("assemble_lean2_kernel<2,1,192> (LDS patches with micro-coloured cell order, one "
-                            "equation row at a time, F+J)")
+
+    @property
+    def assembly_kernel_name(self):
+        sz = self.prob.sizes()
+        if sz["assembly_variant"] != "lds-patches":
+            return f"volume assembly, variant '{sz['assembly_variant']}' (F+J)"
+        return (f"assemble_lean2_kernel<2,1,{sz['patch_threads']}> (LDS patches with micro-coloured cell order, one "
+                "equation row at a time, F+J)")
 
     @property
     def multigrid_levels(self):

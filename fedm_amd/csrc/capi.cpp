@@ -1058,6 +1058,13 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (!h) return;
     Ctx &c = h->c;
     hipSetDevice(c.device);
+    // a failed transport first: its communicator is aborted before anything below waits for the device
+    // (comm.hip, Comm::release_communicator); the error stays readable through fedm_last_error
+    if (c.comm) {
+        comm_poll_async_error(c);
+        if (c.comm->failed && c.comm->release_communicator())
+            set_error(c.comm->error + " -- communicator aborted at teardown");
+    }
     if (c.stream) hipStreamSynchronize(c.stream);
     void *ptrs[] = {c.d_coords, c.d_cells, c.d_ftags, c.d_cell_slots, c.d_colour_cells, c.d_model,
                     c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.d_val, c.d_dinv, c.d_dir_dofs,
@@ -1549,6 +1556,14 @@ int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) 
     return 0;
 }
 
+int fedm_copy_bandwidth(int device, int64_t bytes, int repeats, double *gbs) {
+    if (bytes < (1 << 20) || repeats < 1 || !gbs) {
+        set_error("fedm_copy_bandwidth: at least 1 MiB and one repeat");
+        return -2;
+    }
+    return copy_bandwidth(device, bytes, repeats, gbs);
+}
+
 // latency of the multi-GPU primitives on this context's transport, back to back on the compute
 // stream: kind 0 = halo exchange of a block vector, 1 = of a scalar vector, 2 = all-reduce of 32
 // doubles (what a Krylov step's dot products need)
@@ -1659,7 +1674,7 @@ int fedm_comm_stats(fedm_ctx *h, int64_t out[8]) {
     return 0;
 }
 
-int fedm_debug_comm_fault(int fail_at, int64_t out[4]) { return comm_fault_selftest(fail_at, out); }
+int fedm_debug_comm_fault(int fail_at, int64_t out[6]) { return comm_fault_selftest(fail_at, out); }
 
 int fedm_debug_comm_roundtrip(fedm_ctx *h, double *vec, double *red, int k) {
     Ctx &c = h->c;

@@ -18,6 +18,7 @@ struct NcclApi {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, Id128, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;  // optional; what a failed communicator is torn down with
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -74,6 +75,7 @@ int load_nccl() {
     FEDM_SYM(GetErrorString, "ncclGetErrorString")
 #undef FEDM_SYM
     *(void **)(&g_nccl.CommGetAsyncError) = dlsym(g_nccl.lib, "ncclCommGetAsyncError");
+    *(void **)(&g_nccl.CommAbort) = dlsym(g_nccl.lib, "ncclCommAbort");
     return 0;
 }
 
@@ -112,12 +114,18 @@ int stub_send(const void *, size_t, int, int, void *, hipStream_t) { return stub
 int stub_recv(void *, size_t, int, int, void *, hipStream_t) { return stub_rc(); }
 int stub_group() { return stub_rc(); }
 const char *stub_errstr(int) { return "stub system error"; }
+int g_stub_aborts = 0, g_stub_destroys = 0;
+int stub_abort(void *) { return ++g_stub_aborts, 0; }
+int stub_destroy(void *) { return ++g_stub_destroys, 0; }
 }  // namespace
 static void exchange_packed(Ctx &c, Comm *cm, double *recv_dst, hipStream_t st, int w);
 
-int comm_fault_selftest(int fail_at, int64_t out[4]) {
+int comm_fault_selftest(int fail_at, int64_t out[6]) {
     const NcclApi saved = g_nccl;
     g_nccl = NcclApi{};
+    g_nccl.CommAbort = stub_abort;
+    g_nccl.CommDestroy = stub_destroy;
+    g_stub_aborts = g_stub_destroys = 0;
     g_nccl.AllReduce = stub_allreduce;
     g_nccl.Send = stub_send;
     g_nccl.Recv = stub_recv;
@@ -152,6 +160,13 @@ int comm_fault_selftest(int fail_at, int64_t out[4]) {
     out[1] = g_stub_calls;           // API calls that reached the transport
     out[2] = g_stub_after_failure;   // ... of which after the failing one (only the group's close may follow)
     out[3] = comm_failed(c) ? 1 : 0;
+    // teardown: a failed communicator is aborted (its unfinished collective would make ncclCommDestroy,
+    // and every stream synchronisation behind it, wait for ever), a healthy one destroyed
+    const bool failed = cm.failed;
+    cm.release_communicator();
+    out[4] = g_stub_aborts;
+    out[5] = g_stub_destroys;
+    cm.failed = failed;
     c.comm = nullptr;
     cm.d_sendbuf = nullptr;
     cm.nccl = nullptr;
@@ -182,9 +197,26 @@ int comm_unique_id(void *out128) {
     return 0;
 }
 
-void Comm::release() {
-    if (nccl && g_nccl.CommDestroy) g_nccl.CommDestroy(nccl);
+// Ends the RCCL communicator.  After a latched transport failure (a lost peer, a failing call) the
+// kernel of the unfinished collective may still spin on one of the streams: ncclCommDestroy would wait
+// for it, and so would every later stream synchronisation and hipFree of the context -- the run would
+// hang at teardown instead of ending with the promised error.  ncclCommAbort stops those kernels; it
+// is therefore what a failed communicator gets, BEFORE anything synchronises with the device.
+bool Comm::release_communicator() {
+    if (!nccl) return false;
+    bool aborted = false;
+    if (failed && g_nccl.CommAbort) {
+        g_nccl.CommAbort(nccl);
+        aborted = true;
+    } else if (g_nccl.CommDestroy) {
+        g_nccl.CommDestroy(nccl);
+    }
     nccl = nullptr;
+    return aborted;
+}
+
+void Comm::release() {
+    release_communicator();
     if (d_interior) hipFree(d_interior);
     if (d_boundary) hipFree(d_boundary);
     if (d_patch_interior) hipFree(d_patch_interior);

@@ -47,6 +47,7 @@ struct Comm {
     std::string error;
     long n_exchanges = 0, n_allreduces = 0;   // issued so far (bench.py reports them per step)
     void release();
+    bool release_communicator();   // ncclCommAbort after a latched failure, ncclCommDestroy otherwise; true: aborted
 };
 
 int comm_setup_plan(Ctx &c, Comm &cm, int n_nb, const int32_t *nb_rank, const int32_t *send_ptr,
@@ -67,7 +68,7 @@ void comm_halo_begin(Ctx &c);
 void comm_halo_exchange(Ctx &c, double *d_vec);
 void comm_halo_exchange_f32(Ctx &c, float *d_vec, int w);
 void comm_halo_exchange_scalar(Ctx &c, double *d_vec);
-int comm_fault_selftest(int fail_at, int64_t out[4]);  // error-path test hook (no GPU needed)
+int comm_fault_selftest(int fail_at, int64_t out[6]);  // error-path test hook (no GPU needed)
 bool comm_failed(const Ctx &c);                     // a transport error has been latched
 bool comm_poll_async_error(Ctx &c);                 // RCCL's asynchronous error state; latches, true on error
 

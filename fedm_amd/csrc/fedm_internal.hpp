@@ -264,6 +264,7 @@ void wait_red(Ctx &c);                      // wait for the publication launch_d
 
 void set_error(const std::string &msg);
 void iter_graphs_clear(Ctx &c);
+int copy_bandwidth(int device, int64_t bytes, int repeats, double *gbs);   // kernels.hip
 void prof_begin(Ctx &c, int kind);
 void prof_end(Ctx &c);
 void prof_collect(Ctx &c);

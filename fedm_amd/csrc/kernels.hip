@@ -1588,4 +1588,45 @@ void launch_field_error_slots34(Ctx &c, int comp) {
     hipLaunchKernelGGL(reduce_partials_range_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, 3, c.d_red);
 }
 
+// =============================================================================================
+// Copy ceiling of the box: a 16-byte-per-lane grid-stride copy (what MI355X_MICROARCH.md measures
+// 6.29 TB/s with), read + write bytes over HIP-event time.  Buffers far beyond the 256 MiB Infinity
+// Cache; bench.py prints it next to the 8 TB/s specification.
+// =============================================================================================
+__global__ __launch_bounds__(256) void copy16_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+int copy_bandwidth(int device, int64_t bytes, int repeats, double *gbs) {
+    FEDM_HIP_CHECK(hipSetDevice(device));
+    const size_t n = (size_t)bytes / sizeof(float4);
+    float4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    do {
+        if (hipMalloc((void **)&a, n * sizeof(float4)) != hipSuccess) break;
+        if (hipMalloc((void **)&b, n * sizeof(float4)) != hipSuccess) break;
+        if (hipMemset(a, 1, n * sizeof(float4)) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        const dim3 grid(256 * 8), block(256);   // eight workgroups per CU, each lane 16 B per trip
+        hipLaunchKernelGGL(copy16_kernel, grid, block, 0, 0, a, b, n);
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < repeats; ++i) hipLaunchKernelGGL(copy16_kernel, grid, block, 0, 0, a, b, n);
+        hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        *gbs = 2.0 * (double)(n * sizeof(float4)) * repeats / ((double)ms * 1e-3) / 1e9;
+        rc = 0;
+    } while (false);
+    if (rc) set_error("copy_bandwidth: HIP call failed (out of memory?)");
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    return rc;
+}
+
 }  // namespace fedm

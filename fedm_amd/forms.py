@@ -133,7 +133,23 @@ def _parse_cpp_expression(code):
     except SyntaxError as exc:
         raise NotImplementedError(f"Expression string outside the supported arithmetic subset: {code!r}") from exc
 
+    def integer_valued(node):
+        """An operand that a C++ compiler types `int`: integer literals and arithmetic on them."""
+        if isinstance(node, ast.Constant):
+            return isinstance(node.value, int) and not isinstance(node.value, bool)
+        if isinstance(node, ast.UnaryOp):
+            return integer_valued(node.operand)
+        if isinstance(node, ast.BinOp):
+            return integer_valued(node.left) and integer_valued(node.right)
+        return False
+
     def check(node):
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Div) and integer_valued(node.left) \
+                and integer_valued(node.right):
+            # DOLFIN's JIT divides two ints the C++ way (1/2 == 0, 3/2 == 1); evaluated here it would
+            # silently be 0.5 and 1.5 -- a different source term or initial condition
+            raise NotImplementedError(f"integer division in Expression string {code!r}: C++ truncates it; "
+                                      "write one operand as a floating-point literal (1.0/2)")
         if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)) and not isinstance(node.value, bool):
             return
         if isinstance(node, ast.Name):

@@ -102,13 +102,11 @@ def _positive_cells(p, tri):
 def _laplace_smooth(p, tri, fixed):
     """One Jacobi sweep of Laplacian smoothing (vertices on the sides stay)."""
     n = p.shape[0]
-    e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])
-    e = np.concatenate([e, e[:, ::-1]])
-    e = np.unique(e, axis=0)
-    acc = np.zeros_like(p)
-    cnt = np.zeros(n)
-    np.add.at(acc, e[:, 0], p[e[:, 1]])
-    np.add.at(cnt, e[:, 0], 1.0)
+    e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]).astype(np.int64)
+    key = np.unique(np.concatenate([e[:, 0] * n + e[:, 1], e[:, 1] * n + e[:, 0]]))     # directed edges, once each
+    a, b = key // n, key % n
+    cnt = np.bincount(a, minlength=n).astype(float)
+    acc = np.stack([np.bincount(a, weights=p[b, d], minlength=n) for d in (0, 1)], axis=1)
     q = p.copy()
     move = ~fixed & (cnt > 0)
     q[move] = 0.5 * p[move] + 0.5 * acc[move] / cnt[move, None]

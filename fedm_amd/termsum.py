@@ -69,7 +69,8 @@ class TermSum:
             raise ValueError(f"coefficient has {len(self.terms)} terms, at most {_lib.MAX_TERMS}")
         cstruct.n_terms = len(self.terms)
         for i, (c, p, q, r) in enumerate(self.terms):
-            cstruct.c[i], cstruct.p[i], cstruct.q[i], cstruct.r[i] = c, p, q, r
+            # (+ 0.0: a negative zero left by the algebra becomes +0.0 -- the same model, the same bytes)
+            cstruct.c[i], cstruct.p[i], cstruct.q[i], cstruct.r[i] = c + 0.0, p + 0.0, q + 0.0, r + 0.0
 
     # -- algebra ------------------------------------------------------------------
     def __add__(self, o):

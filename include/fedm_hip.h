@@ -190,7 +190,7 @@ const char *fedm_last_error(void);
 /* Version of this header's structs and entry points; a binding compares it with the constant it was
  * written against and refuses a library of another version (a descriptor that grew would otherwise be
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
- * fedm_pattern_stats out[12]. */
+ * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info. */
 #define FEDM_ABI_VERSION 2
 int fedm_abi_version(void);
 
@@ -354,8 +354,11 @@ int fedm_comm_stats(fedm_ctx *ctx, int64_t out[8]);
 int fedm_time_comm(fedm_ctx *ctx, int kind, int repeats, double *ms_per_op);
 /* Test hook (no GPU needed): drives the RCCL code path with a stub transport whose
  * `fail_at`-th call fails.  out = {failed flag latched, transport calls made, calls made after
- * the failing one, comm_failed()}; returns 1 when a failure was latched. */
-int fedm_debug_comm_fault(int fail_at, int64_t out[4]);
+ * the failing one, comm_failed(), ncclCommAbort calls at teardown, ncclCommDestroy calls at
+ * teardown}: a failed communicator is aborted, never destroyed (its unfinished collective would
+ * block ncclCommDestroy and every stream synchronisation after it).  Returns 1 when a failure was
+ * latched. */
+int fedm_debug_comm_fault(int fail_at, int64_t out[6]);
 /* One halo exchange of the DOF vector `vec` (N values in the caller's order, ghost entries replaced by
  * what the neighbours sent) and one sum over the ranks of `red[0..k)`, through whatever transport the
  * context has: lets a test drive the transport's data path by itself (e.g. RCCL on one rank that is
@@ -383,6 +386,9 @@ int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
  * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only, 3 = one multigrid cycle on the
  * potential block.  ms per launch. */
 int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
+/* Copy rate of the device (GB/s, read + write bytes): a 16-byte-per-lane grid-stride copy between two
+ * buffers of `bytes` each -- the practical HBM ceiling bench.py prints next to the specification. */
+int fedm_copy_bandwidth(int device, int64_t bytes, int repeats, double *gbs);
 /* in-run kernel timing with HIP events on the library's stream.  kind: 0 = assembly F+J,
  * 1 = Jacobian SpMV, 2 = assembly F only, 3 = multigrid V-cycle (whole graph).  Kinds 1 and 3
  * are sampled (every 4th launch carries events; totals are the sampled mean x launches).

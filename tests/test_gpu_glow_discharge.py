@@ -115,9 +115,10 @@ def test_gd_golden_run(golden_dir, device_pipeline, tmp_path):
 
 
 def test_glow_discharge_example_writes_the_reference_outputs(tmp_path, golden_dir):
-    """examples/glow_discharge.py is the reference's fedm-gd.py call for call (deck readers ->
-    semi_implicit_coefficients -> Flux -> Source_term / Energy_Source_term -> weak forms ->
-    Boundary_flux('flux source') -> Problem -> adaptive_solver -> file_output) on the facade: the
+    """examples/glow_discharge.py is our own driver for the case of the reference's fedm-gd.py (deck
+    readers -> semi_implicit_coefficients -> Flux -> Source_term / Energy_Source_term -> weak forms ->
+    Boundary_flux('flux source') -> Problem -> adaptive_solver -> file_output) on the facade;
+    tests/test_reference_scripts.py shows that it hands the device what the reference's script does.  The
     LMEA form is lowered onto the device model by fedm_amd.lmea, the per-step coefficient refresh
     runs on the host through the facade's interpolation functions like in the reference.  The
     run must pass the reference's own assertions (tests/integrated_tests/glow_discharge/

@@ -146,8 +146,9 @@ def test_tof_golden(golden_dir):
 
 
 def test_tof_example_script_reproduces_the_golden(golden_dir, tmp_path):
-    """examples/time_of_flight.py -- fedm-tof.py call for call (C++ Expression strings, the flux
-    written by hand, PETScSNESSolver driven by the script) -- with the harness's sizes
+    """examples/time_of_flight.py -- our own driver for the case of fedm-tof.py (C++ Expression strings,
+    the flux written by hand, PETScSNESSolver driven by the script; tests/test_reference_scripts.py shows
+    that it hands the device what the reference's script does) -- with the harness's sizes
     (tests/integrated_tests/time_of_flight/fedm_tof.py: 40x40, 100 steps) against the same golden."""
     import importlib.util
     from fedm_amd.cases import time_of_flight as tof
@@ -257,8 +258,10 @@ def test_single_precision_hierarchy_is_the_same_preconditioner(streamer_setup, m
 
 
 def test_example_script_in_fedm_shape(tmp_path):
-    """examples/streamer_discharge.py (the call sequence of fedm-streamer.py through the
-    fedm.functions façade) gives the same error log as the case module on the same mesh."""
+    """examples/streamer_discharge.py (our own driver for the case of fedm-streamer.py on the
+    fedm.functions façade) gives the same error log as the case module on the same mesh -- on the graded
+    tensor-product mesh and on the locally refined unstructured mesh it writes to and loads from
+    `mesh.xml` like the reference's script loads its mesh."""
     import importlib.util
     from pathlib import Path
     from fedm_amd.cases import streamer
@@ -266,13 +269,25 @@ def test_example_script_in_fedm_shape(tmp_path):
     spec = importlib.util.spec_from_file_location("ex_streamer", root / "examples" / "streamer_discharge.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    state, log = mod.main(n=24, T_final=2e-11, output_dir=tmp_path, quiet=True)
+    state, log = mod.main(cells=24, end_time=2e-11, output_dir=tmp_path, quiet=True)
     rows = np.loadtxt(log).reshape(-1, 3)
     msh = streamer.mesh(24, 4.0)
     prob = streamer.device_problem(msh.coords, msh.cells)
     ref = streamer.run(prob, T_final=2e-11)
     assert rows.shape == (4, 3) and np.allclose(rows, np.array(ref["log"]), rtol=1e-6)
     assert np.allclose(state, prob.get_state(), rtol=1e-8, atol=1e-8)
+    prob.close()
+    state, log = mod.main(mesh_spacing=60e-6, end_time=2e-11, output_dir=tmp_path / "unstructured", quiet=True)
+    rows = np.loadtxt(log).reshape(-1, 3)
+    from fedm_amd import mesh_io
+    msh = mesh_io.read_dolfin_xml(tmp_path / "unstructured" / "mesh" / "mesh.xml")
+    assert msh.num_vertices() == state.shape[0] > 4000
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    ref = streamer.run(prob, T_final=2e-11)
+    assert rows.shape == (4, 3) and np.allclose(rows, np.array(ref["log"]), rtol=1e-5)
+    # (two Newton solves to rtol 1e-4 with different multigrid set-ups: agreement within that tolerance)
+    assert np.allclose(state, prob.get_state(), rtol=1e-5, atol=1e-6)
+    prob.close()
 
 
 def test_krylov_graphs_match_plain_launches():

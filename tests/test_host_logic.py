@@ -202,7 +202,19 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(_lib.exported_symbols())
-    assert lib.fedm_abi_version() == 1
+    # the version the library reports is the header's, and the one the Python binding was written against
+    assert lib.fedm_abi_version() == int(re.search(r"#define FEDM_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_version(tmp_path, monkeypatch):
+    """A stale .so built against an older header would have its descriptors read past their end: the
+    binding compares fedm_abi_version() with its own constant before anything else."""
+    from fedm_amd import _lib
+    _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.load()
 
 
 def test_product_and_oracle_quadrature_tables_agree():
@@ -379,13 +391,14 @@ def test_rccl_failure_is_latched_and_reported():
     import ctypes as C
     from fedm_amd import _lib
     lib = _lib.load()
-    out = (C.c_int64 * 4)()
-    assert lib.fedm_debug_comm_fault(-1, out) == 0 and list(out) == [0, 10, 0, 0]
+    out = (C.c_int64 * 6)()
+    assert lib.fedm_debug_comm_fault(-1, out) == 0 and list(out) == [0, 10, 0, 0, 0, 1]   # healthy: destroyed
     names = ["ncclGroupStart", "ncclSend", "ncclRecv", "ncclGroupEnd", "ncclAllReduce"]
     for k in range(10):
         assert lib.fedm_debug_comm_fault(k, out) == 1
-        failed, calls, after, reported = list(out)
+        failed, calls, after, reported, aborts, destroys = list(out)
         assert failed == 1 and reported == 1
+        assert (aborts, destroys) == (1, 0)         # a failed communicator is aborted, not destroyed (no hang)
         msg = _lib.last_error()
         assert names[k % 5] in msg and "rank 1 of 2" in msg
         inside_group = k % 5 in (1, 2)              # send / recv failed: the group is still closed
@@ -594,6 +607,26 @@ def test_cpp_expression_subset_evaluates_the_reference_strings_and_refuses_the_r
                 'x[0]; x[1]', '(lambda: 1)()'):
         with pytest.raises((NotImplementedError, SyntaxError, NameError)): # ... evaluation is not
             forms.Expression(bad, degree=1)(x)
+
+
+def test_integer_division_in_expression_strings_is_refused():
+    """`x[0]*(1/2) + pow(x[1], 3/2)` is 4.0 at (2, 4) under DOLFIN's C++ JIT (1/2 == 0, 3/2 == 1) and would be
+    9.0 with Python's division: refused on the host evaluator and on the device-program path alike."""
+    from fedm_amd import forms
+    x = np.array([[2.0, 4.0]])
+    for bad in ("x[0]*(1/2) + pow(x[1], 3/2)", "pow(x[1], -3/2)", "x[0]*((1+1)/(2*2))"):
+        with pytest.raises(NotImplementedError, match="integer division"):
+            forms.Expression(bad, degree=1)(x)
+        with pytest.raises(NotImplementedError, match="integer division"):
+            forms.expression_program(_expression_with_code(forms, bad))
+    assert forms.Expression("x[0]*(1.0/2) + pow(x[1], 3.0/2)", degree=1)(x)[0] == pytest.approx(9.0)
+    assert forms.Expression("x[0]/2 + 3*x[1]/4", degree=1)(x)[0] == pytest.approx(4.0)     # float / int is fine
+
+
+def _expression_with_code(forms, code):
+    e = forms.Expression("1.0", degree=1)
+    e.code = code
+    return e
 
 
 def test_time_of_flight_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):

@@ -20,7 +20,9 @@ every = 100
 
 t0 = time.time()
 channel = (0.0, r_ch) + streamer.CHANNEL[2:]
-msh = streamer.refined_mesh(h_fine, growth=growth, channel=channel, xml_path="gpurun_out/mesh_%d.xml" % round(h_fine * 1e9))
+import tempfile
+with tempfile.TemporaryDirectory(prefix="fedm_mesh_") as tmp:      # (tens of MB of XML: not into gpurun_out/)
+    msh = streamer.refined_mesh(h_fine, growth=growth, channel=channel, xml_path=tmp + "/mesh.xml")
 t_mesh = time.time() - t0
 prob = streamer.device_problem(msh.coords, msh.cells)
 st = streamer.Stepper(prob)
@@ -49,7 +51,7 @@ def field_stats(U):
 
 hist, t_run = [], time.time()
 status = "reached T_final"
-n0 = l0 = a0 = 0
+n0 = l0 = a0 = s0 = 0
 while st.t < T_final * (1 - 1e-9):
     try:
         st.step()
@@ -60,11 +62,12 @@ while st.t < T_final * (1 - 1e-9):
         U = prob.get_state()
         rows = st.log_rows()
         Emax, zhead = field_stats(U)
-        hist.append(dict(step=st.steps, t=st.t, dt=st.dt.time_step, newton_per_step=(st.newton_iterations - n0) / every,
-                         gmres_per_step=(st.linear_iterations - l0) / every, attempts=len(rows) - a0,
+        span = max(st.steps - s0, 1)
+        hist.append(dict(step=st.steps, t=st.t, dt=st.dt.time_step, newton_per_step=(st.newton_iterations - n0) / span,
+                         gmres_per_step=(st.linear_iterations - l0) / span, attempts=len(rows) - a0,
                          ne_max=float(np.exp(U[:, 1].max())), ni_max=float(np.exp(U[:, 0].max())),
                          E_max_axis=Emax, z_head=zhead, wall=round(time.time() - t_run, 2)))
-        n0, l0, a0 = st.newton_iterations, st.linear_iterations, len(rows)
+        n0, l0, a0, s0 = st.newton_iterations, st.linear_iterations, len(rows), st.steps
         print(hist[-1], flush=True)
         if not np.isfinite(hist[-1]["ne_max"]) or hist[-1]["ne_max"] > 1e24 or st.dt.time_step < 2e-15:
             status = "stopped: blow-up (ne_max > 1e24 or dt collapsed)"
