@@ -7,12 +7,17 @@
 # Everything is written under gpurun_out/<tag>_prof/ (merged back by gpurun); copy_profiles.py then
 # copies the summaries into profiles/.  The program follows `--` directly (no env/bash hop).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/${TAG}_prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="bench.py --steps 20 --warmup 5 --no-cpu-baseline --late-start 0"
-SHORT="bench.py --steps 2 --warmup 0 --no-cpu-baseline --late-start 0"
+# The library is built HERE, unprofiled: under rocprofv3 every child process inherits the profiler's
+# preloaded tool, which initialises the GPU, and the compiler driver's exec hops would then happen in
+# GPU-initialised processes (bench.py refuses to compile under a profiler for the same reason).
+python3 -c 'import __graft_entry__ as g; g.build()' || exit 9
+ONLY="--no-cpu-baseline --late-start 0 --unstructured off --big-mesh 0 --no-glow-discharge"
+BENCH="bench.py --steps 20 --warmup 5 $ONLY"
+SHORT="bench.py --steps 2 --warmup 0 $ONLY"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err" || exit 1
 rm -f "$OUT"/trace/t_kernel_trace.csv "$OUT"/trace/*/t_kernel_trace.csv      # tens of MB; the stats are what is kept
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 $SHORT > /dev/null 2> "$OUT/fetch.err" || exit 2
