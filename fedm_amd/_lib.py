@@ -81,7 +81,9 @@ class MeshDesc(C.Structure):
                 ("n_dirichlet", C.c_int32),
                 ("dirichlet_dofs", C.POINTER(C.c_int32)),
                 ("dirichlet_vals", C.POINTER(C.c_double)),
-                ("n_owned_vertices", C.c_int32)]
+                ("n_owned_vertices", C.c_int32),
+                ("n_identity_vertices", C.c_int32), ("identity_vertices", C.POINTER(C.c_int32)),
+                ("halo_depth", C.c_int32)]
 
 
 class NewtonOpts(C.Structure):

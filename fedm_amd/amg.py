@@ -124,12 +124,17 @@ def _csr_struct(M, keep):
                     values.ctypes.data_as(C.POINTER(C.c_double)))
 
 
-def _pack(levels, dense_coarse=True):
+def _pack(levels, dense_coarse=True, restrictions=None):
+    """restrictions: R per level where it is not the prolongator's transpose (several GPUs with deep halos:
+    the prolongator also has rows for ghost vertices, the restriction sums owned rows only)."""
     keep = []
     n = len(levels)
     A = (_lib.Csr * n)(*[_csr_struct(a, keep) for a, _ in levels])
     P = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p, keep) for _, p in levels[:-1]])
-    R = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(p.T, keep) for _, p in levels[:-1]])
+    Rs = [p.T for _, p in levels[:-1]]
+    for l, r in enumerate(restrictions or []):
+        Rs[l] = r
+    R = (_lib.Csr * max(n - 1, 1))(*[_csr_struct(r, keep) for r in Rs])
     coarse = None
     if dense_coarse:
         n_coarse = levels[-1][0].shape[0]
@@ -141,12 +146,12 @@ def _pack(levels, dense_coarse=True):
     return n, A, P, R, coarse, keep
 
 
-def install(handle, levels, nu=2, omega=0.67, dense_coarse=True):
+def install(handle, levels, nu=2, omega=0.67, dense_coarse=True, restrictions=None):
     """Upload a hierarchy built by :func:`build_hierarchy` into a device context.
     ``dense_coarse=False``: no inverse of the last level (a global hierarchy takes over there,
     :func:`install_global`)."""
     lib = _lib.load()
-    n, A, P, R, coarse, keep = _pack(levels, dense_coarse)
+    n, A, P, R, coarse, keep = _pack(levels, dense_coarse, restrictions)
     cptr = coarse.ctypes.data_as(C.POINTER(C.c_double)) if coarse is not None else None
     rc = lib.fedm_amg_setup(handle, n, A, P, R, cptr, int(nu), float(omega))
     if rc != 0:

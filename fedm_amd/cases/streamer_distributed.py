@@ -25,7 +25,8 @@ class Runner(streamer.Stepper):
     fallback_reason = None
 
     def __init__(self, per_gpu_mesh, rank, world, local_rank, grading=4.0, transport="rccl",
-                 group=None, n_per_gpu=None, global_n=None, distributed_multigrid=None, mesh=None, **kw):
+                 group=None, n_per_gpu=None, global_n=None, distributed_multigrid=None, mesh=None,
+                 halo_depth=None, **kw):
         """Mesh: ``mesh`` (any triangle mesh of the box, e.g. `streamer.refined_mesh`) is the GLOBAL
         mesh, partitioned as it is; else ``global_n`` cells per side of the whole tensor-product mesh
         (strong scaling, e.g. BASELINE configs[4]), else ``n_per_gpu`` (or the size of
@@ -38,8 +39,17 @@ class Runner(streamer.Stepper):
         else:
             n_per_gpu = n_per_gpu or int(round(np.sqrt(per_gpu_mesh.num_cells() / 2)))
             gmesh, n = global_mesh(n_per_gpu, world, grading)
+        # Ghost layers: 8 = the first stage, the five further sweeps of the degree-6 species polynomial, the
+        # coupling product, two multigrid smoothings and the Krylov product -- one exchange per Krylov step
+        # instead of ten (fedm_amd/partition.py); 1: the one-layer halo with an exchange per operator.
+        # (also with ONE rank when it runs the several-GPU solver: how the tests and
+        # tools/one_rank_rccl_overhead.py reach that code path)
+        if halo_depth is None:
+            several = world > 1 or bool(distributed_multigrid)
+            halo_depth = int(os.environ.get("FEDM_HALO_DEPTH", "8")) if several else 1
+        self.halo_depth = halo_depth
         part = partition.partition_rcb(gmesh.coords, world)
-        lm = partition.local_mesh(gmesh.coords, gmesh.cells, part, rank)
+        lm = partition.local_mesh(gmesh.coords, gmesh.cells, part, rank, depth=halo_depth)
         self.lm, self.world, self.rank = lm, world, rank
         # (True with one rank: the several-GPU solver -- distributed finest level, replicated coarse
         # levels, their all-reduces -- on a single rank: how the tests reach that code with RCCL)
@@ -51,7 +61,8 @@ class Runner(streamer.Stepper):
         ddofs, dvals = streamer.dirichlet(lm.coords)
         prob = DeviceProblem(lm.coords, lm.cells, streamer.model(), facet_tags=tags,
                              dirichlet_dofs=ddofs, dirichlet_vals=dvals, device=local_rank,
-                             n_owned=lm.n_owned)
+                             n_owned=lm.n_owned, identity_vertices=lm.identity_vertices if halo_depth > 1 else None,
+                             halo_depth=halo_depth)
         self.transport_requested = transport
         if transport == "rccl":
             # Every rank must take the same branch, and no rank may enter ncclCommInitRank alone
@@ -109,7 +120,7 @@ class Runner(streamer.Stepper):
         self.total_dofs = gmesh.num_vertices() * 3
         shape = f"{n}x{n}" if n else f"unstructured, {gmesh.num_vertices()} vertices"
         self.partition_name = (f"RCB vertex partition, {world} parts, global mesh {shape}, "
-                               f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices on rank {rank}, "
+                               f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices in {halo_depth} layer(s) on rank {rank}, "
                                f"{len(lm.neighbours)} neighbours, transport {transport}")
 
     def initialise(self):

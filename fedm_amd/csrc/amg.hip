@@ -317,7 +317,8 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
     // Global mode: the finest level is a truly distributed operator -- the ghost entries of the
     // right-hand side (before the first sweep, whose neighbours' values are formed from b) and of
     // the iterate (before the post-smoothing) come from their owners.
-    const bool exact0 = l == 0 && global && c.comm && !c.capturing;
+    // (deep halos: the right-hand side is exact on enough ghost layers for both smoothings -- no exchange)
+    const bool exact0 = l == 0 && global && c.comm && !c.capturing && !deep_halo_active(c);
     // (when the slices of A are classified -- interior: no ghost column -- the exchange runs on the
     // communication stream while the interior slices are processed)
     static const bool mg_overlap_ok = [] {
@@ -693,7 +694,7 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     // before every sweep (otherwise the sweeps see zeros there: block Jacobi over the ranks)
     // (across GPUs the field split is always on the right -- flexible GMRES --, so the applications
     // need not be one fixed operator; inside a captured step there is no exchange)
-    const bool halo = c.comm && c.fs_halo && !c.capturing && n_sweeps > 0;
+    const bool halo = c.comm && c.fs_halo && !deep_halo_active(c) && !c.capturing && n_sweeps > 0;
     // ... and the exchange overlaps with the sweep's interior slices (those without ghost columns):
     // mark the iterate complete, sweep the interior, exchange on the communication stream, wait,
     // sweep the boundary slices -- as the Krylov halo does with the Jacobian product
@@ -755,6 +756,11 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
     if (!with_cycle) return;  // the caller runs the V-cycle (collectives inside it) and scatters
     amg.run(c);
     if (scatter) hipLaunchKernelGGL(fs_scatter_kernel<NS>, gv, bv, 0, c.stream, c.nvp, amg.levels[0].x, z);
+}
+
+bool deep_halo_active(const Ctx &c) {
+    return c.comm && c.deep_halo && c.halo_depth > 1 && c.halo_depth >= c.fs_sweeps + 2 && !c.fs_upper && c.amg &&
+           c.amg->global && c.amg->pre_smooth && c.amg->nu == 1;
 }
 
 bool fieldsplit_upper(const Ctx &c) { return c.fs_upper && (c.right_precond || c.comm) && c.amg && c.poisson; }
@@ -954,6 +960,8 @@ __global__ void scatter_comp_kernel(int nvp, int neq, int comp, const double *__
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z) {
     const dim3 g((c.nvp + 255) / 256), b(256);
     hipLaunchKernelGGL(gather_comp_kernel, g, b, 0, c.stream, c.nvp, c.neq, c.neq - 1, r, amg.levels[0].b);
+    // deep halos: the cycle exchanges nothing itself and needs its right-hand side on the ghost layers
+    if (deep_halo_active(c)) comm_halo_scalar(c, amg.levels[0].b);
     amg.run(c);
     hipLaunchKernelGGL(scatter_comp_kernel, g, b, 0, c.stream, c.nvp, c.neq, c.neq - 1, amg.levels[0].x, z);
 }

@@ -289,8 +289,10 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
 // The Krylov vectors keep zero ghost entries (ghost rows of the product are zero), so Minv sees
 // the same inputs as on the left.
 static void right_step_plain(Ctx &c, int j, const double *const *vp, double *z, double *w) {
+    const bool deep = deep_halo_active(c);
+    if (deep) comm_halo(c, const_cast<double *>(vp[j]));   // the step's one exchange: its input on all ghost layers
     fieldsplit_apply(c, *c.amg, vp[j], z, 1.0);
-    comm_halo(c, z);
+    if (!deep) comm_halo(c, z);
     prof_begin(c, 1);
     launch_spmv(c, z, w, false);
     prof_end(c);
@@ -365,6 +367,9 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         ++c.mail_seq;
         return true;
     }
+    const bool deep = deep_halo_active(c);
+    // deep halos: v_j on all ghost layers, then sweeps, smoothings and the product without an exchange
+    if (deep) comm_halo(c, const_cast<double *>(vp[j]));
     if (upper) {
         // potential first (the V-cycle with its collectives, then the ghost entries of its result),
         // then the species part: plain launches with the exchanges between the sweeps, or its graph
@@ -376,7 +381,7 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
             c.iter_graphs_ok = false;
             fieldsplit_upper_species(c, *c.amg, vp[j], z, 1.0);  // same result with plain launches
         }
-    } else if (c.fs_halo) {
+    } else if (c.fs_halo && !deep) {
         // exchanges between the sweeps: the rank-local part of the preconditioner is not one graph
         with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct, !c.amg->global); });
     } else if (hipGraphLaunch(c.iter_graph_pre[j], c.stream) != hipSuccess) {
@@ -392,10 +397,15 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         const char *e = std::getenv("FEDM_HALO_OVERLAP");
         return !(e && e[0] == '0');
     }();
-    if (overlap) comm_halo_begin(c);
-    else comm_halo(c, z);
+    if (deep) {
+        // z_j is exact on the first ghost layer already
+    } else if (overlap) {
+        comm_halo_begin(c);
+    } else {
+        comm_halo(c, z);
+    }
     bool ok = !c.iter_graph_interior[j] || hipGraphLaunch(c.iter_graph_interior[j], c.stream) == hipSuccess;
-    if (overlap) comm_halo_exchange(c, z);
+    if (overlap && !deep) comm_halo_exchange(c, z);
     ok = ok && hipGraphLaunch(c.iter_graph[j], c.stream) == hipSuccess;
     if (!ok) {  // z_j is complete on every rank: redo the product with plain launches (same result)
         hipGetLastError();
@@ -915,6 +925,17 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
     c.nvp = c.pat.nvp;
     c.n_owned = (mesh->n_owned_vertices > 0 && mesh->n_owned_vertices <= c.nv) ? mesh->n_owned_vertices : c.nv;
     c.n_dot = (int64_t)c.n_owned * c.neq;
+    c.halo_depth = 1;
+    if (mesh->halo_depth > 1 && (mesh->identity_vertices || mesh->n_identity_vertices == 0)) {
+        for (int i = 0; i < mesh->n_identity_vertices; ++i)
+            if (mesh->identity_vertices[i] < c.n_owned || mesh->identity_vertices[i] >= c.nv) {
+                set_error("identity_vertices must be ghost vertices");
+                return -2;
+            }
+        c.halo_depth = mesh->halo_depth;
+        c.n_identity = mesh->n_identity_vertices;
+        if (upload(c.d_identity, mesh->identity_vertices, (size_t)c.n_identity)) return -1;
+    }
     c.n = (int64_t)c.nv * c.neq;
     c.np = (int64_t)c.nvp * c.neq;
     for (int i = 0; i < mesh->n_dirichlet; ++i)
@@ -1017,6 +1038,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
                 if (e[0] == '0') c.zero_plane_mask = 0;
         }
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
+        if (const char *e = getenv("FEDM_DEEP_HALO")) c.deep_halo = e[0] != '0';
         if (const char *e = getenv("FEDM_FS_LAGGED_COUPLING")) c.fs_lagged_coupling = e[0] != '0';
         if (const char *e = getenv("FEDM_GD_HAND"))
             if (e[0] == '0' || e[0] == '2' || e[0] == '3') c.gd_hand_mode = e[0] - '0';
@@ -1068,7 +1090,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (c.stream) hipStreamSynchronize(c.stream);
     void *ptrs[] = {c.d_coords, c.d_cells, c.d_ftags, c.d_cell_slots, c.d_colour_cells, c.d_model,
                     c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.d_val, c.d_dinv, c.d_dir_dofs,
-                    c.d_dir_vals, c.d_u, c.d_uold, c.d_uold1, c.d_F, c.d_delta, c.d_w, c.d_rhs,
+                    c.d_dir_vals, c.d_identity, c.d_u, c.d_uold, c.d_uold1, c.d_F, c.d_delta, c.d_w, c.d_rhs,
                     c.d_tmp, c.d_fs, c.d_fs_g, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
                     c.d_ext[3], c.d_patch_cell_ptr, c.d_patch_halo_ptr, c.d_patch_halo,
                     c.d_patch_cells, c.d_bfacets, c.d_gd, c.d_gd_fields, c.d_gd_elem, c.d_gd_inv_ptr,

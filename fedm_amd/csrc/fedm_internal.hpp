@@ -78,6 +78,10 @@ struct Ctx {
     Prof prof;
     Comm *comm = nullptr;  // multi-GPU transport (optional)
     int n_owned = 0;       // owned vertices (== nv on a single GPU)
+    // Deep halos: ghost vertices of the inner layers have assembled rows; d_identity lists the ghost
+    // vertices with identity rows (the outermost layer).  halo_depth == 1: all ghosts, no list.
+    int halo_depth = 1, n_identity = 0;
+    int *d_identity = nullptr;
     int64_t n_dot = 0;     // vector entries that take part in reductions: n_owned * neq
     int device = 0;
     hipStream_t stream = nullptr;
@@ -155,6 +159,7 @@ struct Ctx {
     double fs_main_w[16] = {1}, fs_alt_w[16] = {1};
     bool fs_alt_active = false;
     bool fs_halo = true;    // several GPUs: ghost exchange of the species iterate before every sweep
+    bool deep_halo = true;  // use the ghost layers (halo_depth > 1) instead of those exchanges; FEDM_DEEP_HALO=0: off
     // lower-triangular order: b_phi -= J_phi,u z_u formed inside the last species sweep from the
     // iterate before it (FEDM_FS_LAGGED_COUPLING=0: separate kernel on the final iterate)
     bool fs_lagged_coupling = true;
@@ -265,6 +270,10 @@ void wait_red(Ctx &c);                      // wait for the publication launch_d
 void set_error(const std::string &msg);
 void iter_graphs_clear(Ctx &c);
 int copy_bandwidth(int device, int64_t bytes, int repeats, double *gbs);   // kernels.hip
+// Deep halos in force: the mesh carries enough ghost layers for one preconditioner application + Krylov
+// product (first stage, fs_sweeps - 1 species sweeps, coupling product, two multigrid smoothings, SpMV:
+// fs_sweeps + 2 layers), so a Krylov step exchanges its input vector once and nothing else.
+bool deep_halo_active(const Ctx &c);
 void prof_begin(Ctx &c, int kind);
 void prof_end(Ctx &c);
 void prof_collect(Ctx &c);

@@ -660,12 +660,15 @@ __global__ void dirichlet_kernel(int n_dir, const int *__restrict__ dofs,
                                  double *__restrict__ F, double *__restrict__ val,
                                  const int *__restrict__ boff, const int *__restrict__ colidx,
                                  const uint32_t *__restrict__ diag_slot, int neq, int jacobian,
-                                 int id_first, int n_id) {
+                                 int id_first, int n_id, const int *__restrict__ id_list, int n_list) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int neq2 = neq * neq;
     if (t >= n_dir) {
         if (t - n_dir >= n_id) return;
-        const int vtx = id_first + (t - n_dir);
+        // identity rows: the range [id_first, ...) or, with deep halos, the listed ghost vertices (the
+        // outermost layer) followed by the padding range
+        const int k = t - n_dir;
+        const int vtx = id_list ? (k < n_list ? id_list[k] : id_first + (k - n_list)) : id_first + k;
         const int slice = vtx >> 6, lane = vtx & 63;
         for (int cr = 0; cr < neq; ++cr) {
             F[(size_t)vtx * neq + cr] = 0.0;
@@ -680,7 +683,9 @@ __global__ void dirichlet_kernel(int n_dir, const int *__restrict__ dofs,
     }
     const int dof = dofs[t];
     const int vtx = dof / neq, cr = dof % neq;
-    if (n_id > 0 && vtx >= id_first) return;  // a ghost's row: identity with F = 0, written above
+    // a ghost's row (one layer: identity with F = 0, written above; deep halos: an assembled row whose
+    // Dirichlet condition applies as on its owner)
+    if (!id_list && n_id > 0 && vtx >= id_first) return;
     F[dof] = u[dof] - vals[t];
     if (!jacobian) return;
     const int slice = vtx >> 6, lane = vtx & 63;
@@ -715,18 +720,24 @@ __global__ void identity_rows_kernel(int nv, int nvp, int neq, int ns_frozen,
 
 void launch_finalize(Ctx &c, bool jacobian, int mode) {
     const int ns_frozen = (mode == 1) ? c.ns : 0;
-    int n_id = c.nvp - c.n_owned;  // padding + ghost vertices
+    const bool deep = c.d_identity != nullptr;
+    // identity rows: padding + ghost vertices (deep halos: padding + the listed outermost ghost layer)
+    int n_id = deep ? c.n_identity + (c.nvp - c.nv) : c.nvp - c.n_owned;
     if (ns_frozen > 0) {           // frozen species: every vertex has identity rows
+        // (vertices beyond the first argument: all rows -- the ghosts of a one-layer halo and the padding;
+        // deep halos: the padding only, the inner ghost layers keep their potential rows and the
+        // outermost layer is listed)
         hipLaunchKernelGGL(identity_rows_kernel, dim3((c.nvp + 255) / 256), dim3(256), 0, c.stream,
-                           c.n_owned, c.nvp, c.neq, ns_frozen, c.d_F, c.d_val, c.d_slice_boff,
+                           deep ? c.nv : c.n_owned, c.nvp, c.neq, ns_frozen, c.d_F, c.d_val, c.d_slice_boff,
                            c.d_diag_slot, jacobian ? 1 : 0);
-        n_id = 0;
+        n_id = deep ? c.n_identity : 0;
     }
     // (Dirichlet dofs of ghost vertices are left to the identity branch: the row sets are disjoint)
     if (c.n_dir + n_id > 0)
         hipLaunchKernelGGL(dirichlet_kernel, dim3((c.n_dir + n_id + 255) / 256), dim3(256), 0, c.stream,
                            c.n_dir, c.d_dir_dofs, c.d_dir_vals, c.d_u, c.d_F, c.d_val,
-                           c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.neq, jacobian ? 1 : 0, c.n_owned, n_id);
+                           c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.neq, jacobian ? 1 : 0,
+                           deep ? c.nv : c.n_owned, n_id, c.d_identity, c.n_identity);
 }
 
 __global__ void set_dirichlet_state_kernel(int n_dir, const int *__restrict__ dofs,

@@ -324,7 +324,8 @@ class DeviceProblem:
     """Mesh + model + state resident on one MI355X."""
 
     def __init__(self, coords, cells, model: Model, facet_tags=None,
-                 dirichlet_dofs=(), dirichlet_vals=(), device=0, reorder=True, n_owned=None):
+                 dirichlet_dofs=(), dirichlet_vals=(), device=0, reorder=True, n_owned=None,
+                 identity_vertices=None, halo_depth=1):
         self.lib = _lib.load()
         self.model = model
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
@@ -366,6 +367,16 @@ class DeviceProblem:
         mesh.dirichlet_dofs = self._ddofs.ctypes.data_as(C.POINTER(C.c_int32))
         mesh.dirichlet_vals = _dp(self._dvals)
         mesh.n_owned_vertices = self.n_owned
+        # deep halos (partition.local_mesh(depth > 1)): the ghost vertices with identity rows (ghosts keep
+        # their place in the internal numbering, so the caller's ids are the device's)
+        self.halo_depth = int(halo_depth)
+        if identity_vertices is not None and self.halo_depth > 1:
+            self._identity = np.ascontiguousarray(identity_vertices, dtype=np.int32)
+            if self._identity.size and (self._identity.min() < self.n_owned or self._identity.max() >= self.nv):
+                raise ValueError("DeviceProblem: identity_vertices must be ghost vertices")
+            mesh.n_identity_vertices = self._identity.size
+            mesh.identity_vertices = self._identity.ctypes.data_as(C.POINTER(C.c_int32))
+            mesh.halo_depth = self.halo_depth
         handle = C.c_void_p()
         create = self.lib.fedm_ctx_create_gd if isinstance(model, GdModel) else self.lib.fedm_ctx_create
         rc = create(C.byref(mesh), C.byref(md), int(device), C.byref(handle))
@@ -741,9 +752,20 @@ class DeviceProblem:
         A1 = (0.5 * (A1 + A1.T)).tocsr()
         coords1 = np.vstack([c for _, c in pieces])
         # device: finest level (device numbering) with the global level-1 space as its coarse space
-        P_dev = sp.vstack([P_own, sp.csr_matrix((nv - n_own, n_g))]).tocsr()[to_loc]
+        R_dev = sp.vstack([P_own, sp.csr_matrix((nv - n_own, n_g))]).tocsr()[to_loc].T.tocsr()
+        if self.halo_depth > 1:
+            # deep halos: the correction P x_c is formed on the ghost layers too (their prolongator rows came
+            # from the owners for the Galerkin product), so that the post-smoothing of the owned rows finds
+            # exact neighbours without an exchange; the restriction sums OWNED rows only (each fine row once
+            # over all ranks).  The outermost layer (identity rows) gets no correction.
+            keep = np.ones(nv)
+            keep[np.asarray(self._identity, dtype=np.int64)] = 0.0
+            P_dev = (sp.diags(keep) @ P_ext).tocsr()[to_loc]
+        else:
+            P_dev = R_dev.T.tocsr()
         K_dev = K[to_loc][:, to_loc]
-        local_sizes = amg.install(self._h, [(K_dev, P_dev), (A1, None)], nu=nu, omega=omega, dense_coarse=False)
+        local_sizes = amg.install(self._h, [(K_dev, P_dev), (A1, None)], nu=nu, omega=omega, dense_coarse=False,
+                                  restrictions=[R_dev])
         levels_g = amg.build_hierarchy(A1, theta=theta, max_coarse=max_coarse, coords=coords1)
         global_sizes = amg.install_global(self._h, levels_g, n_g, 0, nu=nu, omega=omega)
         self.multigrid_levels = [local_sizes[0], f"{n1} of {n_g} global"] + global_sizes[1:]

@@ -13,6 +13,18 @@ Local numbering of a part: owned vertices first, then ghost vertices grouped by
 owning rank (ascending rank, ascending global id inside a group); both sides of
 a halo link list the shared vertices in ascending global id, so the receive
 side needs no unpacking.
+
+**Deep halos** (``depth`` > 1).  With one ghost layer every operator application needs
+its own exchange: a Krylov step of the field-split solver then contains ten small
+collectives (five species sweeps, two multigrid smoothings, the Krylov product, two
+reductions) and is bound by their latency, not by bandwidth.  With ``depth`` layers a
+rank also ASSEMBLES the rows of its ghost vertices of layers 1 .. depth-1 (redundantly;
+only the outermost layer has identity rows) and applies every operator to them as well:
+after ONE exchange of a vector on all ghost layers, each operator application shrinks
+the region where the result is still exact by one layer, and the owned rows stay exact
+for depth-1 applications in a row -- the sweeps, the coupling product, both smoothings
+and the Krylov product of one step, with no further exchange (overlapping Schwarz
+blocks, computed redundantly instead of communicated).
 """
 from dataclasses import dataclass
 from typing import List
@@ -54,43 +66,104 @@ class LocalMesh:
     send_ptr: np.ndarray        # (n_nb+1)
     send_idx: np.ndarray        # local (owned) vertex ids to send, per neighbour
     recv_ptr: np.ndarray        # (n_nb+1), ghost offsets relative to n_owned
+    layer: np.ndarray = None    # (n_local,): 0 owned, k = ghost vertex k edges away from the owned set
+    depth: int = 1              # ghost layers; rows of layers < depth are assembled, layer == depth: identity
 
     @property
     def n_ghost(self):
         return self.coords.shape[0] - self.n_owned
 
+    @property
+    def identity_vertices(self):
+        """Local ids of the ghost vertices whose rows are identity rows (the outermost layer)."""
+        return np.nonzero(self.layer == self.depth)[0].astype(np.int32)
 
-def local_mesh(coords, cells, part, rank):
-    """Sub-mesh of ``rank``: its owned vertices, every cell touching one, the ghosts."""
+
+def vertex_graph(n_vertices, cells):
+    """Symmetric vertex adjacency (CSR, without the diagonal) of a triangle mesh."""
+    import scipy.sparse as sp
+    c = np.asarray(cells, dtype=np.int64)
+    i = np.concatenate([c[:, 0], c[:, 1], c[:, 2], c[:, 1], c[:, 2], c[:, 0]])
+    j = np.concatenate([c[:, 1], c[:, 2], c[:, 0], c[:, 0], c[:, 1], c[:, 2]])
+    g = sp.csr_matrix((np.ones(i.size, dtype=np.int8), (i, j)), shape=(n_vertices, n_vertices))
+    g.sum_duplicates()
+    return g
+
+
+def _layers(graph, seed, depth):
+    """Edge distance (1 .. depth) of every vertex within `depth` of the set `seed` (bool mask); 0 on the
+    set, -1 beyond.  Frontier expansion: the cost follows the layers, not the mesh."""
+    dist = np.where(seed, 0, -1).astype(np.int32)
+    indptr, indices = graph.indptr, graph.indices
+    nb = indices[_row_entries(indptr, np.nonzero(seed)[0])]    # first frontier: neighbours of the set outside it
+    frontier = np.unique(nb[~seed[nb]])
+    for k in range(1, depth + 1):
+        frontier = frontier[dist[frontier] < 0]
+        if frontier.size == 0:
+            break
+        dist[frontier] = k
+        if k == depth:
+            break
+        nb = indices[_row_entries(indptr, frontier)]
+        frontier = np.unique(nb[dist[nb] < 0])
+    return dist
+
+
+def _row_entries(indptr, rows):
+    """Positions of the entries of the CSR rows `rows`, concatenated."""
+    lens = indptr[rows + 1] - indptr[rows]
+    starts = np.repeat(indptr[rows] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
+    return starts + np.arange(int(lens.sum()))
+
+
+def local_mesh(coords, cells, part, rank, depth=1, graph=None):
+    """Sub-mesh of ``rank``: its owned vertices, ``depth`` layers of ghost vertices around them, and
+    every cell that touches an owned vertex or a ghost vertex of a layer < depth (the cells the rank
+    assembles; with ``depth`` = 1: the cells touching an owned vertex, whose other vertices are the
+    ghosts)."""
     coords = np.asarray(coords, dtype=np.float64)
     cells = np.asarray(cells, dtype=np.int64)
     part = np.asarray(part)
     n_parts = int(part.max()) + 1
-    cpart = part[cells]                                   # (Nc,3)
-    mine = (cpart == rank).any(axis=1)
+    depth = int(depth)
+    if depth < 1:
+        raise ValueError("local_mesh: at least one ghost layer")
+    nv = coords.shape[0]
+    if graph is None and depth > 1:
+        graph = vertex_graph(nv, cells)
+
+    def reach(q):
+        """distance to rank q's owned set, up to `depth` (-1 beyond)"""
+        if depth == 1:      # one layer: the vertices sharing a cell with an owned one (no graph needed)
+            touch = (part[cells] == q).any(axis=1)
+            d = np.full(nv, -1, dtype=np.int32)
+            d[np.unique(cells[touch])] = 1
+            d[part == q] = 0
+            return d
+        return _layers(graph, part == q, depth)
+
+    dist = reach(rank)
+    assembled = (dist >= 0) & (dist < depth)               # vertices whose rows this rank assembles
+    mine = assembled[cells].any(axis=1)
     cell_global = np.nonzero(mine)[0]
     lc = cells[cell_global]
-    verts = np.unique(lc)
-    owner = part[verts]
-    owned = verts[owner == rank]
-    ghosts = verts[owner != rank]
+    owned = np.nonzero(part == rank)[0]
+    ghosts = np.nonzero(dist > 0)[0]
     gorder = np.lexsort((ghosts, part[ghosts]))           # by owner rank, then global id
     ghosts = ghosts[gorder]
     vertex_global = np.concatenate([owned, ghosts])
-    lookup = np.full(coords.shape[0], -1, dtype=np.int64)
+    lookup = np.full(nv, -1, dtype=np.int64)
     lookup[vertex_global] = np.arange(vertex_global.size)
     gowner = part[ghosts]
     neighbours = np.unique(gowner)
     recv_ptr = np.concatenate([[0], np.cumsum([np.count_nonzero(gowner == q) for q in neighbours])])
-    # what rank q needs from me: my owned vertices that sit in a cell with a q-owned vertex
+    # what rank q needs from me: my owned vertices within `depth` of q's owned set -- q's ghosts owned by
+    # me.  (Distances are symmetric, so q finds me among its neighbours exactly when I find q.)
     send_lists = []
     for q in neighbours:
-        touch = (cpart == q).any(axis=1) & mine
-        v = np.unique(cells[touch])
-        v = v[part[v] == rank]
-        send_lists.append(lookup[np.sort(v)])
-    # a rank that needs my vertices also owns ghosts of mine (cells are shared), so the
-    # neighbour sets are symmetric by construction
+        dq = reach(int(q))
+        v = owned[dq[owned] > 0]
+        send_lists.append(lookup[v])                       # owned is ascending: ascending global id
     send_ptr = np.concatenate([[0], np.cumsum([len(s) for s in send_lists])])
     send_idx = np.concatenate(send_lists) if send_lists else np.zeros(0, dtype=np.int64)
     return LocalMesh(rank=rank, n_parts=n_parts, coords=coords[vertex_global],
@@ -98,7 +171,7 @@ def local_mesh(coords, cells, part, rank):
                      vertex_global=vertex_global, n_owned=int(owned.size),
                      neighbours=neighbours.astype(np.int32),
                      send_ptr=send_ptr.astype(np.int32), send_idx=send_idx.astype(np.int32),
-                     recv_ptr=recv_ptr.astype(np.int32))
+                     recv_ptr=recv_ptr.astype(np.int32), layer=dist[vertex_global].astype(np.int32), depth=depth)
 
 
 def exchange_ghosts(lm: LocalMesh, values, group=None):

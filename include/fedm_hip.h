@@ -99,6 +99,14 @@ typedef struct {
     const double *dirichlet_vals;
     int32_t n_owned_vertices;    /* multi-GPU: vertices [0, n_owned) are owned, the rest are
                                     ghosts of neighbouring partitions; 0 = all owned        */
+    /* Deep halos (several ghost layers, fedm_amd/partition.py): the ghost vertices whose rows are
+     * identity rows -- the outermost layer.  The rows of all other ghost vertices are assembled
+     * like owned rows (redundantly), so that a vector exchanged once stays exact on the owned rows
+     * through as many operator applications as there are layers.  NULL: every ghost row is an
+     * identity row (one ghost layer).  halo_depth: the number of layers (1 with NULL). */
+    int32_t n_identity_vertices;
+    const int32_t *identity_vertices;
+    int32_t halo_depth;
 } fedm_mesh_desc;
 
 typedef struct {
@@ -190,7 +198,7 @@ const char *fedm_last_error(void);
 /* Version of this header's structs and entry points; a binding compares it with the constant it was
  * written against and refuses a library of another version (a descriptor that grew would otherwise be
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
- * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info. */
+ * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields. */
 #define FEDM_ABI_VERSION 2
 int fedm_abi_version(void);
 

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, restart=30):
+def _worker(rank, world, port, q, restart=30, halo_depth=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
@@ -30,28 +30,34 @@ def _worker(rank, world, port, q, restart=30):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         run = streamer_distributed.Runner(None, rank, world, 0, grading=2.0, transport="torch",
-                                          n_per_gpu=N_PER_GPU, **TOL)
+                                          n_per_gpu=N_PER_GPU, halo_depth=halo_depth, **TOL)
         run.solver.parameters["krylov_relative_tolerance"] = 1e-11
         run.solver.parameters["krylov_restart"] = restart
         run.initialise()
         for _ in range(STEPS):
             run.step()
         U = run.prob.get_state()[:run.lm.n_owned]
-        q.put((rank, run.lm.vertex_global[:run.lm.n_owned], U, run.log_rows(), run.global_n))
+        stats = run.prob.comm_stats()
+        q.put((rank, run.lm.vertex_global[:run.lm.n_owned], U, run.log_rows(), run.global_n,
+               (stats["halo_exchanges"], stats["allreduces"], run.linear_iterations, int(run.lm.n_ghost))))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("restart", [30, 3])
-def test_two_ranks_match_single_gpu(restart):
+@pytest.mark.parametrize("restart,halo_depth", [(30, None), (3, None), (30, 1), (30, 3)])
+def test_two_ranks_match_single_gpu(restart, halo_depth):
     """restart = 3 makes every linear solve run through several GMRES cycles: the restarted
-    residual rhs - J delta (halo exchange of delta, plain product) and the accumulated update."""
+    residual rhs - J delta (halo exchange of delta, plain product) and the accumulated update.
+    halo_depth: None = the default of eight ghost layers (one exchange per Krylov step: the input
+    vector on all layers; sweeps, smoothings and product on redundantly assembled ghost rows),
+    1 = the one-layer halo with an exchange before every operator, 3 = ghost layers that do NOT
+    cover a preconditioner application (the library must fall back to the exchanges)."""
     import torch.multiprocessing as mp
     from fedm_amd.cases import streamer
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, restart)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, restart, halo_depth)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -68,13 +74,21 @@ def test_two_ranks_match_single_gpu(restart):
         st.step()
     U_ref = prob.get_state()
     U = np.zeros_like(U_ref)
-    for _, gids, Uloc, _, _ in res:
+    for _, gids, Uloc, _, _, _ in res:
         U[gids] = Uloc
     scale = np.abs(U_ref).max(axis=0)
     assert (np.abs(U - U_ref) / scale).max() < 1e-8
     ref_log = np.array(st.log_rows())
     for r in res:
         assert np.allclose(np.array(r[3]), ref_log, rtol=1e-6)
+    # the Krylov counts are those of one GPU whatever the halo, and the deep halo saves the exchanges
+    halos, _, krylov, n_ghost = res[0][5]
+    assert abs(krylov - st.linear_iterations) <= 2       # (rounding at the 1e-11 Krylov tolerance)
+    if restart == 30:
+        if halo_depth is None:
+            assert halos < 3 * krylov            # ~1.5 per Krylov step (its input + the state halos)
+        else:
+            assert halos > 6 * krylov            # an exchange before every sweep, smoothing and product
 
 
 def test_rccl_transport_single_rank():

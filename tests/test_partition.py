@@ -110,3 +110,63 @@ def test_gloo_ghost_exchange_world2():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert all(ng > 0 for _, _, ng in res)
+
+
+def test_deep_halo_layers_plans_and_redundantly_assembled_rows():
+    """partition.local_mesh(depth=k): k ghost layers by edge distance; the halo plans of all ranks fit
+    together; the outermost layer is the list of identity rows; and the cells a rank keeps are exactly
+    what it needs to assemble the rows of its owned vertices AND of its ghost vertices of the inner
+    layers -- the oracle's residual rows of those vertices on the local mesh equal the global ones
+    (that is what lets a Krylov step run sweeps, smoothings and product after ONE exchange)."""
+    from fedm_amd import partition
+    from fedm_amd.cases import streamer
+    from oracle import streamer as ost
+    from oracle.forms import LFAModel
+    from oracle.mesh import Mesh, mark_boundaries
+    m = streamer.refined_mesh(2.5e-4)                       # unstructured, ~700 vertices
+    nv = m.num_vertices()
+    graph = partition.vertex_graph(nv, m.cells)
+    depth, world = 4, 3
+    part = partition.partition_rcb(m.coords, world)
+    lms = [partition.local_mesh(m.coords, m.cells, part, r, depth=depth) for r in range(world)]
+    # layers against a brute-force breadth-first search
+    import scipy.sparse.csgraph as csg
+    for lm in lms:
+        owned = np.nonzero(part == lm.rank)[0]
+        d = csg.shortest_path(graph.astype(float), unweighted=True, indices=owned).min(axis=0)
+        inside = np.nonzero(d <= depth)[0]
+        assert np.array_equal(np.sort(lm.vertex_global), inside)
+        assert np.array_equal(lm.layer, d[lm.vertex_global].astype(int))
+        assert np.array_equal(lm.identity_vertices, np.nonzero(lm.layer == depth)[0])
+        assert (lm.layer[:lm.n_owned] == 0).all() and (lm.layer[lm.n_owned:] > 0).all()
+    for p in range(world):
+        for ip_, q in enumerate(lms[p].neighbours):
+            lq = lms[q]
+            iq = list(lq.neighbours).index(p)
+            sent = lms[p].vertex_global[lms[p].send_idx[lms[p].send_ptr[ip_]:lms[p].send_ptr[ip_ + 1]]]
+            expected = lq.vertex_global[lq.n_owned + lq.recv_ptr[iq]:lq.n_owned + lq.recv_ptr[iq + 1]]
+            assert np.array_equal(sent, expected)
+    # rows of the owned vertices and of the ghost layers 1 .. depth-1 assemble locally
+    gm = Mesh(m.coords, m.cells)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gmodel = ost.build(gm)
+        U = ost.initial_state(gmodel)
+    rng = np.random.default_rng(1)
+    U[:, 1] += rng.normal(0, 0.2, nv)
+    Uo = U + rng.normal(0, 0.01, U.shape)
+    F_glob = gmodel.residual(U, Uo, Uo, 5e-12, 4e-12, apply_bc=False).reshape(nv, 3)
+    gtags = mark_boundaries(gm, ost.BOUNDARIES)
+    scale = np.abs(F_glob).max(axis=0)
+    for lm in lms:
+        lmodel = LFAModel(Mesh(lm.coords, lm.cells), 2, True, ["reaction", "drift-diffusion-reaction"], [1.0, -1.0],
+                          mu=[0.0, ost.MU_E], D=[0.0, ost.D_E], reactions=[(ost.K_ION, [0, 1], [1, 1])],
+                          facet_tags=gtags[lm.cell_global], bc_type=ost.BC_TYPE, qdeg=2)
+        g = lm.vertex_global
+        F_loc = lmodel.residual(U[g], Uo[g], Uo[g], 5e-12, 4e-12, apply_bc=False).reshape(-1, 3)
+        rows = lm.layer < depth
+        assert rows.sum() > lm.n_owned
+        assert (np.abs(F_loc[rows] - F_glob[g[rows]]) / scale).max() < 1e-12
+        # ... and NOT those of the outermost layer (their cells beyond the local mesh are missing)
+        outer = lm.layer == depth
+        assert (np.abs(F_loc[outer] - F_glob[g[outer]]) / scale).max() > 1e-6
