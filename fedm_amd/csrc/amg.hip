@@ -390,6 +390,18 @@ int Amg::capture(Ctx &c) {
     return e == hipSuccess ? 0 : -1;
 }
 
+// sum of the ranks' contributions to the global level-1 right-hand side
+// (it feeds a preconditioner: single precision on the wire halves the largest message of a Krylov step;
+// FEDM_MG_ALLREDUCE_F32=0: double precision)
+void Amg::allreduce_level1(Ctx &c) {
+    static const bool f32 = [] {
+        const char *e = std::getenv("FEDM_MG_ALLREDUCE_F32");
+        return !(e && e[0] == '0');
+    }();
+    if (f32) comm_allreduce_f32_payload(c, d_gb, n_global);
+    else comm_allreduce(c, d_gb, n_global);
+}
+
 void Amg::run(Ctx &c) {
     if (c.capturing) {  // part of a whole-iteration graph: its kernels become nodes of that graph
         vcycle(c, 0, 0);
@@ -398,14 +410,7 @@ void Amg::run(Ctx &c) {
     prof_begin(c, 3);
     if (global) {
         vcycle(c, 0, 1);
-        // (the level-1 right-hand side feeds a preconditioner: single precision on the wire halves the
-        // largest message of a Krylov step; FEDM_MG_ALLREDUCE_F32=0: double precision)
-        static const bool f32 = [] {
-            const char *e = std::getenv("FEDM_MG_ALLREDUCE_F32");
-            return !(e && e[0] == '0');
-        }();
-        if (f32) comm_allreduce_f32_payload(c, d_gb, n_global);
-        else comm_allreduce(c, d_gb, n_global);
+        allreduce_level1(c);
         vcycle(c, 0, 2);
     } else if (graph_exec) {
         hipGraphLaunch(graph_exec, c.stream);

@@ -79,7 +79,8 @@ struct Amg {
     // levels[level].b -> levels[level].x; phase 0 whole cycle, 1 down leg, 2 coarse solve + up leg
     void vcycle(Ctx &c, int level, int phase = 0);
     int capture(Ctx &c);             // record the V-cycle once as a hipGraph
-    void run(Ctx &c);                // levels[0].b -> levels[0].x
+    void run(Ctx &c);
+    void allreduce_level1(Ctx &c);   // several GPUs: between the cycle's phases 1 and 2
     void release();
 };
 

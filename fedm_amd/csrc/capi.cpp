@@ -288,6 +288,20 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
 //   graph B_j (boundary rows, local partial sums) -> all-reduce -> finish/publish -> update.
 // The Krylov vectors keep zero ghost entries (ghost rows of the product are zero), so Minv sees
 // the same inputs as on the left.
+// (deep halos: the caller has exchanged v_j already)
+static void right_step_plain_after_exchange(Ctx &c, int j, const double *const *vp, double *z, double *w) {
+    fieldsplit_apply(c, *c.amg, vp[j], z, 1.0);
+    if (!deep_halo_active(c)) comm_halo(c, z);
+    prof_begin(c, 1);
+    launch_spmv(c, z, w, false);
+    prof_end(c);
+    std::vector<const double *> dotp(j + 2);
+    for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+    dotp[j + 1] = w;
+    launch_dots(c, dotp.data(), w, j + 2, true);
+    launch_cgs_update(c, j + 1, vp, w);
+}
+
 static void right_step_plain(Ctx &c, int j, const double *const *vp, double *z, double *w) {
     const bool deep = deep_halo_active(c);
     if (deep) comm_halo(c, const_cast<double *>(vp[j]));   // the step's one exchange: its input on all ghost layers
@@ -337,6 +351,20 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
                 launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, true);
                 launch_cgs_update(c, j + 1, vp, w);
             });
+        } else if (deep_halo_active(c) && !upper) {
+            // deep halos: nothing is exchanged inside the step, so it is cut at its two all-reduces only --
+            // [field split + the cycle's leg down] | level-1 all-reduce | [the cycle's leg up + the whole
+            // Krylov product + local dot products] | all-reduce
+            ok = capture_graph(c, &c.iter_graph_pre[j], [&] {
+                with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct, false); });
+                c.amg->vcycle(c, 0, 1);
+            });
+            ok = ok && capture_graph(c, &c.iter_graph[j], [&] {
+                with_direct_output([&] { c.amg->vcycle(c, 0, 2); });
+                if (!direct) fieldsplit_scatter(c, *c.amg, z);
+                launch_spmv(c, z, w, false);
+                launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, false);
+            });
         } else {
             Comm &cm = *c.comm;
             const bool cycle_inside = !c.amg->global;  // no collectives in the V-cycle
@@ -370,6 +398,32 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
     const bool deep = deep_halo_active(c);
     // deep halos: v_j on all ghost layers, then sweeps, smoothings and the product without an exchange
     if (deep) comm_halo(c, const_cast<double *>(vp[j]));
+    if (deep && !upper) {
+        if (hipGraphLaunch(c.iter_graph_pre[j], c.stream) != hipSuccess) {
+            hipGetLastError();
+            c.iter_graphs_ok = false;
+            right_step_plain_after_exchange(c, j, vp, z, w);
+            return true;
+        }
+        c.amg->allreduce_level1(c);
+        if (hipGraphLaunch(c.iter_graph[j], c.stream) != hipSuccess) {   // the same leg up and product, plainly
+            hipGetLastError();
+            c.iter_graphs_ok = false;
+            with_direct_output([&] { c.amg->vcycle(c, 0, 2); });
+            if (!direct) fieldsplit_scatter(c, *c.amg, z);
+            std::vector<const double *> dotp(j + 2);
+            for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+            dotp[j + 1] = w;
+            launch_spmv(c, z, w, false);
+            launch_dots(c, dotp.data(), w, j + 2, true);
+            launch_cgs_update(c, j + 1, vp, w);
+            return true;
+        }
+        comm_allreduce(c, c.d_red, j + 2);
+        launch_cgs_finish(c, j + 2);
+        launch_cgs_update(c, j + 1, vp, w);
+        return true;
+    }
     if (upper) {
         // potential first (the V-cycle with its collectives, then the ghost entries of its result),
         // then the species part: plain launches with the exchanges between the sweeps, or its graph
