@@ -48,7 +48,7 @@ class Runner(streamer.Stepper):
             several = world > 1 or bool(distributed_multigrid)
             halo_depth = int(os.environ.get("FEDM_HALO_DEPTH", "8")) if several else 1
         self.halo_depth = halo_depth
-        part = partition.partition_rcb(gmesh.coords, world)
+        part = partition.partition_rcb(gmesh.coords, world, gmesh.cells)     # cuts that sever the fewest mesh edges
         lm = partition.local_mesh(gmesh.coords, gmesh.cells, part, rank, depth=halo_depth)
         self.lm, self.world, self.rank = lm, world, rank
         # (True with one rank: the several-GPU solver -- distributed finest level, replicated coarse
@@ -119,7 +119,7 @@ class Runner(streamer.Stepper):
         self.transport = transport
         self.total_dofs = gmesh.num_vertices() * 3
         shape = f"{n}x{n}" if n else f"unstructured, {gmesh.num_vertices()} vertices"
-        self.partition_name = (f"RCB vertex partition, {world} parts, global mesh {shape}, "
+        self.partition_name = (f"RCB vertex partition (cuts severing the fewest edges), {world} parts, global mesh {shape}, "
                                f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices in {halo_depth} layer(s) on rank {rank}, "
                                f"{len(lm.neighbours)} neighbours, transport {transport}")
 

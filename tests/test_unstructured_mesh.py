@@ -116,6 +116,28 @@ def test_owned_rows_assemble_locally_on_the_unstructured_mesh(refined):
         assert (np.abs(F_loc[own] - F_glob[g[own]]) / scale).max() < 1e-12
 
 
+def test_bisection_that_counts_severed_edges_on_the_refined_mesh(refined):
+    """RCB by physical extent cuts the long, thin refined channel along its length; with the mesh at
+    hand each bisection takes the direction whose cut severs fewer edges: several times smaller edge
+    cut and deep halos at the same (perfect) balance.  On a tensor-product mesh the two agree."""
+    from fedm_amd import partition
+    from fedm_amd.cases import streamer
+    graph = partition.vertex_graph(refined.num_vertices(), refined.cells).tocoo()
+    for k in (2, 4, 8):
+        plain = partition.partition_rcb(refined.coords, k)
+        aware = partition.partition_rcb(refined.coords, k, refined.cells)
+        cut = lambda part: int((part[graph.row] != part[graph.col]).sum() // 2)
+        assert np.bincount(aware).max() - np.bincount(aware).min() <= k
+        assert cut(aware) < 0.5 * cut(plain)
+        ghosts = lambda part: max(partition.local_mesh(refined.coords, refined.cells, part, r, depth=4).n_ghost
+                                  for r in range(k))
+        assert ghosts(aware) < 0.6 * ghosts(plain)
+    tp = streamer.mesh(48, 4.0)
+    g2 = partition.vertex_graph(tp.num_vertices(), tp.cells).tocoo()
+    a, b = partition.partition_rcb(tp.coords, 4), partition.partition_rcb(tp.coords, 4, tp.cells)
+    assert abs(int((a[g2.row] != a[g2.col]).sum()) - int((b[g2.row] != b[g2.col]).sum())) <= 0.05 * (a[g2.row] != a[g2.col]).sum()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
