@@ -847,7 +847,14 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
         return -2;
     }
     if (check_model(*model)) {
-        set_error("unsupported model descriptor (species/reaction/quadrature counts)");
+        // refused, never truncated: the LFA kernels are instantiated for 1-2 species without and 1-3 species
+        // with a Poisson equation (fedm_model_desc's arrays hold FEDM_MAX_SPECIES = 4 and FEDM_MAX_REACTIONS = 8)
+        set_error("unsupported LFA model: " + std::to_string(model->n_species) + " species" +
+                  (model->poisson ? " + Poisson" : "") + ", " + std::to_string(model->n_reactions) +
+                  " reactions, " + std::to_string(model->n_qp) + " quadrature points (supported: 1-2 species, or 1-3 "
+                  "with a Poisson equation; at most " + std::to_string(FEDM_MAX_REACTIONS) + " reactions, " +
+                  std::to_string(FEDM_MAX_TERMS) + " terms per coefficient, " + std::to_string(FEDM_MAX_QP) +
+                  " quadrature points)");
         return -2;
     }
     return ctx_create_guarded(mesh, model, nullptr, device, out);
