@@ -982,7 +982,13 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
     c.neq = c.ns + (c.poisson ? 1 : 0);
     c.nv = mesh->n_vertices;
     c.nc = mesh->n_cells;
-    build_pattern(*mesh, c.pat);
+    {
+        // (Expression sources are tables indexed by (cell, local node): their cells keep their vertex order)
+        bool tables = false;
+        if (model)
+            for (int s_ = 0; s_ < model->n_species; ++s_) tables = tables || model->ext_nodes[s_] > 0;
+        build_pattern(*mesh, c.pat, !tables);
+    }
     c.nvp = c.pat.nvp;
     c.n_owned = (mesh->n_owned_vertices > 0 && mesh->n_owned_vertices <= c.nv) ? mesh->n_owned_vertices : c.nv;
     c.n_dot = (int64_t)c.n_owned * c.neq;

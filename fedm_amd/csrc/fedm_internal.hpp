@@ -49,7 +49,9 @@ struct Pattern {
     bool patch_ok = false;              // false: some patch exceeds the 8-bit local indices
 };
 
-void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat);
+// allow_rotation: the patch cell order may also turn cells (cyclic rotation of their local vertices) to avoid
+// LDS bank clashes; not for models whose tables are indexed by (cell, local node) -- Expression sources
+void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat, bool allow_rotation = true);
 
 struct Amg;
 struct Comm;

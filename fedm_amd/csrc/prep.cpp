@@ -18,7 +18,7 @@ namespace fedm {
 // vertex, whose bank is the owned vertex id modulo `mod`.  Cells are dealt to the lane groups so
 // that within a group, for each local index a, those bank classes are distinct wherever
 // possible (greedy, first group with the fewest clashes; the order within a group is kept).
-static void order_patch_cells(PatchCell *cells, int n, int group, int mod) {
+static void order_patch_cells(PatchCell *cells, int n, int group, int mod, bool allow_rotation) {
     if (n <= group) return;
     const int n_groups = (n + group - 1) / group;
     std::vector<std::vector<int>> members(n_groups);
@@ -32,21 +32,42 @@ static void order_patch_cells(PatchCell *cells, int n, int group, int mod) {
     }();
     const int per_half = 32 / group > 0 ? 32 / group : 1;
     std::vector<std::array<uint32_t, 3>> read_used((n_groups + per_half - 1) / per_half, std::array<uint32_t, 3>{0, 0, 0});
-    for (int c = 0; c < n; ++c) {
-        int best = -1, best_cost = 1 << 30;
-        for (int g = 0; g < n_groups; ++g) {
-            if ((int)members[g].size() >= group) continue;
-            int cost = 0;
-            for (int a = 0; a < 3; ++a) {
-                if (cells[c].lv[a] < SLICE && ((used[g][a] >> (cells[c].lv[a] % mod)) & 1ULL)) cost += 4;
-                if (read_weight && ((read_used[g / per_half][a] >> (cells[c].lv[a] & 31)) & 1u)) cost += read_weight;
-            }
-            if (cost < best_cost) {
-                best_cost = cost;
-                best = g;
-            }
-            if (cost == 0) break;
+    // A cell may also be turned (its three local vertices rotated cyclically: the orientation, and with it
+    // every element tensor, is unchanged) -- three times the freedom to find a clash-free place.
+    static const bool rotate = [] {
+        const char *e = std::getenv("FEDM_PATCH_ROTATE");
+        return !(e && e[0] == '0');
+    }();
+    auto turned = [](const PatchCell &pc, int k) {
+        PatchCell r = pc;
+        for (int a = 0; a < 3; ++a) {
+            const int src = (a + k) % 3;
+            r.lv[a] = pc.lv[src];
+            r.tag[a] = pc.tag[src];
+            for (int b = 0; b < 3; ++b) r.j[a * 3 + b] = pc.j[src * 3 + (b + k) % 3];
         }
+        return r;
+    };
+    for (int c = 0; c < n; ++c) {
+        int best = -1, best_cost = 1 << 30, best_turn = 0;
+        for (int k = 0; k < ((rotate && allow_rotation) ? 3 : 1) && best_cost > 0; ++k) {
+            const PatchCell cand = k ? turned(cells[c], k) : cells[c];
+            for (int g = 0; g < n_groups; ++g) {
+                if ((int)members[g].size() >= group) continue;
+                int cost = 0;
+                for (int a = 0; a < 3; ++a) {
+                    if (cand.lv[a] < SLICE && ((used[g][a] >> (cand.lv[a] % mod)) & 1ULL)) cost += 4;
+                    if (read_weight && ((read_used[g / per_half][a] >> (cand.lv[a] & 31)) & 1u)) cost += read_weight;
+                }
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best = g;
+                    best_turn = k;
+                }
+                if (cost == 0) break;
+            }
+        }
+        if (best_turn) cells[c] = turned(cells[c], best_turn);
         members[best].push_back(c);
         for (int a = 0; a < 3; ++a) {
             if (cells[c].lv[a] < SLICE) used[best][a] |= 1ULL << (cells[c].lv[a] % mod);
@@ -64,7 +85,7 @@ static void order_patch_cells(PatchCell *cells, int n, int group, int mod) {
     std::copy(out.begin(), out.end(), cells);
 }
 
-void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
+void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat, bool allow_rotation) {
     const int nv = mesh.n_vertices, nc = mesh.n_cells;
     const int32_t *cells = mesh.cells;
     pat.nv = nv;
@@ -238,7 +259,7 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat) {
             }
             if (order_group > 0)
                 order_patch_cells(pat.patch_cells.data() + first_cell, (int)(pat.patch_cells.size() - first_cell),
-                                  order_group, order_mod);
+                                  order_group, order_mod, allow_rotation);
             pat.patch_halo.insert(pat.patch_halo.end(), halo.begin(), halo.end());
             pat.patch_cell_ptr[s + 1] = (int)pat.patch_cells.size();
             pat.patch_halo_ptr[s + 1] = (int)pat.patch_halo.size();
