@@ -28,3 +28,11 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_
     --output-format csv -d "$OUT/sq2" -o s -- python3 $SHORT > /dev/null 2> "$OUT/sq2.err" || exit 5
 find "$OUT" -name "*counter_collection.csv" | head
 python3 tools/copy_profiles.py "$TAG" "$OUT"
+# kernel-by-kernel listing of one time step (step 6 of the run): a short traced run of its own
+SEQ="bench.py --steps 6 --warmup 3 $ONLY"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/seq" -o q -- python3 $SEQ > /dev/null 2> "$OUT/seq.err" || exit 6
+TRACE=$(find "$OUT/seq" -name "q_kernel_trace.csv" | head -1)
+{ echo "One accepted time step of the bench case (576x576, step 6 of the run, Krylov steps replayed as graphs), kernel by kernel:";
+  echo "start offset [us], duration [us], gap to the previous kernel [us], kernel (rocprofv3 --kernel-trace of python3 $SEQ; tools/step_sequence.py)";
+  echo; python3 tools/step_sequence.py "$TRACE" -3; } > "profiles/${TAG}_step_sequence.txt"
+rm -f "$TRACE"
