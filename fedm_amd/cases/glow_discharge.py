@@ -30,7 +30,7 @@ class Case:
 
     def __init__(self, nx=100, ny=100, file_input=DECK, device=0, T_final=1e-11,
                  relative_tolerance=1e-4, maximum_iterations=20, quiet=True, error_file=None,
-                 device_pipeline=True):
+                 device_pipeline=True, mesh=None):
         import tempfile
         self.quiet = quiet
         model = "4_particles"
@@ -58,7 +58,9 @@ class Case:
         self.ns, self.nr = ns, len(kfiles)
 
         self.gap = self.wall = 0.01
-        self.mesh = mesh = RectangleMesh((0.0, 0.0), (self.wall, self.gap), nx, ny, "crossed")
+        # (mesh: any triangle mesh of the 1 cm x 1 cm domain instead of the script's crossed one)
+        self.mesh = mesh = mesh if mesh is not None else RectangleMesh((0.0, 0.0), (self.wall, self.gap), nx, ny,
+                                                                      "crossed")
         nv = mesh.num_vertices()
         boundaries = [["line", 0.0, 0.0, 0.0, self.wall], ["line", self.gap, self.gap, 0.0, self.wall],
                       ["line", 0.0, self.gap, 0.0, 0.0], ["line", 0.0, self.gap, self.wall, self.wall]]

@@ -113,13 +113,13 @@ class Deck:
 
 
 class GlowDischarge:
-    def __init__(self, deck_dir, nx=100, ny=100, U_w=-250.0, p0=1.0, Tgas=300.0):
+    def __init__(self, deck_dir, nx=100, ny=100, U_w=-250.0, p0=1.0, Tgas=300.0, mesh=None):
         self.deck = Deck(deck_dir)
         d = self.deck
         self.N0 = p0 * 3.21877e22
         self.Tgas, self.U_w = Tgas, U_w
         self.gap = self.wall = 0.01
-        self.mesh = rectangle_crossed(0.0, 0.0, self.wall, self.gap, nx, ny)
+        self.mesh = mesh if mesh is not None else rectangle_crossed(0.0, 0.0, self.wall, self.gap, nx, ny)
         m = self.mesh
         self.tags = mark_boundaries(m, [["line", 0.0, 0.0, 0.0, self.wall],
                                         ["line", self.gap, self.gap, 0.0, self.wall],

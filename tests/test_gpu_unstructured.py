@@ -216,3 +216,59 @@ def test_two_ranks_match_one_gpu_on_the_unstructured_mesh():
     ref_log = np.array(st.log_rows())
     for r in res:
         assert np.allclose(np.array(r[3]), ref_log, rtol=1e-6)
+
+
+def test_lmea_kernels_on_an_unstructured_mesh(monkeypatch):
+    """The glow-discharge (LMEA) assembly -- element buffer + gather by stored matrix position, coloured
+    dual-number cross-check, 'flux source' walls -- has only ever run on DOLFIN's crossed meshes: residual
+    and Jacobian of all three device variants against the oracle on a locally refined Delaunay mesh of the
+    1 cm x 1 cm discharge domain (refined towards the cathode sheath at z = 0)."""
+    from oracle import gd as ogd
+    from oracle.mesh import Mesh as OMesh
+    from fedm_amd import functions as ff, meshgen
+    from fedm_amd.cases import glow_discharge as gdc
+    deck = ROOT / "decks" / "glow_discharge" / "file_input" / "4_particles"
+    size = meshgen.box_distance_size((0.0, 0.01, 0.0, 0.0015), 1.0e-4, 0.3, 1.2e-3)
+    msh = meshgen.refined_rectangle(0.01, 0.01, size, 1.0e-4, n_levels=5)
+    assert 2000 < msh.num_vertices() < 20000
+    for variant in ("3", "2", "0"):
+        monkeypatch.setenv("FEDM_GD_HAND", variant)
+        case = gdc.Case(device_pipeline=False, mesh=msh)
+        o = ogd.GlowDischarge(deck, mesh=OMesh(msh.coords, msh.cells))
+        nv = o.mesh.nv
+        rng = np.random.default_rng(0)
+        me_old = 3.0 + rng.normal(0, 0.3, nv)
+        me = me_old + rng.normal(0, 0.05, nv)
+        U = case.U.copy()
+        U[:, 0] = np.log(me) + U[:, 3] + rng.normal(0, 0.05, nv)
+        U[:, 1:4] += rng.normal(0, 0.2, (nv, 3))
+        U[:, 4] = -100.0 * (1 - o.mesh.coords[:, 1] / 0.01) + rng.normal(0, 3.0, nv)
+        Uo = U + rng.normal(0, 0.02, U.shape)
+        Uo1 = U + rng.normal(0, 0.02, U.shape)
+        redE = o.reduced_field(U[:, 4])
+        assert np.allclose(case.project_reduced_field(U[:, 4]), redE, rtol=1e-10)
+        co = o.coefficients(me_old, redE)
+        t, dt, dt_old = 2e-12, 1.1e-12, 0.7e-12
+        F_cpu, J_cpu = o.residual_jacobian(U, Uo, Uo1, dt, dt_old, co, me_old, me, Uo[:, 3], o.dirichlet_values(t))
+        case.mean_energy_old.vector()[:] = me_old
+        case.mean_energy.vector()[:] = me
+        case.redE.vector()[:] = redE
+        ff.Transport_coefficient_interpolation("update", case.mu_dep, case.N0, case.Tgas, case.mu, case.mu_x,
+                                               case.mu_y, case.mean_energy_old, case.redE)
+        ff.Transport_coefficient_interpolation("update", case.D_dep, case.N0, case.Tgas, case.D, case.D_x,
+                                               case.D_y, case.mean_energy_old, case.redE, case.mu)
+        ff.Rate_coefficient_interpolation("update", case.k_dep, case.k, case.k_x, case.k_y,
+                                          case.mean_energy_old, case.redE, Te=0, Tgas=0)
+        case.U = Uo
+        case.upload_fields()
+        prob = case.prob
+        prob.set_state(U, Uo, Uo1)
+        prob.set_step(dt, dt_old)
+        prob.set_dirichlet_values(case.dirichlet_values(t))
+        F_gpu, _ = prob.residual()
+        scale = np.abs(F_cpu).reshape(-1, 5).max(axis=0)
+        assert (np.abs(F_gpu - F_cpu).reshape(-1, 5) / scale).max() < 1e-11, variant
+        prob.jacobian()
+        J_gpu = prob.jacobian_csr()
+        assert _rel_rows(J_gpu, J_cpu) < 1e-9, variant
+        prob.close()
