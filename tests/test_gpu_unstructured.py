@@ -272,3 +272,39 @@ def test_lmea_kernels_on_an_unstructured_mesh(monkeypatch):
         J_gpu = prob.jacobian_csr()
         assert _rel_rows(J_gpu, J_cpu) < 1e-9, variant
         prob.close()
+
+
+def test_time_of_flight_kernels_on_an_unstructured_mesh():
+    """The third model family's path -- one equation without Poisson, degree-8 quadrature, an Expression source
+    given as a per-cell table of P2 nodal values (so the patch cell order may NOT turn cells), the unrolled patch
+    routine -- on a refined Delaunay mesh of the time-of-flight domain: residual and Jacobian against the oracle."""
+    from oracle import tof as otof
+    from oracle.forms import LFAModel
+    from oracle.mesh import Mesh as OMesh
+    from fedm_amd import meshgen
+    from fedm_amd.cases import time_of_flight as tof
+    from fedm_amd.device import DeviceProblem
+    w, h = 2.5e-4, 5e-4
+    size = meshgen.box_distance_size((0.0, 0.6e-4, 3.5e-4, 5e-4), 2e-6, 0.25, 4e-5)      # fine around the pulse
+    msh = meshgen.refined_rectangle(w, h, size, 2e-6, n_levels=5)
+    assert msh.num_vertices() > 3000
+    prob = DeviceProblem(msh.coords, msh.cells, tof.model())
+    omesh = OMesh(msh.coords, msh.cells)
+    om = LFAModel(omesh, 1, False, ["drift-diffusion-reaction"], [-1.0], D=[otof.DE], drift_w=[(0.0, otof.WEZ)], qdeg=8)
+    t0, dt = 2.5e-9, 1e-12
+    rng = np.random.default_rng(0)
+    U = otof.log_density(omesh.coords, t0, 3e-16)[:, None] + rng.normal(0, 0.1, (omesh.nv, 1))
+    Uo = otof.log_density(omesh.coords, t0)[:, None]
+    Uo1 = Uo + rng.normal(0, 0.1, (omesh.nv, 1))
+    assert np.allclose(tof.p2_nodes(msh.coords, msh.cells), otof.cell_nodes(omesh, 2))
+    om.set_ext_source(0, 2, otof.source(otof.cell_nodes(omesh, 2), t0 + dt))
+    prob.set_ext_source(0, tof.source(tof.p2_nodes(msh.coords, msh.cells), t0 + dt))
+    for dt_old in (1e30, 2e-12):
+        prob.set_state(U, Uo, Uo1)
+        prob.set_step(dt, dt_old)
+        F_gpu, _ = prob.residual()
+        F_cpu, J_cpu = om.residual_jacobian(U, Uo, Uo1, dt, dt_old)
+        assert np.abs(F_gpu - F_cpu).max() / np.abs(F_cpu).max() < 1e-11
+        prob.jacobian()
+        assert _rel_rows(prob.jacobian_csr(), J_cpu) < 1e-10
+    prob.close()
