@@ -575,6 +575,37 @@ def main():
             "newton_iterations_per_step": nw4 / args.steps, "gmres_iterations_per_step": gm4 / args.steps,
             "partition": r4.partition_name}
 
+    # ---- the refined unstructured mesh split over the ranks (strong scaling; `--unstructured on`) -------
+    if distributed and args.unstructured == "on":
+        from fedm_amd.cases import streamer_distributed
+        try:
+            del runner
+        except NameError:
+            pass
+        umesh = streamer.refined_mesh(args.mesh_spacing, growth=0.1,
+                                      channel=(0.0, 100.0 * args.mesh_spacing) + streamer.CHANNEL[2:])
+        ru = streamer_distributed.Runner(None, rank, world, local_rank, mesh=umesh,
+                                         transport="torch" if args.rehearse_on_one_gpu else "rccl")
+        ru.initialise()
+        for _ in range(args.warmup):
+            ru.step()
+        before = ru.prob.comm_stats()
+        eu, nwu, gmu, _ = timed_steps(ru, args.steps, barrier, torch, dist, distributed)
+        after = ru.prob.comm_stats()
+        ghosts = torch.tensor([float(ru.lm.n_ghost), float(ru.lm.n_owned), float(len(ru.lm.neighbours))],
+                              dtype=torch.float64, device="cuda")
+        dist.all_reduce(ghosts, op=dist.ReduceOp.MAX)
+        out["unstructured_partitioned"] = {
+            "workload": f"the refined unstructured mesh (spacing {args.mesh_spacing:g} m) split over {world} ranks",
+            "dofs_total": ru.total_dofs, "timesteps_per_sec": args.steps / eu, "ms_per_step": 1e3 * eu / args.steps,
+            "newton_iterations_per_step": nwu / args.steps, "gmres_iterations_per_step": gmu / args.steps,
+            "halo_exchanges_per_step": (after["halo_exchanges"] - before["halo_exchanges"]) / args.steps,
+            "allreduces_per_step": (after["allreduces"] - before["allreduces"]) / args.steps,
+            "halo_depth": ru.halo_depth, "largest_halo_vertices": int(ghosts[0].item()),
+            "largest_part_vertices": int(ghosts[1].item()), "most_neighbours": int(ghosts[2].item()),
+            "partition": ru.partition_name, "transport": ru.transport}
+        runner = ru
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:    # (a reported baseline: its failure must not take the measured record with it)
             out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n, args.grading, args.cpu_steps or args.steps,
