@@ -212,12 +212,13 @@ def z_curve_order(coords):
 
 def _vertex_spacing(coords, cells):
     """Mean |dx|, |dy| of the edges at every vertex: the metric in which a patch should be round."""
+    cells = np.asarray(cells)
+    n = coords.shape[0]
     e = np.concatenate([cells[:, [0, 1]], cells[:, [1, 2]], cells[:, [2, 0]]])
     d = np.abs(coords[e[:, 0]] - coords[e[:, 1]])
-    acc, cnt = np.zeros_like(coords), np.zeros(coords.shape[0])
-    for k in (0, 1):
-        np.add.at(acc, e[:, k], d)
-        np.add.at(cnt, e[:, k], 1.0)
+    ends = np.concatenate([e[:, 0], e[:, 1]])
+    cnt = np.bincount(ends, minlength=n).astype(np.float64)
+    acc = np.stack([np.bincount(ends, weights=np.concatenate([d[:, k], d[:, k]]), minlength=n) for k in (0, 1)], axis=1)
     h = acc / np.maximum(cnt, 1.0)[:, None]
     h[h <= 0.0] = h[h > 0.0].mean() if np.any(h > 0.0) else 1.0
     return h
