@@ -241,3 +241,62 @@ def test_configs4_mesh_split_over_two_ranks_matches_one_gpu():
         assert np.allclose(np.array(r[1]), ref, rtol=2e-4)        # Newton to rtol 1e-4 on both sides
         assert r[5] <= st.linear_iterations + 4
         assert r[6] < 4 * r[5] + 40                                # about 1.5 exchanges per Krylov step + set-up
+
+
+# ---- the ~1 M-DOF locally refined unstructured mesh (the bench's second record, the 14 ns run) ----------
+def test_unstructured_mesh_at_1m_dofs_properties(tmp_path):
+    """The refined Delaunay mesh of bench.py's `unstructured` record (4 um spacing in the channel, 341 280
+    vertices = 1 023 840 DOFs) through the DOLFIN XML reader: pattern figures, the initial potential solves
+    Poisson's equation, (F(u + e v) - F(u - e v)) / 2e == J v on every row, the product is linear, the
+    coloured and the patch assembly agree, and two adaptive steps are accepted."""
+    from fedm_amd.cases import streamer
+    msh = streamer.refined_mesh(4e-6, growth=0.1, channel=(0.0, 4e-4) + streamer.CHANNEL[2:], xml_path=tmp_path / "mesh.xml")
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    assert prob.n == 1023840
+    sz = prob.sizes()
+    assert sz["assembly_variant"] == "lds-patches" and sz["max_patch_cells"] <= 256
+    assert sz["stored_blocks"] / sz["nnz_blocks"] < 1.05 and sz["cell_visits"] < 1.3 * sz["n_cells"]
+    st = streamer.Stepper(prob)
+    st.initialise()
+    U = prob.get_state()
+    z = prob.coords[:, 1]
+    assert np.all(U[np.abs(z) < 3e-16, 2] == 0.0) and np.all(U[np.abs(z - streamer.BOX) < 3e-16, 2] == streamer.U_W)
+    prob.set_step(5e-12, 1e30)
+    F, _ = prob.residual()
+    assert np.abs(F.reshape(-1, 3)[:, 2]).max() / (2 * np.pi * streamer.BOX * streamer.U_W) < 1e-9
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=U.shape) * np.array([1e-3, 1e-3, 1e-1])
+    v[(np.abs(z) < 3e-16) | (np.abs(z - streamer.BOX) < 3e-16), 2] = 0.0
+    prob.jacobian()
+    Jv = prob.spmv(v.ravel())
+    e = 1e-3
+    prob.set_state(u_new=U + e * v)
+    Fp, _ = prob.residual()
+    prob.set_state(u_new=U - e * v)
+    Fm, _ = prob.residual()
+    fd = (Fp - Fm) / (2 * e)
+    for c in range(3):
+        a, b = fd.reshape(-1, 3)[:, c], Jv.reshape(-1, 3)[:, c]
+        assert np.abs(a - b).max() / np.abs(b).max() < 1e-6, c
+    x, y = rng.normal(size=prob.n), rng.normal(size=prob.n)
+    lhs, rhs = prob.spmv(2.5 * x - 0.75 * y), 2.5 * prob.spmv(x) - 0.75 * prob.spmv(y)
+    assert np.abs(lhs - rhs).max() / np.abs(rhs).max() < 1e-13
+    Up = U.copy()
+    Up[:, :2] += 0.01 * rng.normal(size=(U.shape[0], 2))
+    prob.set_state(Up, U, U)
+    prob.set_step(5e-12, 5e-12)
+    out = {}
+    for kind in ("colour", "patch"):
+        prob.set_assembly(kind)
+        Fk, _ = prob.residual()
+        prob.jacobian()
+        out[kind] = (Fk, prob.spmv(x))
+    for a, b in zip(out["colour"], out["patch"]):
+        assert np.abs(a - b).max() / np.abs(a).max() < 1e-12
+    prob.set_state(U, U, U)
+    for _ in range(2):
+        st.step()
+    rows = st.log_rows()
+    assert len(rows) == 2 and all(r[0] < 1e-3 and r[2] == 5e-12 for r in rows)
+    assert st.newton_iterations <= 6 and st.linear_iterations <= 14
+    prob.close()
