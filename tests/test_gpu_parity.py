@@ -387,19 +387,20 @@ def test_polynomial_smoother_cycle_is_the_richardson_cycle_and_contracts_faster(
     assert (np.abs(out[None][2] - out[2][2]).max(axis=0) / scale).max() < 1e-6
 
 
-@pytest.mark.parametrize("three_species", [False, True])
-def test_row_at_a_time_assembly_matches_the_unrolled_element(monkeypatch, three_species):
+@pytest.mark.parametrize("three_species,unstructured", [(False, False), (True, False), (True, True)])
+def test_row_at_a_time_assembly_matches_the_unrolled_element(monkeypatch, three_species, unstructured):
     """F + J patches run through element_lean.hpp (one equation row at a time, rows as workgroup
     phases); FEDM_ASSEMBLY_LEAN=0 selects the unrolled element routine the oracle parity tests were
     written against.  Two implementations of the same tensors: residual and Jacobian must agree to
     rounding -- on the streamer model and on a model that exercises what the streamer does not
     (three species, a species drifting with a constant velocity, a reaction that is a loss for two
-    species and a gain for the third, with a field-dependent rate)."""
+    species and a gain for the third, with a field-dependent rate) -- the latter also on a locally refined
+    unstructured mesh (the <3 species, 256 threads> instantiations, turned cells)."""
     from fedm_amd.cases import streamer
     from fedm_amd.device import DeviceProblem, Model, Reaction
     from fedm_amd.mesh import Marking_boundaries, Mesh
     from fedm_amd.termsum import TermSum, parse
-    msh = streamer.mesh(24, 2.0)
+    msh = streamer.refined_mesh(60e-6) if unstructured else streamer.mesh(24, 2.0)
     m = Mesh(msh.coords, msh.cells)
     tags = Marking_boundaries(m, streamer.BOUNDARIES)
     nv = m.coords.shape[0]
