@@ -179,3 +179,40 @@ def test_gloo_ghost_exchange_world2_on_the_unstructured_mesh():
     assert all(ok for _, ok, _, _ in res)
     assert all(ng > 0 for _, _, ng, _ in res)
     assert abs(res[0][3] - res[1][3]) <= 1
+
+
+def test_xml_reader_fast_path_and_parser_fallback_agree(tmp_path):
+    """mesh_io.read_dolfin_xml scans files in DOLFIN's own attribute order with regular expressions and hands
+    anything else to the XML parser: both give the mesh that was written."""
+    from fedm_amd import mesh_io
+    from fedm_amd.cases import streamer
+    msh = streamer.refined_mesh(2e-4)
+    mesh_io.write_dolfin_xml(msh, tmp_path / "a.xml")
+    a = mesh_io.read_dolfin_xml(tmp_path / "a.xml")
+    text = (tmp_path / "a.xml").read_text()
+    # the same file with the vertex attributes in another order: not DOLFIN's layout -> parser path
+    import re
+    shuffled = re.sub(r'<vertex index="(\d+)" x="([^"]+)" y="([^"]+)"', r'<vertex y="\3" index="\1" x="\2"', text)
+    assert shuffled != text
+    (tmp_path / "b.xml").write_text(shuffled)
+    b = mesh_io.read_dolfin_xml(tmp_path / "b.xml")
+    for m in (a, b):
+        assert np.array_equal(m.coords, msh.coords) and np.array_equal(m.cells, msh.cells)
+    (tmp_path / "c.xml").write_text(text.replace('celltype="triangle"', 'celltype="tetrahedron"'))
+    with pytest.raises(ValueError, match="not a DOLFIN XML triangle mesh"):
+        mesh_io.read_dolfin_xml(tmp_path / "c.xml")
+
+
+@pytest.mark.parametrize("n", [5, 64, 65, 1000])
+def test_vertex_orders_are_permutations_for_any_size(n):
+    """Fewer vertices than one slice, exactly one, one more, and a count that is no multiple of 64."""
+    from fedm_amd import device
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 2))
+    from scipy.spatial import Delaunay
+    cells = Delaunay(pts).simplices.astype(np.int32)
+    for order in (device.z_curve_order(pts), device.bisection_order(pts, device._vertex_spacing(pts, cells)),
+                  device.locality_order(pts, cells), device.locality_order(pts)):
+        assert np.array_equal(np.sort(order), np.arange(n))
+    st = device.pattern_stats(pts, cells)
+    assert st["n_slices"] == (n + 63) // 64 and st["nnz_blocks"] > n
