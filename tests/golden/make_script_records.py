@@ -21,5 +21,5 @@ import script_harness as sh     # noqa: E402
 if __name__ == "__main__":
     records = {case: sh.digest(sh.run_reference_script(case, tempfile.mkdtemp(prefix=f"ref_{case}_")))
                for case in sh.SCRIPTS}
-    (HERE / "script_records.json").write_text(json.dumps(records, indent=0))
+    (HERE / "script_records.json").write_text(json.dumps(records, separators=(",", ":")) + "\n")
     print({k: sorted(v) for k, v in records.items()})
