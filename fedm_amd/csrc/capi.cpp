@@ -1,6 +1,7 @@
 // C ABI of libfedm_hip.so (include/fedm_hip.h): context, state, Newton / GMRES drivers.
 // Host logic only; every flop of the hot path runs in kernels.hip.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -89,6 +90,7 @@ static int check_model(const fedm_model_desc &m) {
 // the alternative set of species sweeps and (when installed) the alternative V-cycle, together
 static void set_hard_mode(Ctx &c, bool hard) {
     if (c.fs_alt_active == hard) return;
+    c.fs_skip_sample = true;   // (measured policy: the next solve captures its graphs anew)
     hipStreamSynchronize(c.stream);
     iter_graphs_clear(c);  // the captured steps contain the other sweeps / the other cycle
     c.fs_alt_active = hard;
@@ -1106,6 +1108,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         }
         if (const char *e = getenv("FEDM_FS_HALO")) c.fs_halo = e[0] != '0';
         if (const char *e = getenv("FEDM_DEEP_HALO")) c.deep_halo = e[0] != '0';
+        if (const char *e = getenv("FEDM_FS_POLICY")) c.fs_measured_policy = std::string(e) != "counts";
         if (const char *e = getenv("FEDM_FS_LAGGED_COUPLING")) c.fs_lagged_coupling = e[0] != '0';
         if (const char *e = getenv("FEDM_GD_HAND"))
             if (e[0] == '0' || e[0] == '2' || e[0] == '3') c.gd_hand_mode = e[0] - '0';
@@ -1408,6 +1411,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     fedm_newton_report r{};
     c.err_cache_comp = -1;
+    const auto t_begin = std::chrono::steady_clock::now();
     int it = 0, lin_total = 0, rc = 0;
     double fnorm = 0.0, fnorm0 = 0.0, snorm = 0.0, xnorm = 0.0;
     while (true) {
@@ -1499,9 +1503,36 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     if ((c.fs_alt_sweeps > 0 || c.amg_alt) && it > 0) {
         // same counts on every rank, so every rank takes the same decision
         const double per_solve = (double)lin_total / it;
-        const bool to_alt = !c.fs_alt_active && per_solve >= c.fs_switch_above;
-        const bool to_main = c.fs_alt_active && per_solve <= c.fs_back_below;
-        if (to_alt || to_main) set_hard_mode(c, to_alt);
+        if (!c.fs_measured_policy || c.comm) {
+            const bool to_alt = !c.fs_alt_active && per_solve >= c.fs_switch_above;
+            const bool to_main = c.fs_alt_active && per_solve <= c.fs_back_below;
+            if (to_alt || to_main) set_hard_mode(c, to_alt);
+        } else if (rc == 0) {
+            // measured policy (one GPU): this solve's wall time per Newton iteration goes to the set it ran
+            // with; in the hard regime the cheaper set is used, the other one is looked at again now and then
+            const int cur = c.fs_alt_active ? 1 : 0;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() / it;
+            ++c.fs_age[0];
+            ++c.fs_age[1];
+            if (c.fs_skip_sample) {
+                c.fs_skip_sample = false;
+            } else {
+                c.fs_cost[cur] = c.fs_cost[cur] > 0.0 ? 0.6 * c.fs_cost[cur] + 0.4 * ms : ms;
+                c.fs_age[cur] = 0;
+            }
+            const bool hard_regime = per_solve >= c.fs_switch_above || (c.fs_alt_active && per_solve > c.fs_back_below);
+            if (c.fs_probe_left > 0) {
+                if (--c.fs_probe_left == 0 && c.fs_cost[1 - cur] > 0.0 && c.fs_cost[1 - cur] <= c.fs_cost[cur])
+                    set_hard_mode(c, cur == 0);   // the probed set lost: back to the other one
+            } else if (!hard_regime) {
+                if (c.fs_alt_active) set_hard_mode(c, false);
+            } else if (c.fs_cost[1 - cur] == 0.0 || c.fs_age[1 - cur] >= c.fs_probe_every) {
+                c.fs_probe_left = 3;              // (the first solve after the switch does not count)
+                set_hard_mode(c, cur == 0);
+            } else if (c.fs_cost[1 - cur] < 0.95 * c.fs_cost[cur]) {
+                set_hard_mode(c, cur == 0);
+            }
+        }
     }
     r.iterations = it;
     r.linear_iterations = lin_total;

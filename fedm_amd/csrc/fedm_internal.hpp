@@ -181,6 +181,18 @@ struct Ctx {
     //          a tightly solved run by 4e-3 instead of 6e-6 (tools/fs_order_accuracy.py).  Opt-in.
     bool fs_upper = false;
     double fs_switch_above = 5.0, fs_back_below = 3.5;
+    // One GPU: in the hard regime (>= fs_switch_above Krylov steps per Newton system) the set that is
+    // actually FASTER is used -- measured: wall time per Newton iteration of the solves under each set
+    // (exponential average), the other set probed for two solves every fs_probe_every solves.  Which
+    // set wins depends on the mesh and the phase of the run (tools/late_sweep.py).  FEDM_FS_POLICY=counts:
+    // round 2's rule (the alternative set whenever the count is high); always so across GPUs, where every
+    // rank must take the same decision.
+    bool fs_measured_policy = true;
+    double fs_cost[2] = {0.0, 0.0};     // [main, alternative] ms per Newton iteration (0: unknown)
+    int fs_age[2] = {0, 0};             // solves since that set was last measured
+    int fs_probe_left = 0;              // > 0: probing the other set for that many more solves
+    bool fs_skip_sample = false;        // the next solve re-captures its graphs: its time does not count
+    int fs_probe_every = 60;
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
     int krylov_steps_hint = 0;   // Krylov steps of the previous solve: how far ahead steps are queued
