@@ -464,6 +464,16 @@ def main():
             "mesh_seconds": t_mesh, "setup_seconds": u_setup,
             "run_to_reference_end_time": "profiles/r03_refined_run_*.json: this mesh carries the streamer to the "
                                          "reference's T_final = 1.4e-8 s (2801 accepted steps, none rejected)"}
+        if args.late_start > 0:      # the developed streamer on this mesh too: the same K steps from step late_start on
+            while urun.steps < args.late_start:
+                urun.step()
+            t_late_u = urun.t
+            ul_el, ul_nw, ul_gm, ul_prof = timed_steps(urun, args.steps, barrier, torch, dist, distributed)
+            out["unstructured"]["late_window"] = {
+                "what": f"{args.steps} accepted steps from step {args.late_start + 1} on (t = {t_late_u:.3e} s)",
+                "timesteps_per_sec": args.steps / ul_el, "ms_per_step": 1e3 * ul_el / args.steps,
+                "newton_iterations_per_step": ul_nw / args.steps, "gmres_iterations_per_step": ul_gm / args.steps,
+                "assembly_plus_spmv": uh["path_record"](ul_prof, ul_gm, args.steps)}
         runner = urun
 
     # ---- rates that cannot come from the Infinity Cache: the 4 M-DOF mesh on ONE GPU ------------------

@@ -1503,7 +1503,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     if ((c.fs_alt_sweeps > 0 || c.amg_alt) && it > 0) {
         // same counts on every rank, so every rank takes the same decision
         const double per_solve = (double)lin_total / it;
-        if (!c.fs_measured_policy || c.comm) {
+        if (!c.fs_measured_policy || (c.comm && c.comm->nranks > 1)) {
             const bool to_alt = !c.fs_alt_active && per_solve >= c.fs_switch_above;
             const bool to_main = c.fs_alt_active && per_solve <= c.fs_back_below;
             if (to_alt || to_main) set_hard_mode(c, to_alt);
