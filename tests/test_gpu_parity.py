@@ -726,3 +726,31 @@ def test_non_logarithmic_representation_matches_the_oracle():
             assert its == its_cpu
             assert (np.abs(U_gpu - U_cpu).max(axis=0) / np.abs(U_cpu).max(axis=0)).max() < 1e-8
         prob.close()
+
+
+def test_measured_choice_of_the_hard_regime_set_is_the_same_solve(monkeypatch):
+    """In the hard regime (here forced: thresholds below any Krylov count) the library times its own Newton
+    solves and uses the faster of the two preconditioner sets, probing the other now and then; round 2's rule
+    (FEDM_FS_POLICY=counts) always takes the alternative set there.  Different preconditioners, the same
+    systems solved to the same tolerance: same accepted steps, Newton counts and -- within the Newton
+    tolerance -- states."""
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import chebyshev_weights
+    msh = streamer.mesh(64, 4.0)
+    out = {}
+    for policy in ("measured", "counts"):
+        if policy == "counts":
+            monkeypatch.setenv("FEDM_FS_POLICY", "counts")
+        prob = streamer.device_problem(msh.coords, msh.cells)
+        st = streamer.Stepper(prob)
+        st.initialise()
+        prob.set_fieldsplit(chebyshev_weights(6), hard_weights=chebyshev_weights(4), switch_above=1.0, back_below=0.5)
+        for _ in range(24):
+            st.step()
+        out[policy] = (prob.get_state(), st.newton_iterations, st.linear_iterations, np.array(st.log_rows()))
+        prob.close()
+    (Um, nm, lm, logm), (Uc, nc, lc, logc) = out["measured"], out["counts"]
+    assert nm == nc and logm.shape == logc.shape == (24, 3)
+    assert np.allclose(logm, logc, rtol=1e-4)
+    assert np.allclose(Um, Uc, rtol=1e-5, atol=1e-5)
+    assert 0.5 * lc <= lm <= 2.0 * lc
