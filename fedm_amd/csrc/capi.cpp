@@ -1527,7 +1527,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
             } else if (!hard_regime) {
                 if (c.fs_alt_active) set_hard_mode(c, false);
             } else if (c.fs_cost[1 - cur] == 0.0 || c.fs_age[1 - cur] >= c.fs_probe_every) {
-                c.fs_probe_left = 3;              // (the first solve after the switch does not count)
+                c.fs_probe_left = 2;              // (the first solve after the switch does not count)
                 set_hard_mode(c, cur == 0);
             } else if (c.fs_cost[1 - cur] < 0.95 * c.fs_cost[cur]) {
                 set_hard_mode(c, cur == 0);

@@ -183,7 +183,8 @@ struct Ctx {
     double fs_switch_above = 5.0, fs_back_below = 3.5;
     // One GPU: in the hard regime (>= fs_switch_above Krylov steps per Newton system) the set that is
     // actually FASTER is used -- measured: wall time per Newton iteration of the solves under each set
-    // (exponential average), the other set probed for two solves every fs_probe_every solves.  Which
+    // (exponential average), the other set probed for two solves (the first re-captures its graphs and
+    // is not counted) every fs_probe_every solves.  Which
     // set wins depends on the mesh and the phase of the run (tools/late_sweep.py).  FEDM_FS_POLICY=counts:
     // round 2's rule (the alternative set whenever the count is high); always so across GPUs, where every
     // rank must take the same decision.
@@ -192,7 +193,7 @@ struct Ctx {
     int fs_age[2] = {0, 0};             // solves since that set was last measured
     int fs_probe_left = 0;              // > 0: probing the other set for that many more solves
     bool fs_skip_sample = false;        // the next solve re-captures its graphs: its time does not count
-    int fs_probe_every = 60;
+    int fs_probe_every = 120;
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
     int krylov_steps_hint = 0;   // Krylov steps of the previous solve: how far ahead steps are queued
