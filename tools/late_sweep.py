@@ -50,8 +50,14 @@ configs = {
     "hard: Chebyshev(6) + polynomial cycle (2)": (default_mg, chebyshev_weights(6), chebyshev_weights(6)),
     "no hard mode: Chebyshev(6) + V(1,1) throughout": (no_hard, chebyshev_weights(6), None),
     "no hard mode: Chebyshev(6) + V(1,1) omega 0.95": (dict(no_hard, omega=0.95), chebyshev_weights(6), None),
+    "no hard mode: Chebyshev(6) on [0.6, 2.0] + V(1,1)": (no_hard, chebyshev_weights(6, 0.6, 2.0), None),
+    "no hard mode: Chebyshev(8) on [0.5, 2.5] + V(1,1)": (no_hard, chebyshev_weights(8, 0.5, 2.5), None),
     "polynomial cycle (2) as the main cycle, Chebyshev(6)": (dict(no_hard, poly_degree=2), chebyshev_weights(6), None),
 }
+# (round 3, refined mesh at 4.5 ns, ms per step / GMRES per step: 6.8 / 30.4 with the measured choice [8.9 / 35.9 with
+#  FEDM_FS_POLICY=counts], 7.4 / 28.2, 6.7 / 30.4, 6.5 / 29.2, 6.5 / 29.0, 7.1 / 29.0, 7.4 / 28.0; tensor-product mesh at
+#  1 ns: 5.9 / 28.0, 6.2 / 26.8, 6.9 / 36.0, 8.2 / 41.7, -, -, 6.1 / 26.4.  The interval of the species polynomial hardly
+#  matters around [0.5, 2]; below 0.4 or with degree 8 on a short interval the sweeps amplify and GMRES stalls.)
 for name, (mg, main, hard) in configs.items():
     prob, st = fresh(mg, main, hard)
     prob.set_state(keep["u"], keep["uo"], keep["uo"])
