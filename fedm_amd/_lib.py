@@ -198,6 +198,18 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+def _share_the_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so (soname libamdhip64.so.7, asked for by file name);
+    libfedm_hip.so asks for the soname.  Loaded after torch it binds to torch's copy; loaded BEFORE torch it
+    would bring /opt/rocm's copy in, torch would then add its own, and the second runtime of the process
+    finds no device (measured on the MI355X box: fedm_ctx_create -3 after torch.cuda.set_device).  The
+    multi-GPU layer needs torch.distributed in the same process, so where torch is installed it goes first."""
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401  (importing does not initialise the GPU)
+
+
 def load():
     """Load libfedm_hip.so and attach signatures.  Raises if it is not built."""
     global _lib
@@ -207,6 +219,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  fedm_amd has no CPU fallback.")
+    _share_the_hip_runtime_with_torch()
     lib = C.CDLL(os.fspath(LIB_PATH))
     lib.fedm_abi_version.restype = C.c_int
     if lib.fedm_abi_version() != ABI_VERSION:

@@ -308,3 +308,35 @@ def test_time_of_flight_kernels_on_an_unstructured_mesh():
         prob.jacobian()
         assert _rel_rows(prob.jacobian_csr(), J_cpu) < 1e-10
     prob.close()
+
+
+def test_multi_gpu_example_script_against_the_one_gpu_run(tmp_path):
+    """examples/streamer_discharge_multi_gpu.py as a user launches it (torch.distributed.run, two ranks, here
+    sharing the one GPU over the host-staged transport): its error log and gathered fields against the
+    single-GPU Stepper on the same mesh.  The script loads libfedm_hip before torch initialises the GPU --
+    the order in which the two HIP runtimes of the image used to collide (fedm_amd/_lib.py)."""
+    import subprocess
+    from fedm_amd.cases import streamer
+    out = tmp_path / "mgpu"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(ROOT / "examples" / "streamer_discharge_multi_gpu.py"), "--mesh-spacing", "6e-5", "--end", "3e-11",
+           "--out", str(out), "--share-one-gpu"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert done.returncode == 0, done.stderr[-3000:]
+    assert "halo exchanges" in done.stdout
+    U = np.load(out / "state.npy")
+    rows = np.array([[float(v) for v in line.split()] for line in open(out / "relative error.log")])
+    for name in ("Ions", "electrons", "Phi"):
+        assert (out / name / f"{name}.pvd").exists()
+    msh = streamer.refined_mesh(6e-5)
+    prob = streamer.device_problem(msh.coords, msh.cells)
+    st = streamer.Stepper(prob)
+    st.initialise()
+    while st.t < 3e-11 * (1.0 - 1e-6):
+        st.step()
+    U_ref = prob.get_state()
+    prob.close()
+    ref_rows = np.array(st.log_rows())
+    assert rows.shape == ref_rows.shape and np.allclose(rows, ref_rows, rtol=2e-3)
+    assert (np.abs(U - U_ref) / np.abs(U_ref).max(axis=0)).max() < 1e-5

@@ -948,3 +948,18 @@ def test_models_beyond_the_instantiated_kernels_are_refused_not_truncated():
     assert lib.fedm_ctx_create(C.byref(mesh), C.byref(md), 0, C.byref(handle)) == -2 and not handle
     msg = _lib.last_error()
     assert "4 species + Poisson" in msg and "1-3 with a Poisson equation" in msg
+
+
+def test_binding_brings_torch_in_before_the_hip_library():
+    """Loaded before torch, libfedm_hip.so would pull /opt/rocm's HIP runtime in next to the one PyTorch-ROCm
+    carries, and whichever initialises second finds no device (seen on the MI355X box).  _lib.load() therefore
+    imports torch first; a fresh interpreter shows the order."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from fedm_amd import _lib; assert 'torch' not in sys.modules; "
+            "_lib.load(); assert 'torch' in sys.modules; "
+            "maps = open('/proc/self/maps').read(); "
+            "hip = {l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}; print(len(hip))" % str(ROOT))
+    done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert done.stdout.strip() == "1"                      # one HIP runtime in the process, not two
