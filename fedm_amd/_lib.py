@@ -172,6 +172,9 @@ _SIGNATURES = {
     "fedm_debug_comm_roundtrip": (C.c_int, [_P, _D, _D, C.c_int]),
     "fedm_pattern_stats": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_int64)]),
     "fedm_pattern_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "fedm_fieldsplit_tiles_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "fedm_debug_fieldsplit_apply": (C.c_int, [_P, _D, _D]),
+    "fedm_debug_fieldsplit_tiles": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "fedm_profile": (C.c_int, [_P, C.c_int]),
     "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
     "fedm_set_assembly": (C.c_int, [_P, C.c_int]),
@@ -191,7 +194,7 @@ EXPR_OPS = {"const": 0, "x": 1, "param": 2, "add": 3, "sub": 4, "mul": 5, "div":
 EXPR_MAX_OPS, EXPR_MAX_PARAMS, EXPR_STACK = 256, 16, 24
 
 
-ABI_VERSION = 2          # include/fedm_hip.h FEDM_ABI_VERSION
+ABI_VERSION = 3          # include/fedm_hip.h FEDM_ABI_VERSION
 
 
 def exported_symbols():

@@ -506,15 +506,19 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     const int slice = slice_list ? slice_list[wave_id] : wave_id;
     // this row's own operands first: their latency hides behind the gather loop
     const size_t v = (size_t)slice * SLICE + lane;
-    double gv[NS], zv[NS];
+    // (single precision with the half-precision entry as an operand of the fused multiply-add, the very operations of
+    // fs_tile_sweeps_kernel, fs_tiles.hip: the two give identical bits; the iterate between sweeps is single
+    // precision anyway and a row has seven to a dozen entries)
+    float gv[NS], zv[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         gv[r] = g[v * NS + r];
         zv[r] = zin[v * NS + r];
     }
-    double acc[NS], accp = 0.0;
+    float acc[NS];
+    double accp = 0.0;
 #pragma unroll
-    for (int r = 0; r < NS; ++r) acc[r] = 0.0;
+    for (int r = 0; r < NS; ++r) acc[r] = 0.f;
     // LAST with cpl32: the coupling product of the lower-triangular split rides on this sweep's gather
     // of the neighbours' iterate, b_phi -= J_phi,u (zs z_in) -- the iterate BEFORE this last sweep
     // (a preconditioner may lag; the separate pass over the potential row's planes and z is saved)
@@ -523,27 +527,29 @@ __global__ __launch_bounds__(256) void fs_species_sweep_kernel(
     const int bb0 = boff[slice], bb1 = boff[slice + 1];
     for (int bc = bb0; bc < bb1; ++bc) {
         const int col = colidx[(size_t)bc * SLICE + lane];
-        double zj[NS];
+        float zj[NS];
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx) zj[cidx] = zin[(size_t)col * NS + cidx];
-        const _Float16 *vp = s16 + (size_t)bc * PL * SLICE + lane;
+        const _Float16 *vp = s16 + ((size_t)bc * SLICE + lane) * PL;   // the PL planes of an entry side by side
 #pragma unroll
         for (int r = 0; r < NS; ++r)
 #pragma unroll
             for (int cidx = 0; cidx < NS; ++cidx)
-                if (!((ZS >> (r * NS + cidx)) & 1u)) acc[r] += (double)(float)vp[(size_t)(r * NS + cidx) * SLICE] * zj[cidx];
+                if (!((ZS >> (r * NS + cidx)) & 1u)) acc[r] = __builtin_fmaf((float)vp[r * NS + cidx], zj[cidx], acc[r]);
         if (couple) {
             const float *cp = cpl32 + (size_t)bc * NS * SLICE + lane;
 #pragma unroll
-            for (int cidx = 0; cidx < NS; ++cidx) accp += (double)cp[(size_t)cidx * SLICE] * zj[cidx];
+            for (int cidx = 0; cidx < NS; ++cidx)
+                accp = __builtin_fma((double)cp[(size_t)cidx * SLICE], (double)zj[cidx], accp);
         }
     }
-    if (couple) b0[v] = own_b0 - zs * accp;
+    if (couple) b0[v] = __builtin_fma(-zs, accp, own_b0);
+    const float zsf = (float)zs, omf = (float)omega;
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
-        const double zn = zs * zv[r] + omega * (gv[r] - zs * acc[r]);
-        if (LAST) zout[v * NEQ + r] = zn;
-        else zout32[v * NS + r] = (float)zn;
+        const float zn = __builtin_fmaf(omf, __builtin_fmaf(-zsf, acc[r], gv[r]), zsf * zv[r]);
+        if (LAST) zout[v * NEQ + r] = (double)zn;
+        else zout32[v * NS + r] = zn;
     }
     // full-line stores; the potential entry is the V-cycle's result when that ran first (upper-
     // triangular order), else it is set by the V-cycle that follows
@@ -739,7 +745,13 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
         else FEDM_SWEEP(0u);
 #undef FEDM_SWEEP
     };
-    for (int s = 1; s <= n_sweeps; ++s) {
+    // one GPU: all sweeps in one launch (tiles of slices with their vertex layers in LDS, fs_tiles.hip)
+    const bool tiled = !halo && !c.comm && n_sweeps > 0 &&
+                       fs_tiles_sweeps(c, n_sweeps, zs_mask, g32, ping[0], ping[1], z,
+                                       upper ? (const double *)amg.levels[0].x : (const double *)nullptr,
+                                       lagged ? (const float *)c.d_val32 : (const float *)nullptr,
+                                       lagged ? amg.levels[0].b : (double *)nullptr);
+    for (int s = 1; s <= n_sweeps && !tiled; ++s) {
         const double zs = s == 1 ? c.fs_w[0] : 1.0;
         const bool last = s == n_sweeps;
         float *out = last ? nullptr : ping[s & 1];
@@ -902,18 +914,23 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
 #pragma unroll
             for (int cidx = 0; cidx < NS; ++cidx)
                 J[r][cidx] = ((zs >> (r * NS + cidx)) & 1u) ? 0.0 : vp[(size_t)(r * NEQ + cidx) * SLICE];
+        _Float16 row16[NS * NS];
 #pragma unroll
         for (int r = 0; r < NS; ++r)
 #pragma unroll
             for (int cidx = 0; cidx < NS; ++cidx) {
-                if ((zs >> (r * NS + cidx)) & 1u) continue;   // (wave-uniform)
-                double acc = 0.0;
+                double acc = 0.0;   // (a structurally zero plane stays zero: its J entries were set to 0 above)
 #pragma unroll
                 for (int m = 0; m < NS; ++m) acc += d[r][m] * J[m][cidx];
                 // (out-of-range entries saturate: only the preconditioner's quality is at stake)
                 const float f = fminf(fmaxf((float)acc, -65504.f), 65504.f);
-                s16[((size_t)bc * NS * NS + r * NS + cidx) * SLICE + lane] = (_Float16)f;
+                row16[r * NS + cidx] = ((zs >> (r * NS + cidx)) & 1u) ? (_Float16)0.f : (_Float16)f;
             }
+        // the planes of an entry side by side, [(bc * 64 + lane) * NS^2 + plane]: one 8-byte word per entry and lane
+        // for two species, which the sweeps load as such
+        _Float16 *dst = s16 + ((size_t)bc * SLICE + lane) * (NS * NS);
+#pragma unroll
+        for (int e = 0; e < NS * NS; ++e) dst[e] = row16[e];
 #pragma unroll
         for (int cidx = 0; cidx < NS; ++cidx)
             val32[((size_t)bc * NS + cidx) * SLICE + lane] =
@@ -923,6 +940,7 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
 
 void fieldsplit_setup(Ctx &c) {
     const dim3 b(256);
+    if (c.fs_sweeps > 1 || c.fs_main_sweeps > 1 || c.fs_alt_sweeps > 1) fs_tiles_prepare(c);
     const size_t n_entries = (size_t)c.pat.total_bc * SLICE;
     if (!c.d_val32 && (hipMalloc((void **)&c.d_val32, sizeof(float) * n_entries * c.ns) != hipSuccess ||
                        hipMalloc((void **)&c.d_s16, sizeof(_Float16) * n_entries * c.ns * c.ns) != hipSuccess)) {

@@ -105,5 +105,13 @@ void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, dou
 void fieldsplit_apply_operator_part(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter,
                                     int part, const int *slices, int n_slices);
 void poisson_precondition(Ctx &c, Amg &amg, const double *r, double *z);
+// fs_tiles.hip: the n_sweeps species sweeps after the first stage in as few launches as the tiles' layers allow
+// (one GPU).  false: not applicable to this context, nothing was launched.
+bool fs_tiles_sweeps(Ctx &c, int n_sweeps, unsigned zmask, const float *g32, float *ping0, float *ping1, double *z,
+                     const double *x0, const float *cpl32, double *b0);
+int fs_tiles_info(Ctx &c, long long *out);   // 1 + out[10] = {tiles, slices per tile, layers, row width, max vertices, max rows, bytes, threads, all rows, all vertices}
+void fs_tiles_release(Ctx &c);
+void fs_tiles_prepare(Ctx &c);   // with fieldsplit_setup: the tiles exist before a Krylov step is captured
+void fs_tiles_configure(Ctx &c, int mode, int tile_slices, int depth, int threads);
 
 }  // namespace fedm

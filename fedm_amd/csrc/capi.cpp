@@ -1177,6 +1177,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
         delete c.comm;
     }
     gd_prep_release(c);
+    fs_tiles_release(c);
     for (auto &e : c.prof.ev) hipEventDestroy(e);
     iter_graphs_clear(c);
     if (c.d_mail_seq) hipFree(c.d_mail_seq);
@@ -1822,6 +1823,30 @@ int fedm_debug_comm_roundtrip(fedm_ctx *h, double *vec, double *red, int k) {
     return 0;
 }
 
+int fedm_debug_fieldsplit_tiles(fedm_ctx *h, int mode, int tile_slices, int depth, int threads) {
+    if (!h) return -2;
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    iter_graphs_clear(c);   // captured Krylov steps hold the kernels of the old setting
+    fs_tiles_configure(c, mode, tile_slices, depth, threads);
+    return 0;
+}
+
+int fedm_debug_fieldsplit_apply(fedm_ctx *h, const double *t, double *z) {
+    Ctx &c = h->c;
+    if (!t || !z || !(c.amg && c.poisson)) {
+        set_error("the field split needs a model with a Poisson row and a multigrid hierarchy (fedm_amg_setup)");
+        return -2;
+    }
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (put_vec(c, c.d_rhs, t)) return -1;
+    fieldsplit_setup(c);
+    fieldsplit_apply(c, *c.amg, c.d_rhs, c.d_w, 1.0);
+    FEDM_HIP_CHECK(hipGetLastError());
+    return get_vec(c, z, c.d_w);
+}
+
 int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[12]) {
     if (!mesh || !out || mesh->n_vertices < 3 || mesh->n_cells < 1) {
         set_error("null or empty mesh");
@@ -2036,6 +2061,14 @@ int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
     out[6] = c.assembly_kind == 0 ? 0 : (lean2 ? 2 : 1);
     out[7] = c.assembly_kind == 0 ? 0 : (c.pat.max_patch_cells <= 192 ? 192 : (lean2 ? 256 : 320));
     return 0;
+}
+
+int fedm_fieldsplit_tiles_info(fedm_ctx *h, int64_t out[10]) {
+    if (!h || !out) return -2;
+    long long v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int in_use = fs_tiles_info(h->c, v);
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
+    return in_use;
 }
 
 int64_t fedm_block_nnz(fedm_ctx *h) { return h->c.pat.nnz_blocks; }

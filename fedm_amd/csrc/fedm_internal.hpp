@@ -56,6 +56,7 @@ void build_pattern(const fedm_mesh_desc &mesh, Pattern &pat, bool allow_rotation
 struct Amg;
 struct Comm;
 struct GdPrep;
+struct FsTiles;
 
 // Optional in-run kernel timing with HIP events on the library's stream (bench.py roofline).
 // kinds: 0 assembly F+J, 1 Jacobian SpMV, 2 assembly F only, 3 multigrid V-cycle
@@ -146,7 +147,7 @@ struct Ctx {
     float *d_val32 = nullptr;   // coupling planes in fp32, [(bc*NS + c)*64 + lane]: the potential row's species
                                 // columns J_phi,u (lower-triangular order) or the species rows' potential
                                 // column J_u,phi (upper-triangular order, fs_upper)
-    _Float16 *d_s16 = nullptr;  // Duu^-1 J_uu in fp16: [(bc*NS*NS + r*NS + c)*64 + lane]
+    _Float16 *d_s16 = nullptr;  // Duu^-1 J_uu in fp16: [(bc*64 + lane)*NS*NS + r*NS + c]
     // Dirichlet
     int n_dir = 0;
     int *d_dir_dofs = nullptr;
@@ -160,6 +161,11 @@ struct Ctx {
     int fs_main_sweeps = 1, fs_alt_sweeps = 0;
     double fs_main_w[16] = {1}, fs_alt_w[16] = {1};
     bool fs_alt_active = false;
+    // one GPU: several species sweeps per launch on tiles of slices with their vertex layers in LDS (fs_tiles.hip);
+    // state 0: not looked at yet, 1: in use, -1: not applicable here
+    FsTiles *fs_tiles = nullptr;
+    int fs_tiles_state = 0;
+    int fs_tiles_want_slices = 0, fs_tiles_want_depth = 0, fs_tiles_want_threads = 0;   // > 0: set by fs_tiles_configure
     bool fs_halo = true;    // several GPUs: ghost exchange of the species iterate before every sweep
     bool deep_halo = true;  // use the ghost layers (halo_depth > 1) instead of those exchanges; FEDM_DEEP_HALO=0: off
     // lower-triangular order: b_phi -= J_phi,u z_u formed inside the last species sweep from the

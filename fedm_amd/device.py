@@ -885,6 +885,31 @@ class DeviceProblem:
     def assembly_variant(self):
         return self.sizes()["assembly_variant"]
 
+    def fieldsplit_apply(self, t):
+        """z = Minv t with the field split of the current Jacobian (test hook; call jacobian() first)."""
+        t = np.ascontiguousarray(t, dtype=np.float64).reshape(-1)
+        assert t.size == self.n
+        z = np.empty(self.n)
+        self._check(self.lib.fedm_debug_fieldsplit_apply(self._h, _dp(t), _dp(z)), "fedm_debug_fieldsplit_apply")
+        return z
+
+    def configure_fieldsplit_tiles(self, on, slices_per_tile=0, layers=0, threads=0):
+        """Test hook: species sweeps on tiles (several per launch) or one launch each."""
+        self._check(self.lib.fedm_debug_fieldsplit_tiles(self._h, 1 if on else 0, int(slices_per_tile), int(layers),
+                                                         int(threads)), "fedm_debug_fieldsplit_tiles")
+
+    def fieldsplit_tiles(self):
+        """How the species sweeps of the field split run here: None = one launch per sweep; else the tiles of
+        csrc/fs_tiles.hip (several sweeps per launch, the vertex layers around a tile of slices in LDS)."""
+        info = (C.c_int64 * 10)()
+        rc = self.lib.fedm_fieldsplit_tiles_info(self._h, info)
+        if rc < 0:
+            self._check(rc, "fedm_fieldsplit_tiles_info")
+        if rc == 0:
+            return None
+        return dict(zip(("n_tiles", "slices_per_tile", "layers", "row_width", "max_vertices", "max_rows", "bytes",
+                         "threads", "total_rows", "total_vertices"), (int(v) for v in info[:10])))
+
 
 def rccl_unique_id():
     """128-byte ncclUniqueId (call on one rank, broadcast to the others)."""

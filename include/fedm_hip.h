@@ -198,8 +198,9 @@ const char *fedm_last_error(void);
 /* Version of this header's structs and entry points; a binding compares it with the constant it was
  * written against and refuses a library of another version (a descriptor that grew would otherwise be
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
- * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields. */
-#define FEDM_ABI_VERSION 2
+ * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields.
+ * 3: fedm_fieldsplit_tiles_info, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles. */
+#define FEDM_ABI_VERSION 3
 int fedm_abi_version(void);
 
 /* mesh + model -> device: colouring, sliced block-ELL pattern, buffers.
@@ -386,6 +387,22 @@ int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[12]);
  * assembly variant (0 global colouring, 1 LDS patches / unrolled element routine, 2 LDS patches / one
  * equation row at a time), threads per patch workgroup}. */
 int fedm_pattern_info(fedm_ctx *ctx, int64_t out[8]);
+/* The species sweeps of the field split (the Chebyshev polynomial in Duu^-1 Juu that stands for PETSc's
+ * sub-solver of the species block; no counterpart in the scripts): on one GPU they run several per launch on
+ * tiles of matrix slices whose vertex layers sit in LDS (csrc/fs_tiles.hip).  Returns 1 when this context
+ * does so (builds the tiles if need be), 0 when it runs them one by one (several GPUs, more than two species,
+ * FEDM_FS_TILES=0); out = {tiles, slices per tile, vertex layers (= sweeps per launch), longest matrix row,
+ * most vertices of a tile with its layers, most rows, bytes of the tile tables, threads per tile, rows of all
+ * tiles (the tile's own and the layers': the redundancy is this over the vertex count), vertices of all tiles}. */
+int fedm_fieldsplit_tiles_info(fedm_ctx *ctx, int64_t out[10]);
+/* Test hook: z = Minv t with the field-split preconditioner of the CURRENT Jacobian (fedm_jacobian first; its
+ * species planes are formed here), host vectors of n_vertices * n_eq doubles -- the operator a Krylov step of
+ * fedm_newton_solve applies, alone. */
+int fedm_debug_fieldsplit_apply(fedm_ctx *ctx, const double *t, double *z);
+/* Test hook: mode 0 = species sweeps one launch each from now on; 1 = tiles, rebuilt with `tile_slices` slices
+ * per tile, `depth` vertex layers and `threads` threads per tile (0: defaults, FEDM_FS_TILE_SLICES /
+ * FEDM_FS_TILE_DEPTH / FEDM_FS_TILE_THREADS). */
+int fedm_debug_fieldsplit_tiles(fedm_ctx *ctx, int mode, int tile_slices, int depth, int threads);
 
 /* |new - old + eps| / |old + eps| on one component        fedm/functions.py:1062-1064 */
 int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);

@@ -34,5 +34,5 @@ rocprofv3 --kernel-trace --output-format csv -d "$OUT/seq" -o q -- python3 $SEQ 
 TRACE=$(find "$OUT/seq" -name "q_kernel_trace.csv" | head -1)
 { echo "One accepted time step of the bench case (576x576, step 6 of the run, Krylov steps replayed as graphs), kernel by kernel:";
   echo "start offset [us], duration [us], gap to the previous kernel [us], kernel (rocprofv3 --kernel-trace of python3 $SEQ; tools/step_sequence.py)";
-  echo; python3 tools/step_sequence.py "$TRACE" -3; } > "profiles/${TAG}_step_sequence.txt"
+  echo; python3 tools/step_sequence.py "$TRACE" 6; echo; echo "every step of that process (the last ones are bench.py's profiling pass: plain launches, event pairs):"; python3 tools/step_sequence.py "$TRACE" all; } > "profiles/${TAG}_step_sequence.txt"
 rm -f "$TRACE"
