@@ -151,6 +151,9 @@ void iter_graphs_clear(Ctx &c) {
         if (g) hipGraphExecDestroy(g);
     for (hipGraphExec_t g : c.iter_graph_pre)
         if (g) hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : c.iter_graph_pair)
+        if (g) hipGraphExecDestroy(g);
+    c.iter_graph_pair.clear();
     c.iter_graph.clear();
     c.iter_graph_interior.clear();
     c.iter_graph_pre.clear();
@@ -317,6 +320,51 @@ static void right_step_plain(Ctx &c, int j, const double *const *vp, double *z, 
     dotp[j + 1] = w;
     launch_dots(c, dotp.data(), w, j + 2, true);
     launch_cgs_update(c, j + 1, vp, w);
+}
+
+// One GPU, field split on the right: Krylov steps j and j + 1 as ONE graph (a step needs nothing from the host, and
+// when the previous solve says that both will be needed they are launched together anyway; between two graph
+// launches the GPU idles for 8 us, tools/step_sequence.py).  Publishes twice: mail_seq advances by two.
+static bool iter_graph_launch_right_pair(Ctx &c, int j, const double *const *vp, double *z0, double *w0, double *z1,
+                                         double *w1) {
+    static const bool off = [] {
+        const char *e = std::getenv("FEDM_KRYLOV_PAIRS");
+        return e && e[0] == '0';
+    }();
+    if (off || c.comm || !c.iter_graphs_ok || (c.prof.on && c.prof.all_kinds) || fieldsplit_upper(c)) return false;
+    if ((int)c.iter_graph_pair.size() <= j) c.iter_graph_pair.resize(j + 1, nullptr);
+    if (!c.iter_graph_pair[j]) {
+        const bool direct = c.amg->pre_smooth && c.amg->levels.size() > 1;
+        auto step = [&](int jj, double *z, double *w) {
+            std::vector<const double *> dotp(jj + 2);
+            for (int i = 0; i <= jj; ++i) dotp[i] = vp[i];
+            dotp[jj + 1] = w;
+            if (direct) {
+                c.amg->out = z;
+                c.amg->out_stride = c.neq;
+                c.amg->out_offset = c.neq - 1;
+            }
+            fieldsplit_apply(c, *c.amg, vp[jj], z, 1.0, !direct);
+            c.amg->out = nullptr;
+            launch_spmv(c, z, w, false);
+            launch_dots_fused(c, dotp.data(), w, jj + 2, nullptr, true);
+            launch_cgs_update(c, jj + 1, vp, w);
+        };
+        if (!capture_graph(c, &c.iter_graph_pair[j], [&] {
+                step(j, z0, w0);
+                step(j + 1, z1, w1);
+            })) {
+            c.iter_graphs_ok = false;
+            return false;
+        }
+    }
+    if (hipGraphLaunch(c.iter_graph_pair[j], c.stream) != hipSuccess) {
+        hipGetLastError();
+        c.iter_graphs_ok = false;
+        return false;
+    }
+    c.mail_seq += 2;
+    return true;
 }
 
 static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, double *z, double *w) {
@@ -595,13 +643,20 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             // says that step will be needed (one GPU: no collectives in between); a step launched in
             // vain only writes vectors nobody reads.
             unsigned long long seq_j;
+            const bool next_too = right && !c.comm && j + 1 < m && its + 1 < max_it && j + 1 < c.krylov_steps_hint;
             if (ahead) {
                 seq_j = seq_ahead;
                 ahead = false;
+            } else if (next_too && iter_graph_launch_right_pair(c, j, vp.data(), c.d_Z + (size_t)j * c.np, w,
+                                                                c.d_Z + (size_t)(j + 1) * c.np,
+                                                                c.d_V + (size_t)(j + 2) * c.np)) {
+                seq_j = c.mail_seq - 1;     // this step and the next one in one graph
+                seq_ahead = c.mail_seq;
+                ahead = true;
             } else {
                 seq_j = launch_step(j);
             }
-            if (right && !c.comm && j + 1 < m && its + 1 < max_it && j + 1 < c.krylov_steps_hint) {
+            if (!ahead && next_too) {
                 seq_ahead = launch_step(j + 1);
                 ahead = true;
             }

@@ -220,6 +220,7 @@ struct Ctx {
     std::vector<hipGraphExec_t> iter_graph;
     std::vector<hipGraphExec_t> iter_graph_interior;  // several GPUs: the interior-rows SpMV of step j
     std::vector<hipGraphExec_t> iter_graph_pre;       // several GPUs, field split on the right: z_j = Minv v_j
+    std::vector<hipGraphExec_t> iter_graph_pair;      // one GPU, on the right: steps j and j + 1 as ONE graph
     bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
     bool capturing = false;
     int newton_its_hint = -1;     // Newton iterations of the previous converged solve
