@@ -102,6 +102,7 @@ static void set_hard_mode(Ctx &c, bool hard) {
 }
 
 static int ensure_krylov(Ctx &c, int restart) {
+    if (ensure_spmv_dots(c)) return -1;
     if (restart + 1 <= c.krylov_cap) return 0;
     iter_graphs_clear(c);  // they hold the old Krylov vectors' addresses
     if (c.d_V) hipFree(c.d_V);
@@ -346,8 +347,10 @@ static bool iter_graph_launch_right_pair(Ctx &c, int j, const double *const *vp,
             }
             fieldsplit_apply(c, *c.amg, vp[jj], z, 1.0, !direct);
             c.amg->out = nullptr;
-            launch_spmv(c, z, w, false);
-            launch_dots_fused(c, dotp.data(), w, jj + 2, nullptr, true);
+            if (!launch_spmv_dots(c, z, w, dotp.data(), jj + 2)) {
+                launch_spmv(c, z, w, false);
+                launch_dots_fused(c, dotp.data(), w, jj + 2, nullptr, true);
+            }
             launch_cgs_update(c, jj + 1, vp, w);
         };
         if (!capture_graph(c, &c.iter_graph_pair[j], [&] {
@@ -397,8 +400,10 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         if (!multi) {
             ok = capture_graph(c, &c.iter_graph[j], [&] {
                 with_direct_output([&] { fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct); });
-                launch_spmv(c, z, w, false);
-                launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, true);
+                if (!launch_spmv_dots(c, z, w, dotp.data(), j + 2)) {
+                    launch_spmv(c, z, w, false);
+                    launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, true);
+                }
                 launch_cgs_update(c, j + 1, vp, w);
             });
         } else if (deep_halo_active(c) && !upper) {
@@ -1216,7 +1221,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     void *ptrs[] = {c.d_coords, c.d_cells, c.d_ftags, c.d_cell_slots, c.d_colour_cells, c.d_model,
                     c.d_slice_boff, c.d_colidx, c.d_diag_slot, c.d_val, c.d_dinv, c.d_dir_dofs,
                     c.d_dir_vals, c.d_identity, c.d_u, c.d_uold, c.d_uold1, c.d_F, c.d_delta, c.d_w, c.d_rhs,
-                    c.d_tmp, c.d_fs, c.d_fs_g, c.d_V, c.d_partials, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
+                    c.d_tmp, c.d_fs, c.d_fs_g, c.d_V, c.d_partials, c.d_partials_wide, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
                     c.d_ext[3], c.d_patch_cell_ptr, c.d_patch_halo_ptr, c.d_patch_halo,
                     c.d_patch_cells, c.d_bfacets, c.d_gd, c.d_gd_fields, c.d_gd_elem, c.d_gd_inv_ptr,
                     c.d_gd_inv_idx, c.d_gd_elemF, c.d_gd_vinv_ptr, c.d_gd_vinv_idx};

@@ -209,6 +209,7 @@ struct Ctx {
     bool right_precond = true;
     // reductions
     double *d_partials = nullptr;  // [RED_BLOCKS][RED_K]
+    double *d_partials_wide = nullptr;  // [4][workgroups of the Jacobian product]: spmv_dots_kernel (one GPU)
     double *d_red = nullptr;       // [RED_K]
     double *h_mail = nullptr;      // pinned, host-mapped: two slots of [RED_K] values + sequence tag
     double *h_red = nullptr;       // the slot of the publication last waited for (wait_red); written
@@ -258,6 +259,8 @@ void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, doubl
                             const int *slice_list = nullptr, int n_list = 0, bool compact32 = false);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
+bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k);  // false: not applicable
+int ensure_spmv_dots(Ctx &c);
 void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0,
                        bool finish = true);
 void launch_cgs_finish(Ctx &c, int k);  // finish formulae + publication on d_red[0..k)

@@ -1193,6 +1193,118 @@ __global__ __launch_bounds__(1024) void reduce_finish_kernel(const double *__res
     }
 }
 
+// One GPU, Krylov steps with at most four reduction slots (the first three steps of a solve: all there are early in
+// a streamer run): the Jacobian product w = J z and the step's dot products v_i . w, w . w in ONE kernel -- the wave
+// that has formed a slice's rows of w multiplies them with the same rows of the basis vectors before it stores them
+// (w is not read back: 8 MB and a 9 us kernel less per step).  One partial per workgroup and slot,
+// partials[slot * n_blocks + block]; spmv_dots_finish_kernel reduces them in a fixed order.
+template <int NEQ, unsigned ZMASK, int K>
+__global__ __launch_bounds__(256) void spmv_dots_kernel(int n_slices, int n_owned, const int *__restrict__ boff,
+                                                        const int *__restrict__ colidx,
+                                                        const double *__restrict__ val,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        PtrPack8 xs, double *__restrict__ partials, int xcd) {
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int blk = xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int wave_id = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool live = wave_id < n_slices;          // (no early return: the workgroup reduces together)
+    const int slice = live ? wave_id : 0;
+    const int b0 = boff[slice], b1 = live ? boff[slice + 1] : b0;
+    double acc[NEQ];
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
+    for (int bc = b0; bc < b1; ++bc) {
+        const int col = colidx[(size_t)bc * SLICE + lane];
+        double xj[NEQ];
+#pragma unroll
+        for (int cc = 0; cc < NEQ; ++cc) xj[cc] = x[(size_t)col * NEQ + cc];
+        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NEQ; ++cc)
+                if (!((ZMASK >> (r * NEQ + cc)) & 1u)) acc[r] += vp[(size_t)(r * NEQ + cc) * SLICE] * xj[cc];
+    }
+    const size_t vtx = (size_t)slice * SLICE + lane;
+    const bool owned = live && (int)vtx < n_owned;
+    double d[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) d[i] = 0.0;
+    if (owned) {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i)
+#pragma unroll
+            for (int r = 0; r < NEQ; ++r) d[i] += xs.p[i][vtx * NEQ + r] * acc[r];
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) d[K - 1] += acc[r] * acc[r];
+    }
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) y[vtx * NEQ + r] = owned ? acc[r] : 0.0;
+    }
+    __shared__ double sm[4][K];
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const double t = wave_sum(d[i]);
+        if (lane == 0) sm[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < K)
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+            sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// reduce_finish_kernel for the partials of spmv_dots_kernel (one per workgroup of the product: thousands, not
+// RED_BLOCKS): the 16 waves share the k <= 4 slots, wave w sums the blocks of chunk w / k of slot w % k, the chunks
+// are added in their order; then the formulae and the publication of cgs_finish_kernel.
+__global__ __launch_bounds__(1024) void spmv_dots_finish_kernel(const double *__restrict__ partials, int nblocks,
+                                                               int k, double *__restrict__ out, double *mail,
+                                                               unsigned long long *seq) {
+    __shared__ double fin[RED_K];
+    __shared__ double part[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < RED_K) fin[threadIdx.x] = (threadIdx.x == RED_SPARE) ? out[RED_SPARE] : 0.0;
+    const int chunks = 16 / k, slot = wave % k, chunk = wave / k;
+    double sum = 0.0;
+    if (chunk < chunks)
+        for (int b = chunk * 64 + lane; b < nblocks; b += chunks * 64) sum += partials[(size_t)slot * nblocks + b];
+    sum = wave_sum(sum);
+    if (lane == 0) part[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x < k) {
+        double t = 0.0;
+        for (int ch = 0; ch < chunks; ++ch) t += part[ch * k + threadIdx.x];
+        fin[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ww = fin[k - 1];
+        double hh = 0.0;
+        for (int i = 0; i < k - 1; ++i) hh += fin[i] * fin[i];
+        const double hn2 = ww - hh;
+        fin[RED_K - 2] = ww;
+        fin[k - 1] = hn2;
+        fin[RED_K - 1] = (hn2 > 1e-8 * ww && hn2 > 0.0) ? 1.0 / sqrt(hn2) : 1.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const unsigned long long tag = *seq + 1;
+        double *slot_ = mail + (tag & 1) * (RED_K + 1);
+        for (int i = threadIdx.x; i < RED_K; i += 64) {
+            out[i] = fin[i];
+            slot_[i] = fin[i];
+        }
+        __threadfence_system();
+        if (threadIdx.x == 0) {
+            *seq = tag;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot_ + RED_K), tag, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int K, bool FINAL>
 __global__ void cgs_update_kernel(size_t n, const double *__restrict__ coef, int base, PtrPack8 xs,
                                   double *__restrict__ y) {
@@ -1286,6 +1398,55 @@ void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const 
     hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(1024), 0, c.stream, c.d_partials, grid, k, c.d_red,
                        c.h_mail, c.d_mail_seq);
     if (!c.capturing) ++c.mail_seq;
+}
+
+// w = J z with the step's k = j + 2 reduction slots (xs[0 .. k-2] . w and w . w), finished and published: one GPU,
+// three species-plus-potential equations, k <= 4, buffers of ensure_spmv_dots.  false: not applicable (nothing was
+// launched; the caller runs launch_spmv + launch_dots_fused).
+bool spmv_dots_applicable(const Ctx &c, int k) {
+    static const bool off = [] {
+        const char *e = std::getenv("FEDM_SPMV_DOTS");
+        return e && e[0] == '0';
+    }();
+    return !off && !c.comm && c.neq == 3 && k >= 2 && k <= 4 && c.d_partials_wide && c.n_owned == c.nv;
+}
+
+bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k) {
+    if (!spmv_dots_applicable(c, k)) return false;
+    const int n = c.pat.n_slices;
+    const dim3 g((n + 3) / 4), b(256);
+    PtrPack8 pk;
+    for (int i = 0; i < 8; ++i) pk.p[i] = xs[i < k - 1 ? i : 0];
+    const int xcd = c.xcd_remap ? 1 : 0;
+#define FEDM_SD(Z, K)                                                                                       \
+    hipLaunchKernelGGL((spmv_dots_kernel<3, Z, K>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, \
+                       c.d_val, x, y, pk, c.d_partials_wide, xcd)
+#define FEDM_SD_K(Z)                                                                                        \
+    do {                                                                                                    \
+        if (k == 2) FEDM_SD(Z, 2);                                                                          \
+        else if (k == 3) FEDM_SD(Z, 3);                                                                     \
+        else FEDM_SD(Z, 4);                                                                                 \
+    } while (0)
+    switch (c.zero_plane_mask & 10u) {
+        case 2u: FEDM_SD_K(2u); break;
+        case 8u: FEDM_SD_K(8u); break;
+        case 10u: FEDM_SD_K(10u); break;
+        default: FEDM_SD_K(0u); break;
+    }
+#undef FEDM_SD_K
+#undef FEDM_SD
+    hipLaunchKernelGGL(spmv_dots_finish_kernel, dim3(1), dim3(1024), 0, c.stream, c.d_partials_wide, (int)g.x, k,
+                       c.d_red, c.h_mail, c.d_mail_seq);
+    if (!c.capturing) ++c.mail_seq;
+    return true;
+}
+
+// (one partial per workgroup of the product and slot; allocated with the Krylov vectors, outside any capture)
+int ensure_spmv_dots(Ctx &c) {
+    if (c.d_partials_wide || c.comm || c.neq != 3) return 0;
+    const size_t blocks = (size_t)(c.pat.n_slices + 3) / 4;
+    FEDM_HIP_CHECK(hipMalloc((void **)&c.d_partials_wide, sizeof(double) * 4 * blocks));
+    return 0;
 }
 
 // y = (y - sum_i d_red[i] xs[i]) * d_red[RED_K-1], coefficients stay on the device

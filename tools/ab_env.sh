@@ -4,7 +4,7 @@ NAME=$1; shift
 ONLY="--no-cpu-baseline --late-start 0 --unstructured off --big-mesh 0 --no-glow-discharge"
 python3 -c 'import __graft_entry__ as g; g.build()' || exit 1
 : > gpurun_out/ab_$NAME.txt
-for round in 1 2; do
+for round in $(seq 1 ${ROUNDS:-2}); do
   for setting in "$@"; do
     env $setting timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 $ONLY > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err
     rc=$?
