@@ -814,9 +814,27 @@ void fieldsplit_upper_species(Ctx &c, Amg &amg, const double *t, double *z, doub
 template <int NS>
 static void fs_apply_t(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter, bool with_cycle) {
     const dim3 gv((c.nvp + 255) / 256), bv(256);
-    hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
-                       amg.levels[0].b, alpha, 1.0, fs_first_compact(c) ? 1 : 0);
+    // (GMRES on one GPU: the kernel that completed t has formed this stage already)
+    if (!(c.fs_first_by_producer && fs_first_compact(c) && alpha == 1.0))
+        hipLaunchKernelGGL(fs_species_kernel<NS>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, fs_first_target(c, z),
+                           amg.levels[0].b, alpha, 1.0, fs_first_compact(c) ? 1 : 0);
     fs_finish_t<NS>(c, amg, z, scatter, with_cycle);
+}
+
+void fieldsplit_first_stage(Ctx &c, Amg &amg, const double *t) {
+    const dim3 gv((c.nvp + 255) / 256), bv(256);
+    double *g = c.d_fs_g;
+#define FEDM_FIRST(NS_)                                                                                    \
+    hipLaunchKernelGGL(fs_species_kernel<NS_>, gv, bv, 0, c.stream, c.nvp, c.d_dinv, t, g, amg.levels[0].b, 1.0, \
+                       1.0, 1)
+    switch (c.ns) {
+        case 1: FEDM_FIRST(1); break;
+        case 2: FEDM_FIRST(2); break;
+        case 3: FEDM_FIRST(3); break;
+        case 4: FEDM_FIRST(4); break;
+        case 5: FEDM_FIRST(5); break;
+    }
+#undef FEDM_FIRST
 }
 
 void fieldsplit_scatter(Ctx &c, Amg &amg, double *z) {

@@ -96,6 +96,8 @@ void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha
 bool fieldsplit_upper(const Ctx &c);  // upper-triangular order in force (Ctx::fs_upper, split on the right)
 void fieldsplit_upper_potential(Ctx &c, Amg &amg, const double *t, double alpha);
 void fieldsplit_upper_species(Ctx &c, Amg &amg, const double *t, double *z, double alpha);
+// first stage alone, for the vector t: g = Duu^-1 t_u into the sweeps' start vector, b0 = t_phi (Ctx::fs_first_by_producer)
+void fieldsplit_first_stage(Ctx &c, Amg &amg, const double *t);
 void fieldsplit_scatter(Ctx &c, Amg &amg, double *z);  // potential component of z <- the V-cycle's result
 // z = Minv (J v); scatter = false leaves the potential component in amg.levels[0].x
 void fieldsplit_apply_operator(Ctx &c, Amg &amg, const double *v, double *t, double *z, bool scatter);

@@ -168,6 +168,30 @@ void iter_graphs_clear(Ctx &c) {
 // (those without ghost columns):
 //   mark v_j complete -> graph I_j (interior SpMV)  ||  exchange  -> wait -> graph B_j (boundary
 //   SpMV, preconditioner, local partial sums) -> all-reduce -> finish/publish -> update.
+// Producers of Krylov vectors.  One GPU, field split on the right with species sweeps (Ctx::fs_first_by_producer, set by
+// gmres): the kernel that completes v_j also forms the first stage of the preconditioner for it (cgs_update_fs_kernel).
+static void krylov_vector_update(Ctx &c, int k, const double *const *vp, double *w) {
+    if (c.fs_first_by_producer) {
+        if (!launch_cgs_update_fs(c, k, vp, w, reinterpret_cast<float *>(c.d_fs_g), c.amg->levels[0].b)) {
+            launch_cgs_update(c, k, vp, w);
+            fieldsplit_first_stage(c, *c.amg, w);
+        }
+    } else {
+        launch_cgs_update(c, k, vp, w);
+    }
+}
+
+static void krylov_vector_scale(Ctx &c, double a, const double *x, double *y) {
+    if (c.fs_first_by_producer) {
+        if (!launch_scale_copy_fs(c, a, x, y, reinterpret_cast<float *>(c.d_fs_g), c.amg->levels[0].b)) {
+            launch_scale_copy(c, a, x, y);
+            fieldsplit_first_stage(c, *c.amg, y);
+        }
+    } else {
+        launch_scale_copy(c, a, x, y);
+    }
+}
+
 static bool capture_graph(Ctx &c, hipGraphExec_t *out, const std::function<void()> &body) {
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -218,7 +242,7 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
             ok = capture_graph(c, &c.iter_graph[j], [&] {
                 with_direct_output([&] { fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, false); });
                 launch_dots_fused(c, dotp.data(), w, j + 2, x0, true);
-                launch_cgs_update(c, j + 1, vp, w);
+                krylov_vector_update(c, j + 1, vp, w);
             });
         } else {
             Comm &cm = *c.comm;
@@ -270,7 +294,7 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
         dotp[j + 1] = w;
         fieldsplit_apply_operator(c, *c.amg, vp[j], c.d_tmp, w, true);
         launch_dots(c, dotp.data(), w, j + 2, true);
-        launch_cgs_update(c, j + 1, vp, w);
+        krylov_vector_update(c, j + 1, vp, w);
         return true;
     }
     if (c.amg->global) {  // V-cycle with its collectives, then scatter + local partial sums
@@ -282,7 +306,7 @@ static bool iter_graph_launch(Ctx &c, int j, const double *const *vp, double *w)
     }
     comm_allreduce(c, c.d_red, j + 2);
     launch_cgs_finish(c, j + 2);
-    launch_cgs_update(c, j + 1, vp, w);
+    krylov_vector_update(c, j + 1, vp, w);
     return true;
 }
 
@@ -305,7 +329,7 @@ static void right_step_plain_after_exchange(Ctx &c, int j, const double *const *
     for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
     dotp[j + 1] = w;
     launch_dots(c, dotp.data(), w, j + 2, true);
-    launch_cgs_update(c, j + 1, vp, w);
+    krylov_vector_update(c, j + 1, vp, w);
 }
 
 static void right_step_plain(Ctx &c, int j, const double *const *vp, double *z, double *w) {
@@ -320,7 +344,7 @@ static void right_step_plain(Ctx &c, int j, const double *const *vp, double *z, 
     for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
     dotp[j + 1] = w;
     launch_dots(c, dotp.data(), w, j + 2, true);
-    launch_cgs_update(c, j + 1, vp, w);
+    krylov_vector_update(c, j + 1, vp, w);
 }
 
 // One GPU, field split on the right: Krylov steps j and j + 1 as ONE graph (a step needs nothing from the host, and
@@ -351,7 +375,7 @@ static bool iter_graph_launch_right_pair(Ctx &c, int j, const double *const *vp,
                 launch_spmv(c, z, w, false);
                 launch_dots_fused(c, dotp.data(), w, jj + 2, nullptr, true);
             }
-            launch_cgs_update(c, jj + 1, vp, w);
+            krylov_vector_update(c, jj + 1, vp, w);
         };
         if (!capture_graph(c, &c.iter_graph_pair[j], [&] {
                 step(j, z0, w0);
@@ -404,7 +428,7 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
                     launch_spmv(c, z, w, false);
                     launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, true);
                 }
-                launch_cgs_update(c, j + 1, vp, w);
+                krylov_vector_update(c, j + 1, vp, w);
             });
         } else if (deep_halo_active(c) && !upper) {
             // deep halos: nothing is exchanged inside the step, so it is cut at its two all-reduces only --
@@ -471,12 +495,12 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
             dotp[j + 1] = w;
             launch_spmv(c, z, w, false);
             launch_dots(c, dotp.data(), w, j + 2, true);
-            launch_cgs_update(c, j + 1, vp, w);
+            krylov_vector_update(c, j + 1, vp, w);
             return true;
         }
         comm_allreduce(c, c.d_red, j + 2);
         launch_cgs_finish(c, j + 2);
-        launch_cgs_update(c, j + 1, vp, w);
+        krylov_vector_update(c, j + 1, vp, w);
         return true;
     }
     if (upper) {
@@ -524,12 +548,12 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
         dotp[j + 1] = w;
         launch_spmv(c, z, w, false);
         launch_dots(c, dotp.data(), w, j + 2, true);
-        launch_cgs_update(c, j + 1, vp, w);
+        krylov_vector_update(c, j + 1, vp, w);
         return true;
     }
     comm_allreduce(c, c.d_red, j + 2);
     launch_cgs_finish(c, j + 2);
-    launch_cgs_update(c, j + 1, vp, w);
+    krylov_vector_update(c, j + 1, vp, w);
     return true;
 }
 
@@ -554,6 +578,18 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
     for (int i = 0; i <= m; ++i) vp[i] = c.d_V + (size_t)i * c.np;
     for (int i = 0; i < m; ++i) zp[i] = c.d_Z + (size_t)i * c.np;
     const bool right = right_preconditioned(c);
+    // one GPU, species sweeps, lower-triangular order: the producers of the Krylov vectors form the preconditioner's
+    // first stage (krylov_vector_update); for the duration of this solve
+    static const bool first_by_producer_ok = [] {
+        const char *e = std::getenv("FEDM_FS_FIRST_BY_PRODUCER");
+        return !(e && e[0] == '0');
+    }();
+    struct ProducerMode {
+        Ctx &c;
+        ~ProducerMode() { c.fs_first_by_producer = false; }
+    } producer_mode{c};
+    c.fs_first_by_producer = first_by_producer_ok && right && !c.comm && !fieldsplit_upper(c) && c.fs_sweeps > 1 &&
+                             c.d_fs_g != nullptr;
     // the (unpreconditioned) operator of the right-preconditioned variant
     auto plain_operator = [&](double *v, double *w) {
         comm_halo(c, v);  // ghost inputs from their owners (multi-GPU)
@@ -599,10 +635,11 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 zero_delta();
                 break;
             }
-            launch_scale_copy(c, bscale / beta, bvec, v0);
+            krylov_vector_scale(c, bscale / beta, bvec, v0);
         } else if (deferred) {
             launch_norm2(c, bvec, RED_SPARE);
             launch_normalise_copy(c, RED_SPARE, bvec, v0);  // v0 = b / |b|  (bscale is 1 on this path)
+            if (c.fs_first_by_producer) fieldsplit_first_stage(c, *c.amg, v0);
             first = false;
         } else {
             launch_norm2(c, v0, 0);
@@ -616,7 +653,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             rnorm = beta;
             tol = std::max(rtol * r0, atol);
             if (beta <= tol || its >= max_it) break;
-            launch_scale_copy(c, 1.0 / beta, v0, v0);
+            krylov_vector_scale(c, 1.0 / beta, v0, v0);
         }
         std::fill(gvec.begin(), gvec.end(), 0.0);
         gvec[0] = beta;
@@ -638,7 +675,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                     for (int i = 0; i <= jj; ++i) dotp[i] = vp[i];
                     dotp[jj + 1] = ww;
                     launch_dots(c, dotp.data(), ww, jj + 2, true);
-                    launch_cgs_update(c, jj + 1, vp.data(), ww);
+                    krylov_vector_update(c, jj + 1, vp.data(), ww);
                 }
                 return c.mail_seq;  // the sequence number of this step's publication
             };
@@ -705,7 +742,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 launch_norm2(c, w, 0);
                 read_red(c, 1);
                 hn = std::sqrt(c.h_red[0]);
-                if (hn > 0.0 && std::isfinite(hn)) launch_scale_copy(c, 1.0 / hn, w, w);
+                if (hn > 0.0 && std::isfinite(hn)) krylov_vector_scale(c, 1.0 / hn, w, w);
             } else {
                 hn = std::sqrt(hn2);
             }

@@ -163,6 +163,9 @@ struct Ctx {
     bool fs_alt_active = false;
     // one GPU: several species sweeps per launch on tiles of slices with their vertex layers in LDS (fs_tiles.hip);
     // state 0: not looked at yet, 1: in use, -1: not applicable here
+    // set for the duration of a GMRES solve (one GPU, field split on the right, sweeps): whoever completes a Krylov
+    // vector has formed the preconditioner's first stage for it (g, b0); fieldsplit_apply starts at the sweeps
+    bool fs_first_by_producer = false;
     FsTiles *fs_tiles = nullptr;
     int fs_tiles_state = 0;
     int fs_tiles_want_slices = 0, fs_tiles_want_depth = 0, fs_tiles_want_threads = 0;   // > 0: set by fs_tiles_configure
@@ -261,6 +264,9 @@ void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
 bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k);  // false: not applicable
 int ensure_spmv_dots(Ctx &c);
+// (see cgs_update_fs_kernel, kernels.hip; false: not instantiated for this case)
+bool launch_cgs_update_fs(Ctx &c, int k, const double *const *xs, double *y, float *g32, double *b0);
+bool launch_scale_copy_fs(Ctx &c, double a, const double *x, double *y, float *g32, double *b0);
 void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const double *x0,
                        bool finish = true);
 void launch_cgs_finish(Ctx &c, int k);  // finish formulae + publication on d_red[0..k)

@@ -1477,6 +1477,94 @@ void launch_cgs_update(Ctx &c, int k, const double *const *xs, double *y) {
     }
 }
 
+// One GPU, field split on the right with species sweeps: whoever completes a Krylov vector v_j also forms the first
+// stage of the preconditioner's application to it -- g = Duu^-1 v_u (single precision, what the sweeps start from)
+// and b0 = v_phi (the multigrid's right-hand side) -- while the vector's entries are in registers: the pointwise
+// fs_species_kernel (amg.hip; 5.5 us of launch latency per Krylov step) is gone.  Same operations in the same
+// order as cgs_update_kernel / scale_copy_kernel followed by fs_species_kernel.
+template <int NS>
+__device__ __forceinline__ void first_stage_of(int v, const double (&tv)[NS + 1], const double *__restrict__ dinv_uu,
+                                               float *__restrict__ g32, double *__restrict__ b0) {
+    const double *dp = dinv_uu + (size_t)(v >> 6) * NS * NS * SLICE + (v & 63);
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) acc += dp[(size_t)(r * NS + cidx) * SLICE] * tv[cidx];
+        g32[(size_t)v * NS + r] = (float)acc;
+    }
+    b0[v] = tv[NS];
+}
+
+template <int K, int NS>
+__global__ __launch_bounds__(256) void cgs_update_fs_kernel(int nvp, const double *__restrict__ coef, PtrPack8 xs,
+                                                            double *__restrict__ y,
+                                                            const double *__restrict__ dinv_uu,
+                                                            float *__restrict__ g32, double *__restrict__ b0) {
+    constexpr int NEQ = NS + 1;
+    double cf[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cf[k] = coef[k];
+    const double scale = coef[RED_K - 1];
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvp; v += gridDim.x * blockDim.x) {
+        double tv[NEQ];
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) {
+            const size_t i = (size_t)v * NEQ + r;
+            double t = y[i];
+#pragma unroll
+            for (int k = 0; k < K; ++k) t -= cf[k] * xs.p[k][i];
+            t *= scale;
+            y[i] = t;
+            tv[r] = t;
+        }
+        first_stage_of<NS>(v, tv, dinv_uu, g32, b0);
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void scale_copy_fs_kernel(int nvp, double a, const double *__restrict__ x,
+                                                            double *__restrict__ y,
+                                                            const double *__restrict__ dinv_uu,
+                                                            float *__restrict__ g32, double *__restrict__ b0) {
+    constexpr int NEQ = NS + 1;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvp; v += gridDim.x * blockDim.x) {
+        double tv[NEQ];
+#pragma unroll
+        for (int r = 0; r < NEQ; ++r) {
+            const size_t i = (size_t)v * NEQ + r;
+            tv[r] = a * x[i];
+            y[i] = tv[r];
+        }
+        first_stage_of<NS>(v, tv, dinv_uu, g32, b0);
+    }
+}
+
+// false: no fused kernel for this case (the caller launches the two kernels)
+bool launch_cgs_update_fs(Ctx &c, int k, const double *const *xs, double *y, float *g32, double *b0) {
+    if (c.ns != 2 || k < 1 || k > 4) return false;
+    PtrPack8 pk;
+    for (int i = 0; i < 8; ++i) pk.p[i] = xs[i < k ? i : 0];
+    const dim3 g((c.nvp + 255) / 256), b(256);
+#define FEDM_CGSF(K)                                                                                             \
+    hipLaunchKernelGGL((cgs_update_fs_kernel<K, 2>), g, b, 0, c.stream, c.nvp, c.d_red, pk, y, c.d_dinv, g32, b0)
+    switch (k) {
+        case 1: FEDM_CGSF(1); break;
+        case 2: FEDM_CGSF(2); break;
+        case 3: FEDM_CGSF(3); break;
+        default: FEDM_CGSF(4); break;
+    }
+#undef FEDM_CGSF
+    return true;
+}
+
+bool launch_scale_copy_fs(Ctx &c, double a, const double *x, double *y, float *g32, double *b0) {
+    if (c.ns != 2) return false;
+    hipLaunchKernelGGL(scale_copy_fs_kernel<2>, dim3((c.nvp + 255) / 256), dim3(256), 0, c.stream, c.nvp, a, x, y,
+                       c.d_dinv, g32, b0);
+    return true;
+}
+
 __global__ void reduce_partials_slot_kernel(const double *__restrict__ partials, int nblocks,
                                             int k_src, double *__restrict__ out, int slot) {
     double s = 0.0;
