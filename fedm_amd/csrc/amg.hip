@@ -746,7 +746,7 @@ static void fs_finish_t(Ctx &c, Amg &amg, double *z, bool scatter = true, bool w
 #undef FEDM_SWEEP
     };
     // one GPU: all sweeps in one launch (tiles of slices with their vertex layers in LDS, fs_tiles.hip)
-    const bool tiled = !halo && !c.comm && n_sweeps > 0 &&
+    const bool tiled = !halo && (!c.comm || deep_halo_active(c)) && n_sweeps > 0 &&
                        fs_tiles_sweeps(c, n_sweeps, zs_mask, g32, ping[0], ping[1], z,
                                        upper ? (const double *)amg.levels[0].x : (const double *)nullptr,
                                        lagged ? (const float *)c.d_val32 : (const float *)nullptr,

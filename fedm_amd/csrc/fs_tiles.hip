@@ -303,16 +303,19 @@ void fs_tiles_release(Ctx &c) {
     c.fs_tiles = nullptr;
 }
 
-// The tiles of this context (built at first use); nullptr where the fused sweeps do not apply: several GPUs
-// (their ghost layers are another matter), other than two species (the instantiations), rows too long or layers too wide
-// for the kernel's instantiations, or FEDM_FS_TILES=0.
+// The tiles of this context (built at first use); nullptr where the fused sweeps do not apply: several GPUs with
+// an exchange before every sweep (one-layer halos), other than two species (the instantiations), rows too long or
+// layers too wide for the kernel's instantiations, or FEDM_FS_TILES=0.
 static FsTiles *fs_tiles_get(Ctx &c) {
     if (c.fs_tiles_state < 0) return nullptr;
     if (c.fs_tiles) return c.fs_tiles->usable ? c.fs_tiles : nullptr;
     if (c.capturing) return nullptr;   // (allocations and copies do not belong into a stream capture: fs_tiles_prepare)
+    if (c.comm && !deep_halo_active(c)) return nullptr;   // (not for good: the global hierarchy may not be installed yet)
     c.fs_tiles_state = -1;
     const char *e = std::getenv("FEDM_FS_TILES");
-    if ((e && e[0] == '0') || c.comm || c.ns != 2) return nullptr;   // (instantiated for two species)
+    // (instantiated for two species; several GPUs: only with deep halos, where nothing is exchanged between the sweeps
+    // and the ghost layers are rows of the local matrix like any other)
+    if ((e && e[0] == '0') || (c.comm && !deep_halo_active(c)) || c.ns != 2) return nullptr;
     // 8 slices (512 vertices) and 3 layers a tile, 512 threads: on the 576 x 576 bench mesh 651 workgroups of up to
     // 973 rows, two rows a thread, all resident at once (three workgroups of eight waves per CU); Chebyshev(6) is two
     // launches, 3 + 2 sweeps: 32 us instead of 44 us for five launches.  Measured alternatives (tools/fs_tiles_probe.py):

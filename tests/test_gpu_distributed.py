@@ -39,7 +39,8 @@ def _worker(rank, world, port, q, restart=30, halo_depth=None):
         U = run.prob.get_state()[:run.lm.n_owned]
         stats = run.prob.comm_stats()
         q.put((rank, run.lm.vertex_global[:run.lm.n_owned], U, run.log_rows(), run.global_n,
-               (stats["halo_exchanges"], stats["allreduces"], run.linear_iterations, int(run.lm.n_ghost))))
+               (stats["halo_exchanges"], stats["allreduces"], run.linear_iterations, int(run.lm.n_ghost),
+                run.prob.fieldsplit_tiles() is not None)))
     finally:
         dist.destroy_process_group()
 
@@ -83,7 +84,10 @@ def test_two_ranks_match_single_gpu(restart, halo_depth):
         assert np.allclose(np.array(r[3]), ref_log, rtol=1e-6)
     # the deep halo saves the exchanges (Krylov counts at this 1e-11 tolerance end in rounding and vary by tens
     # of per cent between any two runs; at the default tolerances they are those of one GPU: tools/rehearse_multi_rank.sh)
-    halos, _, krylov, n_ghost = res[0][5]
+    halos, _, krylov, n_ghost, tiled = res[0][5]
+    # deep halos: nothing is exchanged between the species sweeps, so they run several per launch on tiles as on
+    # one GPU (csrc/fs_tiles.hip); with an exchange before every sweep they cannot
+    assert tiled == (halo_depth is None)
     if restart == 30:
         if halo_depth is None:
             assert halos < 3 * krylov            # ~1.5 per Krylov step (its input + the state halos)
