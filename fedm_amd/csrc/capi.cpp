@@ -441,8 +441,10 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
             ok = ok && capture_graph(c, &c.iter_graph[j], [&] {
                 with_direct_output([&] { c.amg->vcycle(c, 0, 2); });
                 if (!direct) fieldsplit_scatter(c, *c.amg, z);
-                launch_spmv(c, z, w, false);
-                launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, false);
+                if (!launch_spmv_dots(c, z, w, dotp.data(), j + 2, false)) {
+                    launch_spmv(c, z, w, false);
+                    launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, false);
+                }
             });
         } else {
             Comm &cm = *c.comm;

@@ -262,7 +262,8 @@ void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, doubl
                             const int *slice_list = nullptr, int n_list = 0, bool compact32 = false);
 void launch_apply_dinv(Ctx &c, const double *x, double *y, double alpha);
 void launch_dots(Ctx &c, const double *const *xs, const double *y, int k, bool finish = false);
-bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k);  // false: not applicable
+// (finish = false, several GPUs: the local sums into d_red[0..k) only)   false: not applicable, nothing launched
+bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k, bool finish = true);
 int ensure_spmv_dots(Ctx &c);
 // (see cgs_update_fs_kernel, kernels.hip; false: not instantiated for this case)
 bool launch_cgs_update_fs(Ctx &c, int k, const double *const *xs, double *y, float *g32, double *b0);

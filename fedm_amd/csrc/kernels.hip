@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int n_slices, int n_owne
 // are added in their order; then the formulae and the publication of cgs_finish_kernel.
 __global__ __launch_bounds__(1024) void spmv_dots_finish_kernel(const double *__restrict__ partials, int nblocks,
                                                                int k, double *__restrict__ out, double *mail,
-                                                               unsigned long long *seq) {
+                                                               unsigned long long *seq, int finish) {
     __shared__ double fin[RED_K];
     __shared__ double part[16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1277,7 +1277,9 @@ __global__ __launch_bounds__(1024) void spmv_dots_finish_kernel(const double *__
         double t = 0.0;
         for (int ch = 0; ch < chunks; ++ch) t += part[ch * k + threadIdx.x];
         fin[threadIdx.x] = t;
+        if (!finish) out[threadIdx.x] = t;   // several GPUs: the local sums, for the all-reduce that follows
     }
+    if (!finish) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         const double ww = fin[k - 1];
@@ -1403,15 +1405,16 @@ void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const 
 // w = J z with the step's k = j + 2 reduction slots (xs[0 .. k-2] . w and w . w), finished and published: one GPU,
 // three species-plus-potential equations, k <= 4, buffers of ensure_spmv_dots.  false: not applicable (nothing was
 // launched; the caller runs launch_spmv + launch_dots_fused).
-bool spmv_dots_applicable(const Ctx &c, int k) {
+static bool spmv_dots_applicable(const Ctx &c, int k) {
     static const bool off = [] {
         const char *e = std::getenv("FEDM_SPMV_DOTS");
         return e && e[0] == '0';
     }();
-    return !off && !c.comm && c.neq == 3 && k >= 2 && k <= 4 && c.d_partials_wide && c.n_owned == c.nv;
+    // (several GPUs: where the whole product is one launch -- deep halos -- with finish = false)
+    return !off && c.neq == 3 && k >= 2 && k <= 4 && c.d_partials_wide;
 }
 
-bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k) {
+bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k, bool finish) {
     if (!spmv_dots_applicable(c, k)) return false;
     const int n = c.pat.n_slices;
     const dim3 g((n + 3) / 4), b(256);
@@ -1436,14 +1439,14 @@ bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *x
 #undef FEDM_SD_K
 #undef FEDM_SD
     hipLaunchKernelGGL(spmv_dots_finish_kernel, dim3(1), dim3(1024), 0, c.stream, c.d_partials_wide, (int)g.x, k,
-                       c.d_red, c.h_mail, c.d_mail_seq);
-    if (!c.capturing) ++c.mail_seq;
+                       c.d_red, c.h_mail, c.d_mail_seq, finish ? 1 : 0);
+    if (finish && !c.capturing) ++c.mail_seq;
     return true;
 }
 
 // (one partial per workgroup of the product and slot; allocated with the Krylov vectors, outside any capture)
 int ensure_spmv_dots(Ctx &c) {
-    if (c.d_partials_wide || c.comm || c.neq != 3) return 0;
+    if (c.d_partials_wide || c.neq != 3) return 0;
     const size_t blocks = (size_t)(c.pat.n_slices + 3) / 4;
     FEDM_HIP_CHECK(hipMalloc((void **)&c.d_partials_wide, sizeof(double) * 4 * blocks));
     return 0;
