@@ -212,7 +212,7 @@ struct Ctx {
     bool right_precond = true;
     // reductions
     double *d_partials = nullptr;  // [RED_BLOCKS][RED_K]
-    double *d_partials_wide = nullptr;  // [4][workgroups of the Jacobian product]: spmv_dots_kernel (one GPU)
+    double *d_partials_wide = nullptr;  // [8][workgroups of the Jacobian product]: spmv_dots_kernel
     double *d_red = nullptr;       // [RED_K]
     double *h_mail = nullptr;      // pinned, host-mapped: two slots of [RED_K] values + sequence tag
     double *h_red = nullptr;       // the slot of the publication last waited for (wait_red); written

@@ -1193,8 +1193,8 @@ __global__ __launch_bounds__(1024) void reduce_finish_kernel(const double *__res
     }
 }
 
-// One GPU, Krylov steps with at most four reduction slots (the first three steps of a solve: all there are early in
-// a streamer run): the Jacobian product w = J z and the step's dot products v_i . w, w . w in ONE kernel -- the wave
+// Krylov steps with at most eight reduction slots (the first seven steps of a solve: all there are early in a
+// streamer run, most of them later): the Jacobian product w = J z and the step's dot products v_i . w, w . w in ONE kernel -- the wave
 // that has formed a slice's rows of w multiplies them with the same rows of the basis vectors before it stores them
 // (w is not read back: 8 MB and a 9 us kernel less per step).  One partial per workgroup and slot,
 // partials[slot * n_blocks + block]; spmv_dots_finish_kernel reduces them in a fixed order.
@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int n_slices, int n_owne
 }
 
 // reduce_finish_kernel for the partials of spmv_dots_kernel (one per workgroup of the product: thousands, not
-// RED_BLOCKS): the 16 waves share the k <= 4 slots, wave w sums the blocks of chunk w / k of slot w % k, the chunks
+// RED_BLOCKS): the 16 waves share the k <= 8 slots, wave w sums the blocks of chunk w / k of slot w % k, the chunks
 // are added in their order; then the formulae and the publication of cgs_finish_kernel.
 __global__ __launch_bounds__(1024) void spmv_dots_finish_kernel(const double *__restrict__ partials, int nblocks,
                                                                int k, double *__restrict__ out, double *mail,
@@ -1403,7 +1403,7 @@ void launch_dots_fused(Ctx &c, const double *const *xs, double *y, int k, const 
 }
 
 // w = J z with the step's k = j + 2 reduction slots (xs[0 .. k-2] . w and w . w), finished and published: one GPU,
-// three species-plus-potential equations, k <= 4, buffers of ensure_spmv_dots.  false: not applicable (nothing was
+// three species-plus-potential equations, k <= 8, buffers of ensure_spmv_dots.  false: not applicable (nothing was
 // launched; the caller runs launch_spmv + launch_dots_fused).
 static bool spmv_dots_applicable(const Ctx &c, int k) {
     static const bool off = [] {
@@ -1411,7 +1411,7 @@ static bool spmv_dots_applicable(const Ctx &c, int k) {
         return e && e[0] == '0';
     }();
     // (several GPUs: where the whole product is one launch -- deep halos -- with finish = false)
-    return !off && c.neq == 3 && k >= 2 && k <= 4 && c.d_partials_wide;
+    return !off && c.neq == 3 && k >= 2 && k <= 8 && c.d_partials_wide;
 }
 
 bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *xs, int k, bool finish) {
@@ -1428,7 +1428,11 @@ bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *x
     do {                                                                                                    \
         if (k == 2) FEDM_SD(Z, 2);                                                                          \
         else if (k == 3) FEDM_SD(Z, 3);                                                                     \
-        else FEDM_SD(Z, 4);                                                                                 \
+        else if (k == 4) FEDM_SD(Z, 4);                                                                     \
+        else if (k == 5) FEDM_SD(Z, 5);                                                                     \
+        else if (k == 6) FEDM_SD(Z, 6);                                                                     \
+        else if (k == 7) FEDM_SD(Z, 7);                                                                     \
+        else FEDM_SD(Z, 8);                                                                                 \
     } while (0)
     switch (c.zero_plane_mask & 10u) {
         case 2u: FEDM_SD_K(2u); break;
@@ -1448,7 +1452,7 @@ bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *x
 int ensure_spmv_dots(Ctx &c) {
     if (c.d_partials_wide || c.neq != 3) return 0;
     const size_t blocks = (size_t)(c.pat.n_slices + 3) / 4;
-    FEDM_HIP_CHECK(hipMalloc((void **)&c.d_partials_wide, sizeof(double) * 4 * blocks));
+    FEDM_HIP_CHECK(hipMalloc((void **)&c.d_partials_wide, sizeof(double) * 8 * blocks));
     return 0;
 }
 
