@@ -323,6 +323,11 @@ def main():
                    "bytes_not_loaded_structural_zero_planes": sz["nnz_blocks"] * 8 * sz.get("zero_planes", 0),
                    "ms_per_launch": ms_spmv, "launches": prof2["spmv"][1],
                    "share_of_profiling_pass": share2["spmv"], "measured": second_pass,
+                   "timed_region_note": ("inside the replayed Krylov steps of the timed region the same product runs as "
+                                         "spmv_dots_kernel<3,ZMASK,K>: the wave that has formed a slice's rows also "
+                                         "multiplies them with the K-1 basis vectors (the step's dot products; w is not "
+                                         "read back) -- 1-3 us longer than the plain product timed here, see "
+                                         "profiles/r03_kernel_stats.csv"),
                    "infinity_cache_note": ("the Jacobian of this mesh (%.0f MB) fits the 256 MiB Infinity Cache and the "
                                            "counters include its hits: the cache-free rates are in "
                                            "'roofline_beyond_infinity_cache'" % (sz["stored_blocks"] * 72 / 1e6))
@@ -379,7 +384,13 @@ def main():
 
     gmres_text = ("flexible, restart 30, rtol 1e-5 on the true residual, right-preconditioned: field split, "
                   "Chebyshev(6) block Jacobi on species (degree 4 once a Newton system needs >= 5 Krylov "
-                  "steps) + multigrid V(1,1) on the potential")
+                  "steps; the sweeps run 3 + 2 per launch on tiles of 8 matrix slices whose vertex layers sit in "
+                  "LDS) + multigrid V(1,1) on the potential; Jacobian product and the step's dot products in one "
+                  "kernel; two Krylov steps per graph launch when the previous solve needed both")
+    try:
+        tiles = runner.prob.fieldsplit_tiles()
+    except Exception:
+        tiles = None
     out = {
         "metric": "BDF2 DOF-updates/sec (streamer_discharge 2D axisym)",
         "value": total_dofs * args.steps / elapsed,
@@ -397,7 +408,7 @@ def main():
                    "mesh": f"{n}x{n} right-diagonal, geometric grading {args.grading} towards "
                            f"the axis, per GPU",
                    "dofs_total": total_dofs, "vertices_per_gpu": sz["n_vertices"],
-                   "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": gmres_text,
+                   "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": gmres_text, "fieldsplit_tiles": tiles,
                    "partition": runner.partition_name, "host_placement": placement,
                    "setup_seconds": setup_s},
         "window": f"steps {args.warmup + 1}..{args.warmup + args.steps} from the initial condition "

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <mutex>
 
@@ -660,8 +661,8 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         std::fill(gvec.begin(), gvec.end(), 0.0);
         gvec[0] = beta;
         int j = 0;
-        bool done = false, ahead = false;
-        unsigned long long seq_ahead = 0;
+        bool done = false;
+        std::deque<unsigned long long> queued;
         for (; j < m && its < max_it; ++j) {
             double *w = c.d_V + (size_t)(j + 1) * c.np;
             // classical Gram-Schmidt with ONE reduction and ONE host wait per iteration:
@@ -686,24 +687,27 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             // not idle through the host's round trip and graph launch.  Done while the previous solve
             // says that step will be needed (one GPU: no collectives in between); a step launched in
             // vain only writes vectors nobody reads.
-            unsigned long long seq_j;
-            const bool next_too = right && !c.comm && j + 1 < m && its + 1 < max_it && j + 1 < c.krylov_steps_hint;
-            if (ahead) {
-                seq_j = seq_ahead;
-                ahead = false;
-            } else if (next_too && iter_graph_launch_right_pair(c, j, vp.data(), c.d_Z + (size_t)j * c.np, w,
-                                                                c.d_Z + (size_t)(j + 1) * c.np,
-                                                                c.d_V + (size_t)(j + 2) * c.np)) {
-                seq_j = c.mail_seq - 1;     // this step and the next one in one graph
-                seq_ahead = c.mail_seq;
-                ahead = true;
-            } else {
-                seq_j = launch_step(j);
-            }
-            if (!ahead && next_too) {
-                seq_ahead = launch_step(j + 1);
-                ahead = true;
-            }
+            // `queued`: publications of the steps j, j + 1, ... that are in the queue already.  Two steps go in as one
+            // graph whenever two are wanted (between two graph launches the GPU idles for 8 us); a new pair is
+            // launched when the queue has run empty, BEFORE this step's numbers are waited for -- so up to three
+            // publications may be unread (MAIL_SLOTS).
+            auto wanted = [&](int q) {   // step q is expected to be needed: launch it without waiting for step q - 1
+                return right && !c.comm && q < m && its + (q - j) < max_it && q < c.krylov_steps_hint;
+            };
+            auto launch_from = [&](int q, bool first_is_needed) {
+                if ((first_is_needed || wanted(q)) && wanted(q + 1) &&
+                    iter_graph_launch_right_pair(c, q, vp.data(), c.d_Z + (size_t)q * c.np, c.d_V + (size_t)(q + 1) * c.np,
+                                                 c.d_Z + (size_t)(q + 1) * c.np, c.d_V + (size_t)(q + 2) * c.np)) {
+                    queued.push_back(c.mail_seq - 1);
+                    queued.push_back(c.mail_seq);
+                } else if (first_is_needed || wanted(q)) {
+                    queued.push_back(launch_step(q));
+                }
+            };
+            if (queued.empty()) launch_from(j, true);
+            const unsigned long long seq_j = queued.front();
+            queued.pop_front();
+            if (queued.empty()) launch_from(j + 1, false);
             wait_red_seq(c, seq_j);  // published by the finish kernel: the host works while the update runs
             if (comm_failed(c)) {  // a lost peer is an error, not a NaN
                 *its_out = its;
@@ -733,9 +737,9 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 // strong cancellation: w was left unscaled; refine (second CGS pass) and
                 // take the norm explicitly (a step launched ahead used the unrefined vector: let it
                 // finish, its results are dropped and the step is repeated)
-                if (ahead) {
-                    wait_red_seq(c, seq_ahead);
-                    ahead = false;
+                if (!queued.empty()) {
+                    wait_red_seq(c, queued.back());
+                    queued.clear();
                 }
                 launch_dots(c, vp.data(), w, j + 1, false);
                 read_red(c, j + 1);
@@ -1231,8 +1235,8 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (alloc_zero(*v, (size_t)c.np, c.stream)) return -1;
     if (alloc_zero(c.d_partials, (size_t)RED_BLOCKS * RED_K, c.stream)) return -1;
     if (alloc_zero(c.d_red, RED_K, c.stream)) return -1;
-    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_mail, sizeof(double) * 2 * (RED_K + 1), hipHostMallocDefault));
-    std::memset(c.h_mail, 0, sizeof(double) * 2 * (RED_K + 1));
+    FEDM_HIP_CHECK(hipHostMalloc((void **)&c.h_mail, sizeof(double) * MAIL_SLOTS * (RED_K + 1), hipHostMallocDefault));
+    std::memset(c.h_mail, 0, sizeof(double) * MAIL_SLOTS * (RED_K + 1));
     c.h_red = c.h_mail;
     FEDM_HIP_CHECK(hipMalloc((void **)&c.d_mail_seq, sizeof(unsigned long long)));
     FEDM_HIP_CHECK(hipMemset(c.d_mail_seq, 0, sizeof(unsigned long long)));

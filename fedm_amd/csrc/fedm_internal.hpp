@@ -214,7 +214,7 @@ struct Ctx {
     double *d_partials = nullptr;  // [RED_BLOCKS][RED_K]
     double *d_partials_wide = nullptr;  // [8][workgroups of the Jacobian product]: spmv_dots_kernel
     double *d_red = nullptr;       // [RED_K]
-    double *h_mail = nullptr;      // pinned, host-mapped: two slots of [RED_K] values + sequence tag
+    double *h_mail = nullptr;      // pinned, host-mapped: MAIL_SLOTS slots of [RED_K] values + sequence tag
     double *h_red = nullptr;       // the slot of the publication last waited for (wait_red); written
                                    // by the last kernel of a reduction and polled by the host
     unsigned long long mail_seq = 0;      // publications queued so far (host count)
@@ -237,7 +237,8 @@ struct Ctx {
 
 constexpr int RED_BLOCKS = 512;
 constexpr int RED_K = 40;
-constexpr int RED_SPARE = RED_K - 3;  // a norm that rides along with the next Krylov publication
+constexpr int RED_SPARE = RED_K - 3;
+constexpr int MAIL_SLOTS = 4;         // publications the host may have unread (GMRES keeps up to three steps in flight)  // a norm that rides along with the next Krylov publication
 // per-block partial sums, one contiguous row per slot: the single workgroup that finishes a
 // reduction reads a slot's RED_BLOCKS partials as 4 KB of consecutive doubles (with [block][slot]
 // it gathered one double per 320-byte stride: most of reduce_finish_kernel's 10 us)

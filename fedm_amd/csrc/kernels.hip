@@ -2,6 +2,7 @@
 // block-ELL Jacobian, Dirichlet rows, block-Jacobi inverse, SpMV and the vector kernels
 // that GMRES / Newton need.  All of it is fp64 and HBM-bound; no MFMA.
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 
@@ -1076,10 +1077,10 @@ __global__ void reduce_partials_kernel(const double *__restrict__ partials, int 
 // The tag is a launch counter kept in device memory (a replayed graph has fixed arguments).
 __device__ __forceinline__ void publish(const double *__restrict__ red, int k, double *mail,
                                         unsigned long long *seq) {
-    // one wave; two mailbox slots, chosen by the tag's parity: the host may still be reading
-    // publication n when n+1 (a Krylov step launched ahead) arrives
+    // one wave; MAIL_SLOTS mailbox slots, chosen by the tag's low bits: the host may still be reading
+    // publication n when n+1 and n+2 (Krylov steps launched ahead) arrive
     const unsigned long long tag = *seq + 1;
-    double *slot = mail + (tag & 1) * (RED_K + 1);
+    double *slot = mail + (tag & (MAIL_SLOTS - 1)) * (RED_K + 1);
     for (int i = threadIdx.x; i < k; i += 64) slot[i] = red[i];
     __threadfence_system();
     if (threadIdx.x == 0) {
@@ -1179,7 +1180,7 @@ __global__ __launch_bounds__(1024) void reduce_finish_kernel(const double *__res
     __syncthreads();
     if (threadIdx.x < 64) {
         const unsigned long long tag = *seq + 1;
-        double *slot = mail + (tag & 1) * (RED_K + 1);
+        double *slot = mail + (tag & (MAIL_SLOTS - 1)) * (RED_K + 1);
         for (int i = threadIdx.x; i < RED_K; i += 64) {
             out[i] = fin[i];
             slot[i] = fin[i];
@@ -1293,7 +1294,7 @@ __global__ __launch_bounds__(1024) void spmv_dots_finish_kernel(const double *__
     __syncthreads();
     if (threadIdx.x < 64) {
         const unsigned long long tag = *seq + 1;
-        double *slot_ = mail + (tag & 1) * (RED_K + 1);
+        double *slot_ = mail + (tag & (MAIL_SLOTS - 1)) * (RED_K + 1);
         for (int i = threadIdx.x; i < RED_K; i += 64) {
             out[i] = fin[i];
             slot_[i] = fin[i];
@@ -1591,7 +1592,7 @@ void launch_norm2(Ctx &c, const double *x, int slot) {
 
 // wait for publication `seq` and point c.h_red at its slot
 void wait_red_seq(Ctx &c, unsigned long long seq) {
-    double *slot = c.h_mail + (seq & 1) * (RED_K + 1);
+    double *slot = c.h_mail + (seq & (MAIL_SLOTS - 1)) * (RED_K + 1);
     c.h_red = slot;
     const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(slot + RED_K);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1610,8 +1611,19 @@ void wait_red_seq(Ctx &c, unsigned long long seq) {
             }
             if (failed || late) {
                 hipStreamSynchronize(c.stream);
-                if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq)
+                if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq) {
+                    // (diagnostics of a publication that never came: expected tag, the tags in the mailbox, the
+                    // device's counter)
+                    unsigned long long dev_seq = 0;
+                    hipMemcpy(&dev_seq, c.d_mail_seq, sizeof(dev_seq), hipMemcpyDeviceToHost);
+                    std::fprintf(stderr, "fedm: publication %llu did not arrive (%s); mailbox tags", seq,
+                                 failed ? "the queue is empty" : "waited 120 s");
+                    for (int k = 0; k < MAIL_SLOTS; ++k)
+                        std::fprintf(stderr, " %llu", *reinterpret_cast<const unsigned long long *>(
+                                                          c.h_mail + (size_t)k * (RED_K + 1) + RED_K));
+                    std::fprintf(stderr, ", host count %llu, device count %llu\n", c.mail_seq, dev_seq);
                     for (int i = 0; i < RED_K; ++i) slot[i] = std::nan("");
+                }
                 return;
             }
         }
@@ -1631,7 +1643,7 @@ __global__ __launch_bounds__(64) void reduce_slot_publish_kernel(const double *_
     s = __shfl(s, 0, 64);
     if (threadIdx.x == 0) out[slot] = s;
     const unsigned long long tag = *seq + 1;
-    double *m = mail + (tag & 1) * (RED_K + 1);
+    double *m = mail + (tag & (MAIL_SLOTS - 1)) * (RED_K + 1);
     for (int i = threadIdx.x; i < k; i += 64) m[i] = (i == slot) ? s : out[i];
     __threadfence_system();
     if (threadIdx.x == 0) {

@@ -10,6 +10,9 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent))
+import mp_results  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 N_PER_GPU, STEPS = 16, 3
@@ -61,7 +64,7 @@ def test_two_ranks_match_single_gpu(restart, halo_depth):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, restart, halo_depth)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = mp_results.collect(procs, q, len(procs), 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -183,7 +186,7 @@ def test_rccl_setup_failure_falls_back_on_every_rank():
     procs = [ctx.Process(target=_worker_rccl, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = mp_results.collect(procs, q, len(procs), 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -252,7 +255,7 @@ def test_distributed_galerkin_operator_is_the_global_one():
     procs = [ctx.Process(target=_worker_galerkin, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = q.get(timeout=300)
+    res = mp_results.collect(procs, q, 1, 300)[0]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -315,7 +318,7 @@ def test_several_gpu_solver_on_one_rank_over_rccl_matches_single_gpu():
     q = ctx.Queue()
     p = ctx.Process(target=_worker_rccl_two_devices, args=(0, 1, _free_port(), q))
     p.start()
-    res = q.get(timeout=600)
+    res = mp_results.collect([p], q, 1, 600)[0]
     p.join(timeout=60)
     assert p.exitcode == 0
     assert res[5] == "rccl" and res[6]["transport"] == "rccl" and not res[6]["failed"] and res[6]["allreduces"] > 0
@@ -348,7 +351,7 @@ def test_two_ranks_over_rccl_match_single_gpu():
     procs = [ctx.Process(target=_worker_rccl_two_devices, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = mp_results.collect(procs, q, len(procs), 600)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -383,7 +386,7 @@ def test_state_halo_behind_interior_assembly_is_the_same_solve(monkeypatch):
         procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
         for p in procs:
             p.start()
-        res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+        res = sorted(mp_results.collect(procs, q, len(procs), 300), key=lambda r: r[0])
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0

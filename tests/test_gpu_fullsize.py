@@ -2,7 +2,12 @@
 (no oracle run needed): the 1 M-DOF streamer workload of bench.py and the 51 681-DOF
 time-of-flight mesh of examples/time_of_flight/fedm-tof.py:87."""
 import numpy as np
+import sys
+
 import pytest
+
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent))
+import mp_results  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -223,7 +228,7 @@ def test_configs4_mesh_split_over_two_ranks_matches_one_gpu():
     procs = [ctx.Process(target=_configs4_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in procs]
+    res = mp_results.collect(procs, q, len(procs), 900)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

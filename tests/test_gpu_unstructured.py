@@ -14,6 +14,9 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent))
+import mp_results  # noqa: E402
 import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
@@ -194,7 +197,7 @@ def test_two_ranks_match_one_gpu_on_the_unstructured_mesh():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = mp_results.collect(procs, q, len(procs), 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -9,6 +9,9 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent))
+import mp_results  # noqa: E402
+
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -104,7 +107,7 @@ def test_gloo_ghost_exchange_world2():
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = mp_results.collect(procs, q, len(procs), 120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

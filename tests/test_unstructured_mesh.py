@@ -11,6 +11,9 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent))
+import mp_results  # noqa: E402
+
 ROOT = Path(__file__).resolve().parent.parent
 H_FINE = 30e-6          # ~17 k vertices
 
@@ -172,7 +175,7 @@ def test_gloo_ghost_exchange_world2_on_the_unstructured_mesh():
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = mp_results.collect(procs, q, len(procs), 180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
