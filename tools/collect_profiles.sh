@@ -5,7 +5,8 @@
 #   profiles/<tag>_pmc_traffic.json      FETCH_SIZE / WRITE_SIZE passes (separate runs), gfx950 corrections
 #   profiles/<tag>_pmc_assembly_sq.txt   SQ counters of the F + J assembly kernel (three passes)
 # Everything is written under gpurun_out/<tag>_prof/ (merged back by gpurun); copy_profiles.py then
-# copies the summaries into profiles/.  The program follows `--` directly (no env/bash hop).
+# copies the summaries into profiles/ -- on the box, and once more at home:
+#   python tools/copy_profiles.py <tag> gpurun_out/<tag>_prof && cp gpurun_out/<tag>_prof/step_sequence.txt profiles/<tag>_step_sequence.txt  The program follows `--` directly (no env/bash hop).
 set -u
 TAG=${1:-r03}
 OUT=gpurun_out/${TAG}_prof
@@ -35,4 +36,5 @@ TRACE=$(find "$OUT/seq" -name "q_kernel_trace.csv" | head -1)
 { echo "One accepted time step of the bench case (576x576, step 6 of the run, Krylov steps replayed as graphs), kernel by kernel:";
   echo "start offset [us], duration [us], gap to the previous kernel [us], kernel (rocprofv3 --kernel-trace of python3 $SEQ; tools/step_sequence.py)";
   echo; python3 tools/step_sequence.py "$TRACE" 6; echo; echo "every step of that process (the last ones are bench.py's profiling pass: plain launches, event pairs):"; python3 tools/step_sequence.py "$TRACE" all; } > "profiles/${TAG}_step_sequence.txt"
+cp "profiles/${TAG}_step_sequence.txt" "$OUT/step_sequence.txt"     # (only gpurun_out/ travels back from the GPU box)
 rm -f "$TRACE"
