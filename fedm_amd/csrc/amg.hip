@@ -289,6 +289,13 @@ void Amg::vcycle(Ctx &c, int l, int phase) {
         const int k = (int)L.w.size();
         double *x = (k % 2 == 0) ? L.x : L.x2, *y = (k % 2 == 0) ? L.x2 : L.x;
         ell_launch(c, L.S, 0, L.b, nullptr, x, 0.0);  // [S | P] on [b ; x_c]
+        if (l == 0 && k <= 4) {
+            // one GPU: the k sweeps in one launch on tiles (fs_tiles.hip); weights in the order they are applied
+            double wk[4];
+            for (int i = 0; i < k; ++i) wk[i] = L.w[k - 1 - i];
+            if (mg_tiles_sweeps(c, L.A, L.b, x, k, wk, out ? out : L.x, out ? out_stride : 1, out ? out_offset : 0))
+                return;
+        }
         for (int s_ = k - 1; s_ >= 0; --s_) {
             if (l == 0 && s_ == 0 && out) {
                 ell_launch(c, L.A, 2, x, L.b, out, L.w[s_], nullptr, out_stride, out_offset);

@@ -1932,7 +1932,12 @@ int fedm_debug_fieldsplit_tiles(fedm_ctx *h, int mode, int tile_slices, int dept
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     iter_graphs_clear(c);   // captured Krylov steps hold the kernels of the old setting
-    fs_tiles_configure(c, mode, tile_slices, depth, threads);
+    fs_tiles_configure(c, mode & 1, tile_slices, depth, threads);
+    c.mg_tiles_off = (mode & 2) != 0;   // mode 3: species sweeps on tiles, the multigrid's finest-level sweeps not
+    if (c.amg && c.amg->graph_exec) {   // the cycle's own graph holds the kernels of the old setting
+        hipGraphExecDestroy(c.amg->graph_exec);
+        c.amg->graph_exec = nullptr;
+    }
     return 0;
 }
 

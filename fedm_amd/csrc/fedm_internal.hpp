@@ -168,6 +168,7 @@ struct Ctx {
     bool fs_first_by_producer = false;
     FsTiles *fs_tiles = nullptr;
     int fs_tiles_state = 0;
+    bool mg_tiles_off = false;   // (test hook: the multigrid's finest-level sweeps as kernels of their own)
     int fs_tiles_want_slices = 0, fs_tiles_want_depth = 0, fs_tiles_want_threads = 0;   // > 0: set by fs_tiles_configure
     bool fs_halo = true;    // several GPUs: ghost exchange of the species iterate before every sweep
     bool deep_halo = true;  // use the ghost layers (halo_depth > 1) instead of those exchanges; FEDM_DEEP_HALO=0: off

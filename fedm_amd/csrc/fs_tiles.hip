@@ -207,6 +207,100 @@ __global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void fs_tile_sweeps_kern
     }
 }
 
+// ---- the same tiles for the finest level of the potential block's multigrid cycle ------------------------------------
+// Behind the [S | P] product of the polynomial-smoother cycle (the one the hard regime of a streamer run uses) its k
+// sweeps  x <- x + w_s Dinv (b - A x)  each stream the finest operator once.  Here they are ONE launch: a workgroup takes
+// a tile with its k vertex layers, reads the incoming iterate on all of them and runs the sweeps in LDS, on the tile and
+// the layers up to k - s.  A's rows are the potential-potential plane of the Jacobian itself (double precision,
+// block-ELL order: the tile tables of the species sweeps apply; the hierarchy's own copy of A is its single-precision
+// rounding), Dinv and b the level's vectors.  16 us of two kernels -> 11 us: +2.6 % steps/s in the late window.
+// (The V(1,1) cycle's pair -- x = w Dinv b + P x_c, then one sweep -- was built the same way, with P's rows gathered
+// for the layer vertices too, and measured 6 us SLOWER than its two kernels: not kept.)
+struct MgTileWeights {
+    int n;
+    double w[4];
+};
+
+template <int W, int SLOTS>
+__global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void mg_tile_sweeps_kernel(
+    const int *__restrict__ tiles, int record, int lds_vertices, int lds_rows, int width, const int *__restrict__ vertex,
+    const uint32_t *__restrict__ cols, const int *__restrict__ boff, const double *__restrict__ val, int neq2, int plane,
+    const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ xin, MgTileWeights wt,
+    double *__restrict__ out, int ostride, int ooff) {
+    constexpr int W2 = (W + 1) / 2;
+    extern __shared__ float fs_tile_lds[];
+    double *xa = reinterpret_cast<double *>(fs_tile_lds), *xb = xa + lds_vertices;
+    uint32_t *lcol = reinterpret_cast<uint32_t *>(xb + lds_vertices);   // [W2][lds_rows]
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int *tl = tiles + (size_t)blockIdx.x * record;
+    const int voff = tl[0], coff = tl[1], rstride = tl[2];
+    const int *cnt = tl + 3;
+    const int n = wt.n;
+    const int n_vertices = cnt[n], n_rows = cnt[n - 1], n_own = cnt[0];
+    double a[SLOTS][W], dv[SLOTS], bv[SLOTS];
+    int vglob[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int r = tid + s * T;
+        vglob[s] = vertex[voff + (r < n_rows ? r : 0)];
+    }
+    const int width2 = (width + 1) >> 1;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int r = tid + s * T;
+        const int rr = r < n_rows ? r : 0;
+        const int v = vglob[s], slice = v >> 6;
+        const int bb0 = boff[slice], wrow = (boff[slice + 1] - bb0) & (r < n_rows ? -1 : 0);
+        const double *base = val + ((size_t)bb0 * neq2 + plane) * SLICE + (v & 63);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            // (branch-free, as in fs_tile_sweeps_kernel: a valid address always, a select on the value)
+            const double x = base[(k < wrow ? (size_t)k : (size_t)0) * neq2 * SLICE];
+            a[s][k] = k < wrow ? x : 0.0;
+        }
+        const uint32_t *cbase = cols + (size_t)coff + rr;
+        const uint32_t self2 = (uint32_t)rr | ((uint32_t)rr << 16);
+#pragma unroll
+        for (int j = 0; j < W2; ++j) {
+            const uint32_t in_table = j < width2 ? 0xffffffffu : 0u;
+            const uint32_t cw = (cbase[(size_t)(j < width2 ? j : 0) * rstride] & in_table) | (self2 & ~in_table);
+            if (r < n_rows) lcol[j * lds_rows + r] = cw;
+        }
+        dv[s] = dinv[v];
+        bv[s] = b[v];
+    }
+    // the incoming iterate on the tile and its n layers
+    for (int i = tid; i < n_vertices; i += T) xa[i] = xin[vertex[voff + i]];
+    __syncthreads();
+    for (int k = 1; k <= n; ++k) {
+        const int active = cnt[n - k];
+        const double w = wt.w[k - 1];
+        const bool fin = k == n;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int r = tid + s * T;
+            if (r >= active) continue;
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                asm volatile("" : "+v"(a[s][e]));   // (keeps the row in its 2 W registers: no hoisted products)
+                const uint32_t cw = lcol[(e >> 1) * lds_rows + r];
+                const int col = (cw >> ((e & 1) * 16)) & 0xffffu;
+                acc = __builtin_fma(a[s][e], xa[col], acc);
+            }
+            const double xn = xa[r] + w * dv[s] * (bv[s] - acc);
+            if (!fin) xb[r] = xn;
+            else if (r < n_own) out[(size_t)vglob[s] * ostride + ooff] = xn;
+        }
+        if (!fin) {
+            __syncthreads();
+            double *t = xa;
+            xa = xb;
+            xb = t;
+        }
+    }
+}
+
 bool FsTiles_build(FsTiles &ft, const Pattern &pat, int tile_slices, int depth) {
     ft.release();
     ft.tile_slices = tile_slices;
@@ -353,7 +447,15 @@ void fs_tiles_configure(Ctx &c, int mode, int tile_slices, int depth, int thread
 }
 
 // builds the tiles where they apply (called with the preconditioner's set-up, outside any stream capture)
-void fs_tiles_prepare(Ctx &c) { fs_tiles_get(c); }
+void fs_tiles_prepare(Ctx &c) {
+    const bool had = c.fs_tiles != nullptr;
+    FsTiles *ft = fs_tiles_get(c);
+    if (ft && !had) {
+        // the cycles' own graphs were recorded before the tiles existed: once more, with mg_tile_sweeps_kernel
+        for (Amg *a : {c.amg, c.amg_alt})
+            if (a && a->graph_exec) a->capture(c);
+    }
+}
 
 int fs_tiles_info(Ctx &c, long long *out) {
     FsTiles *ft = fs_tiles_get(c);
@@ -424,6 +526,45 @@ bool fs_tiles_sweeps(Ctx &c, int n_sweeps, unsigned zmask, const float *g32, flo
         done += n;
         ++launch;
     }
+    return true;
+}
+
+// The n sweeps x <- x + w[s] Dinv (b - A x) of the finest level as one launch (see mg_tile_sweeps_kernel), from xin; the
+// result goes to out[row * ostride + ooff].  false: not applicable here (nothing launched).
+bool mg_tiles_sweeps(Ctx &c, const EllMat &A, const double *b, const double *xin, int n, const double *w, double *out,
+                     int ostride, int ooff) {
+    static const bool off = [] {
+        const char *e = std::getenv("FEDM_MG_TILES");
+        return e && e[0] == '0';
+    }();
+    if (off || c.mg_tiles_off || c.comm || n < 2 || n > 4 || !A.dinv || A.n_rows != c.nv) return false;
+    // (only tiles that exist: this runs inside stream captures -- the cycle's own graph, the Krylov steps'; they are
+    // built with the field split's set-up, fs_tiles_prepare)
+    FsTiles *ft = (c.fs_tiles_state > 0 && c.fs_tiles && c.fs_tiles->usable) ? c.fs_tiles : nullptr;
+    if (!ft || n > ft->depth) return false;
+    MgTileWeights wt;
+    wt.n = n;
+    for (int k = 0; k < 4; ++k) wt.w[k] = k < n ? w[k] : 0.0;
+    const int T = ft->threads;
+    const dim3 g(ft->n_tiles), bl(T);
+    const int slots = (ft->max_rows + T - 1) / T;
+    const int neq2 = c.neq * c.neq;
+#define FEDM_MG_TILE(WW, SL)                                                                                      \
+    hipLaunchKernelGGL((mg_tile_sweeps_kernel<WW, SL>), g, bl,                                                    \
+                       sizeof(double) * 2 * (size_t)ft->max_vertices + sizeof(uint32_t) * (size_t)((WW + 1) / 2) * ft->max_rows, \
+                       c.stream, ft->d_tile, ft->record, ft->max_vertices, ft->max_rows, ft->width, ft->d_vertex, \
+                       ft->d_cols, c.d_slice_boff, c.d_val, neq2, neq2 - 1, A.dinv, b, xin, wt, out, ostride, ooff)
+#define FEDM_MG_TILE_S(WW)                                                                                        \
+    do {                                                                                                          \
+        if (slots <= 2) FEDM_MG_TILE(WW, 2);                                                                      \
+        else if (slots <= 3) FEDM_MG_TILE(WW, 3);                                                                 \
+        else return false;                                                                                        \
+    } while (0)
+    if (ft->width <= 7) FEDM_MG_TILE_S(7);
+    else if (ft->width <= 9) FEDM_MG_TILE_S(9);
+    else FEDM_MG_TILE_S(12);
+#undef FEDM_MG_TILE_S
+#undef FEDM_MG_TILE
     return true;
 }
 

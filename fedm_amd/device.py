@@ -893,9 +893,11 @@ class DeviceProblem:
         self._check(self.lib.fedm_debug_fieldsplit_apply(self._h, _dp(t), _dp(z)), "fedm_debug_fieldsplit_apply")
         return z
 
-    def configure_fieldsplit_tiles(self, on, slices_per_tile=0, layers=0, threads=0):
-        """Test hook: species sweeps on tiles (several per launch) or one launch each."""
-        self._check(self.lib.fedm_debug_fieldsplit_tiles(self._h, 1 if on else 0, int(slices_per_tile), int(layers),
+    def configure_fieldsplit_tiles(self, on, slices_per_tile=0, layers=0, threads=0, multigrid=True):
+        """Test hook: species sweeps on tiles (several per launch) or one launch each; multigrid=False keeps the
+        finest multigrid level's sweeps as kernels of their own."""
+        mode = (1 if on else 0) | (0 if multigrid else 2)
+        self._check(self.lib.fedm_debug_fieldsplit_tiles(self._h, mode, int(slices_per_tile), int(layers),
                                                          int(threads)), "fedm_debug_fieldsplit_tiles")
 
     def fieldsplit_tiles(self):

@@ -399,7 +399,8 @@ int fedm_fieldsplit_tiles_info(fedm_ctx *ctx, int64_t out[10]);
  * species planes are formed here), host vectors of n_vertices * n_eq doubles -- the operator a Krylov step of
  * fedm_newton_solve applies, alone. */
 int fedm_debug_fieldsplit_apply(fedm_ctx *ctx, const double *t, double *z);
-/* Test hook: mode 0 = species sweeps one launch each from now on; 1 = tiles, rebuilt with `tile_slices` slices
+/* Test hook: mode 0 = species sweeps one launch each from now on (and the multigrid's finest-level sweeps kernels of
+ * their own); 3 = species sweeps on tiles, the multigrid's not; 1 = tiles, rebuilt with `tile_slices` slices
  * per tile, `depth` vertex layers and `threads` threads per tile (0: defaults, FEDM_FS_TILE_SLICES /
  * FEDM_FS_TILE_DEPTH / FEDM_FS_TILE_THREADS). */
 int fedm_debug_fieldsplit_tiles(fedm_ctx *ctx, int mode, int tile_slices, int depth, int threads);

@@ -51,23 +51,40 @@ def test_tiled_sweeps_equal_the_sweeps_one_by_one(kind, degree):
     assert np.isfinite(z_ref).all() and np.abs(z_ref).max() > 0
     assert np.array_equal(prob.fieldsplit_apply(t), z_ref)        # (the comparison below is meaningful)
     for slices, layers, threads in ((0, 0, 0), (8, 2, 512), (4, 3, 128), (8, 5, 512), (2, 4, 64)):
-        prob.configure_fieldsplit_tiles(True, slices, layers, threads)
+        prob.configure_fieldsplit_tiles(True, slices, layers, threads, multigrid=False)
         info = prob.fieldsplit_tiles()
         assert info is not None and info["layers"] == (layers or 3) and info["slices_per_tile"] == (slices or 8)
         assert info["threads"] == (threads or 512) and info["max_rows"] <= 8 * info["threads"]
+        # (the multigrid's finest-level sweeps stay kernels of their own here: see the test below)
+        prob.configure_fieldsplit_tiles(True, slices, layers, threads, multigrid=False)
         z = prob.fieldsplit_apply(t)
         assert np.array_equal(z, z_ref), (slices, layers, threads, np.abs(z - z_ref).max())
     prob.close()
 
 
-def test_tiles_cover_the_mesh_and_report_their_size():
+@pytest.mark.parametrize("kind", ["tensor", "refined"])
+def test_polynomial_smoother_sweeps_on_the_same_tiles(kind):
+    """The finest level's sweeps behind the polynomial smoother's product as one launch on the tiles, with the
+    Jacobian's own potential-potential plane as the operator (double precision; the hierarchy's copy is its
+    single-precision rounding): the species part of the preconditioner's output is untouched, the potential part agrees
+    to the rounding of that copy.  (The V(1,1) cycle keeps its kernels: its output must not change at all.)"""
     from fedm_amd.device import chebyshev_weights
-    msh = _mesh("refined")
+    msh = _mesh(kind)
     prob = _problem(msh, chebyshev_weights(6))
-    info, sz = prob.fieldsplit_tiles(), prob.sizes()
+    t = np.random.default_rng(11).standard_normal(3 * msh.num_vertices())
+    out = {}
+    for cycle in ("V(1,1)", "polynomial smoother"):
+        if cycle != "V(1,1)":
+            prob.setup_multigrid(nu=1, omega=0.85, poly_degree=2)
+            prob.jacobian()
+        prob.configure_fieldsplit_tiles(True, multigrid=False)
+        z_ref = prob.fieldsplit_apply(t).reshape(-1, 3)
+        prob.configure_fieldsplit_tiles(True, multigrid=True)
+        out[cycle] = (z_ref, prob.fieldsplit_apply(t).reshape(-1, 3))
     prob.close()
-    assert info["n_tiles"] == -(-sz["n_slices"] // 8)
-    assert info["row_width"] == sz["max_patch_width"]
-    assert 512 < info["max_vertices"] < 65536
-    assert info["bytes"] < 200 * msh.num_vertices()
-    assert msh.num_vertices() <= info["total_rows"] < 4 * msh.num_vertices()       # the redundancy of three layers
+    z_ref, z = out["V(1,1)"]
+    assert np.array_equal(z, z_ref)
+    z_ref, z = out["polynomial smoother"]
+    assert np.array_equal(z[:, :2], z_ref[:, :2])
+    assert not np.array_equal(z[:, 2], z_ref[:, 2])          # (it did take the other path)
+    assert np.abs(z[:, 2] - z_ref[:, 2]).max() < 1e-5 * np.abs(z_ref[:, 2]).max()
