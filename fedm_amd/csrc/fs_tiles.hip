@@ -47,6 +47,12 @@ struct FsTileWeights {
     double w[FS_TILE_MAX_SWEEPS];
 };
 
+__device__ __forceinline__ int tile_of_block(int b, int n, int xcd) {
+    if (!xcd) return b;
+    const int per = n >> 3, full = per << 3;
+    return b < full ? (b & 7) * per + (b >> 3) : b;
+}
+
 // NS species, at most W entries per row, SLOTS rows per thread.  Registers decide how many tiles are resident (all
 // of them at once is the point: 651 tiles of the bench mesh on 768 workgroup slots): a row's planes stay in
 // registers (two halves a word, as they lie in memory), its local column numbers go to LDS, the arithmetic is single
@@ -57,13 +63,15 @@ __global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void fs_tile_sweeps_kern
     const uint32_t *__restrict__ cols, const int *__restrict__ boff, const _Float16 *__restrict__ s16, unsigned zmask,
     const float *__restrict__ g32, const float *__restrict__ zin, float *__restrict__ zout32,
     double *__restrict__ zout, FsTileWeights wt, int last, const double *__restrict__ x0,
-    const float *__restrict__ cpl32, double *__restrict__ b0) {
+    const float *__restrict__ cpl32, double *__restrict__ b0, int xcd) {
     constexpr int NEQ = NS + 1, PL = NS * NS, PW = (PL + 1) / 2, W2 = (W + 1) / 2;
     extern __shared__ float fs_tile_lds[];
     float *za = fs_tile_lds, *zb = fs_tile_lds + (size_t)lds_vertices * NS;
     uint32_t *lcol = reinterpret_cast<uint32_t *>(fs_tile_lds + (size_t)2 * lds_vertices * NS);   // [W2][lds_rows]
     const int T = blockDim.x, tid = threadIdx.x;
-    const int *tl = tiles + (size_t)blockIdx.x * record;
+    // (neighbouring tiles share layer vertices and their rows: a contiguous range of tiles per XCD, so that they meet in
+    // one L2 -- workgroups go to the XCDs round robin)
+    const int *tl = tiles + (size_t)tile_of_block(blockIdx.x, gridDim.x, xcd) * record;
     const int voff = tl[0], coff = tl[1], rstride = tl[2];
     const int *cnt = tl + 3;
     const int n = wt.n;
@@ -226,13 +234,13 @@ __global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void mg_tile_sweeps_kern
     const int *__restrict__ tiles, int record, int lds_vertices, int lds_rows, int width, const int *__restrict__ vertex,
     const uint32_t *__restrict__ cols, const int *__restrict__ boff, const double *__restrict__ val, int neq2, int plane,
     const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ xin, MgTileWeights wt,
-    double *__restrict__ out, int ostride, int ooff) {
+    double *__restrict__ out, int ostride, int ooff, int xcd) {
     constexpr int W2 = (W + 1) / 2;
     extern __shared__ float fs_tile_lds[];
     double *xa = reinterpret_cast<double *>(fs_tile_lds), *xb = xa + lds_vertices;
     uint32_t *lcol = reinterpret_cast<uint32_t *>(xb + lds_vertices);   // [W2][lds_rows]
     const int T = blockDim.x, tid = threadIdx.x;
-    const int *tl = tiles + (size_t)blockIdx.x * record;
+    const int *tl = tiles + (size_t)tile_of_block(blockIdx.x, gridDim.x, xcd) * record;
     const int voff = tl[0], coff = tl[1], rstride = tl[2];
     const int *cnt = tl + 3;
     const int n = wt.n;
@@ -481,10 +489,14 @@ static void fs_tiles_launch(Ctx &c, FsTiles &ft, unsigned zmask, const float *g3
     const dim3 g(ft.n_tiles), b(T);
     const size_t lds = sizeof(float) * 2 * (size_t)ft.max_vertices * NS + sizeof(uint32_t) * (size_t)((W + 1) / 2) * ft.max_rows;
     const int slots = (ft.max_rows + T - 1) / T;
+    static const int tile_xcd = [] {
+        const char *e = std::getenv("FEDM_FS_TILE_XCD");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
 #define FEDM_TILE_SWEEPS(SL)                                                                                     \
     hipLaunchKernelGGL((fs_tile_sweeps_kernel<NS, W, SL>), g, b, lds, c.stream, ft.d_tile, ft.record, ft.max_vertices, \
                        ft.max_rows, ft.width, ft.d_vertex, ft.d_cols, c.d_slice_boff, c.d_s16, zmask, g32, in, out32, z, wt, last ? 1 : 0, \
-                       x0, cpl32, b0)
+                       x0, cpl32, b0, tile_xcd)
     if (slots <= 2) FEDM_TILE_SWEEPS(2);
     else if (slots <= 3) FEDM_TILE_SWEEPS(3);
     else if (slots <= 4) FEDM_TILE_SWEEPS(4);
@@ -553,7 +565,7 @@ bool mg_tiles_sweeps(Ctx &c, const EllMat &A, const double *b, const double *xin
     hipLaunchKernelGGL((mg_tile_sweeps_kernel<WW, SL>), g, bl,                                                    \
                        sizeof(double) * 2 * (size_t)ft->max_vertices + sizeof(uint32_t) * (size_t)((WW + 1) / 2) * ft->max_rows, \
                        c.stream, ft->d_tile, ft->record, ft->max_vertices, ft->max_rows, ft->width, ft->d_vertex, \
-                       ft->d_cols, c.d_slice_boff, c.d_val, neq2, neq2 - 1, A.dinv, b, xin, wt, out, ostride, ooff)
+                       ft->d_cols, c.d_slice_boff, c.d_val, neq2, neq2 - 1, A.dinv, b, xin, wt, out, ostride, ooff, 1)
 #define FEDM_MG_TILE_S(WW)                                                                                        \
     do {                                                                                                          \
         if (slots <= 2) FEDM_MG_TILE(WW, 2);                                                                      \
