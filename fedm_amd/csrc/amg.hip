@@ -116,8 +116,14 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(int n_slices, int n_rows,
                                                        const double *__restrict__ b,
                                                        double *__restrict__ y, double omega,
                                                        double *__restrict__ aux, int ystride, int yoff,
-                                                       const int *__restrict__ slice_list) {
-    const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+                                                       const int *__restrict__ slice_list, int xcd) {
+    // xcd: a contiguous range of slices per XCD (neighbouring rows share most of their x entries: one L2)
+    int blk = blockIdx.x;
+    if (xcd) {
+        const int per = gridDim.x >> 3, full = per << 3;
+        blk = blk < full ? (blk & 7) * per + (blk >> 3) : blk;
+    }
+    const int wave_id = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave_id >= n_slices) return;   // n_slices: number of slices this launch covers
     const int slice = slice_list ? slice_list[wave_id] : wave_id;
@@ -182,16 +188,21 @@ static void ell_launch(Ctx &c, const EllMat &A, int mode, const double *x, const
     if (n == 0) return;
     const dim3 g((n + 3) / 4), bl(256);
     if (!dinv) dinv = A.dinv;
+    static const bool xcd_ok = [] {
+        const char *e = std::getenv("FEDM_ELL_XCD");
+        return !(e && e[0] == '0');
+    }();
+    const int xcd = (xcd_ok && !slice_list && g.x >= 64) ? 1 : 0;
 #define FEDM_ELL(M)                                                                                          \
     do {                                                                                                     \
         if (A.val32)                                                                                         \
             hipLaunchKernelGGL((ell_spmv_kernel<M, float>), g, bl, 0, c.stream, n, A.n_rows, A.log2_split,   \
                                A.width, A.boff, A.col, A.val32, dinv, x, b, y, omega, aux, ystride, yoff,    \
-                               slice_list);                                                                  \
+                               slice_list, xcd);                                                             \
         else                                                                                                 \
             hipLaunchKernelGGL((ell_spmv_kernel<M, double>), g, bl, 0, c.stream, n, A.n_rows, A.log2_split,  \
                                A.width, A.boff, A.col, A.val, dinv, x, b, y, omega, aux, ystride, yoff,      \
-                               slice_list);                                                                  \
+                               slice_list, xcd);                                                             \
     } while (0)
     switch (mode) {
         case 0: FEDM_ELL(0); break;
