@@ -153,9 +153,11 @@ void iter_graphs_clear(Ctx &c) {
         if (g) hipGraphExecDestroy(g);
     for (hipGraphExec_t g : c.iter_graph_pre)
         if (g) hipGraphExecDestroy(g);
-    for (hipGraphExec_t g : c.iter_graph_pair)
-        if (g) hipGraphExecDestroy(g);
-    c.iter_graph_pair.clear();
+    for (auto *vec : {&c.iter_graph_pair, &c.iter_graph_last, &c.iter_graph_pair_last}) {
+        for (hipGraphExec_t g : *vec)
+            if (g) hipGraphExecDestroy(g);
+        vec->clear();
+    }
     c.iter_graph.clear();
     c.iter_graph_interior.clear();
     c.iter_graph_pre.clear();
@@ -352,16 +354,17 @@ static void right_step_plain(Ctx &c, int j, const double *const *vp, double *z, 
 // when the previous solve says that both will be needed they are launched together anyway; between two graph
 // launches the GPU idles for 8 us, tools/step_sequence.py).  Publishes twice: mail_seq advances by two.
 static bool iter_graph_launch_right_pair(Ctx &c, int j, const double *const *vp, double *z0, double *w0, double *z1,
-                                         double *w1) {
+                                         double *w1, bool skip_last_update) {
     static const bool off = [] {
         const char *e = std::getenv("FEDM_KRYLOV_PAIRS");
         return e && e[0] == '0';
     }();
     if (off || c.comm || !c.iter_graphs_ok || (c.prof.on && c.prof.all_kinds) || fieldsplit_upper(c)) return false;
-    if ((int)c.iter_graph_pair.size() <= j) c.iter_graph_pair.resize(j + 1, nullptr);
-    if (!c.iter_graph_pair[j]) {
+    std::vector<hipGraphExec_t> &cache = skip_last_update ? c.iter_graph_pair_last : c.iter_graph_pair;
+    if ((int)cache.size() <= j) cache.resize(j + 1, nullptr);
+    if (!cache[j]) {
         const bool direct = c.amg->pre_smooth && c.amg->levels.size() > 1;
-        auto step = [&](int jj, double *z, double *w) {
+        auto step = [&](int jj, double *z, double *w, bool update) {
             std::vector<const double *> dotp(jj + 2);
             for (int i = 0; i <= jj; ++i) dotp[i] = vp[i];
             dotp[jj + 1] = w;
@@ -376,17 +379,17 @@ static bool iter_graph_launch_right_pair(Ctx &c, int j, const double *const *vp,
                 launch_spmv(c, z, w, false);
                 launch_dots_fused(c, dotp.data(), w, jj + 2, nullptr, true);
             }
-            krylov_vector_update(c, jj + 1, vp, w);
+            if (update) krylov_vector_update(c, jj + 1, vp, w);
         };
-        if (!capture_graph(c, &c.iter_graph_pair[j], [&] {
-                step(j, z0, w0);
-                step(j + 1, z1, w1);
+        if (!capture_graph(c, &cache[j], [&] {
+                step(j, z0, w0, true);
+                step(j + 1, z1, w1, !skip_last_update);
             })) {
             c.iter_graphs_ok = false;
             return false;
         }
     }
-    if (hipGraphLaunch(c.iter_graph_pair[j], c.stream) != hipSuccess) {
+    if (hipGraphLaunch(cache[j], c.stream) != hipSuccess) {
         hipGetLastError();
         c.iter_graphs_ok = false;
         return false;
@@ -395,9 +398,42 @@ static bool iter_graph_launch_right_pair(Ctx &c, int j, const double *const *vp,
     return true;
 }
 
-static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, double *z, double *w) {
+static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, double *z, double *w,
+                                    bool skip_update = false) {
     if (!c.iter_graphs_ok || (c.prof.on && c.prof.all_kinds)) return false;
     const bool multi = c.comm != nullptr;
+    if (skip_update && !multi) {   // one GPU: the step expected to end the solve, without its update
+        if ((int)c.iter_graph_last.size() <= j) c.iter_graph_last.resize(j + 1, nullptr);
+        if (!c.iter_graph_last[j]) {
+            const bool direct_ = !fieldsplit_upper(c) && c.amg->pre_smooth && c.amg->levels.size() > 1;
+            std::vector<const double *> dotp(j + 2);
+            for (int i = 0; i <= j; ++i) dotp[i] = vp[i];
+            dotp[j + 1] = w;
+            if (!capture_graph(c, &c.iter_graph_last[j], [&] {
+                    if (direct_) {
+                        c.amg->out = z;
+                        c.amg->out_stride = c.neq;
+                        c.amg->out_offset = c.neq - 1;
+                    }
+                    fieldsplit_apply(c, *c.amg, vp[j], z, 1.0, !direct_);
+                    c.amg->out = nullptr;
+                    if (!launch_spmv_dots(c, z, w, dotp.data(), j + 2)) {
+                        launch_spmv(c, z, w, false);
+                        launch_dots_fused(c, dotp.data(), w, j + 2, nullptr, true);
+                    }
+                })) {
+                c.iter_graphs_ok = false;
+                return false;
+            }
+        }
+        if (hipGraphLaunch(c.iter_graph_last[j], c.stream) != hipSuccess) {
+            hipGetLastError();
+            c.iter_graphs_ok = false;
+            return false;
+        }
+        ++c.mail_seq;
+        return true;
+    }
     if ((int)c.iter_graph.size() <= j) {
         c.iter_graph.resize(j + 1, nullptr);
         c.iter_graph_interior.resize(j + 1, nullptr);
@@ -560,6 +596,11 @@ static bool iter_graph_launch_right(Ctx &c, int j, const double *const *vp, doub
     return true;
 }
 
+static const bool skip_last_ok = [] {
+    const char *e = std::getenv("FEDM_KRYLOV_SKIP_LAST_UPDATE");
+    return !(e && e[0] == '0');
+}();
+
 // ---- GMRES(m) ---------------------------------------------------------------------------------
 // Preconditioner on the left (point-block Jacobi; field split across GPUs): solves
 // Minv J delta = Minv rhs (rhs in c.d_rhs, already scaled), convergence on the preconditioned
@@ -663,16 +704,21 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         int j = 0;
         bool done = false;
         std::deque<unsigned long long> queued;
+        int update_skipped_for = -1;   // step whose vector has not been orthonormalised yet (launched as 'the last one')
         for (; j < m && its < max_it; ++j) {
             double *w = c.d_V + (size_t)(j + 1) * c.np;
             // classical Gram-Schmidt with ONE reduction and ONE host wait per iteration:
             // h_i = v_i.w and ww = w.w together; |w - V h|^2 = ww - |h|^2 on the device;
             // the update and the normalisation read their coefficients from device memory.
-            auto launch_step = [&](int jj) {
+            auto launch_step = [&](int jj, bool skip_update = false) {
                 double *ww = c.d_V + (size_t)(jj + 1) * c.np;
                 if (right) {
                     double *z = c.d_Z + (size_t)jj * c.np;
-                    if (!iter_graph_launch_right(c, jj, vp.data(), z, ww)) right_step_plain(c, jj, vp.data(), z, ww);
+                    if (skip_update && iter_graph_launch_right(c, jj, vp.data(), z, ww, true)) {
+                        update_skipped_for = jj;
+                    } else if (!iter_graph_launch_right(c, jj, vp.data(), z, ww)) {
+                        right_step_plain(c, jj, vp.data(), z, ww);
+                    }
                 } else if (!iter_graph_launch(c, jj, vp.data(), ww)) {
                     apply_operator(c, vp[jj], ww);
                     for (int i = 0; i <= jj; ++i) dotp[i] = vp[i];
@@ -694,14 +740,27 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
             auto wanted = [&](int q) {   // step q is expected to be needed: launch it without waiting for step q - 1
                 return right && !c.comm && q < m && its + (q - j) < max_it && q < c.krylov_steps_hint;
             };
+            // The step expected to end the solve (the previous solve's count; early in a run: the second one) goes in
+            // WITHOUT the update that would orthonormalise its vector for a next step: 8 us of kernel nobody needs when
+            // the guess is right; when it is wrong the update is launched by itself before the solve goes on.
+            auto ends_here = [&](int q) {
+                return skip_last_ok && right && !c.comm && c.krylov_steps_hint >= 1 && c.krylov_steps_hint <= 4 &&
+                       q + 1 == c.krylov_steps_hint && cycle == 0;
+            };
             auto launch_from = [&](int q, bool first_is_needed) {
+                if (update_skipped_for == q - 1 && (first_is_needed || wanted(q))) {   // (the guess was wrong)
+                    krylov_vector_update(c, q, vp.data(), c.d_V + (size_t)q * c.np);
+                    update_skipped_for = -1;
+                }
                 if ((first_is_needed || wanted(q)) && wanted(q + 1) &&
                     iter_graph_launch_right_pair(c, q, vp.data(), c.d_Z + (size_t)q * c.np, c.d_V + (size_t)(q + 1) * c.np,
-                                                 c.d_Z + (size_t)(q + 1) * c.np, c.d_V + (size_t)(q + 2) * c.np)) {
+                                                 c.d_Z + (size_t)(q + 1) * c.np, c.d_V + (size_t)(q + 2) * c.np,
+                                                 ends_here(q + 1))) {
+                    if (ends_here(q + 1)) update_skipped_for = q + 1;
                     queued.push_back(c.mail_seq - 1);
                     queued.push_back(c.mail_seq);
                 } else if (first_is_needed || wanted(q)) {
-                    queued.push_back(launch_step(q));
+                    queued.push_back(launch_step(q, ends_here(q)));
                 }
             };
             if (queued.empty()) launch_from(j, true);
@@ -740,6 +799,10 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 if (!queued.empty()) {
                     wait_red_seq(c, queued.back());
                     queued.clear();
+                }
+                if (update_skipped_for == j) {   // the first Gram-Schmidt pass has not been applied to w yet
+                    krylov_vector_update(c, j + 1, vp.data(), w);
+                    update_skipped_for = -1;
                 }
                 launch_dots(c, vp.data(), w, j + 1, false);
                 read_red(c, j + 1);
@@ -789,7 +852,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
         }
         if (k > 0) {
             if (u_update && done && cycle == 0 && k <= 8) {
-                launch_newton_update(c, yv.data(), k, right ? zp.data() : vp.data(), u_update, c.d_delta);
+                launch_newton_update(c, yv.data(), k, right ? zp.data() : vp.data(), u_update, nullptr);
                 *u_updated = true;
             } else {
                 zero_delta();

@@ -226,6 +226,9 @@ struct Ctx {
     std::vector<hipGraphExec_t> iter_graph_interior;  // several GPUs: the interior-rows SpMV of step j
     std::vector<hipGraphExec_t> iter_graph_pre;       // several GPUs, field split on the right: z_j = Minv v_j
     std::vector<hipGraphExec_t> iter_graph_pair;      // one GPU, on the right: steps j and j + 1 as ONE graph
+    // the same two kinds without the update of their last step (the step expected to end the solve: its
+    // normalised vector is only needed if the solve goes on, and is then formed by a launch of its own)
+    std::vector<hipGraphExec_t> iter_graph_last, iter_graph_pair_last;
     bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
     bool capturing = false;
     int newton_its_hint = -1;     // Newton iterations of the previous converged solve

@@ -1787,7 +1787,7 @@ __global__ __launch_bounds__(256) void newton_update_kernel(size_t n, size_t n_d
         for (int k = 0; k < K; ++k) d += cf.c[k] * zs.p[k][i];
         const double un = u[i] + d;
         u[i] = un;
-        delta[i] = d;
+        if (delta) delta[i] = d;   // (nobody reads it after a solve that converged in its first cycle)
         if (i < n_dot) {
             acc[0] += d * d;
             acc[1] += un * un;
