@@ -748,7 +748,7 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                        q + 1 == c.krylov_steps_hint && cycle == 0;
             };
             auto launch_from = [&](int q, bool first_is_needed) {
-                if (update_skipped_for == q - 1 && (first_is_needed || wanted(q))) {   // (the guess was wrong)
+                if (q > 0 && update_skipped_for == q - 1 && (first_is_needed || wanted(q))) {   // (the guess was wrong)
                     krylov_vector_update(c, q, vp.data(), c.d_V + (size_t)q * c.np);
                     update_skipped_for = -1;
                 }
