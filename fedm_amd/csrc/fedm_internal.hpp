@@ -85,6 +85,10 @@ struct Ctx {
     // vertices with identity rows (the outermost layer).  halo_depth == 1: all ghosts, no list.
     int halo_depth = 1, n_identity = 0;
     int *d_identity = nullptr;
+    // one GPU: the boundary facets' terms (species rows) and the Dirichlet / padding rows in ONE launch when no row
+    // belongs to both (boundary_rows_disjoint, found at set-up); launch_assemble leaves the facets to launch_finalize
+    bool boundary_rows_disjoint = false;
+    int boundary_pending = 0;   // 1: residual, 2: residual + Jacobian
     int64_t n_dot = 0;     // vector entries that take part in reductions: n_owned * neq
     int device = 0;
     hipStream_t stream = nullptr;

@@ -633,7 +633,19 @@ void launch_assemble(Ctx &c, bool jacobian, int mode) {
     else if (c.ns == 2 && !c.poisson) assemble_dispatch<2, false>(c, jacobian, mode);
     else if (c.ns == 3 && c.poisson) assemble_dispatch<3, true>(c, jacobian, mode);
     prof_end(c);
-    if (mode == 0) launch_boundary(c, jacobian);
+    if (mode == 0) {
+        static const bool fuse_off = [] {
+            const char *e = std::getenv("FEDM_FUSED_BOUNDARY");
+            return e && e[0] == '0';
+        }();
+        // one GPU, patch assembly (the facets in one launch, with atomics), no row shared with a Dirichlet dof: the
+        // facets go into launch_finalize's launch
+        if (!fuse_off && !c.comm && c.n_owned == c.nv && !c.d_identity && c.assembly_kind == 1 && c.poisson &&
+            c.n_bfacets > 0 && c.boundary_rows_disjoint && c.ns >= 1 && c.ns <= 3)
+            c.boundary_pending = jacobian ? 2 : 1;
+        else
+            launch_boundary(c, jacobian);
+    }
 }
 
 // =============================================================================================
@@ -719,7 +731,80 @@ __global__ void identity_rows_kernel(int nv, int nvp, int neq, int ns_frozen,
     }
 }
 
+// boundary_kernel<NS, true> and dirichlet_kernel in one launch (128-thread blocks: the first ones take the facets, the
+// rest the Dirichlet and padding rows) -- allowed when no row belongs to both (Ctx::boundary_rows_disjoint)
+template <int NS>
+__global__ __launch_bounds__(128) void boundary_dirichlet_kernel(
+    const fedm_model_desc *__restrict__ md, int n_facets, int facet_blocks, const int *__restrict__ facets,
+    const int *__restrict__ cells, const double *__restrict__ coords, const uint32_t *__restrict__ cell_slots,
+    const double *__restrict__ u, double *__restrict__ val, double *__restrict__ F, int jacobian, int n_dir,
+    const int *__restrict__ dofs, const double *__restrict__ vals, const int *__restrict__ boff,
+    const uint32_t *__restrict__ diag_slot, int id_first, int n_id) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    if ((int)blockIdx.x < facet_blocks) {
+        const int t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= n_facets) return;
+        const int c = facets[3 * t], fi = facets[3 * t + 1], tag = facets[3 * t + 2];
+        int v[3];
+        double x[3][2], Uc[3][NEQ];
+        for (int a = 0; a < 3; ++a) {
+            v[a] = cells[3 * c + a];
+            x[a][0] = coords[2 * v[a]];
+            x[a][1] = coords[2 * v[a] + 1];
+            for (int s = 0; s < NEQ; ++s) Uc[a][s] = u[(size_t)v[a] * NEQ + s];
+        }
+        auto addR = [&](int a, int s, double value) { unsafeAtomicAdd(&F[(size_t)v[a] * NEQ + s], value); };
+        auto addJ = [&](int a, int b, int sr, int scol, double value) {
+            const uint32_t slot = cell_slots[(size_t)c * 9 + a * 3 + b];
+            unsafeAtomicAdd(&val[((size_t)(slot >> 6) * NEQ2 + sr * NEQ + scol) * SLICE + (slot & 63)], value);
+        };
+        boundary_facet<NS>(md, x, Uc, fi, tag, jacobian != 0, addR, addJ);
+        return;
+    }
+    // the rows of dirichlet_kernel (one GPU: Dirichlet dofs, then the padding vertices [id_first, id_first + n_id))
+    const int t = ((int)blockIdx.x - facet_blocks) * blockDim.x + threadIdx.x;
+    if (t >= n_dir + n_id) return;
+    if (t >= n_dir) {
+        const int vtx = id_first + (t - n_dir), slice = vtx >> 6, lane = vtx & 63;
+        for (int cr = 0; cr < NEQ; ++cr) {
+            F[(size_t)vtx * NEQ + cr] = 0.0;
+            if (!jacobian) continue;
+            for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc)
+                for (int cc = 0; cc < NEQ; ++cc) val[((size_t)bc * NEQ2 + cr * NEQ + cc) * SLICE + lane] = 0.0;
+            const uint32_t ds = diag_slot[vtx];
+            val[((size_t)(ds >> 6) * NEQ2 + cr * NEQ + cr) * SLICE + (ds & 63)] = 1.0;
+        }
+        return;
+    }
+    const int dof = dofs[t], vtx = dof / NEQ, cr = dof % NEQ;
+    F[dof] = u[dof] - vals[t];
+    if (!jacobian) return;
+    const int slice = vtx >> 6, lane = vtx & 63;
+    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc)
+        for (int cc = 0; cc < NEQ; ++cc) val[((size_t)bc * NEQ2 + cr * NEQ + cc) * SLICE + lane] = 0.0;
+    const uint32_t ds = diag_slot[vtx];
+    val[((size_t)(ds >> 6) * NEQ2 + cr * NEQ + cr) * SLICE + (ds & 63)] = 1.0;
+}
+
 void launch_finalize(Ctx &c, bool jacobian, int mode) {
+    if (c.boundary_pending) {
+        const bool jac = c.boundary_pending == 2;
+        c.boundary_pending = 0;
+        if (mode == 0 && jac == jacobian) {
+            const int fb = (c.n_bfacets + 127) / 128, n_id = c.nvp - c.nv;
+            const int rb = (c.n_dir + n_id + 127) / 128;
+#define FEDM_BD(NS_)                                                                                              \
+    hipLaunchKernelGGL(boundary_dirichlet_kernel<NS_>, dim3(fb + rb), dim3(128), 0, c.stream, c.d_model, c.n_bfacets, fb, \
+                       c.d_bfacets, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0, c.n_dir, \
+                       c.d_dir_dofs, c.d_dir_vals, c.d_slice_boff, c.d_diag_slot, c.nv, n_id)
+            if (c.ns == 1) FEDM_BD(1);
+            else if (c.ns == 2) FEDM_BD(2);
+            else FEDM_BD(3);
+#undef FEDM_BD
+            return;
+        }
+        launch_boundary(c, jac);   // (not the pair this was deferred for: the facets first, then the rows as usual)
+    }
     const int ns_frozen = (mode == 1) ? c.ns : 0;
     const bool deep = c.d_identity != nullptr;
     // identity rows: padding + ghost vertices (deep halos: padding + the listed outermost ghost layer)
