@@ -173,6 +173,7 @@ _SIGNATURES = {
     "fedm_pattern_stats": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_int64)]),
     "fedm_pattern_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fedm_fieldsplit_tiles_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "fedm_fieldsplit_tiles_stats": (C.c_int, [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "fedm_debug_fieldsplit_apply": (C.c_int, [_P, _D, _D]),
     "fedm_debug_fieldsplit_tiles": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "fedm_profile": (C.c_int, [_P, C.c_int]),

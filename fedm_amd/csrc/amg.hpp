@@ -113,6 +113,7 @@ bool fs_tiles_sweeps(Ctx &c, int n_sweeps, unsigned zmask, const float *g32, flo
                      const double *x0, const float *cpl32, double *b0);
 int fs_tiles_info(Ctx &c, long long *out);   // 1 + out[10] = {tiles, slices per tile, layers, row width, max vertices, max rows, bytes, threads, all rows, all vertices}
 void fs_tiles_release(Ctx &c);
+int fs_tiles_host_stats(const fedm_mesh_desc &mesh, int tile_slices, int depth, long long *out);   // no GPU needed
 // the finest multigrid level's sweeps behind the polynomial smoother's product as one launch on the same tiles (fs_tiles.hip)
 bool mg_tiles_sweeps(Ctx &c, const EllMat &A, const double *b, const double *xin, int n, const double *w, double *out,
                      int ostride, int ooff);

@@ -2247,6 +2247,26 @@ int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
     return 0;
 }
 
+int fedm_fieldsplit_tiles_stats(const fedm_mesh_desc *mesh, int tile_slices, int depth, int64_t out[8]) {
+    if (!mesh || !out || mesh->n_vertices < 3 || mesh->n_cells < 1) {
+        set_error("null or empty mesh");
+        return -2;
+    }
+    for (int i = 0; i < 3 * mesh->n_cells; ++i)
+        if (mesh->cells[i] < 0 || mesh->cells[i] >= mesh->n_vertices) {
+            set_error("cell vertex index out of range");
+            return -2;
+        }
+    long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int rc = fs_tiles_host_stats(*mesh, tile_slices, depth, v);
+    if (rc) {
+        set_error("tile parameters out of range (1..8 slices, 1..8 layers) or a tile too large for 16-bit local indices");
+        return rc;
+    }
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return 0;
+}
+
 int fedm_fieldsplit_tiles_info(fedm_ctx *h, int64_t out[10]) {
     if (!h || !out) return -2;
     long long v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

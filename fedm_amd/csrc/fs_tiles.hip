@@ -309,25 +309,32 @@ __global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void mg_tile_sweeps_kern
     }
 }
 
-bool FsTiles_build(FsTiles &ft, const Pattern &pat, int tile_slices, int depth) {
-    ft.release();
-    ft.tile_slices = tile_slices;
-    ft.depth = depth;
+// Host side of the tiles: vertex lists [tile | layer 1 | ... | layer depth] by a breadth-first walk over the block
+// pattern, and the local column numbers (two to a word) of the rows of the layers < depth.  No device call in here:
+// fedm_fieldsplit_tiles_stats runs it without a GPU.
+struct FsTileTables {
+    int tile_slices = 0, depth = 0, n_tiles = 0, width = 0, record = 0, max_vertices = 0, max_rows = 0;
+    long long total_rows = 0, total_vertices = 0;
+    std::vector<int> tiles, vertices;
+    std::vector<uint32_t> cols;
+};
+
+static bool fs_tile_tables(const Pattern &pat, int tile_slices, int depth, FsTileTables &tt) {
+    tt = FsTileTables();
+    tt.tile_slices = tile_slices;
+    tt.depth = depth;
     const int T = tile_slices * SLICE;
-    ft.n_tiles = (pat.n_slices + tile_slices - 1) / tile_slices;
-    ft.record = 3 + depth + 1;
-    ft.width = 0;
-    for (int s = 0; s < pat.n_slices; ++s) ft.width = std::max(ft.width, pat.slice_boff[s + 1] - pat.slice_boff[s]);
-    std::vector<int> tiles((size_t)ft.n_tiles * ft.record), vertices, stamp(pat.nvp, -1), loc(pat.nvp, 0);
-    std::vector<size_t> coff(ft.n_tiles);
+    tt.n_tiles = (pat.n_slices + tile_slices - 1) / tile_slices;
+    tt.record = 3 + depth + 1;
+    for (int s = 0; s < pat.n_slices; ++s) tt.width = std::max(tt.width, pat.slice_boff[s + 1] - pat.slice_boff[s]);
+    const int width2 = (tt.width + 1) / 2;
+    tt.tiles.assign((size_t)tt.n_tiles * tt.record, 0);
+    std::vector<int> stamp(pat.nvp, -1), loc(pat.nvp, 0), list, frontier, next;
+    std::vector<size_t> coff(tt.n_tiles);
     size_t n_cols = 0;
-    const int width2 = (ft.width + 1) / 2;
-    ft.max_vertices = ft.max_rows = 0;
-    ft.total_rows = ft.total_vertices = 0;
-    std::vector<int> list, frontier, next;
     // pass 1: vertex lists and counts
-    for (int t = 0; t < ft.n_tiles; ++t) {
-        int *tl = &tiles[(size_t)t * ft.record];
+    for (int t = 0; t < tt.n_tiles; ++t) {
+        int *tl = &tt.tiles[(size_t)t * tt.record];
         const int v0 = t * T, v1 = std::min(v0 + T, pat.nvp);
         list.clear();
         for (int v = v0; v < v1; ++v) {
@@ -353,47 +360,107 @@ bool FsTiles_build(FsTiles &ft, const Pattern &pat, int tile_slices, int depth) 
             frontier.swap(next);
         }
         const int rows = tl[3 + depth - 1];
-        if ((long long)vertices.size() + (long long)list.size() > 0x7fffffffLL || n_cols + (size_t)rows * width2 > 0x7fffffffULL)
+        if ((long long)tt.vertices.size() + (long long)list.size() > 0x7fffffffLL ||
+            n_cols + (size_t)rows * width2 > 0x7fffffffULL)
             return false;
-        tl[0] = (int)vertices.size();
+        tl[0] = (int)tt.vertices.size();
         tl[1] = (int)n_cols;
         tl[2] = rows;
         coff[t] = n_cols;
         n_cols += (size_t)rows * width2;
-        vertices.insert(vertices.end(), list.begin(), list.end());
-        ft.max_vertices = std::max(ft.max_vertices, (int)list.size());
-        ft.max_rows = std::max(ft.max_rows, rows);
-        ft.total_rows += rows;
-        ft.total_vertices += (long long)list.size();
+        tt.vertices.insert(tt.vertices.end(), list.begin(), list.end());
+        tt.max_vertices = std::max(tt.max_vertices, (int)list.size());
+        tt.max_rows = std::max(tt.max_rows, rows);
+        tt.total_rows += rows;
+        tt.total_vertices += (long long)list.size();
     }
-    if (ft.max_vertices > 65535) return false;
+    if (tt.max_vertices > 65535) return false;
     // pass 2: local column numbers of the rows of the layers < depth
-    std::vector<uint32_t> cols(n_cols, 0u);
-    for (int t = 0; t < ft.n_tiles; ++t) {
-        const int *tl = &tiles[(size_t)t * ft.record];
+    tt.cols.assign(n_cols, 0u);
+    for (int t = 0; t < tt.n_tiles; ++t) {
+        const int *tl = &tt.tiles[(size_t)t * tt.record];
         const int nvt = tl[3 + depth], rows = tl[2];
-        const int *vl = &vertices[tl[0]];
+        const int *vl = &tt.vertices[tl[0]];
         for (int i = 0; i < nvt; ++i) loc[vl[i]] = i;   // (every neighbour of a row below is in the list)
         for (int r = 0; r < rows; ++r) {
             const int v = vl[r], slice = v >> 6, lane = v & 63;
             const int b0 = pat.slice_boff[slice], w = pat.slice_boff[slice + 1] - b0;
             for (int k = 0; k < 2 * width2; ++k) {
                 const uint32_t lc = (uint32_t)(k < w ? loc[pat.colidx[(size_t)(b0 + k) * SLICE + lane]] : r);
-                cols[coff[t] + (size_t)(k >> 1) * rows + r] |= lc << ((k & 1) * 16);
+                tt.cols[coff[t] + (size_t)(k >> 1) * rows + r] |= lc << ((k & 1) * 16);
             }
         }
     }
-    ft.bytes = sizeof(int) * (tiles.size() + vertices.size()) + sizeof(uint32_t) * cols.size();
-    if (hipMalloc((void **)&ft.d_tile, sizeof(int) * tiles.size()) != hipSuccess ||
-        hipMalloc((void **)&ft.d_vertex, sizeof(int) * vertices.size()) != hipSuccess ||
-        hipMalloc((void **)&ft.d_cols, sizeof(uint32_t) * std::max<size_t>(cols.size(), 1)) != hipSuccess) {
+    return true;
+}
+
+// the tables of a mesh without a GPU, and a self-check of them: out = {tiles, longest row, most vertices of a tile with
+// its layers, most rows, rows of all tiles, vertices of all tiles, bytes, violations found}.  Checked: every vertex is
+// the own vertex of exactly one tile; the layer counts grow; every local column of every row is a valid index and names
+// the vertex the pattern names; entries beyond a row's own name the row itself.
+int fs_tiles_host_stats(const fedm_mesh_desc &mesh, int tile_slices, int depth, long long *out) {
+    Pattern pat;
+    build_pattern(mesh, pat);
+    FsTileTables tt;
+    if (tile_slices < 1 || tile_slices > 8 || depth < 1 || depth > FS_TILE_MAX_SWEEPS || !fs_tile_tables(pat, tile_slices, depth, tt))
+        return -2;
+    long long bad = 0;
+    std::vector<int> owner(pat.nvp, 0);
+    const int width2 = (tt.width + 1) / 2;
+    for (int t = 0; t < tt.n_tiles; ++t) {
+        const int *tl = &tt.tiles[(size_t)t * tt.record];
+        const int *vl = &tt.vertices[tl[0]];
+        for (int L = 0; L < depth; ++L) bad += tl[3 + L + 1] < tl[3 + L];
+        bad += tl[2] != tl[3 + depth - 1];
+        for (int i = 0; i < tl[3]; ++i) ++owner[vl[i]];
+        const int nvt = tl[3 + depth], rows = tl[2];
+        for (int r = 0; r < rows; ++r) {
+            const int v = vl[r], slice = v >> 6, lane = v & 63;
+            const int b0 = pat.slice_boff[slice], w = pat.slice_boff[slice + 1] - b0;
+            for (int k = 0; k < 2 * width2; ++k) {
+                const int lc = (int)((tt.cols[(size_t)tl[1] + (size_t)(k >> 1) * rows + r] >> ((k & 1) * 16)) & 0xffffu);
+                if (lc >= nvt) ++bad;
+                else if (k < w) bad += vl[lc] != pat.colidx[(size_t)(b0 + k) * SLICE + lane];
+                else bad += lc != r;
+            }
+        }
+    }
+    for (int v = 0; v < pat.nvp; ++v) bad += owner[v] != 1;
+    out[0] = tt.n_tiles;
+    out[1] = tt.width;
+    out[2] = tt.max_vertices;
+    out[3] = tt.max_rows;
+    out[4] = tt.total_rows;
+    out[5] = tt.total_vertices;
+    out[6] = (long long)(sizeof(int) * (tt.tiles.size() + tt.vertices.size()) + sizeof(uint32_t) * tt.cols.size());
+    out[7] = bad;
+    return 0;
+}
+
+bool FsTiles_build(FsTiles &ft, const Pattern &pat, int tile_slices, int depth) {
+    ft.release();
+    FsTileTables tt;
+    if (!fs_tile_tables(pat, tile_slices, depth, tt)) return false;
+    ft.tile_slices = tile_slices;
+    ft.depth = depth;
+    ft.n_tiles = tt.n_tiles;
+    ft.record = tt.record;
+    ft.width = tt.width;
+    ft.max_vertices = tt.max_vertices;
+    ft.max_rows = tt.max_rows;
+    ft.total_rows = tt.total_rows;
+    ft.total_vertices = tt.total_vertices;
+    ft.bytes = sizeof(int) * (tt.tiles.size() + tt.vertices.size()) + sizeof(uint32_t) * tt.cols.size();
+    if (hipMalloc((void **)&ft.d_tile, sizeof(int) * tt.tiles.size()) != hipSuccess ||
+        hipMalloc((void **)&ft.d_vertex, sizeof(int) * tt.vertices.size()) != hipSuccess ||
+        hipMalloc((void **)&ft.d_cols, sizeof(uint32_t) * std::max<size_t>(tt.cols.size(), 1)) != hipSuccess) {
         hipGetLastError();
         ft.release();
         return false;
     }
-    hipMemcpy(ft.d_tile, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice);
-    hipMemcpy(ft.d_vertex, vertices.data(), sizeof(int) * vertices.size(), hipMemcpyHostToDevice);
-    hipMemcpy(ft.d_cols, cols.data(), sizeof(uint32_t) * cols.size(), hipMemcpyHostToDevice);
+    hipMemcpy(ft.d_tile, tt.tiles.data(), sizeof(int) * tt.tiles.size(), hipMemcpyHostToDevice);
+    hipMemcpy(ft.d_vertex, tt.vertices.data(), sizeof(int) * tt.vertices.size(), hipMemcpyHostToDevice);
+    hipMemcpy(ft.d_cols, tt.cols.data(), sizeof(uint32_t) * tt.cols.size(), hipMemcpyHostToDevice);
     ft.usable = true;
     return true;
 }

@@ -321,6 +321,30 @@ def pattern_stats(coords, cells, reorder=True):
     return dict(zip(keys, (int(v) for v in out)))
 
 
+def fieldsplit_tiles_stats(coords, cells, slices_per_tile=8, layers=3, reorder=True):
+    """The tile tables of the species sweeps (csrc/fs_tiles.hip) built on the host alone
+    (``fedm_fieldsplit_tiles_stats``; runs without a GPU), for the mesh as the device would number it, with the
+    library's self-check of them (``violations`` must be 0)."""
+    lib = _lib.load()
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    order = locality_order(coords, cells) if reorder else np.arange(coords.shape[0])
+    inv = np.empty(coords.shape[0], dtype=np.int64)
+    inv[order] = np.arange(coords.shape[0])
+    cdev = np.ascontiguousarray(coords[order])
+    kdev = np.ascontiguousarray(inv[cells], dtype=np.int32)
+    mesh = _lib.MeshDesc()
+    mesh.n_vertices, mesh.n_cells = coords.shape[0], cells.shape[0]
+    mesh.coords = _dp(cdev)
+    mesh.cells = kdev.ctypes.data_as(C.POINTER(C.c_int32))
+    out = (C.c_int64 * 8)()
+    rc = lib.fedm_fieldsplit_tiles_stats(C.byref(mesh), int(slices_per_tile), int(layers), out)
+    if rc != 0:
+        raise RuntimeError(f"fedm_fieldsplit_tiles_stats failed ({rc}): {_lib.last_error()}")
+    keys = ("n_tiles", "row_width", "max_vertices", "max_rows", "total_rows", "total_vertices", "bytes", "violations")
+    return dict(zip(keys, (int(v) for v in out)))
+
+
 class DeviceProblem:
     """Mesh + model + state resident on one MI355X."""
 

@@ -199,7 +199,7 @@ const char *fedm_last_error(void);
  * written against and refuses a library of another version (a descriptor that grew would otherwise be
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
  * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields.
- * 3: fedm_fieldsplit_tiles_info, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles. */
+ * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles. */
 #define FEDM_ABI_VERSION 3
 int fedm_abi_version(void);
 
@@ -395,6 +395,11 @@ int fedm_pattern_info(fedm_ctx *ctx, int64_t out[8]);
  * most vertices of a tile with its layers, most rows, bytes of the tile tables, threads per tile, rows of all
  * tiles (the tile's own and the layers': the redundancy is this over the vertex count), vertices of all tiles}. */
 int fedm_fieldsplit_tiles_info(fedm_ctx *ctx, int64_t out[10]);
+/* The tile tables of a mesh built on the host alone (no GPU needed), with a self-check: out = {tiles, longest
+ * matrix row, most vertices of a tile with its layers, most rows, rows of all tiles, vertices of all tiles, bytes,
+ * violations found (0: every vertex is the own vertex of exactly one tile, the layers nest, every local column
+ * number names the vertex the block pattern names)}. */
+int fedm_fieldsplit_tiles_stats(const fedm_mesh_desc *mesh, int tile_slices, int depth, int64_t out[8]);
 /* Test hook: z = Minv t with the field-split preconditioner of the CURRENT Jacobian (fedm_jacobian first; its
  * species planes are formed here), host vectors of n_vertices * n_eq doubles -- the operator a Krylov step of
  * fedm_newton_solve applies, alone. */

@@ -219,3 +219,32 @@ def test_vertex_orders_are_permutations_for_any_size(n):
         assert np.array_equal(np.sort(order), np.arange(n))
     st = device.pattern_stats(pts, cells)
     assert st["n_slices"] == (n + 63) // 64 and st["nnz_blocks"] > n
+
+
+@pytest.mark.parametrize("kind", ["tensor", "refined"])
+@pytest.mark.parametrize("slices,layers", [(8, 3), (8, 5), (4, 2), (1, 1)])
+def test_tiles_of_the_species_sweeps_are_consistent(kind, slices, layers, refined):
+    """The host-built tables behind the tiled species sweeps (fedm_amd/csrc/fs_tiles.hip: vertex lists
+    [tile | layer 1 | ...], 16-bit local column numbers) checked by the library itself, without a GPU:
+    every vertex owned by exactly one tile, nested layers, every local column naming the pattern's vertex."""
+    from fedm_amd import device
+    from fedm_amd.cases import streamer
+    msh = streamer.mesh(96, 4.0) if kind == "tensor" else refined
+    st = device.fieldsplit_tiles_stats(msh.coords, msh.cells, slices, layers)
+    nv = msh.num_vertices()
+    assert st["violations"] == 0
+    assert st["n_tiles"] == -(-(-(-nv // 64)) // slices)
+    assert nv <= st["total_rows"] <= st["total_vertices"]
+    assert st["max_rows"] <= st["max_vertices"] < 65536
+    assert st["row_width"] == device.pattern_stats(msh.coords, msh.cells)["max_patch_width"]
+    if (slices, layers) == (8, 3):
+        # what the default costs: the rows of the layers are computed redundantly by every tile that needs them
+        assert st["total_rows"] < (1.6 if kind == "tensor" else 2.0) * nv
+        assert st["max_rows"] <= 3 * 512          # three rows a thread at most (the kernel's instantiations)
+
+
+def test_tile_parameters_out_of_range_are_refused(refined):
+    from fedm_amd import device
+    for slices, layers in ((0, 3), (9, 3), (8, 0), (8, 9)):
+        with pytest.raises(RuntimeError, match="tile parameters out of range"):
+            device.fieldsplit_tiles_stats(refined.coords, refined.cells, slices, layers)
