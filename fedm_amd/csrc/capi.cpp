@@ -1288,7 +1288,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (const char *e = getenv("FEDM_FS_POLICY")) c.fs_measured_policy = std::string(e) != "counts";
         if (const char *e = getenv("FEDM_FS_LAGGED_COUPLING")) c.fs_lagged_coupling = e[0] != '0';
         if (const char *e = getenv("FEDM_GD_HAND"))
-            if (e[0] == '0' || e[0] == '2' || e[0] == '3') c.gd_hand_mode = e[0] - '0';
+            if (e[0] == '0' || e[0] == '2' || e[0] == '3' || e[0] == '4') c.gd_hand_mode = e[0] - '0';
         if (const char *e = getenv("FEDM_FS_ORDER")) c.fs_upper = std::string(e) == "upper";
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;
@@ -1341,7 +1341,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
                     c.d_tmp, c.d_fs, c.d_fs_g, c.d_V, c.d_partials, c.d_partials_wide, c.d_red, c.d_ext[0], c.d_ext[1], c.d_ext[2],
                     c.d_ext[3], c.d_patch_cell_ptr, c.d_patch_halo_ptr, c.d_patch_halo,
                     c.d_patch_cells, c.d_bfacets, c.d_gd, c.d_gd_fields, c.d_gd_elem, c.d_gd_inv_ptr,
-                    c.d_gd_inv_idx, c.d_gd_elemF, c.d_gd_vinv_ptr, c.d_gd_vinv_idx};
+                    c.d_gd_inv_idx, c.d_gd_elemF, c.d_gd_vinv_ptr, c.d_gd_vinv_idx, c.d_gd_kpos};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (Amg *a : {c.amg, c.amg_alt})

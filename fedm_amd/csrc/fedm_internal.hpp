@@ -120,6 +120,7 @@ struct Ctx {
     double *d_gd_elemF = nullptr;         // element residuals [3 * neq][nc]
     int *d_gd_vinv_ptr = nullptr, *d_gd_vinv_idx = nullptr;   // vertex -> cell * 3 + local vertex
     int gd_hand_mode = 3;                 // gd.hip, launch_assemble_gd
+    uint32_t *d_gd_kpos = nullptr;        // (cell, a, b) -> place in the contributions sorted by matrix position
     GdPrep *gd_prep = nullptr;  // on-device per-step coefficient refresh (LMEA)
     Pattern pat;
     double dt = 1.0, dt_old = 1e30;

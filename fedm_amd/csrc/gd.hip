@@ -898,6 +898,17 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             else unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
         }
         if (STORE == 0) continue;
+        if (STORE == 3) {
+            // element buffer in the order of the DESTINATIONS: [row * NEQ + s][k], k = this (cell, a, b)'s place in the
+            // list of contributions sorted by stored matrix position (`cell_slots` carries that table here): the gather
+            // kernel then reads consecutive addresses for consecutive matrix rows, and these stores, scattered over
+            // the few hundred positions around a workgroup's 64 cells, meet in the L2
+            const size_t n_k = (size_t)9 * n_cells;
+            double *dst = val + (size_t)(row * NEQ) * n_k + cell_slots[(size_t)cidx * 9 + a * 3 + b];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_k] = Jacc[a][s];
+            continue;
+        }
         if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
             double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
 #pragma unroll
@@ -939,6 +950,29 @@ __global__ __launch_bounds__(256) void gd_gather_kernel(int n_pos, const int *__
         if (e / NEQ >= row_first && e / NEQ <= row_last) dst[(size_t)e * SLICE] = acc[e];
 }
 
+// the same for the element buffer in destination order (STORE 3): position p's contributions are the entries
+// [inv_ptr[p], inv_ptr[p + 1]) of every plane -- consecutive positions read consecutive addresses
+template <int NEQ>
+__global__ __launch_bounds__(256) void gd_gather_dest_kernel(int n_pos, const int *__restrict__ inv_ptr,
+                                                             const double *__restrict__ elem, double *__restrict__ val,
+                                                             int row_first, int row_last, int n_cells) {
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pos) return;
+    const size_t n_k = (size_t)9 * n_cells;
+    double acc[NEQ2];
+#pragma unroll
+    for (int e = 0; e < NEQ2; ++e) acc[e] = 0.0;
+    for (int k = inv_ptr[p]; k < inv_ptr[p + 1]; ++k) {
+#pragma unroll
+        for (int e = 0; e < NEQ2; ++e) acc[e] += elem[(size_t)e * n_k + k];
+    }
+    double *dst = val + ((size_t)(p >> 6) * NEQ2) * SLICE + (p & 63);
+#pragma unroll
+    for (int e = 0; e < NEQ2; ++e)
+        if (e / NEQ >= row_first && e / NEQ <= row_last) dst[(size_t)e * SLICE] = acc[e];
+}
+
 // every vertex sums the element residuals of its cells (inverse of the connectivity), fixed order
 template <int NEQ>
 __global__ __launch_bounds__(256) void gd_gather_residual_kernel(int nv, const int *__restrict__ inv_ptr,
@@ -970,6 +1004,8 @@ static int gd_elem_setup(Ctx &c) {
     for (size_t p = 0; p < n_pos; ++p) ptr[p + 1] += ptr[p];
     std::vector<int> fill(ptr.begin(), ptr.end() - 1);
     for (size_t e = 0; e < n_e; ++e) idx[fill[c.pat.cell_slots[e]]++] = (int)e;
+    std::vector<uint32_t> kpos(n_e);   // (cell, a, b) -> its place in that list (the destination-ordered buffer)
+    for (size_t k = 0; k < n_e; ++k) kpos[idx[k]] = (uint32_t)k;
     // vertex -> (cell, local vertex): read back from the device copy of the connectivity
     std::vector<int> cells_h((size_t)c.nc * 3), vptr((size_t)c.nv + 1, 0), vidx((size_t)c.nc * 3);
     if (hipMemcpy(cells_h.data(), c.d_cells, sizeof(int) * cells_h.size(), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -988,6 +1024,8 @@ static int gd_elem_setup(Ctx &c) {
         hipMemcpy(c.d_gd_vinv_ptr, vptr.data(), sizeof(int) * vptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c.d_gd_vinv_idx, vidx.data(), sizeof(int) * vidx.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c.d_gd_elemF, 0, sizeof(double) * (size_t)c.nc * 3 * c.neq) != hipSuccess ||
+        hipMalloc((void **)&c.d_gd_kpos, sizeof(uint32_t) * kpos.size()) != hipSuccess ||
+        hipMemcpy(c.d_gd_kpos, kpos.data(), sizeof(uint32_t) * kpos.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void **)&c.d_gd_inv_ptr, sizeof(int) * ptr.size()) != hipSuccess ||
         hipMalloc((void **)&c.d_gd_inv_idx, sizeof(int) * idx.size()) != hipSuccess ||
         hipMalloc((void **)&c.d_gd_elem, sizeof(double) * n_e * c.neq * c.neq) != hipSuccess ||
@@ -996,8 +1034,9 @@ static int gd_elem_setup(Ctx &c) {
         hipMemset(c.d_gd_elem, 0, sizeof(double) * n_e * c.neq * c.neq) != hipSuccess) {
         hipGetLastError();
         for (void *q : {(void *)c.d_gd_inv_ptr, (void *)c.d_gd_inv_idx, (void *)c.d_gd_elem, (void *)c.d_gd_vinv_ptr,
-                        (void *)c.d_gd_vinv_idx, (void *)c.d_gd_elemF})
+                        (void *)c.d_gd_vinv_idx, (void *)c.d_gd_elemF, (void *)c.d_gd_kpos})
             if (q) hipFree(q);
+        c.d_gd_kpos = nullptr;
         c.d_gd_inv_ptr = c.d_gd_inv_idx = c.d_gd_vinv_ptr = c.d_gd_vinv_idx = nullptr;
         c.d_gd_elem = c.d_gd_elemF = nullptr;
         return -1;   // the caller falls back to the atomics
@@ -1010,12 +1049,13 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
     const int ncol = (int)c.pat.colour_ptr.size() - 1;
     // Ctx::gd_hand_mode (FEDM_GD_HAND when the context is created): 0 = dual numbers, a launch per
     // colour (the cross-check of the hand-derived blocks), 2 = hand-derived blocks, fp64 atomics into the
-    // matrix, 3 (default) = hand-derived blocks, element buffer + gather
+    // matrix, 3 (default) = hand-derived blocks, element buffer in destination order + gather, 4 = the buffer in cell order
     const int hand_mode = c.gd_hand_mode;
     if (jacobian && hand_mode >= 2) {
         // in Poisson-only mode the other rows keep the zeros of the memset (identity rows follow)
         const int n = c.nc;
-        const bool gather = hand_mode == 3 && gd_elem_setup(c) == 0;
+        const bool gather = hand_mode >= 3 && gd_elem_setup(c) == 0;
+        const bool dest_order = hand_mode == 3;   // (4: the buffer in cell order, round 2's layout)
         if (!gather || mode != 0)   // (the gather writes every value of the rows it covers)
             hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * c.neq * c.neq, c.stream);
         const int cpb = SLICE, nf = c.gd_n_fields;
@@ -1032,6 +1072,8 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
     do {                                                                                                          \
         static bool lds_attr_set = false;   /* per instantiation: a property of these kernels */            \
         if (lds_h > 64 * 1024 && !lds_attr_set) {   /* more dynamic LDS than the default limit */               \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 2, NRC, NQC>),                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 1, NRC, NQC>),                 \
@@ -1040,7 +1082,15 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                          \
             lds_attr_set = true;                                                                                  \
         }                                                                                                         \
-        if (gather) {                                                                                             \
+        if (gather && dest_order) {                                                                               \
+            hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
+                               c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_gd_kpos,      \
+                               c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \
+            hipLaunchKernelGGL((gd_gather_dest_kernel<NEQ>), dim3((n_pos + 255) / 256), dim3(256), 0, c.stream, n_pos, \
+                               c.d_gd_inv_ptr, c.d_gd_elem, c.d_val, row_first, row_last, n);                     \
+            hipLaunchKernelGGL((gd_gather_residual_kernel<NEQ>), dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, \
+                               c.nv, c.d_gd_vinv_ptr, c.d_gd_vinv_idx, c.d_gd_elemF, c.d_F, row_first, n);        \
+        } else if (gather) {                                                                                      \
             hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 2, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_cell_slots,   \
                                c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \

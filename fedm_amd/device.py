@@ -12,6 +12,7 @@ DOLFIN's ``error_on_nonconvergence`` would, so ``adaptive_solver``'s catch-all
 retry (fedm/functions.py:1080) keeps working.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -381,6 +382,14 @@ class DeviceProblem:
         self._dvals = np.ascontiguousarray(dirichlet_vals, dtype=np.float64)
         self._coords_dev = np.ascontiguousarray(self.coords[self._order])
         self._cells_dev = np.ascontiguousarray(self._inv[self.cells], dtype=np.int32)
+        if isinstance(model, GdModel) and reorder and os.environ.get("FEDM_GD_CELL_ORDER", "1") != "0":
+            # LMEA: the element kernels take 64 consecutive cells a workgroup and the gather kernel reads, for
+            # consecutive matrix rows, the blocks of the cells around them -- cells in the order of their vertices
+            # (nothing the caller passes or gets back is indexed by cell besides the facet tags)
+            by_vertex = np.argsort(self._cells_dev.min(axis=1), kind="stable")
+            self._cells_dev = np.ascontiguousarray(self._cells_dev[by_vertex])
+            if self._tags is not None:
+                self._tags = np.ascontiguousarray(self._tags.reshape(self.nc, 3)[by_vertex])
         md = model.to_c()
         mesh = _lib.MeshDesc()
         mesh.n_vertices, mesh.n_cells = self.nv, self.nc

@@ -234,7 +234,7 @@ def test_lmea_kernels_on_an_unstructured_mesh(monkeypatch):
     size = meshgen.box_distance_size((0.0, 0.01, 0.0, 0.0015), 1.0e-4, 0.3, 1.2e-3)
     msh = meshgen.refined_rectangle(0.01, 0.01, size, 1.0e-4, n_levels=5)
     assert 2000 < msh.num_vertices() < 20000
-    for variant in ("3", "2", "0"):
+    for variant in ("3", "4", "2", "0"):
         monkeypatch.setenv("FEDM_GD_HAND", variant)
         case = gdc.Case(device_pipeline=False, mesh=msh)
         o = ogd.GlowDischarge(deck, mesh=OMesh(msh.coords, msh.cells))
