@@ -5,10 +5,19 @@
 adaptive BDF2 time step of examples/streamer_discharge/fedm-streamer.py:304-340
 (shift states, Newton solve with F/J assembly and GMRES, error norm, step
 controller) on the state resident in HBM.  Workload at N = 1 (BASELINE.json configs[3]):
-2-D axisymmetric streamer, 576x576 "right" mesh graded towards the axis
-(332 929 vertices x 3 equations = 998 787 DOFs); N > 1: the same mesh size PER GPU (weak
-scaling), plus -- at N = 8 -- a second record on BASELINE configs[4] (1152x1152, ~4 M DOFs).
+2-D axisymmetric streamer on the mesh KIND the reference's case runs on (fedm-streamer.py:116,
+Mesh('mesh.xml')): a locally refined unstructured mesh, 4 um in the streamer channel, written to
+and read back from DOLFIN XML (341 280 vertices x 3 equations = 1 023 840 DOFs); N > 1: the same
+mesh family with N times the vertices (spacing / sqrt(N): weak scaling), plus -- at N = 8 -- a
+second record on BASELINE configs[4] (1152x1152 tensor-product mesh, ~4 M DOFs, strong scaling).
+`--family tensor` puts the headline on round 1-3's 576x576 graded tensor-product mesh instead.
 Prints ONE JSON line (rank 0).
+
+The timed region: W warm-up steps, a checkpoint of the time loop on the device
+(fedm_state_snapshot), >= 0.3 s of real stepping from it (clocks up, graphs captured), then the
+window of EXACTLY K steps between two barriers R times, each from the checkpoint (the restore is
+untimed).  ``ms_per_step`` is the MEDIAN window; the first window, the spread and the per-step
+spans of the median window are in ``windows``.
 
 Records in the line, besides the driver's contract:
 * ``roofline`` / ``roofline_other`` / ``assembly_plus_spmv``: HIP-event timings of the hot kernels
@@ -16,9 +25,8 @@ Records in the line, besides the driver's contract:
 * ``late_window``: the same K steps timed again from the developed streamer (step 200, t ~ 1 ns),
   where a step needs several times the Krylov iterations of the first steps;
 * ``multi_gpu`` (N > 1): transport, ranks, halo exchanges / all-reduces per step and their latency;
-* ``unstructured`` (N = 1): the same K steps on the locally refined UNSTRUCTURED mesh (Delaunay, written
-  to and read back from DOLFIN XML like the reference's ``Mesh('mesh.xml')``, ~1 M DOFs) with its own
-  roofline block -- the mesh kind the reference's streamer case runs on;
+* ``tensor_mesh`` (N = 1): the same K steps on the 576x576 graded tensor-product mesh (998 787 DOFs: the
+  headline of rounds 1-3) with its own roofline blocks;
 * ``roofline_beyond_infinity_cache`` (N = 1): assembly and SpMV fractions on the 1152x1152 mesh (4 M
   DOFs, Jacobian 670 MB > the 256 MiB Infinity Cache): rates that cannot come from the last-level cache;
 * ``glow_discharge`` (N = 1): BASELINE configs[2] (LMEA, 141x141 crossed, 200 225 DOFs) with the roofline
@@ -43,7 +51,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md, chip-level parameters (spec)
-PMC_PROFILE = ROOT / "profiles" / "r03_pmc_traffic.json"
+PMC_PROFILE = ROOT / "profiles" / "r04_pmc_traffic.json"
 
 
 def library_ready():
@@ -61,7 +69,7 @@ def library_ready():
                          "(python3 -c 'import __graft_entry__ as g; g.build()')")
     entry.build()
     return entry
-KERNEL_SOURCES = ["kernels.hip", "element.hpp", "element_lean.hpp", "prep.cpp", "fedm_internal.hpp"]
+KERNEL_SOURCES = ["kernels.hip", "assemble3.hip", "element.hpp", "element_lean.hpp", "prep.cpp", "fedm_internal.hpp"]
 
 
 def parse_args():
@@ -69,7 +77,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mesh", type=int, default=576, help="cells per side (per GPU)")
+    ap.add_argument("--family", choices=["unstructured", "tensor"], default="unstructured",
+                    help="mesh family of the headline: the locally refined unstructured mesh (the kind the "
+                         "reference's case loads) or the graded tensor-product mesh of rounds 1-3")
+    ap.add_argument("--repeats", type=int, default=7, help="timed windows of K steps, each from the same checkpoint")
+    ap.add_argument("--preroll", type=float, default=0.3, help="seconds of untimed stepping before the first window")
+    ap.add_argument("--mesh", type=int, default=576, help="tensor-product meshes: cells per side (per GPU)")
     ap.add_argument("--grading", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=int, default=None, help="CPU baseline mesh (default: --mesh)")
@@ -80,8 +93,8 @@ def parse_args():
     ap.add_argument("--configs4", choices=["auto", "on", "off"], default="auto",
                     help="second record on the ~4 M-DOF mesh of BASELINE configs[4] (auto: at 8 GPUs)")
     ap.add_argument("--configs4-mesh", type=int, default=1152, help="global cells per side of that record")
-    ap.add_argument("--unstructured", choices=["auto", "on", "off"], default="auto",
-                    help="second record on the locally refined unstructured mesh (auto: on one GPU)")
+    ap.add_argument("--second-mesh", choices=["auto", "on", "off"], default="auto",
+                    help="second record on the other mesh family (auto: on one GPU)")
     ap.add_argument("--mesh-spacing", type=float, default=4e-6,
                     help="finest spacing of that mesh [m] (4e-6: 341 280 vertices, 1 023 840 DOFs)")
     ap.add_argument("--big-mesh", type=int, default=1152,
@@ -129,10 +142,10 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the committed PMC passes of this same workload
-    (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied).  {} when the profile is absent or was
-    measured on other kernel sources."""
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed PMC passes of this same workload ("unstructured" /
+    "tensor": the profile holds one block per mesh family; 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction
+    applied).  {} when the profile is absent or was measured on other kernel sources."""
     if not PMC_PROFILE.exists():
         return {}, "no committed PMC profile"
     prof = json.loads(PMC_PROFILE.read_text())
@@ -140,8 +153,11 @@ def pmc_traffic():
     if prof.get("kernel_source_sha") != sha:
         return {}, (f"{PMC_PROFILE.name} was measured on kernel sources {prof.get('kernel_source_sha')}, "
                     f"this run uses {sha}: traffic dropped")
-    out = {n: v["traffic_bytes_corrected"] for n, v in prof["kernels"].items() if "traffic_bytes_corrected" in v}
-    return out, f"{PMC_PROFILE.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, kernel sources {sha})"
+    block = prof.get("workloads", {}).get(workload)
+    if block is None:
+        return {}, f"{PMC_PROFILE.name} has no pass on the {workload} mesh"
+    out = {n: v["traffic_bytes_corrected"] for n, v in block["kernels"].items() if "traffic_bytes_corrected" in v}
+    return out, f"{PMC_PROFILE.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this mesh, kernel sources {sha})"
 
 
 def pick(tr, *needles):
@@ -163,12 +179,18 @@ def measured_copy_ceiling(device_index):
     return gbs.value if rc == 0 else None
 
 
-def cpu_baseline(n, grading, steps, threads):
+def cpu_baseline(mesh, steps, threads, label):
     """oracle/cpu_backend (C + OpenMP: coloured element loop -> block CSR -> Newton -> flexible
     GMRES with the same field split, Chebyshev sweeps and multigrid V-cycle as the device path),
-    'CPU restatement, not FEniCS', on the same mesh, timed on this box's host cores."""
+    'CPU restatement, not FEniCS', on the SAME mesh as the headline, timed on this box's host cores."""
     from oracle import cpu_backend
-    return cpu_backend.bench(n, grading, steps, threads)
+    from fedm_amd.device import locality_order
+    # the vertex order the device path gives itself (compact slices of 64): the CPU's caches profit alike
+    order = locality_order(mesh.coords, mesh.cells)
+    inv = np.empty(order.size, dtype=np.int64)
+    inv[order] = np.arange(order.size)
+    return cpu_backend.bench_mesh(mesh.coords[order], inv[mesh.cells].astype(np.int32), steps, threads,
+                                  label + "; vertices in the device path's locality order")
 
 
 def pin_to_gpu_numa_node(torch, local_rank):
@@ -200,13 +222,15 @@ def pin_to_gpu_numa_node(torch, local_rank):
 
 def timed_steps(runner, steps, barrier, torch, dist, distributed):
     """K steps between two barriers; wall time is the MAX over ranks.  Returns (seconds, Newton
-    iterations, GMRES iterations, assembly profile)."""
+    iterations, GMRES iterations, assembly profile, per-step spans in ms on this rank)."""
     runner.profile(1)             # HIP events around the assembly kernels, on the library's stream
     barrier()
     t0 = time.perf_counter()
     n0 = (runner.newton_iterations, runner.linear_iterations)
+    marks = [t0]
     for _ in range(steps):
-        runner.step()
+        runner.step()             # (returns once the step's last norm has reached the host)
+        marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
     n1 = (runner.newton_iterations, runner.linear_iterations)
@@ -216,7 +240,49 @@ def timed_steps(runner, steps, barrier, torch, dist, distributed):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    return elapsed, n1[0] - n0[0], n1[1] - n0[1], prof
+    spans = [1e3 * (b - a) for a, b in zip(marks[:-1], marks[1:])]
+    return elapsed, n1[0] - n0[0], n1[1] - n0[1], prof, spans
+
+
+def timed_windows(runner, steps, repeats, preroll_s, barrier, torch, dist, distributed):
+    """The contract's window -- EXACTLY `steps` steps between two barriers -- `repeats` times from ONE
+    checkpoint of the time loop (device-side copy of the three states + the script's scalars; the restore
+    is outside the timed region), after `preroll_s` seconds of untimed stepping from the same checkpoint
+    (clock ramp, graph capture, first-touch effects: the first 31-ms window of round 3's driver run was 20 %
+    slower than the same window on a warm chip).  Returns the MEDIAN window's record plus the spread; the
+    runner is left at the end of the last window."""
+    snap = runner.snapshot()
+    # pre-roll: whole windows, their number agreed between the ranks
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step()
+    first = time.perf_counter() - t0
+    extra = int(min(20, max(0, np.ceil(preroll_s / max(first, 1e-4)) - 1)))
+    if distributed:
+        e = torch.tensor([float(extra)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        extra = int(e.item())
+    for _ in range(extra):
+        runner.restore(snap)
+        for _ in range(steps):
+            runner.step()
+    windows = []
+    prof_sum = None
+    for r in range(max(1, repeats)):
+        runner.restore(snap)
+        el, nw, gm, prof, spans = timed_steps(runner, steps, barrier, torch, dist, distributed)
+        windows.append(dict(elapsed=el, newton=nw, gmres=gm, spans=spans))
+        prof_sum = prof if prof_sum is None else {k: (prof_sum[k][0] + v[0], prof_sum[k][1] + v[1]) for k, v in prof.items()}
+    order = sorted(range(len(windows)), key=lambda i: windows[i]["elapsed"])
+    med = windows[order[len(order) // 2]]
+    ms = [1e3 * w["elapsed"] / steps for w in windows]
+    record = {"repeats": len(windows), "window_ms_per_step": ms, "window_ms_min": min(ms), "window_ms_max": max(ms),
+              "window_spread": (max(ms) - min(ms)) / min(ms), "first_window_ms_per_step": ms[0],
+              "median_window_step_spans_ms": med["spans"], "preroll_windows": 1 + extra,
+              "preroll": f"{1 + extra} untimed windows of {steps} steps from the checkpoint before the first timed one",
+              "how": "every window restarts from the same device-side checkpoint taken after the warm-up steps "
+                     "(fedm_state_snapshot / fedm_state_restore, untimed); ms_per_step and value are the median window's"}
+    return med["elapsed"], med["newton"], med["gmres"], prof_sum, len(windows), record
 
 
 def main():
@@ -256,35 +322,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_runner(n_per_gpu=None, global_n=None):
+    def refined(spacing):
+        """The locally refined unstructured mesh through DOLFIN XML (every rank generates the same one)."""
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="fedm_mesh_") as tmp:
+            return streamer.refined_mesh(spacing, growth=0.1, xml_path=Path(tmp) / "mesh.xml",
+                                         channel=(0.0, 100.0 * spacing) + streamer.CHANNEL[2:])
+
+    def check_transport(r):
+        if r.transport != "rccl" and not (args.allow_fallback or args.rehearse_on_one_gpu):
+            if rank == 0:
+                print(json.dumps({"error": "RCCL transport unavailable", "reason": r.fallback_reason,
+                                  "hint": "--allow-fallback times the host-staged (gloo) transport instead"}))
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        return r
+
+    def make_runner(family, n_per_gpu=None, global_n=None, spacing=None):
+        """(runner, mesh or None, seconds spent generating the mesh)"""
+        t_m = time.perf_counter()
+        if family == "unstructured":
+            msh = refined(spacing)
+            t_mesh = time.perf_counter() - t_m
+            if distributed:
+                from fedm_amd.cases import streamer_distributed
+                r = streamer_distributed.Runner(None, rank, world, local_rank, mesh=msh,
+                                                transport="torch" if args.rehearse_on_one_gpu else "rccl")
+                return check_transport(r), msh, t_mesh
+            return streamer.Stepper(streamer.device_problem(msh.coords, msh.cells, device=local_rank)), msh, t_mesh
         if distributed:
             from fedm_amd.cases import streamer_distributed
             r = streamer_distributed.Runner(None, rank, world, local_rank, args.grading,
-                                            n_per_gpu=n_per_gpu, global_n=global_n)
-            if r.transport != "rccl" and not (args.allow_fallback or args.rehearse_on_one_gpu):
-                if rank == 0:
-                    print(json.dumps({"error": "RCCL transport unavailable", "reason": r.fallback_reason,
-                                      "hint": "--allow-fallback times the host-staged (gloo) transport instead"}))
-                dist.destroy_process_group()
-                raise SystemExit(3)
-            return r
+                                            n_per_gpu=n_per_gpu, global_n=global_n,
+                                            transport="torch" if args.rehearse_on_one_gpu else "rccl")
+            return check_transport(r), None, 0.0
         msh = streamer.mesh(n_per_gpu, args.grading)
-        return streamer.Stepper(streamer.device_problem(msh.coords, msh.cells, device=local_rank))
+        return streamer.Stepper(streamer.device_problem(msh.coords, msh.cells, device=local_rank)), msh, 0.0
 
     copy_gbs = measured_copy_ceiling(local_rank) if rank == 0 else None
 
-    def hot_path(runner, steps, warmup, tr, tr_source):
-        """W warm-up steps, K timed steps (HIP events around the assembly kernels, on the library's stream),
-        then a second, untimed pass with plain launches for the kernels inside the Krylov iterations
-        (events cannot sit inside the replayed per-iteration graphs).  Returns the record pieces."""
+    def hot_path(runner, steps, warmup, tr, tr_source, repeats):
+        """W warm-up steps, the window of K timed steps `repeats` times from one checkpoint (HIP events around
+        the assembly kernels, on the library's stream), then a second, untimed pass with plain launches for the
+        kernels inside the Krylov iterations (events cannot sit inside the replayed per-iteration graphs).
+        Returns the record pieces."""
         for _ in range(warmup):
             runner.step()
         before = runner.prob.comm_stats() if distributed else None
-        elapsed, newton, gmres, prof = timed_steps(runner, steps, barrier, torch, dist, distributed)
+        elapsed, newton, gmres, prof, n_win, windows = timed_windows(runner, steps, repeats, args.preroll, barrier,
+                                                                    torch, dist, distributed)
+        prof_steps = steps * n_win           # the assembly events cover every timed window
         comm0 = runner.prob.comm_stats() if distributed else None
-        if distributed:      # what travelled INSIDE the timed region (set-up and warm-up apart)
-            for key in ("halo_exchanges", "allreduces"):
-                comm0[key + "_timed"] = comm0[key] - before[key]
+        if distributed:      # what travelled inside ONE timed window (set-up, warm-up and pre-roll apart)
+            for key in ("halo_exchanges", "allreduces", "allreduce_bytes", "halo_bytes"):
+                if key in comm0:
+                    comm0[key + "_timed"] = (comm0[key] - before[key]) / (n_win + windows["preroll_windows"])
         pass_steps = max(1, min(steps, 5))
         runner.profile(2)
         barrier()
@@ -296,26 +388,30 @@ def main():
         prof2 = runner.profile_read()
         runner.profile(False)
         sz = runner.sizes()
-        # average launch duration of the hot kernels inside the timed region
+        # average launch duration of the hot kernels inside the timed windows
         ms_asm = prof["assembly_FJ"][0] / max(prof["assembly_FJ"][1], 1)
         ms_spmv = prof2["spmv"][0] / max(prof2["spmv"][1], 1)
         ms_res = prof["assembly_F"][0] / max(prof["assembly_F"][1], 1)
         b_spmv, b_asm, b_res = spmv_bytes(sz), assembly_bytes(sz), residual_bytes(sz)
         gbs_spmv = b_spmv / (ms_spmv * 1e-3) / 1e9
         gbs_asm = b_asm / (ms_asm * 1e-3) / 1e9
-        share = {k: v[0] / (elapsed * 1e3) for k, v in prof.items()}
+        share = {k: v[0] / (elapsed * n_win * 1e3) for k, v in prof.items()}
         share2 = {k: v[0] / (elapsed2 * 1e3) for k, v in prof2.items()}
         second_pass = (f"separate profiling pass of {pass_steps} steps right after the timed region, "
                        f"kernels launched one by one ({1e3 * elapsed2 / pass_steps:.2f} ms/step)")
 
         def moved(traffic, ms):          # HBM bytes the counters saw, over the kernel's time
             return traffic / (ms * 1e-3) / 1e9 if traffic and ms else None
+
+        def below_ceiling(gbs):          # fraction of the box's own copy rate; a "ceiling" a kernel exceeds is noise
+            return gbs / copy_gbs if copy_gbs and gbs <= copy_gbs else None
         t_spmv = pick(tr, "fedm::spmv_kernel<3, false", "fedm::spmv_kernel<3,false")
-        t_asm = pick(tr, "assemble_lean2", "assemble_patch")
+        t_asm = pick(tr, "assemble_lean3", "assemble_lean2", "assemble_patch")
+        t_res = pick(tr, "residual_lean3", "residual_lean2", "residual_patch")
         rl_spmv = {"bound": "hbm", "kernel": "spmv_kernel<3,false,ZMASK> (Jacobian SpMV, sliced block-ELL; structurally zero value planes not loaded)",
                    "achieved": gbs_spmv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": gbs_spmv / HBM_PEAK_GBS,
-                   "frac_of_measured_copy": gbs_spmv / copy_gbs if copy_gbs else None,
+                   "frac_of_measured_copy": below_ceiling(gbs_spmv),
                    "traffic": t_spmv, "achieved_traffic_GBs": moved(t_spmv, ms_spmv),
                    "algorithmic_bytes": b_spmv,
                    # SURVEY 8(d) counts every structural block whole; the kernel does not load value
@@ -327,7 +423,7 @@ def main():
                                          "spmv_dots_kernel<3,ZMASK,K>: the wave that has formed a slice's rows also "
                                          "multiplies them with the K-1 basis vectors (the step's dot products; w is not "
                                          "read back) -- 1-3 us longer than the plain product timed here, see "
-                                         "profiles/r03_kernel_stats.csv"),
+                                         "profiles/r04_kernel_stats.csv"),
                    "infinity_cache_note": ("the Jacobian of this mesh (%.0f MB) fits the 256 MiB Infinity Cache and the "
                                            "counters include its hits: the cache-free rates are in "
                                            "'roofline_beyond_infinity_cache'" % (sz["stored_blocks"] * 72 / 1e6))
@@ -336,7 +432,7 @@ def main():
         rl_asm = {"bound": "hbm", "kernel": runner.assembly_kernel_name,
                   "achieved": gbs_asm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": gbs_asm / HBM_PEAK_GBS,
-                  "frac_of_measured_copy": gbs_asm / copy_gbs if copy_gbs else None,
+                  "frac_of_measured_copy": below_ceiling(gbs_asm),
                   "traffic": t_asm, "achieved_traffic_GBs": moved(t_asm, ms_asm),
                   "traffic_source": tr_source, "algorithmic_bytes": b_asm,
                   # ... and the assembly neither recomputes nor rewrites planes that cannot change
@@ -345,6 +441,7 @@ def main():
                   "ms_per_launch": ms_asm, "launches": prof["assembly_FJ"][1],
                   "ms_residual_only": ms_res, "residual_only_algorithmic_bytes": b_res,
                   "residual_only_frac": b_res / (ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_res else None,
+                  "residual_only_traffic": t_res,
                   "share_of_timed_region": share["assembly_FJ"]}
 
         # BASELINE.json's target is quoted on the assembly + SpMV path together: algorithmic bytes of
@@ -363,23 +460,58 @@ def main():
                     "residual_only_assemblies_per_step": n_res, "spmv_per_step": n_spmv,
                     "algorithmic_bytes_per_step": path_bytes, "kernel_ms_per_step": path_ms,
                     "measured_copy_ceiling_GBs": copy_gbs,
-                    "frac_of_measured_copy": (path_gbs / copy_gbs) if copy_gbs else None}
+                    "frac_of_measured_copy": below_ceiling(path_gbs)}
         vcycle = {"ms_per_cycle": prof2["vcycle"][0] / max(prof2["vcycle"][1], 1),
                   "cycles": prof2["vcycle"][1], "share_of_profiling_pass": share2["vcycle"],
                   "levels": runner.multigrid_levels, "measured": second_pass}
         return dict(elapsed=elapsed, newton=newton, gmres=gmres, prof=prof, sz=sz, comm0=comm0, rl_asm=rl_asm,
-                    rl_spmv=rl_spmv, path=path_record(prof, gmres, steps), path_record=path_record, vcycle=vcycle)
+                    rl_spmv=rl_spmv, path=path_record(prof, gmres * n_win, prof_steps), path_record=path_record,
+                    vcycle=vcycle, windows=windows)
 
+    def late_window(runner, hp, steps):
+        """The developed streamer: the same K steps from step `late_start` on (one window: every step there
+        is a different system)."""
+        while runner.steps < args.late_start:
+            runner.step()
+        t_late = runner.t
+        l_elapsed, l_newton, l_gmres, l_prof, _ = timed_steps(runner, steps, barrier, torch, dist, distributed)
+        return {"what": f"{steps} accepted steps timed the same way from step {args.late_start + 1} on "
+                        f"(t = {t_late:.3e} s: the streamer has formed and propagates)",
+                "value": runner.total_dofs * steps / l_elapsed, "unit": "DOF-updates/s",
+                "timesteps_per_sec": steps / l_elapsed, "ms_per_step": 1e3 * l_elapsed / steps,
+                "newton_iterations_per_step": l_newton / steps,
+                "gmres_iterations_per_step": l_gmres / steps,
+                "assembly_plus_spmv": hp["path_record"](l_prof, l_gmres, steps)}
+
+    def pattern_of(sz):
+        return {"stored_blocks_over_nnz_blocks": sz["stored_blocks"] / sz["nnz_blocks"],
+                "max_block_columns_per_slice": sz["max_patch_width"],
+                "max_cells_per_patch": sz["max_patch_cells"], "max_staged_vertices_per_patch": sz["max_patch_verts"],
+                "cell_visits_over_cells": sz["cell_visits"] / sz["n_cells"],
+                "patch_workgroup_threads": sz["patch_threads"], "assembly_variant": sz["assembly_variant"]}
+
+    def mesh_text(family, n, spacing):
+        if family == "unstructured":
+            return (f"locally refined unstructured mesh: Delaunay triangulation of nested hexagonal lattices, spacing "
+                    f"{spacing:g} m in the streamer channel (r < {100.0 * spacing:g} m), growing 0.1 per unit distance "
+                    "outside; written to DOLFIN XML and read back through the mesh reader (the way of the reference's "
+                    "Mesh('mesh.xml'), fedm-streamer.py:116); vertices ordered by recursive bisection in the metric of "
+                    "the local spacing (device.locality_order)")
+        return f"{n}x{n} right-diagonal tensor-product mesh, geometric grading {args.grading} towards the axis"
+
+    # ---- the headline: K steps right after the warm-up (SURVEY 8(d)'s window) -----------------------
+    family = args.family
     n = args.mesh
+    spacing = args.mesh_spacing / np.sqrt(world)          # weak scaling: N times the vertices
     t_setup = time.perf_counter()
-    runner = make_runner(n_per_gpu=n)
+    runner, hmesh, t_mesh = make_runner(family, n_per_gpu=n, spacing=spacing)
     runner.initialise()
-    setup_s = time.perf_counter() - t_setup
-    tr, tr_source = pmc_traffic() if (world == 1 and n == 576) else ({}, "not the profiled workload")
-    # ---- the timed region: K steps right after the warm-up (SURVEY 8(d)'s window) -------------
-    hp = hot_path(runner, args.steps, args.warmup, tr, tr_source)
+    setup_s = time.perf_counter() - t_setup - t_mesh
+    profiled = world == 1 and ((family == "unstructured" and args.mesh_spacing == 4e-6) or (family == "tensor" and n == 576))
+    tr, tr_source = pmc_traffic(family) if profiled else ({}, "not a profiled workload")
+    hp = hot_path(runner, args.steps, args.warmup, tr, tr_source, args.repeats)
     elapsed, newton, gmres, sz, comm0 = hp["elapsed"], hp["newton"], hp["gmres"], hp["sz"], hp["comm0"]
-    rl_asm, rl_spmv, path_record = hp["rl_asm"], hp["rl_spmv"], hp["path_record"]
+    rl_asm, rl_spmv = hp["rl_asm"], hp["rl_spmv"]
     total_dofs = runner.total_dofs
 
     gmres_text = ("flexible, restart 30, rtol 1e-5 on the true residual, right-preconditioned: field split, "
@@ -391,6 +523,8 @@ def main():
         tiles = runner.prob.fieldsplit_tiles()
     except Exception:
         tiles = None
+    weak = "" if world == 1 else (f"; weak scaling: the mesh family at {world} x the vertices (spacing / sqrt({world}))"
+                                  if family == "unstructured" else f"; weak scaling: {n}x{n} cells per GPU")
     out = {
         "metric": "BDF2 DOF-updates/sec (streamer_discharge 2D axisym)",
         "value": total_dofs * args.steps / elapsed,
@@ -401,18 +535,20 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "streamer_discharge 2D axisymmetric, LFA, 3 equations "
-                               "(ions, electrons, Poisson), analytic Bagheri-2018 seed"
-                               + ("" if world == 1 else f"; weak scaling: {n}x{n} cells per GPU"),
-                   "baseline_config": "configs[3] (~1M DOFs, 1 GPU)" if world == 1 and n == 576 else
+                               "(ions, electrons, Poisson), analytic Bagheri-2018 seed, on a "
+                               + ("locally refined unstructured mesh (the reference's mesh kind)" if family == "unstructured"
+                                  else "graded tensor-product mesh") + weak,
+                   "baseline_config": "configs[3] (~1M DOFs, 1 GPU)" if world == 1 else
                                       f"configs[3]'s mesh size per GPU x {world} GPUs (configs[4] itself: see 'configs4')",
-                   "mesh": f"{n}x{n} right-diagonal, geometric grading {args.grading} towards "
-                           f"the axis, per GPU",
-                   "dofs_total": total_dofs, "vertices_per_gpu": sz["n_vertices"],
+                   "mesh": mesh_text(family, n, spacing),
+                   "dofs_total": total_dofs, "vertices_per_gpu": sz["n_vertices"], "cells_per_gpu": sz["n_cells"],
                    "dt_max": 5e-12, "newton_rtol": 1e-4, "gmres": gmres_text, "fieldsplit_tiles": tiles,
                    "partition": runner.partition_name, "host_placement": placement,
-                   "setup_seconds": setup_s},
+                   "pattern": pattern_of(sz),
+                   "mesh_seconds": t_mesh, "setup_seconds": setup_s},
         "window": f"steps {args.warmup + 1}..{args.warmup + args.steps} from the initial condition "
-                  "(SURVEY 8(d)); the developed streamer is 'late_window'",
+                  "(SURVEY 8(d)), repeated from a checkpoint: 'windows'; the developed streamer is 'late_window'",
+        "windows": hp["windows"],
         "newton_iterations_per_step": newton / args.steps,
         "gmres_iterations_per_step": gmres / args.steps,
         "roofline": rl_asm,
@@ -420,72 +556,68 @@ def main():
         "assembly_plus_spmv": hp["path"],
         "vcycle": hp["vcycle"],
         "measured_copy_ceiling_GBs": copy_gbs,
-        "copy_ceiling_how": "fedm_copy_bandwidth: 16-byte-per-lane grid-stride copy kernel, 2 x 1 GiB, HIP events",
+        "copy_ceiling_how": "fedm_copy_bandwidth: the fastest of six 16-byte-per-lane copy kernels (1-8 loads in flight per "
+                            "lane, plain / non-temporal), 2 x 1 GiB, HIP events",
+        "run_to_reference_end_time": ("profiles/r03_refined_run_*.json: this mesh carries the streamer to the reference's "
+                                      "T_final = 1.4e-8 s (2801 accepted steps, none rejected)") if family == "unstructured" else None,
     }
-
-    # ---- the developed streamer: the same K steps from step `late_start` on ---------------------
     if args.late_start > 0:
-        while runner.steps < args.late_start:
-            runner.step()
-        t_late = runner.t
-        l_elapsed, l_newton, l_gmres, l_prof = timed_steps(runner, args.steps, barrier, torch, dist, distributed)
-        out["late_window"] = {
-            "what": f"{args.steps} accepted steps timed the same way from step {args.late_start + 1} on "
-                    f"(t = {t_late:.3e} s: the streamer has formed and propagates)",
-            "value": total_dofs * args.steps / l_elapsed, "unit": "DOF-updates/s",
-            "timesteps_per_sec": args.steps / l_elapsed, "ms_per_step": 1e3 * l_elapsed / args.steps,
-            "newton_iterations_per_step": l_newton / args.steps,
-            "gmres_iterations_per_step": l_gmres / args.steps,
-            "assembly_plus_spmv": path_record(l_prof, l_gmres, args.steps)}
-        out["sustained_timesteps_per_sec"] = args.steps / l_elapsed
+        out["late_window"] = late_window(runner, hp, args.steps)
+        out["sustained_timesteps_per_sec"] = out["late_window"]["timesteps_per_sec"]
 
-    # ---- the same K steps on the locally refined UNSTRUCTURED mesh (what the reference's case runs on) ----
-    if world == 1 and args.unstructured != "off":
-        import tempfile
+    # ---- multi-GPU plumbing: what travelled, and what one exchange / reduction costs ------------
+    if distributed:
+        cs = comm0
+        lat = {}
+        for name, kind in (("halo_state_us", 0), ("halo_scalar_us", 1), ("allreduce_32_doubles_us", 2)):
+            barrier()
+            lat[name] = 1e3 * runner.prob.time_comm(kind, 50)
+        per_step = lambda key: cs[key + "_timed"] / args.steps if key + "_timed" in cs else None    # noqa: E731
+        out["multi_gpu"] = {
+            "transport": runner.transport, "transport_requested": runner.transport_requested,
+            "ranks_in_communicator": cs["ranks"], "neighbours_rank0": cs["neighbours"],
+            "halo_exchanges_per_step": per_step("halo_exchanges"),
+            "allreduces_per_step": per_step("allreduces"),
+            "halo_bytes_per_step": per_step("halo_bytes"),
+            "allreduce_bytes_per_step": per_step("allreduce_bytes"),
+            "halo_exchanges_per_krylov_step": cs["halo_exchanges_timed"] / max(gmres, 1),
+            "allreduces_per_krylov_step": cs["allreduces_timed"] / max(gmres, 1),
+            "halo_depth": getattr(runner, "halo_depth", 1),
+            "counting": "collectives of rank 0 per timed window (the initial Poisson solve and the warm-up apart); "
+                        "per Krylov step: all of a time step's collectives -- Newton norms, state halos -- over its Krylov steps",
+            "assembly_patches_rank0": {"interior (assembled while the state halo travels)": cs["interior_patches"],
+                                       "boundary": cs["boundary_patches"]},
+            **lat,
+            "halo_ms_per_step_if_serial": per_step("halo_exchanges") * lat["halo_state_us"] * 1e-3,
+            "allreduce_ms_per_step_if_serial": per_step("allreduces") * lat["allreduce_32_doubles_us"] * 1e-3,
+            "note": "latencies are back-to-back micro-benchmarks on the compute stream after the run; in the "
+                    "run the exchanges overlap interior SpMV rows / sweeps / assembly patches"}
+
+    # ---- the same K steps on the other mesh family (one GPU) ---------------------------------------
+    if world == 1 and args.second_mesh != "off":
+        other = "tensor" if family == "unstructured" else "unstructured"
         del runner
-        t_u = time.perf_counter()
-        with tempfile.TemporaryDirectory(prefix="fedm_mesh_") as tmp:
-            umesh = streamer.refined_mesh(args.mesh_spacing, growth=0.1, xml_path=Path(tmp) / "mesh.xml",
-                                          channel=(0.0, 100.0 * args.mesh_spacing) + streamer.CHANNEL[2:])
-        t_mesh = time.perf_counter() - t_u
-        urun = streamer.Stepper(streamer.device_problem(umesh.coords, umesh.cells, device=local_rank))
-        urun.initialise()
-        u_setup = time.perf_counter() - t_u - t_mesh
-        uh = hot_path(urun, args.steps, args.warmup, {}, "no PMC pass on this mesh")
-        usz = uh["sz"]
-        out["unstructured"] = {
-            "workload": "the same streamer case on a locally refined unstructured mesh: Delaunay triangulation of "
-                        f"nested hexagonal lattices, spacing {args.mesh_spacing:g} m in the streamer channel "
-                        f"(r < {100.0 * args.mesh_spacing:g} m), growing 0.1 per unit distance outside; written to "
-                        "DOLFIN XML and read back through the mesh reader (the way of the reference's Mesh('mesh.xml'))",
-            "vertices": usz["n_vertices"], "cells": usz["n_cells"], "dofs_total": urun.total_dofs,
-            "hmin": umesh.hmin(), "hmax": umesh.hmax(),
-            "value": urun.total_dofs * args.steps / uh["elapsed"], "unit": "DOF-updates/s",
-            "timesteps_per_sec": args.steps / uh["elapsed"], "ms_per_step": 1e3 * uh["elapsed"] / args.steps,
-            "newton_iterations_per_step": uh["newton"] / args.steps,
-            "gmres_iterations_per_step": uh["gmres"] / args.steps,
-            "roofline": uh["rl_asm"], "roofline_other": uh["rl_spmv"], "assembly_plus_spmv": uh["path"],
-            "vcycle": uh["vcycle"],
-            "pattern": {"stored_blocks_over_nnz_blocks": usz["stored_blocks"] / usz["nnz_blocks"],
-                        "max_block_columns_per_slice": usz["max_patch_width"],
-                        "max_cells_per_patch": usz["max_patch_cells"], "max_staged_vertices_per_patch": usz["max_patch_verts"],
-                        "cell_visits_over_cells": usz["cell_visits"] / usz["n_cells"],
-                        "patch_workgroup_threads": usz["patch_threads"], "assembly_variant": usz["assembly_variant"],
-                        "vertex_order": "recursive bisection in the metric of the local spacing (device.locality_order)"},
-            "mesh_seconds": t_mesh, "setup_seconds": u_setup,
-            "run_to_reference_end_time": "profiles/r03_refined_run_*.json: this mesh carries the streamer to the "
-                                         "reference's T_final = 1.4e-8 s (2801 accepted steps, none rejected)"}
-        if args.late_start > 0:      # the developed streamer on this mesh too: the same K steps from step late_start on
-            while urun.steps < args.late_start:
-                urun.step()
-            t_late_u = urun.t
-            ul_el, ul_nw, ul_gm, ul_prof = timed_steps(urun, args.steps, barrier, torch, dist, distributed)
-            out["unstructured"]["late_window"] = {
-                "what": f"{args.steps} accepted steps from step {args.late_start + 1} on (t = {t_late_u:.3e} s)",
-                "timesteps_per_sec": args.steps / ul_el, "ms_per_step": 1e3 * ul_el / args.steps,
-                "newton_iterations_per_step": ul_nw / args.steps, "gmres_iterations_per_step": ul_gm / args.steps,
-                "assembly_plus_spmv": uh["path_record"](ul_prof, ul_gm, args.steps)}
-        runner = urun
+        t_o = time.perf_counter()
+        orun, omesh, o_tmesh = make_runner(other, n_per_gpu=n, spacing=args.mesh_spacing)
+        orun.initialise()
+        o_setup = time.perf_counter() - t_o - o_tmesh
+        o_prof = (other == "unstructured" and args.mesh_spacing == 4e-6) or (other == "tensor" and n == 576)
+        otr, otr_source = pmc_traffic(other) if o_prof else ({}, "not a profiled workload")
+        oh = hot_path(orun, args.steps, args.warmup, otr, otr_source, min(args.repeats, 3))
+        osz = oh["sz"]
+        rec = {"workload": "the same streamer case on the " + mesh_text(other, n, args.mesh_spacing),
+               "vertices": osz["n_vertices"], "cells": osz["n_cells"], "dofs_total": orun.total_dofs,
+               "value": orun.total_dofs * args.steps / oh["elapsed"], "unit": "DOF-updates/s",
+               "timesteps_per_sec": args.steps / oh["elapsed"], "ms_per_step": 1e3 * oh["elapsed"] / args.steps,
+               "windows": oh["windows"],
+               "newton_iterations_per_step": oh["newton"] / args.steps,
+               "gmres_iterations_per_step": oh["gmres"] / args.steps,
+               "roofline": oh["rl_asm"], "roofline_other": oh["rl_spmv"], "assembly_plus_spmv": oh["path"],
+               "vcycle": oh["vcycle"], "pattern": pattern_of(osz), "mesh_seconds": o_tmesh, "setup_seconds": o_setup}
+        if args.late_start > 0:
+            rec["late_window"] = late_window(orun, oh, args.steps)
+        out["tensor_mesh" if other == "tensor" else "unstructured"] = rec
+        runner = orun
 
     # ---- rates that cannot come from the Infinity Cache: the 4 M-DOF mesh on ONE GPU ------------------
     if world == 1 and args.big_mesh > 0:
@@ -496,12 +628,13 @@ def main():
         brun.initialise()
         b_setup = time.perf_counter() - t_b
         bsteps = max(2, min(args.steps, 5))
-        bh = hot_path(brun, bsteps, 1, {}, "no PMC pass on this mesh")
+        bh = hot_path(brun, bsteps, 1, {}, "no PMC pass on this mesh", 1)
         keep = ("achieved", "frac", "frac_of_measured_copy", "algorithmic_bytes", "ms_per_launch", "launches")
         out["roofline_beyond_infinity_cache"] = {
             "workload": f"{args.big_mesh}x{args.big_mesh} graded mesh on one GPU ({brun.total_dofs} DOFs; Jacobian values "
                         f"{bh['sz']['stored_blocks'] * 72 / 1e6:.0f} MB, more than twice the 256 MiB Infinity Cache)",
             "assembly_FJ": {k: bh["rl_asm"][k] for k in keep},
+            "assembly_F_ms": bh["rl_asm"]["ms_residual_only"],
             "spmv": {k: bh["rl_spmv"][k] for k in keep},
             "assembly_plus_spmv_frac": bh["path"]["frac"],
             "timesteps_per_sec": bsteps / bh["elapsed"], "ms_per_step": 1e3 * bh["elapsed"] / bsteps,
@@ -537,6 +670,7 @@ def main():
         g_bytes = nv * (16 + 24 * neq) + nc * (12 + 36) + nnzb * neq * neq * 8 + nv * neq * 8 + n_fields * nv * 8
         g_ms = gp["assembly_FJ"][0] / max(gp["assembly_FJ"][1], 1)
         g_gbs = g_bytes / (g_ms * 1e-3) / 1e9
+        gtr, gtr_source = pmc_traffic("glow_discharge")
         out["glow_discharge"] = {
             "workload": "BASELINE configs[2]: argon glow discharge, LMEA (energy + 3 particle balances + Poisson), "
                         "141x141 crossed mesh, device-resident per-step pipeline (fedm_amd.cases.glow_discharge)",
@@ -544,93 +678,41 @@ def main():
             "value": case.prob.n * gsteps / g_el, "unit": "DOF-updates/s",
             "newton_iterations_per_step": (case.newton_iterations - n0) / gsteps,
             "gmres_iterations_per_step": (case.linear_iterations - l0) / gsteps,
-            "roofline": {"bound": "hbm", "kernel": "gd_jacobian_rows_kernel + gd_gather_kernel (element blocks of all cells, "
-                                                   "summed per stored matrix position; F + J)",
+            "roofline": {"bound": "hbm", "kernel": case.prob.gd_assembly_kernel_name(),
                          "achieved": g_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": g_bytes, "ms_per_launch": g_ms, "launches": gp["assembly_FJ"][1],
-                         "traffic": None,
-                         "note": "compute/latency-bound (two waves per SIMD, 9.6 k vector instructions per wave), "
-                                 "not bandwidth-bound: DESIGN.md 8.3"}}
+                         "traffic": sum(gtr.values()) if gtr else None, "traffic_source": gtr_source}}
         case.prob.close()
-
-    # ---- multi-GPU plumbing: what travelled, and what one exchange / reduction costs ------------
-    if distributed:
-        cs = comm0
-        steps_done = args.steps
-        lat = {}
-        for name, kind in (("halo_state_us", 0), ("halo_scalar_us", 1), ("allreduce_32_doubles_us", 2)):
-            barrier()
-            lat[name] = 1e3 * runner.prob.time_comm(kind, 50)
-        out["multi_gpu"] = {
-            "transport": runner.transport, "transport_requested": runner.transport_requested,
-            "ranks_in_communicator": cs["ranks"], "neighbours_rank0": cs["neighbours"],
-            "halo_exchanges_per_step": cs["halo_exchanges_timed"] / steps_done,
-            "allreduces_per_step": cs["allreduces_timed"] / steps_done,
-            "halo_exchanges_per_krylov_step": cs["halo_exchanges_timed"] / max(gmres, 1),
-            "allreduces_per_krylov_step": cs["allreduces_timed"] / max(gmres, 1),
-            "halo_depth": getattr(runner, "halo_depth", 1),
-            "counting": "collectives issued inside the timed region (the initial Poisson solve and the warm-up apart); "
-                        "per Krylov step: all of a time step's collectives -- Newton norms, state halos -- over its Krylov steps",
-            "assembly_patches_rank0": {"interior (assembled while the state halo travels)": cs["interior_patches"],
-                                       "boundary": cs["boundary_patches"]},
-            **lat,
-            "halo_ms_per_step_if_serial": cs["halo_exchanges_timed"] / steps_done * lat["halo_state_us"] * 1e-3,
-            "allreduce_ms_per_step_if_serial": cs["allreduces_timed"] / steps_done * lat["allreduce_32_doubles_us"] * 1e-3,
-            "note": "latencies are back-to-back micro-benchmarks on the compute stream after the run; in the "
-                    "run the exchanges overlap interior SpMV rows / sweeps / assembly patches"}
 
     # ---- BASELINE configs[4]: ~4 M DOFs over 8 GPUs (strong-scaled counterpart of the line above) ----
     want4 = args.configs4 == "on" or (args.configs4 == "auto" and world == 8)
     if want4 and distributed:
         del runner
-        r4 = make_runner(global_n=args.configs4_mesh)
+        r4, _, _ = make_runner("tensor", global_n=args.configs4_mesh)
         r4.initialise()
         for _ in range(args.warmup):
             r4.step()
-        e4, nw4, gm4, _ = timed_steps(r4, args.steps, barrier, torch, dist, distributed)
+        b4 = r4.prob.comm_stats()
+        e4, nw4, gm4, _, _ = timed_steps(r4, args.steps, barrier, torch, dist, distributed)
+        a4 = r4.prob.comm_stats()
         out["configs4"] = {
             "workload": f"BASELINE configs[4]: streamer_discharge, {args.configs4_mesh}x{args.configs4_mesh} "
                         f"global mesh over {world} GPUs",
             "dofs_total": r4.total_dofs, "value": r4.total_dofs * args.steps / e4, "unit": "DOF-updates/s",
             "timesteps_per_sec": args.steps / e4, "ms_per_step": 1e3 * e4 / args.steps,
             "newton_iterations_per_step": nw4 / args.steps, "gmres_iterations_per_step": gm4 / args.steps,
+            "halo_exchanges_per_step": (a4["halo_exchanges"] - b4["halo_exchanges"]) / args.steps,
+            "allreduces_per_step": (a4["allreduces"] - b4["allreduces"]) / args.steps,
+            "halo_bytes_per_step": (a4.get("halo_bytes", 0) - b4.get("halo_bytes", 0)) / args.steps,
+            "allreduce_bytes_per_step": (a4.get("allreduce_bytes", 0) - b4.get("allreduce_bytes", 0)) / args.steps,
             "partition": r4.partition_name}
-
-    # ---- the refined unstructured mesh split over the ranks (strong scaling; `--unstructured on`) -------
-    if distributed and args.unstructured == "on":
-        from fedm_amd.cases import streamer_distributed
-        try:
-            del runner
-        except NameError:
-            pass
-        umesh = streamer.refined_mesh(args.mesh_spacing, growth=0.1,
-                                      channel=(0.0, 100.0 * args.mesh_spacing) + streamer.CHANNEL[2:])
-        ru = streamer_distributed.Runner(None, rank, world, local_rank, mesh=umesh,
-                                         transport="torch" if args.rehearse_on_one_gpu else "rccl")
-        ru.initialise()
-        for _ in range(args.warmup):
-            ru.step()
-        before = ru.prob.comm_stats()
-        eu, nwu, gmu, _ = timed_steps(ru, args.steps, barrier, torch, dist, distributed)
-        after = ru.prob.comm_stats()
-        ghosts = torch.tensor([float(ru.lm.n_ghost), float(ru.lm.n_owned), float(len(ru.lm.neighbours))],
-                              dtype=torch.float64, device="cuda")
-        dist.all_reduce(ghosts, op=dist.ReduceOp.MAX)
-        out["unstructured_partitioned"] = {
-            "workload": f"the refined unstructured mesh (spacing {args.mesh_spacing:g} m) split over {world} ranks",
-            "dofs_total": ru.total_dofs, "timesteps_per_sec": args.steps / eu, "ms_per_step": 1e3 * eu / args.steps,
-            "newton_iterations_per_step": nwu / args.steps, "gmres_iterations_per_step": gmu / args.steps,
-            "halo_exchanges_per_step": (after["halo_exchanges"] - before["halo_exchanges"]) / args.steps,
-            "allreduces_per_step": (after["allreduces"] - before["allreduces"]) / args.steps,
-            "halo_depth": ru.halo_depth, "largest_halo_vertices": int(ghosts[0].item()),
-            "largest_part_vertices": int(ghosts[1].item()), "most_neighbours": int(ghosts[2].item()),
-            "partition": ru.partition_name, "transport": ru.transport}
-        runner = ru
+        runner = r4
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:    # (a reported baseline: its failure must not take the measured record with it)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_mesh or n, args.grading, args.cpu_steps or args.steps,
-                                               args.cpu_threads)
+            label = mesh_text(family, n, spacing)
+            cmesh = hmesh if hmesh is not None else streamer.mesh(args.cpu_mesh or n, args.grading)
+            out["cpu_baseline"] = cpu_baseline(cmesh, args.cpu_steps or args.steps, args.cpu_threads, label)
         except Exception as exc:                          # noqa: BLE001 - reported in the record
             out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif rank == 0:

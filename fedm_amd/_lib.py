@@ -130,6 +130,8 @@ _SIGNATURES = {
     "fedm_get_state": (C.c_int, [_P, _D]),
     "fedm_shift_state": (C.c_int, [_P]),
     "fedm_reset_state": (C.c_int, [_P]),
+    "fedm_state_snapshot": (C.c_int, [_P]),
+    "fedm_state_restore": (C.c_int, [_P]),
     "fedm_set_step": (C.c_int, [_P, C.c_double, C.c_double]),
     "fedm_set_dirichlet_values": (C.c_int, [_P, _D]),
     "fedm_set_ext_source": (C.c_int, [_P, C.c_int, _D]),
@@ -195,7 +197,7 @@ EXPR_OPS = {"const": 0, "x": 1, "param": 2, "add": 3, "sub": 4, "mul": 5, "div":
 EXPR_MAX_OPS, EXPR_MAX_PARAMS, EXPR_STACK = 256, 16, 24
 
 
-ABI_VERSION = 3          # include/fedm_hip.h FEDM_ABI_VERSION
+ABI_VERSION = 4          # include/fedm_hip.h FEDM_ABI_VERSION
 
 
 def exported_symbols():

@@ -153,6 +153,9 @@ class Stepper:
     @property
     def assembly_kernel_name(self):
         sz = self.prob.sizes()
+        if sz["assembly_variant"] == "lds-patches/one-pass":
+            return (f"assemble_lean3_kernel<2,1,{sz['patch_threads']},kept planes> (LDS patches with micro-coloured cell "
+                    "order, one pass over the cells, live planes only, F+J)")
         if sz["assembly_variant"] != "lds-patches":
             return f"volume assembly, variant '{sz['assembly_variant']}' (F+J)"
         return (f"assemble_lean2_kernel<2,1,{sz['patch_threads']}> (LDS patches with micro-coloured cell order, one "
@@ -209,6 +212,21 @@ class Stepper:
         self.max_error[1] = self.max_error[0]
         self.steps += 1
         return self.t
+
+    def snapshot(self):
+        """Checkpoint of the time loop: the three states stay on the device (fedm_state_snapshot), the
+        script-level scalars (time, step sizes, error history, counters) are returned."""
+        self.prob.snapshot_state()
+        return dict(t=self.t, steps=self.steps, dt=self.dt.time_step, dt_old=self.dt_old.time_step,
+                    error=list(self.error), max_error=list(self.max_error),
+                    newton=self.newton_iterations, linear=self.linear_iterations)
+
+    def restore(self, snap):
+        self.prob.restore_state()
+        self.t, self.steps = snap["t"], snap["steps"]
+        self.dt.time_step, self.dt_old.time_step = snap["dt"], snap["dt_old"]
+        self.error[:], self.max_error[:] = snap["error"], snap["max_error"]
+        self.newton_iterations, self.linear_iterations = snap["newton"], snap["linear"]
 
     def log_rows(self):
         return [tuple(float(v) for v in line.split()) for line in open(self.error_file)]

@@ -1263,7 +1263,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         // (glow discharge, 402k DOFs: 70 against 100 steps per time step).  FEDM_PRECOND_SIDE or
         // fedm_set_preconditioner_side override.
         c.right_precond = c.model_kind == 0;
-        if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] == '0' ? 0 : 2;
+        if (const char *lean = getenv("FEDM_ASSEMBLY_LEAN")) c.assembly_lean = lean[0] == '0' ? 0 : (lean[0] == '3' ? 3 : 2);
         if (const char *e = getenv("FEDM_XCD_REMAP")) c.xcd_remap = e[0] != '0';
         if (const char *e = getenv("FEDM_ASSEMBLY_OVERLAP")) c.assembly_overlap = e[0] != '0';
         if (const char *e = getenv("FEDM_SKIP_CONST_PLANES")) c.skip_const_planes = e[0] != '0';
@@ -1363,6 +1363,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (c.d_s16) hipFree(c.d_s16);
     if (c.d_Z) hipFree(c.d_Z);
     if (c.h_stage) hipHostFree(c.h_stage);
+    if (c.d_snapshot) hipFree(c.d_snapshot);
     for (int s_ = 0; s_ < FEDM_MAX_SPECIES; ++s_) {
         if (c.d_expr_ops[s_]) hipFree(c.d_expr_ops[s_]);
         if (c.d_expr_consts[s_]) hipFree(c.d_expr_consts[s_]);
@@ -1421,6 +1422,39 @@ int fedm_reset_state(fedm_ctx *h) {
     c.err_cache_comp = -1;   // the state changes: the kept error norm is stale
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     launch_scale_copy(c, 1.0, c.d_uold, c.d_u);
+    return 0;
+}
+
+int fedm_state_snapshot(fedm_ctx *h) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (c.halo_pending) {   // (several GPUs: the ghost entries of the state are exchanged lazily)
+        comm_halo(c, c.d_u);
+        c.halo_pending = false;
+    }
+    if (!c.d_snapshot) FEDM_HIP_CHECK(hipMalloc((void **)&c.d_snapshot, sizeof(double) * 3 * c.np));
+    const double *src[3] = {c.d_u, c.d_uold, c.d_uold1};
+    for (int k = 0; k < 3; ++k)
+        FEDM_HIP_CHECK(hipMemcpyAsync(c.d_snapshot + (size_t)k * c.np, src[k], sizeof(double) * c.np,
+                                      hipMemcpyDeviceToDevice, c.stream));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int fedm_state_restore(fedm_ctx *h) {
+    Ctx &c = h->c;
+    if (!c.d_snapshot) {
+        set_error("fedm_state_restore: no snapshot taken");
+        return -2;
+    }
+    c.err_cache_comp = -1;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    c.halo_pending = false;   // the snapshot was taken with exchanged ghosts
+    double *dst[3] = {c.d_u, c.d_uold, c.d_uold1};
+    for (int k = 0; k < 3; ++k)
+        FEDM_HIP_CHECK(hipMemcpyAsync(dst[k], c.d_snapshot + (size_t)k * c.np, sizeof(double) * c.np,
+                                      hipMemcpyDeviceToDevice, c.stream));
+    FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
     return 0;
 }
 
@@ -2210,7 +2244,7 @@ int fedm_set_fieldsplit_order(fedm_ctx *h, int upper) {
 
 int fedm_plane_masks(fedm_ctx *h, uint32_t *kept_planes, uint32_t *zero_planes) {
     Ctx &c = h->c;
-    if (kept_planes) *kept_planes = (c.skip_const_planes && c.assembly_kind == 1 && c.assembly_lean == 2) ? c.const_plane_mask : 0u;
+    if (kept_planes) *kept_planes = (c.skip_const_planes && c.assembly_kind == 1 && c.assembly_lean >= 2) ? c.const_plane_mask : 0u;
     if (zero_planes) *zero_planes = c.neq == 3 ? (c.zero_plane_mask & 10u) : 0u;
     return 0;
 }
@@ -2242,12 +2276,13 @@ int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
     for (int s = 0; s < c.ns; ++s) ext = ext || (c.model_kind == 0 && c.model.ext_nodes[s] > 0);
     const bool lean2 = c.assembly_kind == 1 && c.assembly_lean >= 2 && c.poisson && c.model_kind == 0 && !ext &&
                        c.model.n_qp == 3 && !c.model.linear_representation && c.pat.max_patch_cells <= 256;
-    out[6] = c.assembly_kind == 0 ? 0 : (lean2 ? 2 : 1);
+    // 3: LDS patches, one pass over the cells (lean3 kernels, assemble3.hip)
+    out[6] = c.assembly_kind == 0 ? 0 : (lean2 ? (c.assembly_lean >= 3 && lean3_applies(c) ? 3 : 2) : 1);
     out[7] = c.assembly_kind == 0 ? 0 : (c.pat.max_patch_cells <= 192 ? 192 : (lean2 ? 256 : 320));
     return 0;
 }
 
-int fedm_fieldsplit_tiles_stats(const fedm_mesh_desc *mesh, int tile_slices, int depth, int64_t out[8]) {
+int fedm_fieldsplit_tiles_stats(const fedm_mesh_desc *mesh, int tile_slices, int depth, int64_t out[10]) {
     if (!mesh || !out || mesh->n_vertices < 3 || mesh->n_cells < 1) {
         set_error("null or empty mesh");
         return -2;
@@ -2257,13 +2292,13 @@ int fedm_fieldsplit_tiles_stats(const fedm_mesh_desc *mesh, int tile_slices, int
             set_error("cell vertex index out of range");
             return -2;
         }
-    long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int rc = fs_tiles_host_stats(*mesh, tile_slices, depth, v);
     if (rc) {
         set_error("tile parameters out of range (1..8 slices, 1..8 layers) or a tile too large for 16-bit local indices");
         return rc;
     }
-    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
     return 0;
 }
 

@@ -96,8 +96,8 @@ struct Ctx {
     bool poisson = false;
     int64_t n = 0, np = 0;  // nv*neq, nvp*neq
     fedm_model_desc model{};
-    int assembly_lean = 2;   // patch assembly through element_lean.hpp where it applies: 0 unrolled element,
-                             // 1 first generation (F + J only), 2 second (F + J and residual-only)
+    int assembly_lean = 3;   // patch assembly generation where it applies: 0 unrolled element, 2 one equation
+                             // row at a time (element_lean.hpp), 3 one pass over the cells (assemble3.hip)
     bool xcd_remap = true;   // patch / slice -> workgroup mapping contiguous per XCD
     // Planes (row, col) of the Jacobian that never change: potential-potential, and species planes that
     // are structurally zero.  bit row * neq + col; kept between assemblies once a full one has written them.
@@ -242,6 +242,7 @@ struct Ctx {
     int err_cache_comp = -1;
     double err_cache = 0.0;
     double *h_stage = nullptr;     // pinned staging, np doubles
+    double *d_snapshot = nullptr;  // fedm_state_snapshot: u, u_old, u_old1 (3 np doubles, allocated on first use)
 };
 
 constexpr int RED_BLOCKS = 512;
@@ -257,6 +258,8 @@ constexpr int MAIL_SLOTS = 4;         // publications the host may have unread (
 // mode: 0 = full model, 1 = Poisson row only (species rows become identity)
 void launch_assemble(Ctx &c, bool jacobian, int mode);
 void launch_assemble_gd(Ctx &c, bool jacobian, int mode);
+bool lean3_applies(const Ctx &c);                                   // assemble3.hip
+bool launch_assemble_lean3(Ctx &c, bool jacobian, const int *patch_list, int n, uint32_t cmask);
 int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
                   const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs);
 int gd_prep_step(Ctx &c);

@@ -14,7 +14,9 @@
 // tile the vertex list [tile | layer 1 | ... | layer depth] and, for the rows of the layers < depth, 16-bit local
 // column numbers ([entry][row]: coalesced).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "amg.hpp"
@@ -30,6 +32,7 @@ struct FsTiles {
     uint32_t *d_cols = nullptr;   // [column offset + (entry / 2) * row stride + row]: two 16-bit local columns a word
     long long total_rows = 0, total_vertices = 0;
     size_t bytes = 0;
+    size_t lds_limit = 64 * 1024;   // dynamic LDS a workgroup may ask for on this device (fs_tiles_get)
     bool usable = false;
     void release() {
         for (void *p : {(void *)d_tile, (void *)d_vertex, (void *)d_cols})
@@ -398,6 +401,30 @@ static bool fs_tile_tables(const Pattern &pat, int tile_slices, int depth, FsTil
 // its layers, most rows, rows of all tiles, vertices of all tiles, bytes, violations found}.  Checked: every vertex is
 // the own vertex of exactly one tile; the layer counts grow; every local column of every row is a valid index and names
 // the vertex the pattern names; entries beyond a row's own name the row itself.
+// Dynamic LDS of one workgroup of the tile kernels: the iterate of the tile and its layers twice (ping, pong)
+// and the packed 16-bit local column numbers of its rows, in the kernel instantiation for that row width.
+static int fs_tiles_width_class(int width) { return width <= 7 ? 7 : width <= 9 ? 9 : 12; }
+size_t fs_tiles_lds_bytes(int width, int max_vertices, int max_rows, int ns) {
+    const int W = fs_tiles_width_class(width);
+    return sizeof(float) * 2 * (size_t)max_vertices * ns + sizeof(uint32_t) * (size_t)((W + 1) / 2) * max_rows;
+}
+size_t mg_tiles_lds_bytes(int width, int max_vertices, int max_rows) {
+    const int W = fs_tiles_width_class(width);
+    return sizeof(double) * 2 * (size_t)max_vertices + sizeof(uint32_t) * (size_t)((W + 1) / 2) * max_rows;
+}
+// What a workgroup may ask for: the device's limit (160 KiB on gfx950), queried once per device; a mesh within the
+// 16-bit index caps of the tables can need more -- scattered ghost layers of a partition make tiles of thousands
+// of vertices -- and a launch beyond the limit fails WITHOUT a report inside a captured graph, leaving a stale
+// preconditioner output: such tiles are refused when they are built, the sweeps then run one launch each.
+static size_t fs_tiles_lds_limit(int device) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || v <= 0) {
+        hipGetLastError();
+        v = 64 * 1024;
+    }
+    return (size_t)v;
+}
+
 int fs_tiles_host_stats(const fedm_mesh_desc &mesh, int tile_slices, int depth, long long *out) {
     Pattern pat;
     build_pattern(mesh, pat);
@@ -434,6 +461,8 @@ int fs_tiles_host_stats(const fedm_mesh_desc &mesh, int tile_slices, int depth, 
     out[5] = tt.total_vertices;
     out[6] = (long long)(sizeof(int) * (tt.tiles.size() + tt.vertices.size()) + sizeof(uint32_t) * tt.cols.size());
     out[7] = bad;
+    out[8] = (long long)fs_tiles_lds_bytes(tt.width, tt.max_vertices, tt.max_rows, 2);
+    out[9] = (long long)mg_tiles_lds_bytes(tt.width, tt.max_vertices, tt.max_rows);
     return 0;
 }
 
@@ -502,7 +531,20 @@ static FsTiles *fs_tiles_get(Ctx &c) {
     threads = std::max(64, std::min(512, (threads + 63) / 64 * 64));
     FsTiles *ft = new FsTiles();
     ft->threads = threads;
-    if (!FsTiles_build(*ft, c.pat, tile_slices, depth) || ft->width > 12 || ft->max_rows > 8 * threads) {
+    bool ok = FsTiles_build(*ft, c.pat, tile_slices, depth) && ft->width <= 12 && ft->max_rows <= 8 * threads;
+    if (ok) {
+        // the species kernel must fit the workgroup's LDS budget (the multigrid kernel is checked at its launch:
+        // it is an extra on the same tiles)
+        const size_t need = fs_tiles_lds_bytes(ft->width, ft->max_vertices, ft->max_rows, c.ns);
+        ft->lds_limit = fs_tiles_lds_limit(c.device);
+        if (need > ft->lds_limit) {
+            fprintf(stderr, "[fedm_amd] species-sweep tiles need %zu B of LDS per workgroup (%d vertices, %d rows a tile), "
+                            "the device grants %zu: sweeps one launch each\n", need, ft->max_vertices, ft->max_rows,
+                    ft->lds_limit);
+            ok = false;
+        }
+    }
+    if (!ok) {
         ft->release();
         delete ft;
         return nullptr;
@@ -556,19 +598,27 @@ static void fs_tiles_launch(Ctx &c, FsTiles &ft, unsigned zmask, const float *g3
     const dim3 g(ft.n_tiles), b(T);
     const size_t lds = sizeof(float) * 2 * (size_t)ft.max_vertices * NS + sizeof(uint32_t) * (size_t)((W + 1) / 2) * ft.max_rows;
     const int slots = (ft.max_rows + T - 1) / T;
+    static size_t lds_granted[5] = {0, 0, 0, 0, 0};   // per instantiation <NS, W, SL>: beyond the 64 KiB default it is opt-in
     static const int tile_xcd = [] {
         const char *e = std::getenv("FEDM_FS_TILE_XCD");
         return (e && e[0] == '0') ? 0 : 1;
     }();
-#define FEDM_TILE_SWEEPS(SL)                                                                                     \
-    hipLaunchKernelGGL((fs_tile_sweeps_kernel<NS, W, SL>), g, b, lds, c.stream, ft.d_tile, ft.record, ft.max_vertices, \
-                       ft.max_rows, ft.width, ft.d_vertex, ft.d_cols, c.d_slice_boff, c.d_s16, zmask, g32, in, out32, z, wt, last ? 1 : 0, \
-                       x0, cpl32, b0, tile_xcd)
-    if (slots <= 2) FEDM_TILE_SWEEPS(2);
-    else if (slots <= 3) FEDM_TILE_SWEEPS(3);
-    else if (slots <= 4) FEDM_TILE_SWEEPS(4);
-    else if (slots <= 6) FEDM_TILE_SWEEPS(6);
-    else FEDM_TILE_SWEEPS(8);
+#define FEDM_TILE_SWEEPS(SL, IDX)                                                                                \
+    do {                                                                                                         \
+        if (lds > 64 * 1024 && lds > lds_granted[IDX]) {                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&fs_tile_sweeps_kernel<NS, W, SL>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            lds_granted[IDX] = lds;                                                                              \
+        }                                                                                                        \
+        hipLaunchKernelGGL((fs_tile_sweeps_kernel<NS, W, SL>), g, b, lds, c.stream, ft.d_tile, ft.record, ft.max_vertices, \
+                           ft.max_rows, ft.width, ft.d_vertex, ft.d_cols, c.d_slice_boff, c.d_s16, zmask, g32, in, out32, z, wt, last ? 1 : 0, \
+                           x0, cpl32, b0, tile_xcd);                                                             \
+    } while (0)
+    if (slots <= 2) FEDM_TILE_SWEEPS(2, 0);
+    else if (slots <= 3) FEDM_TILE_SWEEPS(3, 1);
+    else if (slots <= 4) FEDM_TILE_SWEEPS(4, 2);
+    else if (slots <= 6) FEDM_TILE_SWEEPS(6, 3);
+    else FEDM_TILE_SWEEPS(8, 4);
 #undef FEDM_TILE_SWEEPS
 }
 
@@ -601,6 +651,14 @@ bool fs_tiles_sweeps(Ctx &c, int n_sweeps, unsigned zmask, const float *g32, flo
     } while (0)
         FEDM_TILE_W(2);
 #undef FEDM_TILE_W
+        if (hipPeekAtLastError() != hipSuccess) {
+            // a refused launch (not seen on the meshes tried): no tiles from now on; outside a capture the caller
+            // repeats the sweeps one by one, inside one the capture fails and the solver falls back to plain launches
+            set_error(std::string("fs_tile_sweeps_kernel launch: ") + hipGetErrorString(hipGetLastError()));
+            ft->usable = false;
+            c.fs_tiles_state = -1;
+            return false;
+        }
         in = out;
         done += n;
         ++launch;
@@ -628,22 +686,36 @@ bool mg_tiles_sweeps(Ctx &c, const EllMat &A, const double *b, const double *xin
     const dim3 g(ft->n_tiles), bl(T);
     const int slots = (ft->max_rows + T - 1) / T;
     const int neq2 = c.neq * c.neq;
-#define FEDM_MG_TILE(WW, SL)                                                                                      \
-    hipLaunchKernelGGL((mg_tile_sweeps_kernel<WW, SL>), g, bl,                                                    \
-                       sizeof(double) * 2 * (size_t)ft->max_vertices + sizeof(uint32_t) * (size_t)((WW + 1) / 2) * ft->max_rows, \
-                       c.stream, ft->d_tile, ft->record, ft->max_vertices, ft->max_rows, ft->width, ft->d_vertex, \
-                       ft->d_cols, c.d_slice_boff, c.d_val, neq2, neq2 - 1, A.dinv, b, xin, wt, out, ostride, ooff, 1)
-#define FEDM_MG_TILE_S(WW)                                                                                        \
+    const size_t mg_lds = mg_tiles_lds_bytes(ft->width, ft->max_vertices, ft->max_rows);
+    if (mg_lds > ft->lds_limit) return false;     // (the sweeps as kernels of their own)
+    static size_t mg_granted[6] = {0, 0, 0, 0, 0, 0};
+#define FEDM_MG_TILE(WW, SL, IDX)                                                                                 \
     do {                                                                                                          \
-        if (slots <= 2) FEDM_MG_TILE(WW, 2);                                                                      \
-        else if (slots <= 3) FEDM_MG_TILE(WW, 3);                                                                 \
+        if (mg_lds > 64 * 1024 && mg_lds > mg_granted[IDX]) {                                                     \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_tile_sweeps_kernel<WW, SL>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)mg_lds);                         \
+            mg_granted[IDX] = mg_lds;                                                                             \
+        }                                                                                                         \
+        hipLaunchKernelGGL((mg_tile_sweeps_kernel<WW, SL>), g, bl, mg_lds,                                        \
+                           c.stream, ft->d_tile, ft->record, ft->max_vertices, ft->max_rows, ft->width, ft->d_vertex, \
+                           ft->d_cols, c.d_slice_boff, c.d_val, neq2, neq2 - 1, A.dinv, b, xin, wt, out, ostride, ooff, 1); \
+    } while (0)
+#define FEDM_MG_TILE_S(WW, BASE)                                                                                  \
+    do {                                                                                                          \
+        if (slots <= 2) FEDM_MG_TILE(WW, 2, BASE);                                                                \
+        else if (slots <= 3) FEDM_MG_TILE(WW, 3, BASE + 1);                                                       \
         else return false;                                                                                        \
     } while (0)
-    if (ft->width <= 7) FEDM_MG_TILE_S(7);
-    else if (ft->width <= 9) FEDM_MG_TILE_S(9);
-    else FEDM_MG_TILE_S(12);
+    if (ft->width <= 7) FEDM_MG_TILE_S(7, 0);
+    else if (ft->width <= 9) FEDM_MG_TILE_S(9, 2);
+    else FEDM_MG_TILE_S(12, 4);
 #undef FEDM_MG_TILE_S
 #undef FEDM_MG_TILE
+    if (hipPeekAtLastError() != hipSuccess) {
+        set_error(std::string("mg_tile_sweeps_kernel launch: ") + hipGetErrorString(hipGetLastError()));
+        c.mg_tiles_off = true;
+        return false;
+    }
     return true;
 }
 

@@ -1,6 +1,7 @@
 // HIP kernels (gfx950) of the FEDM hot path: coloured element assembly into the sliced
 // block-ELL Jacobian, Dirichlet rows, block-Jacobi inverse, SpMV and the vector kernels
 // that GMRES / Newton need.  All of it is fp64 and HBM-bound; no MFMA.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -495,20 +496,28 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     } while (0)
             // the constant potential-potential plane: written by the first full assembly, kept afterwards
             const uint32_t cmask = (jacobian && c.skip_const_planes && c.const_planes_valid) ? c.const_plane_mask : 0u;
+            // third generation (assemble3.hip: one pass over the cells, compile-time plane mask) where it is
+            // instantiated; FEDM_ASSEMBLY_LEAN=2 keeps the row-phase kernels below
+            const bool gen3 = c.assembly_lean >= 3 && lean3_applies(c);
+#define FEDM_LEAN3_OR(LIST, N) (gen3 && launch_assemble_lean3(c, jacobian, LIST, N, cmask))
             if (c.halo_pending && c.comm && c.comm->d_patch_interior) {
                 // the ghost values of the new state travel on the communication stream while the
                 // patches that stage no ghost vertex are assembled (north_star: "ghost exchange
                 // overlapped with interior assembly"); the patches that do follow the exchange
                 Comm &cm = *c.comm;
                 comm_halo_begin(c);
-                FEDM_LEAN2_BOTH(cm.d_patch_interior, cm.n_patch_interior);
+                if (!FEDM_LEAN3_OR(cm.d_patch_interior, cm.n_patch_interior))
+                    FEDM_LEAN2_BOTH(cm.d_patch_interior, cm.n_patch_interior);
                 comm_halo_exchange(c, c.d_u);
-                FEDM_LEAN2_BOTH(cm.d_patch_boundary, cm.n_patch_boundary);
+                if (!FEDM_LEAN3_OR(cm.d_patch_boundary, cm.n_patch_boundary))
+                    FEDM_LEAN2_BOTH(cm.d_patch_boundary, cm.n_patch_boundary);
                 c.halo_pending = false;
             } else {
                 flush_pending_halo(c);
-                FEDM_LEAN2_BOTH((const int *)nullptr, c.pat.n_slices);
+                if (!FEDM_LEAN3_OR((const int *)nullptr, c.pat.n_slices))
+                    FEDM_LEAN2_BOTH((const int *)nullptr, c.pat.n_slices);
             }
+#undef FEDM_LEAN3_OR
 #undef FEDM_LEAN2_BOTH
 #undef FEDM_LEAN2_LAUNCH
 #undef FEDM_LEAN2_LAUNCH_T
@@ -1953,36 +1962,81 @@ void launch_field_error_slots34(Ctx &c, int comp) {
 }
 
 // =============================================================================================
-// Copy ceiling of the box: a 16-byte-per-lane grid-stride copy (what MI355X_MICROARCH.md measures
-// 6.29 TB/s with), read + write bytes over HIP-event time.  Buffers far beyond the 256 MiB Infinity
-// Cache; bench.py prints it next to the 8 TB/s specification.
+// Copy ceiling of the box: 16-byte-per-lane copies (what MI355X_MICROARCH.md measures 6.29 TB/s
+// with), read + write bytes over HIP-event time.  Buffers far beyond the 256 MiB Infinity Cache;
+// bench.py prints the rate next to the 8 TB/s specification.  A ceiling has to be the best a copy
+// reaches on the box, so several shapes are timed and the fastest one is reported: U loads in
+// flight per lane before the first store (round 3's single load per trip left the memory system
+// half empty: 4.8 TB/s, below what the Jacobian product moves), plain or non-temporal.
 // =============================================================================================
-__global__ __launch_bounds__(256) void copy16_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+typedef float copy_f4 __attribute__((ext_vector_type(4)));   // (the non-temporal builtins take native vectors)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy16_kernel(const copy_f4 *__restrict__ src, copy_f4 *__restrict__ dst, size_t n) {
+    // a workgroup takes contiguous chunks of U * 256 pieces; the grid strides over the chunks
+    const size_t chunk = (size_t)U * 256;
+    for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+        copy_f4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const size_t i = base + (size_t)k * 256 + threadIdx.x;
+            if (i < n) {
+                if (NT) v[k] = __builtin_nontemporal_load(src + i);
+                else v[k] = src[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const size_t i = base + (size_t)k * 256 + threadIdx.x;
+            if (i < n) {
+                if (NT) __builtin_nontemporal_store(v[k], dst + i);
+                else dst[i] = v[k];
+            }
+        }
+    }
 }
 
 int copy_bandwidth(int device, int64_t bytes, int repeats, double *gbs) {
     FEDM_HIP_CHECK(hipSetDevice(device));
-    const size_t n = (size_t)bytes / sizeof(float4);
-    float4 *a = nullptr, *b = nullptr;
+    const size_t n = (size_t)bytes / sizeof(copy_f4);
+    copy_f4 *a = nullptr, *b = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = -1;
     do {
-        if (hipMalloc((void **)&a, n * sizeof(float4)) != hipSuccess) break;
-        if (hipMalloc((void **)&b, n * sizeof(float4)) != hipSuccess) break;
-        if (hipMemset(a, 1, n * sizeof(float4)) != hipSuccess) break;
+        if (hipMalloc((void **)&a, n * sizeof(copy_f4)) != hipSuccess) break;
+        if (hipMalloc((void **)&b, n * sizeof(copy_f4)) != hipSuccess) break;
+        if (hipMemset(a, 1, n * sizeof(copy_f4)) != hipSuccess) break;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
-        const dim3 grid(256 * 8), block(256);   // eight workgroups per CU, each lane 16 B per trip
-        hipLaunchKernelGGL(copy16_kernel, grid, block, 0, 0, a, b, n);
-        if (hipDeviceSynchronize() != hipSuccess) break;
-        hipEventRecord(e0, 0);
-        for (int i = 0; i < repeats; ++i) hipLaunchKernelGGL(copy16_kernel, grid, block, 0, 0, a, b, n);
-        hipEventRecord(e1, 0);
-        if (hipEventSynchronize(e1) != hipSuccess) break;
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        *gbs = 2.0 * (double)(n * sizeof(float4)) * repeats / ((double)ms * 1e-3) / 1e9;
+        double best = 0.0;
+        bool failed = false;
+        for (int variant = 0; variant < 6 && !failed; ++variant) {
+            // grids: as many workgroups as there are chunks, up to 16 per CU (256 CUs)
+            static const int unroll_of[6] = {1, 4, 4, 8, 8, 2};
+            const size_t per = (size_t)unroll_of[variant] * 256;
+            const unsigned g = (unsigned)std::min<size_t>((n + per - 1) / per, (size_t)256 * 16);
+            auto launch = [&]() {
+                switch (variant) {
+                    case 0: hipLaunchKernelGGL((copy16_kernel<1, false>), dim3(256 * 8), dim3(256), 0, 0, a, b, n); break;
+                    case 1: hipLaunchKernelGGL((copy16_kernel<4, false>), dim3(g), dim3(256), 0, 0, a, b, n); break;
+                    case 2: hipLaunchKernelGGL((copy16_kernel<4, true>), dim3(g), dim3(256), 0, 0, a, b, n); break;
+                    case 3: hipLaunchKernelGGL((copy16_kernel<8, false>), dim3(g), dim3(256), 0, 0, a, b, n); break;
+                    case 4: hipLaunchKernelGGL((copy16_kernel<8, true>), dim3(g), dim3(256), 0, 0, a, b, n); break;
+                    default: hipLaunchKernelGGL((copy16_kernel<2, false>), dim3(g), dim3(256), 0, 0, a, b, n); break;
+                }
+            };
+            launch();
+            if (hipDeviceSynchronize() != hipSuccess) { failed = true; break; }
+            hipEventRecord(e0, 0);
+            for (int i = 0; i < repeats; ++i) launch();
+            hipEventRecord(e1, 0);
+            if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double rate = 2.0 * (double)(n * sizeof(copy_f4)) * repeats / ((double)ms * 1e-3) / 1e9;
+            if (std::getenv("FEDM_COPY_VERBOSE")) fprintf(stderr, "copy_bandwidth variant %d: %.0f GB/s\n", variant, rate);
+            best = std::max(best, rate);
+        }
+        if (failed) break;
+        *gbs = best;
         rc = 0;
     } while (false);
     if (rc) set_error("copy_bandwidth: HIP call failed (out of memory?)");

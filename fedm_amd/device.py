@@ -338,11 +338,12 @@ def fieldsplit_tiles_stats(coords, cells, slices_per_tile=8, layers=3, reorder=T
     mesh.n_vertices, mesh.n_cells = coords.shape[0], cells.shape[0]
     mesh.coords = _dp(cdev)
     mesh.cells = kdev.ctypes.data_as(C.POINTER(C.c_int32))
-    out = (C.c_int64 * 8)()
+    out = (C.c_int64 * 10)()
     rc = lib.fedm_fieldsplit_tiles_stats(C.byref(mesh), int(slices_per_tile), int(layers), out)
     if rc != 0:
         raise RuntimeError(f"fedm_fieldsplit_tiles_stats failed ({rc}): {_lib.last_error()}")
-    keys = ("n_tiles", "row_width", "max_vertices", "max_rows", "total_rows", "total_vertices", "bytes", "violations")
+    keys = ("n_tiles", "row_width", "max_vertices", "max_rows", "total_rows", "total_vertices", "bytes", "violations",
+            "lds_bytes_species_kernel", "lds_bytes_multigrid_kernel")
     return dict(zip(keys, (int(v) for v in out)))
 
 
@@ -465,6 +466,13 @@ class DeviceProblem:
 
     def reset_state(self):
         self._check(self.lib.fedm_reset_state(self._h), "fedm_reset_state")
+
+    def snapshot_state(self):
+        """u, u_old, u_old1 into a device-side copy (fedm_state_snapshot)."""
+        self._check(self.lib.fedm_state_snapshot(self._h), "fedm_state_snapshot")
+
+    def restore_state(self):
+        self._check(self.lib.fedm_state_restore(self._h), "fedm_state_restore")
 
     def set_step(self, dt, dt_old):
         self._check(self.lib.fedm_set_step(self._h, float(dt), float(dt_old)), "fedm_set_step")
@@ -900,6 +908,11 @@ class DeviceProblem:
             out[name] = (ms.value, cnt.value)
         return out
 
+    def gd_assembly_kernel_name(self):
+        """The LMEA F + J assembly kernels in use (bench.py's glow-discharge roofline block)."""
+        return ("gd_jacobian_rows_kernel + gd_gather_kernel (element blocks of all cells, summed per stored "
+                "matrix position; F + J)")
+
     def sizes(self):
         v = [C.c_int64() for _ in range(6)]
         self.lib.fedm_sizes(self._h, *[C.byref(x) for x in v])
@@ -911,7 +924,7 @@ class DeviceProblem:
         self._check(self.lib.fedm_pattern_info(self._h, info), "fedm_pattern_info")
         out.update(zip(("n_slices", "max_patch_cells", "max_patch_width", "max_patch_verts", "cell_visits",
                         "halo_vertices"), (int(v) for v in info[:6])))
-        out["assembly_variant"] = ("global colouring", "lds-patches/unrolled", "lds-patches")[int(info[6])]
+        out["assembly_variant"] = ("global colouring", "lds-patches/unrolled", "lds-patches", "lds-patches/one-pass")[int(info[6])]
         out["patch_threads"] = int(info[7])
         return out
 

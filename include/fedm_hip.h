@@ -199,8 +199,9 @@ const char *fedm_last_error(void);
  * written against and refuses a library of another version (a descriptor that grew would otherwise be
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
  * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields.
- * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles. */
-#define FEDM_ABI_VERSION 3
+ * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles.
+ * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]. */
+#define FEDM_ABI_VERSION 4
 int fedm_abi_version(void);
 
 /* mesh + model -> device: colouring, sliced block-ELL pattern, buffers.
@@ -228,6 +229,11 @@ int fedm_get_state_old(fedm_ctx *ctx, double *u_old);
 int fedm_shift_state(fedm_ctx *ctx);
 /* u_new <- u_old (step rejection, fedm/functions.py:1103) */
 int fedm_reset_state(fedm_ctx *ctx);
+/* The three resident states kept in / brought back from a device-side copy (no host transfer): a
+ * checkpoint of the time loop, what a script does with Function.copy(deepcopy=True) before a
+ * speculative step.  bench.py repeats its timed window from one. */
+int fedm_state_snapshot(fedm_ctx *ctx);
+int fedm_state_restore(fedm_ctx *ctx);
 
 /* dt.time_step / dt_old.time_step, fedm/functions.py:350 */
 int fedm_set_step(fedm_ctx *ctx, double dt, double dt_old);
@@ -398,8 +404,10 @@ int fedm_fieldsplit_tiles_info(fedm_ctx *ctx, int64_t out[10]);
 /* The tile tables of a mesh built on the host alone (no GPU needed), with a self-check: out = {tiles, longest
  * matrix row, most vertices of a tile with its layers, most rows, rows of all tiles, vertices of all tiles, bytes,
  * violations found (0: every vertex is the own vertex of exactly one tile, the layers nest, every local column
- * number names the vertex the block pattern names)}. */
-int fedm_fieldsplit_tiles_stats(const fedm_mesh_desc *mesh, int tile_slices, int depth, int64_t out[8]);
+ * number names the vertex the block pattern names), dynamic LDS bytes per workgroup of the species-sweep kernel
+ * (two species) and of the multigrid-sweep kernel on these tiles: tiles whose kernels would need more than the
+ * device grants a workgroup (160 KiB on gfx950) are refused when a context builds them}. */
+int fedm_fieldsplit_tiles_stats(const fedm_mesh_desc *mesh, int tile_slices, int depth, int64_t out[10]);
 /* Test hook: z = Minv t with the field-split preconditioner of the CURRENT Jacobian (fedm_jacobian first; its
  * species planes are formed here), host vectors of n_vertices * n_eq doubles -- the operator a Krylov step of
  * fedm_newton_solve applies, alone. */

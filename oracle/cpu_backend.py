@@ -355,14 +355,24 @@ def usable_cores():
 
 
 def bench(n, grading, steps, threads):
+    """bench.py's cpu_baseline record on the n x n graded tensor-product mesh."""
+    xs = graded_axis(ost.BOX, n, grading) if grading != 1.0 else None
+    mesh = rectangle_right(0.0, 0.0, ost.BOX, ost.BOX, n, n, xs=xs)
+    return bench_mesh(mesh.coords, mesh.cells, steps, threads, f"{n}x{n} graded mesh")
+
+
+def bench_mesh(coords, cells, steps, threads, label):
     """bench.py's cpu_baseline record: `steps` accepted BDF2 steps of the streamer case on the
-    n x n mesh, timed after set-up (mesh, pattern, multigrid hierarchy, initial Poisson solve are
-    untimed on the device side too)."""
+    given triangle mesh of the box (the device run's own mesh), timed after set-up (mesh, pattern,
+    multigrid hierarchy, initial Poisson solve are untimed on the device side too)."""
+    from .mesh import Mesh
     lib = load()
     cores, avail, why = usable_cores()
     used = cores if threads <= 0 else min(threads, avail)
     lib.cpu_set_threads(used)
-    prob, mesh = streamer_problem(n, grading)
+    mesh = Mesh(coords, cells)
+    prob = CpuProblem(ost.build(mesh))
+    n = label
     _, _, t, stats = run_streamer(prob, mesh, steps)
     ndof = mesh.nv * 3
     counters = prob.counters()
@@ -370,8 +380,8 @@ def bench(n, grading, steps, threads):
            "timesteps_per_sec": steps / stats["seconds"], "ms_per_step": 1e3 * stats["seconds"] / steps,
            "newton_iterations_per_step": stats["newton"] / steps, "gmres_iterations_per_step": stats["linear"] / steps,
            "multigrid_levels": prob.levels, "dofs": ndof,
-           "sample": f"{steps} accepted BDF2 steps of the same streamer case on the same {n}x{n} graded mesh "
-                     f"({ndof} DOFs), timed after set-up like the device run; oracle/cpu/fedm_cpu.c: C + OpenMP, "
+           "sample": f"{steps} accepted BDF2 steps of the same streamer case on the same mesh ({n}; "
+                     f"{ndof} DOFs), timed after set-up like the device run; oracle/cpu/fedm_cpu.c: C + OpenMP, "
                      f"coloured element loop -> block CSR -> Newton -> flexible GMRES(30) with the same field "
                      f"split (Chebyshev(6) species sweeps + smoothed-aggregation V(1,1)) -- 'CPU restatement, not "
                      f"FEniCS'; {used} OpenMP threads ({why}; affinity mask {avail} of {os.cpu_count()} host CPUs)",

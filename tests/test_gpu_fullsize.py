@@ -259,7 +259,7 @@ def test_unstructured_mesh_at_1m_dofs_properties(tmp_path):
     prob = streamer.device_problem(msh.coords, msh.cells)
     assert prob.n == 1023840
     sz = prob.sizes()
-    assert sz["assembly_variant"] == "lds-patches" and sz["max_patch_cells"] <= 256
+    assert sz["assembly_variant"] == "lds-patches/one-pass" and sz["max_patch_cells"] <= 256
     assert sz["stored_blocks"] / sz["nnz_blocks"] < 1.05 and sz["cell_visits"] < 1.3 * sz["n_cells"]
     st = streamer.Stepper(prob)
     st.initialise()

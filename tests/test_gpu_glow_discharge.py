@@ -75,18 +75,27 @@ def test_gd_device_pipeline_matches_host_pipeline():
     from fedm_amd.cases import glow_discharge as gdc
     host = gdc.Case(nx=24, ny=24, device_pipeline=False, T_final=1.0)
     dev = gdc.Case(nx=24, ny=24, device_pipeline=True, T_final=1.0)
+    # A self-comparison of two PIPELINES, so the solves in between must not add a Krylov-path dependent
+    # difference of their own: Newton to 1e-12 and GMRES to 1e-13 pin every step's state to a few hundred
+    # ulp whatever the path (at the script's tolerances, 1e-4 / 1e-5, rounding-level input differences come
+    # back as 1e-12 .. 1e-9: what round 3's widened 1e-8 papered over).  What is left is the pipelines' own
+    # disagreement -- table look-ups and products (a few ulp), the projection's Jacobi-CG against a sparse LU
+    # (stopped at 1e-13) -- times the condition of a step, bounded here by 1e-10.
+    for case in (host, dev):
+        case.solver.parameters["relative_tolerance"] = 1e-12
+        case.solver.parameters["krylov_relative_tolerance"] = 1e-13
+    worst = 0.0
     for _ in range(4):
         host.step()
         dev.step()
         fh, fd = host.prob.get_gd_fields(), dev.prob.get_gd_fields()
         fh[-2] = host.mean_energy.vector()     # the host uploads this row before the next solve
         scale = np.maximum(np.abs(fh).max(axis=1, keepdims=True), 1e-300)
-        # two runs through Newton-Krylov solves (rtol 1e-5): rounding-level differences of the inputs
-        # come back as 1e-12 .. 1e-9 depending on the Krylov path; agreement far beyond the solver
-        # tolerances
-        assert (np.abs(fh - fd) / scale).max() < 1e-8
-    assert np.allclose(host.prob.get_state(), dev.prob.get_state(), rtol=1e-9, atol=1e-9)
-    assert np.allclose(np.loadtxt(host.error_file), np.loadtxt(dev.error_file), rtol=1e-7)
+        worst = max(worst, (np.abs(fh - fd) / scale).max())
+    print(f"host pipeline vs device pipeline, nodal fields over 4 steps: {worst:.2e}")
+    assert worst < 1e-10
+    assert np.allclose(host.prob.get_state(), dev.prob.get_state(), rtol=1e-10, atol=1e-10)
+    assert np.allclose(np.loadtxt(host.error_file), np.loadtxt(dev.error_file), rtol=1e-8)
 
 
 @pytest.mark.parametrize("device_pipeline", [False, True])

@@ -64,7 +64,7 @@ def test_the_lean_patch_kernels_run_on_this_mesh(setup):
     sz = prob.sizes()
     assert sz["max_patch_cells"] <= 192
     assert sz["stored_blocks"] < 1.08 * sz["nnz_blocks"]
-    assert prob.assembly_variant() == "lds-patches"
+    assert prob.assembly_variant() == "lds-patches/one-pass"
 
 
 @pytest.mark.parametrize("dt,dt_old", [(5e-12, 1e30), (5e-12, 4.977e-12)])
@@ -94,8 +94,8 @@ def test_residual_jacobian_and_product_against_both_cpu_statements(setup, dt, dt
 
 
 def test_every_assembly_variant_gives_the_same_system(setup, monkeypatch):
-    """The bitwise reproducible global-colouring assembly (FEDM_ASSEMBLY=colour) and the unrolled
-    patch routine against the default row-phase kernels, on the unstructured pattern."""
+    """The bitwise reproducible global-colouring assembly (FEDM_ASSEMBLY=colour), the unrolled patch routine
+    and the row-phase kernels against the default one-pass kernels, on the unstructured pattern."""
     from fedm_amd.cases import streamer
     msh, omodel, U0, prob = setup
     U, Uo, Uo1 = _developed_state(msh, 3)
@@ -103,7 +103,7 @@ def test_every_assembly_variant_gives_the_same_system(setup, monkeypatch):
     prob.set_step(5e-12, 4e-12)
     prob.jacobian()
     F_ref, J_ref = prob.residual()[0], prob.jacobian_csr()
-    for env in (dict(FEDM_ASSEMBLY="colour"), dict(FEDM_ASSEMBLY_LEAN="0")):
+    for env in (dict(FEDM_ASSEMBLY="colour"), dict(FEDM_ASSEMBLY_LEAN="0"), dict(FEDM_ASSEMBLY_LEAN="2")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other = streamer.device_problem(msh.coords, msh.cells)

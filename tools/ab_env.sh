@@ -1,7 +1,7 @@
 # A/B of an environment switch on the bench's headline window (no profiler): usage (GPU box)
 #   bash tools/ab_env.sh NAME "VAR=a" "VAR=b" ...      -> gpurun_out/ab_NAME.txt
 NAME=$1; shift
-ONLY="--no-cpu-baseline --late-start 0 --unstructured off --big-mesh 0 --no-glow-discharge"
+ONLY="--no-cpu-baseline --late-start 0 --second-mesh off --big-mesh 0 --no-glow-discharge"
 python3 -c 'import __graft_entry__ as g; g.build()' || exit 1
 : > gpurun_out/ab_$NAME.txt
 for round in $(seq 1 ${ROUNDS:-2}); do

@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # preloaded tool, which initialises the GPU, and the compiler driver's exec hops would then happen in
 # GPU-initialised processes (bench.py refuses to compile under a profiler for the same reason).
 python3 -c 'import __graft_entry__ as g; g.build()' || exit 9
-ONLY="--no-cpu-baseline --late-start 0 --unstructured off --big-mesh 0 --no-glow-discharge"
+ONLY="--no-cpu-baseline --late-start 0 --second-mesh off --big-mesh 0 --no-glow-discharge"
 BENCH="bench.py --steps 20 --warmup 5 $ONLY"
 SHORT="bench.py --steps 2 --warmup 0 $ONLY"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err" || exit 1

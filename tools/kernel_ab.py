@@ -3,9 +3,9 @@ Jacobian SpMV: `fedm_time_kernel`, back to back -- the SpMV therefore runs from 
 on the bench mesh under run-time switches; one child process per configuration (the switches are
 read when the context is created).  Prints one JSON line per configuration.
 
-usage: kernel_ab.py [mesh] [KEY=VAL[,KEY=VAL...]] ...      one argument per configuration, e.g.
+usage: kernel_ab.py [mesh | -k] [KEY=VAL[,KEY=VAL...]] ...      one argument per configuration, e.g.
     kernel_ab.py 576 FEDM_PATCH_ORDER=0 FEDM_PATCH_ORDER=16,16 FEDM_SKIP_CONST_PLANES=0
-Switches: FEDM_ASSEMBLY_LEAN=0|1|2, FEDM_XCD_REMAP=0|1, FEDM_PATCH_ORDER=group,mod|0,
+Switches: FEDM_ASSEMBLY_LEAN=0|2|3, FEDM_XCD_REMAP=0|1, FEDM_PATCH_ORDER=group,mod|0,
 FEDM_PATCH_ORDER_READS=w, FEDM_SKIP_CONST_PLANES=0|1, FEDM_SPMV_SKIP_ZERO_PLANES=0|1,
 FEDM_HIP_LIB=<experiment build>.
 Boxes of the pool differ by up to 12 % (MI355X_MICROARCH.md, DVFS): compare within one call only.
@@ -23,7 +23,11 @@ KEYS = ("FEDM_ASSEMBLY_LEAN", "FEDM_XCD_REMAP", "FEDM_PATCH_ORDER", "FEDM_PATCH_
 
 def child(n):
     from fedm_amd.cases import streamer
-    msh = streamer.mesh(n, 4.0)
+    if n < 0:     # -k: the refined unstructured mesh with k um in the channel (bench.py's headline mesh: -4)
+        h = -n * 1e-6
+        msh = streamer.refined_mesh(h, growth=0.1, channel=(0.0, 100.0 * h) + streamer.CHANNEL[2:])
+    else:
+        msh = streamer.mesh(n, 4.0)
     prob = streamer.device_problem(msh.coords, msh.cells)
     streamer.initialise(prob, multigrid=False)
     prob.set_step(5e-12, 5e-12)
@@ -51,7 +55,7 @@ if __name__ == "__main__":
         child(int(os.environ.get("FEDM_AB_MESH", "576")))
     else:
         args = sys.argv[1:]
-        mesh = args.pop(0) if args and args[0].isdigit() else "576"
+        mesh = args.pop(0) if args and args[0].lstrip("-").isdigit() else "576"
         for cfg in ([parse(a) for a in args] or [{}]):
             env = dict(os.environ, FEDM_AB_MESH=mesh, **cfg)
             r = subprocess.run([sys.executable, __file__, "--one"], env=env, capture_output=True, text=True,
