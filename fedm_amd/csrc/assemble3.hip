@@ -20,13 +20,32 @@
 // Same element tensors as element.hpp / element_lean.hpp (held against each other and against the oracle in
 // tests/test_gpu_parity.py, tests/test_gpu_unstructured.py), same patch tables, same micro-coloured cell order.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "element_lean.hpp"
 #include "fedm_internal.hpp"
 
 namespace fedm {
+
+// -DFEDM_LEAN3_PROBE=bits: an experiment build whose kernel leaves out a phase (WRONG results): 1 no stream-out
+// stores, 2 the LDS accumulation as plain stores instead of atomics, 4 no cell arithmetic at all -- what each
+// phase costs (tools/kernel_ab.py with FEDM_HIP_LIB).
+#ifndef FEDM_LEAN3_PROBE
+#define FEDM_LEAN3_PROBE 0
+#endif
+#if FEDM_LEAN3_PROBE & 32
+#define termsum_eval(ts, E, iE, lE, v, d) do { v = (ts).c[0] * (E); d = (ts).c[0] * (iE); } while (0)
+#endif
+#if FEDM_LEAN3_PROBE & 2
+#define LEAN3_ADD(ptr, v) (*(ptr) = (v))
+#else
+#define LEAN3_ADD(ptr, v) unsafeAtomicAdd(ptr, v)
+#endif
 
 // Planes of the (row, col) block that are accumulated and streamed out: those NOT in CMASK, numbered in
 // row-major order.
@@ -50,8 +69,23 @@ struct LivePlanes {
     }
 };
 
+// -DFEDM_PHASE_TIMING: wave 0's view of a workgroup's phases (100 MHz wall clock), summed over all workgroups:
+// tools/phase_time3.py
+#ifdef FEDM_PHASE_TIMING
+__device__ unsigned long long g_phase3[8];
+#define LEAN3_T(k) if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase3[k], now_ - t_prev_); t_prev_ = now_; }
+extern "C" void fedm_debug_phase3(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase3), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_phase3), z, sizeof(z));
+    }
+}
+#else
+#define LEAN3_T(k)
+#endif
+
 struct Lean3Params {
-    const fedm_model_desc *md;
     int nv;
     const int *boff, *cell_ptr;
     const PatchCell *pcells;
@@ -61,6 +95,7 @@ struct Lean3Params {
     double *val, *F;
     int acc_doubles, max_verts, xcd;
     const int *patch_list;
+    int n_patches;         // (persistent kernels: the grid is smaller than the number of patches)
 };
 
 __device__ __forceinline__ int lean3_xcd_contiguous(int b, int n) {
@@ -83,6 +118,57 @@ __device__ __forceinline__ void p1_moments2(const double (&X)[3], double (&m)[6]
     m[5] = fma(1.0 / 12.0, X[1] + X[2], s36);   // sym6(1, 2)
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The model compiled for these kernels (host: lean3_build_plan).  fedm_model_desc holds the deck's coefficient
+// functions as general sums  sum_i c_i E^p_i exp(q_i E^r_i)  and the kernels of the earlier generations walked
+// them term by term: a dependent scalar load from the descriptor, a wait and a branch per term and property, one
+// exponential per term -- 13 of the F + J kernel's 74 us on the refined bench mesh (probe builds).  Here the
+// functions arrive in the kernel arguments (scalar registers from the start, no descriptor loads at all) as
+// products of a few ATOMS shared by all terms of the model:  E^p = E^m * exp(pf ln E)  with m integer and
+// 0 <= pf < 1 (the streamer's E^0.74, E^-0.26, E^-2.26 share pf = 0.74), and  exp(q / E)  per distinct q -- three
+// exponentials per cell for the streamer deck instead of five.  Models whose functions do not fit (r other than
+// -1, more than two atoms of a kind, more than three terms) stay on the second generation.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int L3_TERMS = 3, L3_ATOMS = 2;
+struct Lean3Slot {
+    int n;                 // terms
+    int code[L3_TERMS];    // bits 0-1: power atom (0 none, 1, 2), bits 2-3: exp atom, bits 4-8: m + 8
+    double c[L3_TERMS], p[L3_TERMS], q[L3_TERMS];
+};
+template <int NS, int NR>
+struct Lean3Plan {
+    int nP, nQ, nreac, axisymmetric;
+    double pf[L3_ATOMS], qv[L3_ATOMS];
+    double coe;                              // e / eps0
+    int eq_type[NS], has_drift_w[NS];
+    double Z[NS], drift_w[NS][2];
+    int power[NR][NS], net[NR][NS];
+    Lean3Slot k[NR], D[NS], mu[NS];
+};
+
+struct Lean3Atoms {
+    double P[L3_ATOMS], Q[L3_ATOMS], E, invE;
+};
+
+// value and d/dE of one coefficient function (all tests are on scalar registers: wave-uniform)
+__device__ __forceinline__ void lean3_coef(const Lean3Slot *__restrict__ slot, const Lean3Atoms &at, double &val, double &der) {
+    const Lean3Slot sl = *slot;    // the whole record at once: two wide scalar loads and ONE wait, not one per term and property
+    val = 0.0;
+    der = 0.0;
+#pragma unroll
+    for (int t = 0; t < L3_TERMS; ++t) {
+        if (t >= sl.n) break;
+        const int code = sl.code[t], iP = code & 3, iQ = (code >> 2) & 3, m = ((code >> 4) & 31) - 8;
+        double x = sl.c[t];
+        if (iP) x *= (iP == 1 ? at.P[0] : at.P[1]);
+        if (iQ) x *= (iQ == 1 ? at.Q[0] : at.Q[1]);
+        const double f = m < 0 ? at.invE : at.E;
+        for (int e = 0; e < (m < 0 ? -m : m); ++e) x *= f;
+        val += x;
+        der += x * (sl.p[t] - sl.q[t] * at.invE) * at.invE;
+    }
+}
+
 // What the rows of a cell share.
 template <int NS, int NR>
 struct Lean3Cell {
@@ -93,11 +179,13 @@ struct Lean3Cell {
     double gg[6];          // grad(phi_a) . grad(phi_b), sym6 order
     double nq[NS][3];      // exp(u_i) at the quadrature points
     double kv[NR], kd[NR];
+    double rq[NR][3];      // prod_i n_i^P_ji at the quadrature points (fedm/functions.py:835-843)
+    Lean3Atoms at;
 };
 
 // Species row S (fedm/functions.py:350-368 with Flux :219-237 and the source of :777-843).
 template <int NS, int NR, uint32_t CMASK, bool JAC, int S>
-__device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restrict__ md, const Lean3Cell<NS, NR> &c,
+__device__ __forceinline__ void lean3_species_row(const Lean3Plan<NS, NR> *__restrict__ md, const Lean3Cell<NS, NR> &c,
                                                   const double *__restrict__ Ul, const double *__restrict__ Hl,
                                                   const StepCoef sc, const uint32_t (&dst)[9], double *__restrict__ Fl,
                                                   char *__restrict__ lds_base) {
@@ -120,7 +208,7 @@ __device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restr
             gradu[0] += Us[a] * c.G[a][0];
             gradu[1] += Us[a] * c.G[a][1];
         }
-        termsum_eval(md->D[S], c.Em, c.invEm, c.lnE, Dv, Dd);
+        lean3_coef(&md->D[S], c.at, Dv, Dd);
         vel[0] = -Dv * gradu[0];
         vel[1] = -Dv * gradu[1];
         if (eq == FEDM_EQ_DRIFT_DIFFUSION_REACTION) {
@@ -128,7 +216,7 @@ __device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restr
                 vel[0] += md->drift_w[S][0];
                 vel[1] += md->drift_w[S][1];
             } else {
-                termsum_eval(md->mu[S], c.Em, c.invEm, c.lnE, muv, mud);
+                lean3_coef(&md->mu[S], c.at, muv, mud);
                 vel[0] += Z * muv * c.E[0];
                 vel[1] += Z * muv * c.E[1];
                 fdrift = true;
@@ -137,7 +225,7 @@ __device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restr
     }
     // weighted point values: H (residual integrand), N (density), SP (d source / d|E|), Xg[i] (d integrand / d u_i)
     const double usum6 = (Us[0] + Us[1] + Us[2]) * (1.0 / 6.0), hsum6 = (Hs[0] + Hs[1] + Hs[2]) * (1.0 / 6.0);
-    const int nreac = md->n_reactions;
+    const int nreac = md->nreac;
     double XH[3], XN[3], XS[3], XG[NS][3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -151,12 +239,7 @@ __device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restr
             if (j >= nreac) break;
             const double nu = (double)md->net[j][S];
             if (nu == 0.0) continue;
-            double prod = 1.0;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const int Pw = md->power[j][i];
-                for (int e = 0; e < Pw; ++e) prod *= c.nq[i][q];
-            }
+            const double prod = c.rq[j][q];
             const double nk = nu * c.kv[j] * prod;
             h -= nk;
             sp += nu * c.kd[j] * prod;
@@ -201,11 +284,22 @@ __device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restr
             }
         }
     }
+    if (FEDM_LEAN3_PROBE & 16) {    // no emission: the moments kept alive by one add
+        double sum = m1h[0] + m1h[1] + m1h[2] + velG[0] + velG[1] + velG[2] + m0n;
+        if constexpr (JAC) {
+            sum += m1n[0] + m1n[1] + m1n[2] + T[0] + T[1] + T[2] + DGm + Kd;
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (PL::live(S, i)) sum += m2[i][0] + m2[i][1] + m2[i][2] + m2[i][3] + m2[i][4] + m2[i][5];
+        }
+        unsafeAtomicAdd(&Fl[c.lv[0] & 63], sum);
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const int lane = c.lv[a];
         if (lane >= SLICE) continue;   // row vertex owned by another patch
-        unsafeAtomicAdd(&Fl[lane * NEQ + S], m1h[a] - velG[a] * m0n);
+        LEAN3_ADD(&Fl[lane * NEQ + S], m1h[a] - velG[a] * m0n);
         if constexpr (JAC) {
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
@@ -214,10 +308,10 @@ __device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restr
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
                     if (PL::live(S, i))
-                        unsafeAtomicAdd(&d[PL::index(S, i) * SLICE],
+                        LEAN3_ADD(&d[PL::index(S, i) * SLICE],
                                         m2[i][k] + ((i == S) ? DGm * c.gg[k] - velG[a] * m1n[b] : 0.0));
                 if constexpr (PL::live(S, IPHI))
-                    unsafeAtomicAdd(&d[PL::index(S, IPHI) * SLICE], Kd * c.gg[k] + c.Qa[b] * c.invEm * T[a]);
+                    LEAN3_ADD(&d[PL::index(S, IPHI) * SLICE], Kd * c.gg[k] + c.Qa[b] * c.invEm * T[a]);
             }
         }
     }
@@ -225,12 +319,12 @@ __device__ __forceinline__ void lean3_species_row(const fedm_model_desc *__restr
 
 // Poisson row (fedm/functions.py:401): 2 pi r (grad Phi . grad v - sum_i Z_i e n_i / eps0 v)
 template <int NS, int NR, uint32_t CMASK, bool JAC>
-__device__ __forceinline__ void lean3_poisson_row(const fedm_model_desc *__restrict__ md, const Lean3Cell<NS, NR> &c,
+__device__ __forceinline__ void lean3_poisson_row(const Lean3Plan<NS, NR> *__restrict__ md, const Lean3Cell<NS, NR> &c,
                                                   const uint32_t (&dst)[9], double *__restrict__ Fl,
                                                   char *__restrict__ lds_base) {
     constexpr int NEQ = NS + 1, IPHI = NS;
     using PL = LivePlanes<NS, CMASK>;
-    const double coe = md->charge_over_eps;
+    const double coe = md->coe;
     double XH[3] = {0.0, 0.0, 0.0}, XG[NS][3];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -252,7 +346,7 @@ __device__ __forceinline__ void lean3_poisson_row(const fedm_model_desc *__restr
     for (int a = 0; a < 3; ++a) {
         const int lane = c.lv[a];
         if (lane >= SLICE) continue;
-        unsafeAtomicAdd(&Fl[lane * NEQ + IPHI], m1h[a] - c.Qa[a] * c.m01);
+        LEAN3_ADD(&Fl[lane * NEQ + IPHI], m1h[a] - c.Qa[a] * c.m01);
         if constexpr (JAC) {
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
@@ -260,15 +354,15 @@ __device__ __forceinline__ void lean3_poisson_row(const fedm_model_desc *__restr
                 double *d = reinterpret_cast<double *>(lds_base + dst[a * 3 + b]);
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
-                    if (PL::live(IPHI, i)) unsafeAtomicAdd(&d[PL::index(IPHI, i) * SLICE], m2[i][k]);
-                if constexpr (PL::live(IPHI, IPHI)) unsafeAtomicAdd(&d[PL::index(IPHI, IPHI) * SLICE], c.gg[k] * c.m01);
+                    if (PL::live(IPHI, i)) LEAN3_ADD(&d[PL::index(IPHI, i) * SLICE], m2[i][k]);
+                if constexpr (PL::live(IPHI, IPHI)) LEAN3_ADD(&d[PL::index(IPHI, IPHI) * SLICE], c.gg[k] * c.m01);
             }
         }
     }
 }
 
 template <int NS, int NR, uint32_t CMASK, bool JAC, int S>
-__device__ __forceinline__ void lean3_species_rows(const fedm_model_desc *__restrict__ md, const Lean3Cell<NS, NR> &c,
+__device__ __forceinline__ void lean3_species_rows(const Lean3Plan<NS, NR> *__restrict__ md, const Lean3Cell<NS, NR> &c,
                                                    const double *__restrict__ Ul, const double *__restrict__ Hl,
                                                    const StepCoef sc, const uint32_t (&dst)[9], double *__restrict__ Fl,
                                                    char *__restrict__ lds_base) {
@@ -279,8 +373,136 @@ __device__ __forceinline__ void lean3_species_rows(const fedm_model_desc *__rest
     }
 }
 
+// The local indices of a cell in its patch, as the kernels keep them (PatchCell without the cell number and the tags)
+struct CellIdx {
+    uint32_t lv;           // local vertex ids, a byte each
+    uint32_t j0, j1, j2;   // local block columns of the nine (a, b) pairs, a byte each
+};
+__device__ __forceinline__ CellIdx cell_idx(const PatchCell &pc) {
+    CellIdx ci;
+    ci.lv = pc.lv[0] | (pc.lv[1] << 8) | (pc.lv[2] << 16);
+    ci.j0 = pc.j[0] | (pc.j[1] << 8) | (pc.j[2] << 16) | ((uint32_t)pc.j[3] << 24);
+    ci.j1 = pc.j[4] | (pc.j[5] << 8) | (pc.j[6] << 16) | ((uint32_t)pc.j[7] << 24);
+    ci.j2 = pc.j[8];
+    return ci;
+}
+
+// One cell: everything its rows share, then the rows one after the other (straight-line code).
+template <int NS, int NR, uint32_t CMASK, bool JAC>
+__device__ __forceinline__ void lean3_cell(const Lean3Plan<NS, NR> *__restrict__ md, const CellIdx ci,
+                                           const double *__restrict__ vx, const double *__restrict__ Ul,
+                                           const double *__restrict__ Hl, const double *__restrict__ Al,
+                                           const StepCoef sc, double *__restrict__ acc, double *__restrict__ Fl) {
+    constexpr int NEQ = NS + 1, IPHI = NS;
+    using PL = LivePlanes<NS, CMASK>;
+    constexpr int NPL = PL::N;
+        Lean3Cell<NS, NR> c;
+    double x[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c.lv[a] = (ci.lv >> (8 * a)) & 255u;
+        x[a][0] = vx[2 * c.lv[a]];
+        x[a][1] = vx[2 * c.lv[a] + 1];
+    }
+    CellGeom cg;
+    cg.init(x, md->axisymmetric);
+    const double two_pi = 6.283185307179586476925286766559;
+    {
+        // weights of the three points times 2 pi r: r(q) = (r0 + r1 + r2)/6 + r_q/2
+        const double w6 = (1.0 / 6.0) * cg.detJ * two_pi;
+        const double rs6 = (cg.rn[0] + cg.rn[1] + cg.rn[2]) * (1.0 / 6.0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c.W[q] = w6 * fma(0.5, cg.rn[q], rs6);
+        c.m01 = c.W[0] + c.W[1] + c.W[2];
+    }
+    c.E[0] = c.E[1] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c.G[a][0] = cg.G[a][0];
+        c.G[a][1] = cg.G[a][1];
+        const double ph = Ul[c.lv[a] * NEQ + IPHI];
+        c.E[0] -= ph * cg.G[a][0];
+        c.E[1] -= ph * cg.G[a][1];
+    }
+    {
+        // 1/|E| by reciprocal square root, |E| = E^2 / |E|, ln|E| = ln(E^2)/2
+        const double E2 = c.E[0] * c.E[0] + c.E[1] * c.E[1];
+        c.invEm = rsqrt(E2);
+        c.Em = E2 * c.invEm;
+        c.lnE = 0.5 * log(E2);
+        // the atoms of the model's coefficient functions (all of the cell's exponentials)
+        c.at.E = c.Em;
+        c.at.invE = c.invEm;
+#pragma unroll
+        for (int i = 0; i < L3_ATOMS; ++i) {
+            c.at.P[i] = i < md->nP ? exp(md->pf[i] * c.lnE) : 1.0;
+            c.at.Q[i] = i < md->nQ ? exp(md->qv[i] * c.invEm) : 1.0;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c.Qa[a] = c.E[0] * c.G[a][0] + c.E[1] * c.G[a][1];
+        if constexpr (JAC) {
+#pragma unroll
+            for (int b = a; b < 3; ++b) c.gg[sym6(a, b)] = c.G[a][0] * c.G[b][0] + c.G[a][1] * c.G[b][1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        // u(q) = (u0 + u1 + u2)/6 + u_q/2: exp of it from the per-vertex factors exp(u_v / 6)
+        const double a0 = Al[c.lv[0] * NS + i], a1 = Al[c.lv[1] * NS + i], a2 = Al[c.lv[2] * NS + i];
+        const double P = a0 * a1 * a2;
+        c.nq[i][0] = P * (a0 * a0 * a0);
+        c.nq[i][1] = P * (a1 * a1 * a1);
+        c.nq[i][2] = P * (a2 * a2 * a2);
+    }
+    {
+        const int nreac = md->nreac;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            c.kv[j] = c.kd[j] = 0.0;
+            c.rq[j][0] = c.rq[j][1] = c.rq[j][2] = 1.0;
+            if (j < nreac) {
+                lean3_coef(&md->k[j], c.at, c.kv[j], c.kd[j]);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int Pw = md->power[j][i];
+                    for (int e = 0; e < Pw; ++e) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) c.rq[j][q] *= c.nq[i][q];
+                    }
+                }
+            }
+        }
+    }
+    // byte offsets of the nine (a, b) accumulators of this cell (row vertex a owned: lane < 64)
+    uint32_t dst[9];
+    char *lds_base = reinterpret_cast<char *>(acc);
+    if constexpr (JAC) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const uint32_t jab = ((e < 4 ? ci.j0 : e < 8 ? ci.j1 : ci.j2) >> (8 * (e & 3))) & 255u;
+            dst[e] = (jab * (NPL * SLICE) + (uint32_t)c.lv[e / 3]) * (uint32_t)sizeof(double);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (FEDM_LEAN3_PROBE & 8) {     // no rows: what the rows share, kept alive by one add
+        double sum = c.m01 + c.invEm + c.lnE + c.kv[0] + c.kd[0] + c.rq[0][0] + c.rq[0][1] + c.rq[0][2];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sum += c.nq[i][0] + c.nq[i][1] + c.nq[i][2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum += c.gg[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sum += c.Qa[a] + c.W[a];
+        unsafeAtomicAdd(&Fl[c.lv[0] & 63], sum);
+        return;
+    }
+    lean3_species_rows<NS, NR, CMASK, JAC, 0>(md, c, Ul, Hl, sc, dst, Fl, lds_base);
+    lean3_poisson_row<NS, NR, CMASK, JAC>(md, c, dst, Fl, lds_base);
+}
+
 template <int NS, int NR, int THREADS, uint32_t CMASK, bool JAC>
-__device__ __forceinline__ void assemble_lean3_body(const Lean3Params &p) {
+__device__ __forceinline__ void assemble_lean3_body(const Lean3Plan<NS, NR> *__restrict__ plan, const Lean3Params &p) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, IPHI = NS;
     using PL = LivePlanes<NS, CMASK>;
     constexpr int NPL = PL::N;
@@ -291,19 +513,33 @@ __device__ __forceinline__ void assemble_lean3_body(const Lean3Params &p) {
     double *Ul = vx + 2 * p.max_verts;          // [max_verts][NEQ]
     double *Hl = Ul + NEQ * p.max_verts;        // [max_verts][NS]
     double *Al = Hl + NS * p.max_verts;         // [max_verts][NS]: exp(u / 6)
+#ifdef FEDM_PHASE_TIMING
+    unsigned long long t_prev_ = wall_clock64();
+#endif
+#ifdef FEDM_LEAN3_STAGGER
+    // experiment: the workgroups of the first round start at different times
+    if (blockIdx.x < FEDM_LEAN3_STAGGER_BLOCKS) {
+        const unsigned b = blockIdx.x;
+        const unsigned k = FEDM_LEAN3_STAGGER == 1 ? (b >> 8) & 3u : FEDM_LEAN3_STAGGER == 2 ? b & 3u
+                           : ((b * 2654435761u) >> 13) & 3u;
+        for (unsigned i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(FEDM_LEAN3_STAGGER_SLEEP);
+    }
+#endif
     const int blk = p.xcd ? lean3_xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int S = p.patch_list ? p.patch_list[blk] : blk;
     const int b0 = p.boff[S], width = p.boff[S + 1] - b0;
     const int c0 = p.cell_ptr[S], n_cells = p.cell_ptr[S + 1] - c0;
-    const bool active = (int)threadIdx.x < n_cells;   // one cell per thread (n_cells <= THREADS)
+    // a cell per thread; the rare patch with more cells than threads (3 of 5 333 on the refined bench mesh)
+    // gives its first threads a second one
     PatchCell pc = {};
-    if (active) pc = p.pcells[c0 + threadIdx.x];
+    if ((int)threadIdx.x < n_cells) pc = p.pcells[c0 + threadIdx.x];
     if constexpr (JAC) {
         double2 *acc2 = reinterpret_cast<double2 *>(acc);
         const int n2 = width * NPL * (SLICE / 2);
         for (int k = threadIdx.x; k < n2; k += THREADS) acc2[k] = make_double2(0.0, 0.0);
     }
     for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) Fl[k] = 0.0;
+    LEAN3_T(0)   // header, cell record request, zeroing
     const int h0 = p.halo_ptr[S], n_local = SLICE + p.halo_ptr[S + 1] - h0;
     for (int i = threadIdx.x; i < n_local; i += THREADS) {
         const int g = (i < SLICE) ? S * SLICE + i : p.halo[h0 + i - SLICE];
@@ -322,82 +558,21 @@ __device__ __forceinline__ void assemble_lean3_body(const Lean3Params &p) {
             for (int s = 0; s < NS; ++s) Al[i * NS + s] = exp(un[s] * (1.0 / 6.0));
         }
     }
+    LEAN3_T(1)   // staging: halo id, vertex data, exponentials, LDS writes
     __syncthreads();
-    if (active) {
-        const fedm_model_desc *__restrict__ md = p.md;
-        Lean3Cell<NS, NR> c;
-        double x[3][2];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            c.lv[a] = pc.lv[a];
-            x[a][0] = vx[2 * c.lv[a]];
-            x[a][1] = vx[2 * c.lv[a] + 1];
-        }
-        CellGeom cg;
-        cg.init(x, md->axisymmetric);
-        const double two_pi = 6.283185307179586476925286766559;
-        {
-            // weights of the three points times 2 pi r: r(q) = (r0 + r1 + r2)/6 + r_q/2
-            const double w6 = (1.0 / 6.0) * cg.detJ * two_pi;
-            const double rs6 = (cg.rn[0] + cg.rn[1] + cg.rn[2]) * (1.0 / 6.0);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) c.W[q] = w6 * fma(0.5, cg.rn[q], rs6);
-            c.m01 = c.W[0] + c.W[1] + c.W[2];
-        }
-        c.E[0] = c.E[1] = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            c.G[a][0] = cg.G[a][0];
-            c.G[a][1] = cg.G[a][1];
-            const double ph = Ul[c.lv[a] * NEQ + IPHI];
-            c.E[0] -= ph * cg.G[a][0];
-            c.E[1] -= ph * cg.G[a][1];
-        }
-        {
-            // 1/|E| by reciprocal square root, |E| = E^2 / |E|, ln|E| = ln(E^2)/2
-            const double E2 = c.E[0] * c.E[0] + c.E[1] * c.E[1];
-            c.invEm = rsqrt(E2);
-            c.Em = E2 * c.invEm;
-            c.lnE = 0.5 * log(E2);
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            c.Qa[a] = c.E[0] * c.G[a][0] + c.E[1] * c.G[a][1];
-            if constexpr (JAC) {
-#pragma unroll
-                for (int b = a; b < 3; ++b) c.gg[sym6(a, b)] = c.G[a][0] * c.G[b][0] + c.G[a][1] * c.G[b][1];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            // u(q) = (u0 + u1 + u2)/6 + u_q/2: exp of it from the per-vertex factors exp(u_v / 6)
-            const double a0 = Al[c.lv[0] * NS + i], a1 = Al[c.lv[1] * NS + i], a2 = Al[c.lv[2] * NS + i];
-            const double P = a0 * a1 * a2;
-            c.nq[i][0] = P * (a0 * a0 * a0);
-            c.nq[i][1] = P * (a1 * a1 * a1);
-            c.nq[i][2] = P * (a2 * a2 * a2);
-        }
-        {
-            const int nreac = md->n_reactions;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                c.kv[j] = c.kd[j] = 0.0;
-                if (j < nreac) termsum_eval(md->k[j], c.Em, c.invEm, c.lnE, c.kv[j], c.kd[j]);
-            }
-        }
-        // byte offsets of the nine (a, b) accumulators of this cell (row vertex a owned: lane < 64)
-        uint32_t dst[9];
-        char *lds_base = reinterpret_cast<char *>(acc);
-        if constexpr (JAC) {
-#pragma unroll
-            for (int e = 0; e < 9; ++e)
-                dst[e] = ((uint32_t)pc.j[e] * (NPL * SLICE) + (uint32_t)pc.lv[e / 3]) * (uint32_t)sizeof(double);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        lean3_species_rows<NS, NR, CMASK, JAC, 0>(md, c, Ul, Hl, p.sc, dst, Fl, lds_base);
-        lean3_poisson_row<NS, NR, CMASK, JAC>(md, c, dst, Fl, lds_base);
+    LEAN3_T(2)   // barrier 1
+    auto one_cell = [&](const PatchCell &pcx) { lean3_cell<NS, NR, CMASK, JAC>(plan, cell_idx(pcx), vx, Ul, Hl, Al, p.sc, acc, Fl); };
+    // Straight-line code for the thread's cell; a second copy of it (never fetched by the other workgroups) for
+    // the patches with more cells than threads.  As a loop the invariants the compiler hoists out of it cost 35
+    // spilled registers.
+    if (!(FEDM_LEAN3_PROBE & 4) && (int)threadIdx.x < n_cells) one_cell(pc);
+    if ((int)threadIdx.x + THREADS < n_cells) {     // (n_cells <= 2 THREADS: lean3_applies)
+        const PatchCell pc2 = p.pcells[c0 + threadIdx.x + THREADS];
+        one_cell(pc2);
     }
+    LEAN3_T(3)   // the cell
     __syncthreads();
+    LEAN3_T(4)   // barrier 2
     if constexpr (JAC) {
         // stream-out: every live plane of every block column is 64 consecutive doubles in the matrix
         static_assert(THREADS % (SLICE / 2) == 0, "a thread keeps its 16-byte piece of the plane");
@@ -409,11 +584,204 @@ __device__ __forceinline__ void assemble_lean3_body(const Lean3Params &p) {
         for (int k = threadIdx.x / (SLICE / 2); k < n_pl; k += STEP) {
             const int bc = k / NPL, pl = k - bc * NPL;
             const int rc = (int)((RC >> (4 * pl)) & 15u);
+            if (FEDM_LEAN3_PROBE & 1) {
+                if (src[k * (SLICE / 2)].x == 1.2345e-300) p.val[0] = 1.0;   // (keeps the LDS read alive)
+                continue;
+            }
             reinterpret_cast<double2 *>(p.val + ((size_t)(b0 + bc) * NEQ2 + rc) * SLICE)[piece] = src[k * (SLICE / 2)];
         }
     }
     double *fdst = p.F + (size_t)S * SLICE * NEQ;
     for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) fdst[k] = Fl[k];
+    LEAN3_T(5)   // stream-out (issue)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same assembly as a PERSISTENT, software-pipelined kernel.  Measured on the one-shot kernel above (probe
+// builds, tools/kernel_ab.py): without the cell arithmetic it takes 30 us (the refined bench mesh; 6.4 TB/s:
+// the memory system's limit), the arithmetic adds 45 us, and the whole takes 75 us -- the SUM.  A workgroup's
+// life was: three dependent memory round trips (patch header -> halo vertex ids and cell records -> vertex data),
+// the exponentials, a barrier, the arithmetic, a barrier, the stream-out; with three to four workgroups per CU the
+// waves that compute at any moment are 1.3 per SIMD, and their dependent fp64 chains leave the vector pipes idle
+// half of the time.  Here a workgroup stays and takes patch after patch:
+//   * the NEXT patch's header is read two patches ahead (scalar loads), the id of the halo vertex a thread will
+//     stage one patch ahead, at the start of the current patch's arithmetic -- one register that lives through it;
+//   * behind the arithmetic's barrier the next patch's vertex data and cell records are REQUESTED FIRST, then the
+//     current patch is streamed out (and its accumulators zeroed in the same pass) while they travel; the
+//     exponentials and LDS writes of the staging follow;
+//   * a patch therefore costs its arithmetic plus one stream-out instead of arithmetic plus three round trips
+//     plus stream-out, and the only time a wave waits for memory is the prologue of its workgroup.
+// The workgroups of an XCD share a contiguous range of patches (neighbouring patches stage the same halo vertices:
+// one L2) and take them round robin.
+// ---------------------------------------------------------------------------------------------------------------
+struct PatchHdr {
+    int S, b0, width, c0, nc, h0, nloc;
+};
+
+template <int NS, int NR, int THREADS, uint32_t CMASK, bool JAC>
+__device__ __forceinline__ void assemble_lean3p_body(const Lean3Plan<NS, NR> *__restrict__ md, double *__restrict__ gval,
+                                                     double *__restrict__ gF, const Lean3Params &p) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    using PL = LivePlanes<NS, CMASK>;
+    constexpr int NPL = PL::N;
+    extern __shared__ __align__(16) double lds[];
+    double *acc = lds;                          // [max width][NPL][64]
+    double *Fl = acc + p.acc_doubles;           // [64][NEQ]
+    double *vx = Fl + SLICE * NEQ;              // [max_verts][2]
+    double *Ul = vx + 2 * p.max_verts;          // [max_verts][NEQ]
+    double *Hl = Ul + NEQ * p.max_verts;        // [max_verts][NS]
+    double *Al = Hl + NS * p.max_verts;         // [max_verts][NS]: exp(u / 6)
+    const int tid = threadIdx.x;
+    // this workgroup's patches: first, first + stride, ... below end
+    int first, stride, end;
+    if (p.xcd) {
+        const int x = blockIdx.x & 7, per = (p.n_patches + 7) >> 3;
+        first = x * per + (blockIdx.x >> 3);
+        stride = gridDim.x >> 3;                // (the grid is a multiple of 8 workgroups: lean3_launch_one)
+        end = min((x + 1) * per, p.n_patches);
+    } else {
+        first = blockIdx.x;
+        stride = gridDim.x;
+        end = p.n_patches;
+    }
+    if (first >= end) return;
+    auto load_hdr = [&](int idx) {
+        PatchHdr h;
+        h.S = p.patch_list ? p.patch_list[idx] : idx;
+        h.b0 = p.boff[h.S];
+        h.width = p.boff[h.S + 1] - h.b0;
+        h.c0 = p.cell_ptr[h.S];
+        h.nc = p.cell_ptr[h.S + 1] - h.c0;
+        h.h0 = p.halo_ptr[h.S];
+        h.nloc = SLICE + p.halo_ptr[h.S + 1] - h.h0;
+        return h;
+    };
+    // the thread's cell of a patch and the vertex it stages (nv: none)
+    auto load_cell = [&](int t, const PatchHdr &h) {
+        CellIdx ci = {0, 0, 0, 0};
+        if (t < h.nc) ci = cell_idx(p.pcells[h.c0 + t]);
+        return ci;
+    };
+    auto load_gid = [&](int t, const PatchHdr &h) {
+        return t < h.nloc ? (t < SLICE ? h.S * SLICE + t : p.halo[h.h0 + t - SLICE]) : p.nv;
+    };
+    struct VData {
+        double x0, x1, un[NEQ], uo[NS], uoo[NS];
+    };
+    auto load_data = [&](int gid) {
+        VData d = {};
+        if (gid < p.nv) {
+            d.x0 = p.coords[2 * (size_t)gid];
+            d.x1 = p.coords[2 * (size_t)gid + 1];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) d.un[s] = p.u[(size_t)gid * NEQ + s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                d.uo[s] = p.uold[(size_t)gid * NEQ + s];
+                d.uoo[s] = p.uold1[(size_t)gid * NEQ + s];
+            }
+        }
+        return d;
+    };
+    auto stage = [&](int t, int gid, const VData &d) {
+        if (gid < p.nv) {
+            vx[2 * t] = d.x0;
+            vx[2 * t + 1] = d.x1;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Hl[t * NS + s] = p.sc.c_old * d.uo[s] + p.sc.c_old1 * d.uoo[s];
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) Ul[t * NEQ + s] = d.un[s];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Al[t * NS + s] = exp(d.un[s] * (1.0 / 6.0));
+        }
+    };
+    // ---- prologue: the first patch the slow way ----
+    PatchHdr h = load_hdr(first);
+    CellIdx ci = load_cell(tid, h);
+    const int gid = load_gid(tid, h);
+    if constexpr (JAC) {
+        double2 *acc2 = reinterpret_cast<double2 *>(acc);
+        for (int k = tid; k < p.acc_doubles / 2; k += THREADS) acc2[k] = make_double2(0.0, 0.0);
+    }
+    for (int k = tid; k < SLICE * NEQ; k += THREADS) Fl[k] = 0.0;
+    {
+        const VData d = load_data(gid);
+        stage(tid, gid, d);
+    }
+    int idx = first;
+    bool has_next = idx + stride < end;
+    PatchHdr hn = has_next ? load_hdr(idx + stride) : h;
+    __syncthreads();
+    while (true) {
+        // the next patch's indices and the header of the one after it: in flight during this patch's arithmetic
+        // (t: an opaque copy of the thread index per patch -- the addresses derived from it would otherwise be kept in
+        // registers across the arithmetic as loop invariants)
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int gidn = has_next ? load_gid(t, hn) : p.nv;
+        const bool has_next2 = idx + 2 * stride < end;
+        const PatchHdr hn2 = has_next2 ? load_hdr(idx + 2 * stride) : hn;
+        if (!(FEDM_LEAN3_PROBE & 4) && tid < h.nc) lean3_cell<NS, NR, CMASK, JAC>(md, ci, vx, Ul, Hl, Al, p.sc, acc, Fl);
+        if (tid + THREADS < h.nc) {     // (n_cells <= 2 THREADS: lean3_applies)
+            const CellIdx ci2 = cell_idx(p.pcells[h.c0 + tid + THREADS]);
+            lean3_cell<NS, NR, CMASK, JAC>(md, ci2, vx, Ul, Hl, Al, p.sc, acc, Fl);
+        }
+        __syncthreads();
+        asm volatile("" : "+v"(t));
+        // the next patch's vertex data and cell records: issued before this patch is streamed out
+        VData dn = {};
+        CellIdx cin = {0, 0, 0, 0};
+        if (has_next) {
+            dn = load_data(gidn);
+            cin = load_cell(t, hn);
+        }
+        if constexpr (JAC) {
+            static_assert(THREADS % (SLICE / 2) == 0, "a thread keeps its 16-byte piece of the plane");
+            constexpr uint64_t RC = PL::packed();
+            constexpr int STEP = THREADS / (SLICE / 2);
+            const int piece = t % (SLICE / 2);
+            const int n_pl = h.width * NPL;
+            double2 *src = reinterpret_cast<double2 *>(acc) + piece;
+            for (int k = t / (SLICE / 2); k < n_pl; k += STEP) {
+                const int bc = k / NPL, pl = k - bc * NPL;
+                const int rc = (int)((RC >> (4 * pl)) & 15u);
+                const double2 v = src[k * (SLICE / 2)];
+                src[k * (SLICE / 2)] = make_double2(0.0, 0.0);
+                if (FEDM_LEAN3_PROBE & 1) {
+                    if (v.x == 1.2345e-300) gval[0] = 1.0;
+                    continue;
+                }
+                reinterpret_cast<double2 *>(gval + ((size_t)(h.b0 + bc) * NEQ2 + rc) * SLICE)[piece] = v;
+            }
+        }
+        {
+            double *fdst = gF + (size_t)h.S * SLICE * NEQ;
+            for (int k = t; k < SLICE * NEQ; k += THREADS) {
+                fdst[k] = Fl[k];
+                Fl[k] = 0.0;
+            }
+        }
+        if (!has_next) break;
+        stage(t, gidn, dn);
+        __syncthreads();
+        h = hn;
+        hn = hn2;
+        ci = cin;
+        idx += stride;
+        has_next = has_next2;
+    }
+}
+
+template <int NS, int NR, int THREADS, uint32_t CMASK>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void assemble_lean3p_kernel(
+    const Lean3Plan<NS, NR> *__restrict__ plan, double *__restrict__ val, double *__restrict__ F, const Lean3Params p) {
+    assemble_lean3p_body<NS, NR, THREADS, CMASK, true>(plan, val, F, p);
+}
+
+template <int NS, int NR, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void residual_lean3p_kernel(
+    const Lean3Plan<NS, NR> *__restrict__ plan, double *__restrict__ val, double *__restrict__ F, const Lean3Params p) {
+    assemble_lean3p_body<NS, NR, THREADS, 0u, false>(plan, val, F, p);
 }
 
 #ifndef FEDM_LEAN3_WAVES
@@ -421,27 +789,181 @@ __device__ __forceinline__ void assemble_lean3_body(const Lean3Params &p) {
 #endif
 template <int NS, int NR, int THREADS, uint32_t CMASK>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_LEAN3_WAVES, FEDM_LEAN3_WAVES))) void assemble_lean3_kernel(
-    const Lean3Params p) {
-    assemble_lean3_body<NS, NR, THREADS, CMASK, true>(p);
+    const Lean3Plan<NS, NR> *__restrict__ plan, const Lean3Params p) {
+    assemble_lean3_body<NS, NR, THREADS, CMASK, true>(plan, p);
 }
 
+#ifndef FEDM_RES3_WAVES
+#define FEDM_RES3_WAVES 4
+#endif
 template <int NS, int NR, int THREADS>
-__global__ __launch_bounds__(THREADS) void residual_lean3_kernel(const Lean3Params p) {
-    assemble_lean3_body<NS, NR, THREADS, 0u, false>(p);
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_RES3_WAVES, FEDM_RES3_WAVES))) void residual_lean3_kernel(
+    const Lean3Plan<NS, NR> *__restrict__ plan, const Lean3Params p) {
+    assemble_lean3_body<NS, NR, THREADS, 0u, false>(plan, p);
 }
 
-// LDS of one workgroup: live planes of the widest slice + residual + staged vertex data
-static size_t lean3_lds_bytes(const Ctx &c, int n_live_planes, bool jacobian) {
-    const int neq = c.neq, mv = c.pat.max_patch_verts;
-    const size_t acc = jacobian ? (size_t)c.pat.max_patch_width * n_live_planes * SLICE : 0;
-    return sizeof(double) * (acc + SLICE * neq + 2 * (size_t)mv + (size_t)(neq + 2 * c.ns) * mv);
+// fedm_model_desc -> Lean3Plan.  false: the model's coefficient functions do not fit the plan's form.
+template <int NS, int NR>
+static bool lean3_build_plan(const fedm_model_desc &m, Lean3Plan<NS, NR> &pl) {
+    if (m.n_species != NS || m.n_reactions > NR || !m.poisson) return false;
+    pl = Lean3Plan<NS, NR>{};
+    pl.nreac = m.n_reactions;
+    pl.axisymmetric = m.axisymmetric;
+    pl.coe = m.charge_over_eps;
+    for (int s = 0; s < NS; ++s) {
+        pl.eq_type[s] = m.eq_type[s];
+        pl.has_drift_w[s] = m.has_drift_w[s];
+        pl.Z[s] = m.Z[s];
+        pl.drift_w[s][0] = m.drift_w[s][0];
+        pl.drift_w[s][1] = m.drift_w[s][1];
+    }
+    for (int j = 0; j < NR; ++j)
+        for (int s = 0; s < NS; ++s) {
+            pl.power[j][s] = j < m.n_reactions ? m.power[j][s] : 0;
+            pl.net[j][s] = j < m.n_reactions ? m.net[j][s] : 0;
+        }
+    auto atom = [](double *list, int &n, double v) {     // index + 1 of v in the list (added when new); 0: no room
+        for (int i = 0; i < n; ++i)
+            if (std::fabs(list[i] - v) <= 1e-13 * std::max(1.0, std::fabs(v))) return i + 1;
+        if (n >= L3_ATOMS) return 0;
+        list[n] = v;
+        return ++n;
+    };
+    auto slot = [&](const fedm_termsum &ts, Lean3Slot &sl) {
+        sl.n = 0;
+        for (int i = 0; i < ts.n_terms; ++i) {
+            if (ts.c[i] == 0.0) continue;
+            if (sl.n >= L3_TERMS) return false;
+            const double pw = ts.p[i], q = ts.q[i];
+            if (q != 0.0 && ts.r[i] != -1.0) return false;                 // exp(q / E) only
+            const double fl = std::floor(pw + 1e-13), fr = pw - fl;        // E^p = E^m exp(fr ln E)
+            const int mpow = (int)fl;
+            if (mpow < -8 || mpow > 8) return false;
+            int iP = 0, iQ = 0;
+            if (fr > 1e-13 && !(iP = atom(pl.pf, pl.nP, fr))) return false;
+            if (q != 0.0 && !(iQ = atom(pl.qv, pl.nQ, q))) return false;
+            sl.code[sl.n] = iP | (iQ << 2) | ((mpow + 8) << 4);
+            sl.c[sl.n] = ts.c[i];
+            sl.p[sl.n] = pw;
+            sl.q[sl.n] = q;
+            ++sl.n;
+        }
+        return true;
+    };
+    for (int j = 0; j < m.n_reactions; ++j)
+        if (!slot(m.k[j], pl.k[j])) return false;
+    for (int s = 0; s < NS; ++s) {
+        // (only what the rows evaluate: no flux, no coefficient)
+        if (m.eq_type[s] == FEDM_EQ_REACTION) continue;
+        if (!slot(m.D[s], pl.D[s])) return false;
+        if (m.eq_type[s] == FEDM_EQ_DRIFT_DIFFUSION_REACTION && !m.has_drift_w[s] && !slot(m.mu[s], pl.mu[s])) return false;
+    }
+    return true;
+}
+
+// LDS of one workgroup: live planes of its block columns + residual + staged vertex data
+static size_t lean3_lds_bytes(int neq, int ns, int width, int verts, int n_live_planes, bool jacobian) {
+    const size_t acc = jacobian ? (size_t)width * n_live_planes * SLICE : 0;
+    return sizeof(double) * (acc + SLICE * neq + 2 * (size_t)verts + (size_t)(neq + 2 * ns) * verts);
+}
+
+// Two classes of patches.  Dynamic LDS is one number per launch, and a launch sized by the widest slice and the
+// patch with the most staged vertices (9 block columns and 141 vertices on the refined bench mesh: 44 KB, three
+// workgroups per CU) wastes it on the many that need less (4 722 of 5 333 slices there have 7 block columns:
+// 35 KB, four per CU).  The patches that fit a quarter of the CU's LDS with the planes kept go in one launch,
+// the rest in a second one sized for them -- when the split is worth a second launch.
+struct Lean3Classes {
+    int *d_list[2] = {nullptr, nullptr};
+    int n[2] = {0, 0}, width[2] = {0, 0}, verts[2] = {0, 0};
+    bool split = false;
+};
+
+static Lean3Classes *lean3_classes(Ctx &c, int n_live_planes) {
+    if (c.lean3_classes) return static_cast<Lean3Classes *>(c.lean3_classes);
+    Lean3Classes *k = new Lean3Classes();
+    c.lean3_classes = k;
+    // (measured on the refined bench mesh, tools/kernel_ab.py: 79-81 us with the split against 74-75 us for one
+    // launch sized for everything -- the second launch's start-up and the first one's tail cost more than the
+    // fourth workgroup per CU gains: opt-in, FEDM_LEAN3_CLASSES=1)
+    static const bool off = [] {
+        const char *e = std::getenv("FEDM_LEAN3_CLASSES");
+        return !(e && e[0] == '1');
+    }();
+    const Pattern &pat = c.pat;
+    const size_t budget = 160 * 1024 / 4;
+    std::vector<int> lists[2];
+    for (int S = 0; S < pat.n_slices; ++S) {
+        const int w = pat.slice_boff[S + 1] - pat.slice_boff[S];
+        const int v = SLICE + pat.patch_halo_ptr[S + 1] - pat.patch_halo_ptr[S];
+        const int cls = lean3_lds_bytes(c.neq, c.ns, w, v, n_live_planes, true) <= budget ? 0 : 1;
+        lists[cls].push_back(S);
+        k->width[cls] = std::max(k->width[cls], w);
+        k->verts[cls] = std::max(k->verts[cls], v);
+    }
+    // worth it: the launch sized for everything does not fit four workgroups a CU, most patches do
+    k->split = !off && !lists[1].empty() && lists[0].size() >= 3 * lists[1].size();
+    if (k->split) {
+        for (int cls = 0; cls < 2; ++cls) {
+            k->n[cls] = (int)lists[cls].size();
+            if (hipMalloc((void **)&k->d_list[cls], sizeof(int) * lists[cls].size()) != hipSuccess ||
+                hipMemcpy(k->d_list[cls], lists[cls].data(), sizeof(int) * lists[cls].size(), hipMemcpyHostToDevice) != hipSuccess) {
+                hipGetLastError();
+                k->split = false;
+                break;
+            }
+        }
+    }
+    return k;
+}
+
+void lean3_release(Ctx &c) {
+    if (c.d_lean3_plan) hipFree(c.d_lean3_plan);
+    c.d_lean3_plan = nullptr;
+    if (!c.lean3_classes) return;
+    Lean3Classes *k = static_cast<Lean3Classes *>(c.lean3_classes);
+    for (int cls = 0; cls < 2; ++cls)
+        if (k->d_list[cls]) hipFree(k->d_list[cls]);
+    delete k;
+    c.lean3_classes = nullptr;
+}
+
+// In-run timing (fedm_profile): when this launch is the whole assembly, the pair of events prof_begin has reserved
+// is handed to the dispatch itself (hipExtLaunchKernel: the events then carry the kernel's own begin and end, what
+// rocprofv3 reports) instead of bracketing it with two hipEventRecord, whose marker packets add 3-5 us of
+// command-processor time to an 80 us kernel.  FEDM_PROF_EXT=0: bracketing events.
+template <class K, class... Args>
+static void lean3_dispatch(Ctx &c, bool whole, K kernel, int grid, int threads, size_t lds, Args... args) {
+    static const bool ext = [] {
+        const char *e = std::getenv("FEDM_PROF_EXT");
+        return !(e && e[0] == '0');
+    }();
+    Prof &pf = c.prof;
+    if (ext && whole && pf.on && pf.recording && !c.capturing && pf.used + 2 <= (int)pf.ev.size()) {
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (uint32_t)lds, c.stream, pf.ev[pf.used], pf.ev[pf.used + 1], 0,
+                              args...);
+        pf.used += 2;            // the record is complete: prof_end has nothing to add
+        pf.recording = false;
+        return;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, c.stream, args...);
 }
 
 template <int NS, int NR, uint32_t CMASK>
-static void lean3_launch(Ctx &c, bool jacobian, const int *list, int n) {
+static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int width, int verts, bool whole = true) {
     using PL = LivePlanes<NS, CMASK>;
+    if (n <= 0) return true;
+    // the compiled model in device memory, uploaded at first use (fedm_ctx_destroy frees it: lean3_release)
+    if (!c.d_lean3_plan) {
+        Lean3Plan<NS, NR> host_plan;
+        if (!lean3_build_plan<NS, NR>(c.model, host_plan)) return false;
+        if (hipMalloc(&c.d_lean3_plan, sizeof(host_plan)) != hipSuccess ||
+            hipMemcpy(c.d_lean3_plan, &host_plan, sizeof(host_plan), hipMemcpyHostToDevice) != hipSuccess) {
+            hipGetLastError();
+            return false;
+        }
+    }
+    const Lean3Plan<NS, NR> *plan = static_cast<const Lean3Plan<NS, NR> *>(c.d_lean3_plan);
     Lean3Params p;
-    p.md = c.d_model;
     p.nv = c.nv;
     p.boff = c.d_slice_boff;
     p.cell_ptr = c.d_patch_cell_ptr;
@@ -455,19 +977,87 @@ static void lean3_launch(Ctx &c, bool jacobian, const int *list, int n) {
     p.sc = step_coef(c.dt, c.dt_old);
     p.val = c.d_val;
     p.F = c.d_F;
-    p.acc_doubles = jacobian ? c.pat.max_patch_width * PL::N * SLICE : 0;
-    p.max_verts = c.pat.max_patch_verts;
+    p.acc_doubles = jacobian ? width * PL::N * SLICE : 0;
+    p.max_verts = verts;
     p.xcd = c.xcd_remap ? 1 : 0;
     p.patch_list = list;
-    const size_t lds = lean3_lds_bytes(c, PL::N, jacobian);
-    const bool wide = c.pat.max_patch_cells > 192;
-    if (jacobian) {
-        if (wide) hipLaunchKernelGGL((assemble_lean3_kernel<NS, NR, 256, CMASK>), dim3(n), dim3(256), lds, c.stream, p);
-        else hipLaunchKernelGGL((assemble_lean3_kernel<NS, NR, 192, CMASK>), dim3(n), dim3(192), lds, c.stream, p);
-    } else {
-        if (wide) hipLaunchKernelGGL((residual_lean3_kernel<NS, NR, 256>), dim3(n), dim3(256), lds, c.stream, p);
-        else hipLaunchKernelGGL((residual_lean3_kernel<NS, NR, 192>), dim3(n), dim3(192), lds, c.stream, p);
+    const size_t lds = lean3_lds_bytes(c.neq, c.ns, width, verts, PL::N, jacobian);
+    if (lds > 160 * 1024) return false;
+    constexpr int T = 192;
+    p.n_patches = n;
+    // one workgroup per patch (default) or the persistent, software-pipelined kernels (FEDM_LEAN3_PERSISTENT=1:
+    // measured equal on the refined mesh, 79.4 against 79.5 us in the bench, and slower on the tensor-product mesh,
+    // 88.8 against 66.5 us, whose 5 203 patches leave 1 024 resident workgroups with six or five patches each)
+    static const bool persistent = [] {
+        const char *e = std::getenv("FEDM_LEAN3_PERSISTENT");
+        return e && e[0] == '1';
+    }();
+    static const int wgs_per_cu_env = [] {
+        const char *e = std::getenv("FEDM_LEAN3_WGS_PER_CU");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (persistent && verts <= T) {
+        // as many workgroups as the chip holds at once (a multiple of 8: the XCDs' shares), each taking its patches
+        // one after the other
+        static int n_cu = 0;
+        if (n_cu == 0 && (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || n_cu <= 0)) {
+            hipGetLastError();
+            n_cu = 256;
+        }
+        auto grid_for = [&](const void *kernel, size_t &granted) {
+            if (lds > 64 * 1024 && lds > granted) {
+                hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                granted = lds;
+            }
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, T, lds) != hipSuccess || per_cu <= 0) {
+                hipGetLastError();
+                per_cu = 1;
+            }
+            if (wgs_per_cu_env > 0) per_cu = wgs_per_cu_env;
+            int g = std::min(n, n_cu * per_cu);
+            if (p.xcd) g = std::max(8, g / 8 * 8);
+            return g;
+        };
+        if (jacobian) {
+            static size_t granted = 0;
+            const int g = grid_for(reinterpret_cast<const void *>(&assemble_lean3p_kernel<NS, NR, T, CMASK>), granted);
+            lean3_dispatch(c, whole, assemble_lean3p_kernel<NS, NR, T, CMASK>, g, T, lds, plan, p.val, p.F, p);
+        } else {
+            static size_t granted = 0;
+            const int g = grid_for(reinterpret_cast<const void *>(&residual_lean3p_kernel<NS, NR, T>), granted);
+            lean3_dispatch(c, whole, residual_lean3p_kernel<NS, NR, T>, g, T, lds, plan, p.val, p.F, p);
+        }
+        return true;
     }
+    if (jacobian) {
+        static size_t granted = 0;   // per instantiation: beyond the 64 KiB default the dynamic LDS is opt-in
+        if (lds > 64 * 1024 && lds > granted) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_lean3_kernel<NS, NR, T, CMASK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            granted = lds;
+        }
+        lean3_dispatch(c, whole, assemble_lean3_kernel<NS, NR, T, CMASK>, n, T, lds, plan, p);
+    } else {
+        lean3_dispatch(c, whole, residual_lean3_kernel<NS, NR, T>, n, T, lds, plan, p);
+    }
+    return true;
+}
+
+template <int NS, int NR, uint32_t CMASK>
+static bool lean3_launch(Ctx &c, bool jacobian, const int *list, int n) {
+    using PL = LivePlanes<NS, CMASK>;
+    // the split applies to the Jacobian assembly of a whole mesh with the planes kept (the steady state of a run);
+    // the listed launches of the several-GPU path and the first full assembly take one launch sized for everything
+    if (jacobian && !list && CMASK != 0u) {
+        Lean3Classes *k = lean3_classes(c, PL::N);
+        if (k->split) {
+            // the few large ones first: their tail overlaps nothing, so it should be short
+            return lean3_launch_one<NS, NR, CMASK>(c, true, k->d_list[1], k->n[1], k->width[1], k->verts[1], false) &&
+                   lean3_launch_one<NS, NR, CMASK>(c, true, k->d_list[0], k->n[0], k->width[0], k->verts[0], false);
+        }
+    }
+    return lean3_launch_one<NS, NR, CMASK>(c, jacobian, list, n, c.pat.max_patch_width, c.pat.max_patch_verts, list == nullptr);
 }
 
 // The models this generation is instantiated for: two species and one reaction (the streamer family) with the
@@ -478,24 +1068,22 @@ bool lean3_applies(const Ctx &c) {
         const char *e = std::getenv("FEDM_ASSEMBLY_LEAN");
         return e && std::atoi(e) < 3;
     }();
-    if (off || c.ns != 2 || !c.poisson || c.model.n_reactions > 1 || c.pat.max_patch_cells > 256) return false;
-    return true;
+    if (off || c.ns != 2 || !c.poisson || c.model.n_reactions > 1 || c.pat.max_patch_cells > 2 * 192) return false;
+    Lean3Plan<2, 1> plan;
+    return lean3_build_plan<2, 1>(c.model, plan);
 }
 
 // cmask: the planes that are kept for this launch (0 on a context's first full assembly: everything is written).
 // false: no instantiation for this mask (the caller takes the second generation).
 bool launch_assemble_lean3(Ctx &c, bool jacobian, const int *list, int n, uint32_t cmask) {
     if (n <= 0) return true;
-    if (!jacobian) {
-        lean3_launch<2, 1, 0u>(c, false, list, n);
-        return true;
-    }
+    if (!jacobian) return lean3_launch<2, 1, 0u>(c, false, list, n);
     constexpr uint32_t PHIPHI = 1u << 8;
     switch (cmask) {
-        case 0u: lean3_launch<2, 1, 0u>(c, true, list, n); return true;
-        case PHIPHI: lean3_launch<2, 1, PHIPHI>(c, true, list, n); return true;
-        case PHIPHI | (1u << 3): lean3_launch<2, 1, PHIPHI | (1u << 3)>(c, true, list, n); return true;   // + d(row 1)/d(u_0)
-        case PHIPHI | (1u << 1): lean3_launch<2, 1, PHIPHI | (1u << 1)>(c, true, list, n); return true;   // + d(row 0)/d(u_1)
+        case 0u: return lean3_launch<2, 1, 0u>(c, true, list, n);
+        case PHIPHI: return lean3_launch<2, 1, PHIPHI>(c, true, list, n);
+        case PHIPHI | (1u << 3): return lean3_launch<2, 1, PHIPHI | (1u << 3)>(c, true, list, n);   // + d(row 1)/d(u_0)
+        case PHIPHI | (1u << 1): return lean3_launch<2, 1, PHIPHI | (1u << 1)>(c, true, list, n);   // + d(row 0)/d(u_1)
         default: return false;
     }
 }

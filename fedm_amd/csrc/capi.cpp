@@ -1364,6 +1364,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (c.d_Z) hipFree(c.d_Z);
     if (c.h_stage) hipHostFree(c.h_stage);
     if (c.d_snapshot) hipFree(c.d_snapshot);
+    lean3_release(c);
     for (int s_ = 0; s_ < FEDM_MAX_SPECIES; ++s_) {
         if (c.d_expr_ops[s_]) hipFree(c.d_expr_ops[s_]);
         if (c.d_expr_consts[s_]) hipFree(c.d_expr_consts[s_]);
@@ -2106,7 +2107,19 @@ int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[12]) {
     out[8] = pat.total_bc * SLICE;
     out[9] = (int64_t)pat.patch_halo.size();
     out[10] = (int64_t)pat.colour_ptr.size() - 1;
-    out[11] = 0;
+    // emission blocks: (wave of 64 cells, local row a) pairs in which some cell owns its a-th vertex -- the
+    // assembly kernels skip the others (at most 3 per wave)
+    int64_t blocks = 0;
+    for (int s = 0; s < pat.n_slices; ++s) {
+        const int c0 = pat.patch_cell_ptr[s], c1 = pat.patch_cell_ptr[s + 1];
+        for (int w0 = c0; w0 < c1; w0 += SLICE)
+            for (int a = 0; a < 3; ++a) {
+                bool any = false;
+                for (int k = w0; k < std::min(w0 + SLICE, c1); ++k) any = any || pat.patch_cells[k].lv[a] < SLICE;
+                blocks += any;
+            }
+    }
+    out[11] = blocks;
     return 0;
 }
 
@@ -2278,7 +2291,7 @@ int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
                        c.model.n_qp == 3 && !c.model.linear_representation && c.pat.max_patch_cells <= 256;
     // 3: LDS patches, one pass over the cells (lean3 kernels, assemble3.hip)
     out[6] = c.assembly_kind == 0 ? 0 : (lean2 ? (c.assembly_lean >= 3 && lean3_applies(c) ? 3 : 2) : 1);
-    out[7] = c.assembly_kind == 0 ? 0 : (c.pat.max_patch_cells <= 192 ? 192 : (lean2 ? 256 : 320));
+    out[7] = c.assembly_kind == 0 ? 0 : (c.pat.max_patch_cells <= 192 || out[6] == 3 ? 192 : (lean2 ? 256 : 320));
     return 0;
 }
 

@@ -242,6 +242,8 @@ struct Ctx {
     int err_cache_comp = -1;
     double err_cache = 0.0;
     double *h_stage = nullptr;     // pinned staging, np doubles
+    void *d_lean3_plan = nullptr;  // assemble3.hip: the model compiled for the one-pass kernels (Lean3Plan), device memory
+    void *lean3_classes = nullptr; // assemble3.hip: patch lists by LDS need (Lean3Classes), built at first use
     double *d_snapshot = nullptr;  // fedm_state_snapshot: u, u_old, u_old1 (3 np doubles, allocated on first use)
 };
 
@@ -259,6 +261,7 @@ constexpr int MAIL_SLOTS = 4;         // publications the host may have unread (
 void launch_assemble(Ctx &c, bool jacobian, int mode);
 void launch_assemble_gd(Ctx &c, bool jacobian, int mode);
 bool lean3_applies(const Ctx &c);                                   // assemble3.hip
+void lean3_release(Ctx &c);
 bool launch_assemble_lean3(Ctx &c, bool jacobian, const int *patch_list, int n, uint32_t cmask);
 int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
                   const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs);

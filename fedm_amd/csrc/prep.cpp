@@ -48,23 +48,68 @@ static void order_patch_cells(PatchCell *cells, int n, int group, int mod, bool 
         }
         return r;
     };
-    for (int c = 0; c < n; ++c) {
+    // Third criterion (the assembly kernels skip the emission of local row a for a whole wave when none of its
+    // cells owns its a-th vertex): the patch's LAST wave -- the one that is not full: 34 of 64 lanes on the
+    // tensor-product bench mesh -- takes the cells that own the fewest vertices, turned so that their owned
+    // vertices come first: rows 1 and 2 (or row 2) of that wave are skipped, 7 instead of 9 emission blocks a
+    // patch.  The other cells keep every freedom of the bank criteria above in the full waves.
+    // (measured, tools/kernel_ab.py: 7 instead of 9 emission blocks a patch, but the chosen cells lose the freedom of
+    // the bank criteria -- clashing pairs 1.8 -> 8.9 % on the tensor-product mesh, 6.7 -> 9.9 % on the refined one --
+    // and the F + J kernel takes the same time within the noise, 74-75 us / 63-65 us: opt-in, FEDM_PATCH_CLASSES=1)
+    static const bool by_class = [] {
+        const char *e = std::getenv("FEDM_PATCH_CLASSES");
+        return e && e[0] == '1';
+    }();
+    const bool classes = by_class && rotate && allow_rotation && n > SLICE;
+    auto n_owned = [](const PatchCell &pc) { return (pc.lv[0] < SLICE) + (pc.lv[1] < SLICE) + (pc.lv[2] < SLICE); };
+    std::vector<int> seq(n);
+    for (int c = 0; c < n; ++c) seq[c] = c;
+    std::vector<char> in_last(n, 0);
+    const int last_first_group = ((n - 1) / SLICE) * (SLICE / group);   // first lane group of the last wave
+    if (classes && group > 0 && SLICE % group == 0) {
+        const int room = n - ((n - 1) / SLICE) * SLICE;               // cells of the last wave
+        std::stable_sort(seq.begin(), seq.end(), [&](int x, int y) { return n_owned(cells[x]) < n_owned(cells[y]); });
+        for (int k = 0; k < room; ++k) {
+            const int c = seq[k];
+            const int own = n_owned(cells[c]);
+            if (own == 3) break;                                      // (nothing to skip for a cell that owns all three)
+            in_last[c] = 1;
+            int turn = 0;
+            if (own == 2) turn = cells[c].lv[0] >= SLICE ? 1 : cells[c].lv[1] >= SLICE ? 2 : 0;
+            else if (own == 1) turn = cells[c].lv[0] < SLICE ? 0 : cells[c].lv[1] < SLICE ? 1 : 2;
+            if (turn) cells[c] = turned(cells[c], turn);
+        }
+        // the full waves first (so that they are full before anything spills over), the chosen cells last
+        std::stable_sort(seq.begin(), seq.end(), [&](int x, int y) { return in_last[x] < in_last[y]; });
+    }
+    int first_group[2] = {0, 0}, end_group[2] = {n_groups, n_groups};
+    if (classes) {
+        end_group[0] = last_first_group;
+        first_group[1] = last_first_group;
+    }
+    for (int ci = 0; ci < n; ++ci) {
+        const int c = seq[ci];
+        const int cls = in_last[c] ? 1 : 0;
         int best = -1, best_cost = 1 << 30, best_turn = 0;
-        for (int k = 0; k < ((rotate && allow_rotation) ? 3 : 1) && best_cost > 0; ++k) {
-            const PatchCell cand = k ? turned(cells[c], k) : cells[c];
-            for (int g = 0; g < n_groups; ++g) {
-                if ((int)members[g].size() >= group) continue;
-                int cost = 0;
-                for (int a = 0; a < 3; ++a) {
-                    if (cand.lv[a] < SLICE && ((used[g][a] >> (cand.lv[a] % mod)) & 1ULL)) cost += 4;
-                    if (read_weight && ((read_used[g / per_half][a] >> (cand.lv[a] & 31)) & 1u)) cost += read_weight;
+        const int n_turns = (rotate && allow_rotation && !in_last[c]) ? 3 : 1;
+        for (int pass = 0; pass < 2 && best < 0; ++pass) {   // second pass: any group with room (rounding at class borders)
+            const int g_lo = (classes && pass == 0) ? first_group[cls] : 0, g_hi = (classes && pass == 0) ? end_group[cls] : n_groups;
+            for (int k = 0; k < n_turns && best_cost > 0; ++k) {
+                const PatchCell cand = k ? turned(cells[c], k) : cells[c];
+                for (int g = g_lo; g < g_hi; ++g) {
+                    if ((int)members[g].size() >= group) continue;
+                    int cost = 0;
+                    for (int a = 0; a < 3; ++a) {
+                        if (cand.lv[a] < SLICE && ((used[g][a] >> (cand.lv[a] % mod)) & 1ULL)) cost += 4;
+                        if (read_weight && ((read_used[g / per_half][a] >> (cand.lv[a] & 31)) & 1u)) cost += read_weight;
+                    }
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best = g;
+                        best_turn = k;
+                    }
+                    if (cost == 0) break;
                 }
-                if (cost < best_cost) {
-                    best_cost = cost;
-                    best = g;
-                    best_turn = k;
-                }
-                if (cost == 0) break;
             }
         }
         if (best_turn) cells[c] = turned(cells[c], best_turn);

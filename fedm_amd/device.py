@@ -318,7 +318,7 @@ def pattern_stats(coords, cells, reorder=True):
         raise RuntimeError(f"fedm_pattern_stats failed ({rc}): {_lib.last_error()}")
     keys = ("n_slices", "max_patch_cells", "max_patch_width", "max_patch_verts", "cell_visits",
             "owned_pairs", "bank_clashes", "nnz_blocks", "stored_blocks", "halo_vertices", "n_colours",
-            "reserved")
+            "emission_blocks")
     return dict(zip(keys, (int(v) for v in out)))
 
 

@@ -386,7 +386,8 @@ int fedm_debug_comm_roundtrip(fedm_ctx *ctx, double *vec, double *red, int k);
  * of all patches, owned (cell, local vertex) pairs, pairs that clash with another cell of their
  * 16-lane group on an LDS accumulator bank (FEDM_PATCH_ORDER, see csrc/prep.cpp), structural blocks,
  * stored blocks of the sliced block-ELL layout (structural + padding), halo vertices staged by all
- * patches, colours of the global cell colouring, 0}. */
+ * patches, colours of the global cell colouring, (wave of 64 patch cells, local row) pairs in which some
+ * cell owns that vertex: what the assembly kernels emit; the others are skipped}. */
 int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[12]);
 /* The same for a live context, and which volume-assembly kernels it runs: out = {slices, max cells per
  * patch, max block columns per slice, max staged vertices per patch, cell visits, halo vertices,

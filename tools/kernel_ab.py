@@ -18,7 +18,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KEYS = ("FEDM_ASSEMBLY_LEAN", "FEDM_XCD_REMAP", "FEDM_PATCH_ORDER", "FEDM_PATCH_ORDER_READS",
-        "FEDM_SKIP_CONST_PLANES", "FEDM_SPMV_SKIP_ZERO_PLANES", "FEDM_HIP_LIB")
+        "FEDM_SKIP_CONST_PLANES", "FEDM_SPMV_SKIP_ZERO_PLANES", "FEDM_HIP_LIB", "FEDM_PATCH_CLASSES",
+        "FEDM_LEAN3_CLASSES", "FEDM_LEAN3_PERSISTENT", "FEDM_LEAN3_WGS_PER_CU")
 
 
 def child(n):
