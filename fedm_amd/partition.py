@@ -10,9 +10,15 @@ partition boundary are evaluated on both sides -- so nothing but ghost *input*
 values ever has to be communicated.
 
 Local numbering of a part: owned vertices first, then ghost vertices grouped by
-owning rank (ascending rank, ascending global id inside a group); both sides of
-a halo link list the shared vertices in ascending global id, so the receive
-side needs no unpacking.
+owning rank (ascending rank).  Inside a group both sides of a halo link list the
+shared vertices in the SAME order, so the receive side needs no unpacking: ascending
+global id with one ghost layer; with deep halos (below) the group's own locality
+order -- recursive bisection of the group's coordinates in the metric of the local
+spacing, a deterministic function of the vertex set that owner and receiver both
+evaluate -- because the ghost rows are then assembled, swept and tiled like owned
+rows and 64 consecutive ones must form a compact patch (by global id a ghost band of
+eight layers made slices that span the whole interface: tiles of 3 600 vertices
+instead of 1 200, assembly patches of 258 cells).
 
 **Deep halos** (``depth`` > 1).  With one ghost layer every operator application needs
 its own exchange: a Krylov step of the field-split solver then contains ten small
@@ -174,6 +180,21 @@ def local_mesh(coords, cells, part, rank, depth=1, graph=None):
     ghosts = np.nonzero(dist > 0)[0]
     gorder = np.lexsort((ghosts, part[ghosts]))           # by owner rank, then global id
     ghosts = ghosts[gorder]
+    if depth > 1:
+        from .device import _vertex_spacing, bisection_order
+        spacing = _vertex_spacing(coords, cells)
+
+        def link_order(v):
+            """The order of a halo link's vertices (given in ascending global id): both ends compute it from
+            the same set, so it needs no agreement."""
+            if v.size <= 64:
+                return v
+            return v[bisection_order(coords[v], spacing[v])]
+        gown = part[ghosts]
+        ghosts = np.concatenate([link_order(ghosts[gown == q]) for q in np.unique(gown)]) if ghosts.size else ghosts
+    else:
+        def link_order(v):
+            return v
     vertex_global = np.concatenate([owned, ghosts])
     lookup = np.full(nv, -1, dtype=np.int64)
     lookup[vertex_global] = np.arange(vertex_global.size)
@@ -185,8 +206,8 @@ def local_mesh(coords, cells, part, rank, depth=1, graph=None):
     send_lists = []
     for q in neighbours:
         dq = reach(int(q))
-        v = owned[dq[owned] > 0]
-        send_lists.append(lookup[v])                       # owned is ascending: ascending global id
+        v = owned[dq[owned] > 0]                           # (ascending global id)
+        send_lists.append(lookup[link_order(v)])           # ... in the order rank q lists them
     send_ptr = np.concatenate([[0], np.cumsum([len(s) for s in send_lists])])
     send_idx = np.concatenate(send_lists) if send_lists else np.zeros(0, dtype=np.int64)
     return LocalMesh(rank=rank, n_parts=n_parts, coords=coords[vertex_global],
