@@ -1993,9 +1993,9 @@ int fedm_comm_init_callbacks(fedm_ctx *h, int n_nb, const int32_t *nb_rank, cons
     return 0;
 }
 
-int fedm_comm_stats(fedm_ctx *h, int64_t out[8]) {
+int fedm_comm_stats(fedm_ctx *h, int64_t out[10]) {
     Ctx &c = h->c;
-    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int i = 0; i < 10; ++i) out[i] = 0;
     if (!c.comm) return 0;
     const Comm &cm = *c.comm;
     out[0] = cm.kind;
@@ -2006,6 +2006,8 @@ int fedm_comm_stats(fedm_ctx *h, int64_t out[8]) {
     out[5] = cm.n_nb;
     out[6] = cm.n_patch_interior;
     out[7] = cm.n_patch_boundary;
+    out[8] = cm.halo_bytes;
+    out[9] = cm.allreduce_bytes;
     return 0;
 }
 

@@ -345,6 +345,8 @@ void comm_allreduce(Ctx &c, double *d_buf, int n) {
     Comm *cm = c.comm;
     if (!cm || cm->kind == 0 || cm->failed) return;
     ++cm->n_allreduces;
+    cm->allreduce_bytes += (long long)n * (long long)(cm->f32_payload_pending ? sizeof(float) : sizeof(double));
+    cm->f32_payload_pending = false;
     if (cm->kind == 2) {
         nccl_ok(cm, g_nccl.AllReduce(d_buf, d_buf, (size_t)n, kNcclDouble, kNcclSum, cm->nccl, c.stream),
                 "ncclAllReduce");
@@ -388,12 +390,14 @@ void comm_allreduce_f32_payload(Ctx &c, double *d_buf, int n) {
     hipLaunchKernelGGL(to_f32_kernel, g, b, 0, c.stream, n, d_buf, cm->d_red32);
     if (cm->kind == 2) {
         ++cm->n_allreduces;
+        cm->allreduce_bytes += (long long)n * (long long)sizeof(float);
         nccl_ok(cm, g_nccl.AllReduce(cm->d_red32, cm->d_red32, (size_t)n, kNcclFloat, kNcclSum, cm->nccl, c.stream),
                 "ncclAllReduce (fp32 payload)");
         hipLaunchKernelGGL(from_f32_kernel, g, b, 0, c.stream, n, cm->d_red32, d_buf);
         return;
     }
     hipLaunchKernelGGL(from_f32_kernel, g, b, 0, c.stream, n, cm->d_red32, d_buf);   // rounded contributions
+    cm->f32_payload_pending = true;      // (counted as the fp32 payload the RCCL path moves)
     comm_allreduce(c, d_buf, n);
 }
 
@@ -410,6 +414,7 @@ __global__ void halo_pack_kernel(int n_send, int neq, const int *__restrict__ id
 static void exchange_packed(Ctx &c, Comm *cm, double *recv_dst, hipStream_t st, int w) {
     if (cm->failed) return;
     ++cm->n_exchanges;
+    cm->halo_bytes += (long long)cm->n_send * w * (long long)sizeof(double);
     if (cm->kind == 2) {
         // a group that was opened is always closed, whatever its members returned
         if (!nccl_ok(cm, g_nccl.GroupStart(), "ncclGroupStart")) return;

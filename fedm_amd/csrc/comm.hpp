@@ -46,6 +46,8 @@ struct Comm {
     bool failed = false;
     std::string error;
     long n_exchanges = 0, n_allreduces = 0;   // issued so far (bench.py reports them per step)
+    bool f32_payload_pending = false;
+    long long halo_bytes = 0, allreduce_bytes = 0;   // payload this rank sent in halo exchanges / contributed to all-reduces
     void release();
     bool release_communicator();   // ncclCommAbort after a latched failure, ncclCommDestroy otherwise; true: aborted
 };

@@ -660,12 +660,12 @@ class DeviceProblem:
 
     def comm_stats(self):
         """Transport kind and counters of the multi-GPU plumbing (``fedm_comm_stats``)."""
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 10)()
         self._check(self.lib.fedm_comm_stats(self._h, out), "fedm_comm_stats")
         kind = {0: "none", 1: "host-staged callbacks", 2: "rccl"}[int(out[0])]
         return dict(transport=kind, ranks=int(out[1]), halo_exchanges=int(out[2]), allreduces=int(out[3]),
                     failed=bool(out[4]), neighbours=int(out[5]), interior_patches=int(out[6]),
-                    boundary_patches=int(out[7]))
+                    boundary_patches=int(out[7]), halo_bytes=int(out[8]), allreduce_bytes=int(out[9]))
 
     # -- linear-solver set-up ---------------------------------------------------
     def block_csr(self, cr, cc):

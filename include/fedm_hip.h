@@ -200,7 +200,7 @@ const char *fedm_last_error(void);
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
  * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields.
  * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles.
- * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]. */
+ * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]; fedm_comm_stats out[10]. */
 #define FEDM_ABI_VERSION 4
 int fedm_abi_version(void);
 
@@ -361,8 +361,9 @@ int fedm_sync_ghosts(fedm_ctx *ctx);
  * fedm_newton_solve, fedm_poisson_solve, fedm_sync_ghosts and fedm_field_error return -1.
  * fedm_comm_stats: out = {transport kind (0 none, 1 host callbacks, 2 RCCL), ranks, halo
  * exchanges issued, all-reduces issued, failed flag, neighbours, assembly patches without /
- * with ghost vertices (the former are assembled while the state halo travels)}. */
-int fedm_comm_stats(fedm_ctx *ctx, int64_t out[8]);
+ * with ghost vertices (the former are assembled while the state halo travels), bytes this rank has
+ * sent in halo exchanges, payload bytes it has contributed to all-reduces}. */
+int fedm_comm_stats(fedm_ctx *ctx, int64_t out[10]);
 /* latency of the transport's primitives, back to back on the compute stream (all ranks must call
  * it together): kind 0 = halo exchange of a block vector, 1 = of one value per vertex,
  * 2 = all-reduce of 32 doubles.  ms per operation. */
