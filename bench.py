@@ -323,11 +323,13 @@ def main():
         torch.cuda.synchronize()
 
     def refined(spacing):
-        """The locally refined unstructured mesh through DOLFIN XML (every rank generates the same one)."""
+        """The locally refined unstructured mesh through DOLFIN XML (every rank generates the same one).  The
+        refined channel keeps its radius (100 x --mesh-spacing) when the spacing shrinks for N > 1: N times the
+        vertices."""
         import tempfile
         with tempfile.TemporaryDirectory(prefix="fedm_mesh_") as tmp:
             return streamer.refined_mesh(spacing, growth=0.1, xml_path=Path(tmp) / "mesh.xml",
-                                         channel=(0.0, 100.0 * spacing) + streamer.CHANNEL[2:])
+                                         channel=(0.0, 100.0 * args.mesh_spacing) + streamer.CHANNEL[2:])
 
     def check_transport(r):
         if r.transport != "rccl" and not (args.allow_fallback or args.rehearse_on_one_gpu):
@@ -493,7 +495,7 @@ def main():
     def mesh_text(family, n, spacing):
         if family == "unstructured":
             return (f"locally refined unstructured mesh: Delaunay triangulation of nested hexagonal lattices, spacing "
-                    f"{spacing:g} m in the streamer channel (r < {100.0 * spacing:g} m), growing 0.1 per unit distance "
+                    f"{spacing:g} m in the streamer channel (r < {100.0 * args.mesh_spacing:g} m), growing 0.1 per unit distance "
                     "outside; written to DOLFIN XML and read back through the mesh reader (the way of the reference's "
                     "Mesh('mesh.xml'), fedm-streamer.py:116); vertices ordered by recursive bisection in the metric of "
                     "the local spacing (device.locality_order)")

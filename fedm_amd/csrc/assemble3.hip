@@ -1074,7 +1074,7 @@ bool lean3_applies(const Ctx &c) {
 }
 
 // cmask: the planes that are kept for this launch (0 on a context's first full assembly: everything is written).
-// false: no instantiation for this mask (the caller takes the second generation).
+// false: the launch does not fit (LDS beyond the device's limit: the caller takes the second generation).
 bool launch_assemble_lean3(Ctx &c, bool jacobian, const int *list, int n, uint32_t cmask) {
     if (n <= 0) return true;
     if (!jacobian) return lean3_launch<2, 1, 0u>(c, false, list, n);
@@ -1084,7 +1084,9 @@ bool launch_assemble_lean3(Ctx &c, bool jacobian, const int *list, int n, uint32
         case PHIPHI: return lean3_launch<2, 1, PHIPHI>(c, true, list, n);
         case PHIPHI | (1u << 3): return lean3_launch<2, 1, PHIPHI | (1u << 3)>(c, true, list, n);   // + d(row 1)/d(u_0)
         case PHIPHI | (1u << 1): return lean3_launch<2, 1, PHIPHI | (1u << 1)>(c, true, list, n);   // + d(row 0)/d(u_1)
-        default: return false;
+        // any other set of kept planes: the instantiation that keeps the potential-potential plane alone (the
+        // other kept planes are recomputed and rewritten with the values they already hold), or none
+        default: return (cmask & PHIPHI) ? lean3_launch<2, 1, PHIPHI>(c, true, list, n) : lean3_launch<2, 1, 0u>(c, true, list, n);
     }
 }
 

@@ -2289,10 +2289,12 @@ int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
     // unrolled element routine, 2 LDS patches one equation row at a time (lean2 kernels)
     bool ext = false;
     for (int s = 0; s < c.ns; ++s) ext = ext || (c.model_kind == 0 && c.model.ext_nodes[s] > 0);
-    const bool lean2 = c.assembly_kind == 1 && c.assembly_lean >= 2 && c.poisson && c.model_kind == 0 && !ext &&
-                       c.model.n_qp == 3 && !c.model.linear_representation && c.pat.max_patch_cells <= 256;
+    const bool lean_model = c.assembly_kind == 1 && c.assembly_lean >= 2 && c.poisson && c.model_kind == 0 && !ext &&
+                            c.model.n_qp == 3 && !c.model.linear_representation;
+    const bool lean3 = lean_model && c.assembly_lean >= 3 && lean3_applies(c);
+    const bool lean2 = lean_model && c.pat.max_patch_cells <= 256;
     // 3: LDS patches, one pass over the cells (lean3 kernels, assemble3.hip)
-    out[6] = c.assembly_kind == 0 ? 0 : (lean2 ? (c.assembly_lean >= 3 && lean3_applies(c) ? 3 : 2) : 1);
+    out[6] = c.assembly_kind == 0 ? 0 : (lean3 ? 3 : lean2 ? 2 : 1);
     out[7] = c.assembly_kind == 0 ? 0 : (c.pat.max_patch_cells <= 192 || out[6] == 3 ? 192 : (lean2 ? 256 : 320));
     return 0;
 }

@@ -466,7 +466,10 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
     if constexpr (PO && CACHE == 2 && NS >= 1 && !LIN) {
         bool ext = false;
         for (int s_ = 0; s_ < NS; ++s_) ext = ext || c.model.ext_nodes[s_] > 0;
-        if (mode == 0 && !ext && c.assembly_lean >= 2 && c.pat.max_patch_cells <= 256) {
+        // (the third generation takes patches of up to 384 cells -- a second cell for some threads --, the second
+        // one cell per thread of at most 256)
+        const bool gen3_ok = c.assembly_lean >= 3 && lean3_applies(c);
+        if (mode == 0 && !ext && c.assembly_lean >= 2 && (c.pat.max_patch_cells <= 256 || gen3_ok)) {
             // one cell per thread: 192 threads where every patch has at most 192 cells (tensor-product
             // meshes: 160; compact patches of an unstructured mesh: 170-190), else 256
             const int T = c.pat.max_patch_cells <= 192 ? 192 : 256;
@@ -498,7 +501,7 @@ static void assemble_patch_t(Ctx &c, bool jacobian, int mode) {
             const uint32_t cmask = (jacobian && c.skip_const_planes && c.const_planes_valid) ? c.const_plane_mask : 0u;
             // third generation (assemble3.hip: one pass over the cells, compile-time plane mask) where it is
             // instantiated; FEDM_ASSEMBLY_LEAN=2 keeps the row-phase kernels below
-            const bool gen3 = c.assembly_lean >= 3 && lean3_applies(c);
+            const bool gen3 = gen3_ok;
 #define FEDM_LEAN3_OR(LIST, N) (gen3 && launch_assemble_lean3(c, jacobian, LIST, N, cmask))
             if (c.halo_pending && c.comm && c.comm->d_patch_interior) {
                 // the ghost values of the new state travel on the communication stream while the

@@ -450,6 +450,72 @@ def test_row_at_a_time_assembly_matches_the_unrolled_element(monkeypatch, three_
         assert (d.max(axis=1).toarray().ravel() <= 1e-11 * rowmax + 1e-300).all(), lean
 
 
+def test_persistent_assembly_kernels_give_the_same_system(monkeypatch):
+    """assemble3.hip holds two launch forms of the one-pass assembly: a workgroup per patch (default) and the
+    persistent, software-pipelined kernels whose workgroups take patch after patch (FEDM_LEAN3_PERSISTENT=1).  Same
+    cell routine, different staging: residual and Jacobian must agree to the order of the LDS atomics -- also for
+    the first full assembly (every plane written) and on a mesh whose patch count is not a multiple of the grid."""
+    from fedm_amd.cases import streamer
+    msh = streamer.refined_mesh(40e-6)
+    nv = msh.coords.shape[0]
+    rng = np.random.default_rng(5)
+    x, y = msh.coords[:, 0] / streamer.BOX, msh.coords[:, 1] / streamer.BOX
+    U = np.zeros((nv, 3))
+    U[:, 0] = 30.0 + 2.0 * np.sin(5 * x) * np.cos(3 * y)
+    U[:, 1] = 28.0 + 3.0 * np.cos(4 * x) * np.sin(6 * y)
+    U[:, 2] = streamer.U_W * y + 50.0 * np.sin(3 * x) * np.sin(np.pi * y)
+    U0 = U + 0.01 * rng.standard_normal(U.shape)
+    U1 = U + 0.02 * rng.standard_normal(U.shape)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FEDM_LEAN3_PERSISTENT", mode)
+        prob = streamer.device_problem(msh.coords, msh.cells)
+        assert prob.assembly_variant() == "lds-patches/one-pass"
+        prob.set_state(U, U0, U1)
+        prob.set_step(5e-12, 4e-12)
+        prob.jacobian()                       # the first assembly writes every plane
+        J_first = prob.jacobian_csr()
+        prob.jacobian()                       # ... the later ones keep the constant ones
+        F, _ = prob.residual()
+        out[mode] = (F, J_first, prob.jacobian_csr())
+        prob.close()
+    F0, Ja0, Jb0 = out["0"]
+    F1, Ja1, Jb1 = out["1"]
+    assert np.abs(F1 - F0).max() <= 1e-13 * np.abs(F0).max()
+    rowmax = abs(Jb0).max(axis=1).toarray().ravel()
+    for A, B in ((Ja0, Ja1), (Jb0, Jb1), (Ja0, Jb0)):
+        assert (abs(A - B).max(axis=1).toarray().ravel() <= 1e-12 * rowmax + 1e-300).all()
+
+
+def test_state_checkpoint_on_the_device_repeats_the_steps(streamer_setup):
+    """fedm_state_snapshot / fedm_state_restore (what bench.py repeats its timed window from): steps taken from
+    a restored checkpoint reproduce the error log and the state of the steps taken after the checkpoint was made."""
+    from fedm_amd.cases import streamer
+    msh = streamer.mesh(48, 4.0)
+    st = streamer.Stepper(streamer.device_problem(msh.coords, msh.cells))
+    st.initialise()
+    for _ in range(3):
+        st.step()
+    snap = st.snapshot()
+    first = []
+    for _ in range(4):
+        st.step()
+        first.append((st.t, st.dt.time_step, tuple(st.max_error)))
+    U_first = st.prob.get_state()
+    st.restore(snap)
+    assert st.steps == 3
+    again = []
+    for _ in range(4):
+        st.step()
+        again.append((st.t, st.dt.time_step, tuple(st.max_error)))
+    U_again = st.prob.get_state()
+    for a, b in zip(first, again):
+        assert a[0] == b[0] and a[1] == b[1] and np.allclose(a[2], b[2], rtol=1e-6)
+    # (the Krylov path of a repeated solve may differ -- launch-ahead hints -- within the solver tolerances)
+    assert (np.abs(U_again - U_first).max(axis=0) / np.abs(U_first).max(axis=0)).max() < 1e-7
+    st.prob.close()
+
+
 def test_preconditioner_side_left_and_right_agree():
     """The Newton systems are solved by flexible GMRES with the field split on the right (true
     residual norm) or, selectable, on the left (preconditioned residual norm).  Both solve

@@ -424,6 +424,68 @@ def test_patch_micro_colouring_removes_lds_bank_clashes(monkeypatch):
     assert ordered["bank_clashes"] < 0.06 * ordered["owned_pairs"]
 
 
+def test_tile_tables_report_the_lds_their_kernels_need():
+    """The species-sweep tiles keep a tile's vertices and its layers in LDS; the bytes a workgroup of the
+    kernels asks for come with the host-side tile statistics (a context refuses tiles beyond the device's limit
+    and runs the sweeps one launch each).  A compact numbering fits the 64 KiB default easily; the SAME mesh with
+    a scattered block of vertices at the end of the numbering -- what the ghost layers of a partition were before
+    they were given a locality order of their own -- needs several times as much."""
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import fieldsplit_tiles_stats, locality_order
+    msh = streamer.mesh(160, 4.0)
+    compact = fieldsplit_tiles_stats(msh.coords, msh.cells)
+    assert compact["violations"] == 0
+    need = 4 * 2 * compact["max_vertices"] * 2 + 4 * 4 * compact["max_rows"]           # two species, row width 7
+    assert compact["lds_bytes_species_kernel"] == need < 64 * 1024
+    assert compact["lds_bytes_multigrid_kernel"] == 8 * 2 * compact["max_vertices"] + 4 * 4 * compact["max_rows"]
+    # the last 12 % of the vertices in a random order (by global id across an interface, a ghost band looks like that)
+    order = locality_order(msh.coords, msh.cells)
+    rng = np.random.default_rng(0)
+    n_tail = msh.coords.shape[0] // 8
+    order[-n_tail:] = order[-n_tail:][rng.permutation(n_tail)]
+    inv = np.empty(order.size, dtype=np.int64)
+    inv[order] = np.arange(order.size)
+    scattered = fieldsplit_tiles_stats(msh.coords[order], inv[msh.cells].astype(np.int32), reorder=False)
+    assert scattered["violations"] == 0
+    assert scattered["lds_bytes_species_kernel"] > 3 * compact["lds_bytes_species_kernel"]
+
+
+def test_ghost_layers_of_a_deep_halo_are_compact_patches():
+    """Deep halos assemble, sweep and tile the ghost rows like owned rows, so 64 consecutive ghost vertices must be
+    a compact patch: each halo link is numbered by the bisection of its own vertices (fedm_amd/partition.py; both
+    ends compute the same order).  With the links in ascending global id the tiles of a four-rank split of the
+    288 x 288 mesh hold twice the vertices."""
+    from fedm_amd import partition
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import fieldsplit_tiles_stats, locality_order
+    g = streamer.mesh(288, 4.0)
+    part = partition.partition_rcb(g.coords, 4, g.cells)
+
+    def tiles(lm):
+        nv = lm.coords.shape[0]
+        order = np.arange(nv)
+        own = lm.cells[(lm.cells < lm.n_owned).all(axis=1)]
+        order[:lm.n_owned] = locality_order(lm.coords[:lm.n_owned], own)      # the device's numbering: ghosts keep their place
+        inv = np.empty(nv, dtype=np.int64)
+        inv[order] = np.arange(nv)
+        return fieldsplit_tiles_stats(lm.coords[order], inv[lm.cells].astype(np.int32), reorder=False)
+    lm = partition.local_mesh(g.coords, g.cells, part, 0, depth=8)
+    ordered = tiles(lm)
+    # the same local mesh with every link back in ascending global id
+    ghosts = np.arange(lm.n_owned, lm.coords.shape[0])
+    by_id = np.concatenate([ghosts[lm.recv_ptr[k]:lm.recv_ptr[k + 1]][np.argsort(lm.vertex_global[lm.n_owned + lm.recv_ptr[k]:lm.n_owned + lm.recv_ptr[k + 1]])]
+                            for k in range(len(lm.neighbours))])
+    perm = np.concatenate([np.arange(lm.n_owned), by_id])
+    inv = np.empty(perm.size, dtype=np.int64)
+    inv[perm] = np.arange(perm.size)
+    import copy
+    lm2 = copy.copy(lm)
+    lm2.coords, lm2.cells = lm.coords[perm], inv[lm.cells].astype(np.int32)
+    plain = tiles(lm2)
+    assert ordered["violations"] == 0 and plain["violations"] == 0
+    assert ordered["max_vertices"] < 0.7 * plain["max_vertices"]
+
+
 def test_lmea_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):
     """examples/glow_discharge.py (our own driver for the case of fedm-gd.py) builds the LMEA form
     with the facade's functions; `Problem()` hands it to fedm_amd.lmea.compile_lmea, which must
