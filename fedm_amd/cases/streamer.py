@@ -72,7 +72,7 @@ def mesh(n, grading=1.0):
 CHANNEL = (0.0, 0.9e-3, 1.0e-3, 10.8e-3)           # (r0, r1, z0, z1) of the finest region
 
 
-def refined_mesh(h_fine, growth=0.2, channel=CHANNEL, h_max=BOX / 12, n_levels=None, xml_path=None):
+def refined_mesh(h_fine, growth=0.2, channel=CHANNEL, h_max=BOX / 12, n_levels=None, xml_path=None, retriangulate=True):
     """Locally refined unstructured mesh of the box: spacing ``h_fine`` in the streamer channel,
     growing with the distance from it (`fedm_amd.meshgen`): the stand-in for the reference's
     ``mesh.xml`` (fedm-streamer.py:116; missing from its checkout).  With ``xml_path`` the mesh
@@ -82,7 +82,7 @@ def refined_mesh(h_fine, growth=0.2, channel=CHANNEL, h_max=BOX / 12, n_levels=N
     if n_levels is None:
         n_levels = max(2, int(np.ceil(np.log2(h_max / h_fine))) + 1)
     size = meshgen.box_distance_size(channel, h_fine, growth, h_max)
-    msh = meshgen.refined_rectangle(BOX, BOX, size, h_fine, n_levels=n_levels)
+    msh = meshgen.refined_rectangle(BOX, BOX, size, h_fine, n_levels=n_levels, retriangulate=retriangulate)
     if xml_path is not None:
         mesh_io.write_dolfin_xml(msh, xml_path)
         msh = mesh_io.read_dolfin_xml(xml_path)
