@@ -1288,7 +1288,7 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
         if (const char *e = getenv("FEDM_FS_POLICY")) c.fs_measured_policy = std::string(e) != "counts";
         if (const char *e = getenv("FEDM_FS_LAGGED_COUPLING")) c.fs_lagged_coupling = e[0] != '0';
         if (const char *e = getenv("FEDM_GD_HAND"))
-            if (e[0] == '0' || e[0] == '2' || e[0] == '3' || e[0] == '4') c.gd_hand_mode = e[0] - '0';
+            if (e[0] == '0' || (e[0] >= '2' && e[0] <= '5')) c.gd_hand_mode = e[0] - '0';
         if (const char *e = getenv("FEDM_FS_ORDER")) c.fs_upper = std::string(e) == "upper";
         const char *side = getenv("FEDM_PRECOND_SIDE");
         if (side && std::string(side) == "left") c.right_precond = false;

@@ -119,7 +119,7 @@ struct Ctx {
     int *d_gd_inv_idx = nullptr;          // cell * 9 + (a * 3 + b)
     double *d_gd_elemF = nullptr;         // element residuals [3 * neq][nc]
     int *d_gd_vinv_ptr = nullptr, *d_gd_vinv_idx = nullptr;   // vertex -> cell * 3 + local vertex
-    int gd_hand_mode = 3;                 // gd.hip, launch_assemble_gd
+    int gd_hand_mode = 5;                 // gd.hip, launch_assemble_gd
     uint32_t *d_gd_kpos = nullptr;        // (cell, a, b) -> place in the contributions sorted by matrix position
     GdPrep *gd_prep = nullptr;  // on-device per-step coefficient refresh (LMEA)
     Pattern pat;

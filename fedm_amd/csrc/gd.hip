@@ -13,6 +13,7 @@
 // per (cell, local dof) for the Jacobian -- a colour alone has too few cells to fill the chip.
 #include "fedm_internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -475,8 +476,12 @@ __device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, 
 // NRC, NQC > 0: the numbers of reactions and of quadrature points at compile time (the loops over them
 // unroll, the model's scalars -- weights, powers, points -- are loaded once instead of by a dependent
 // scalar load and a wait in every pass of the innermost loops); 0: taken from the descriptor.
-template <int NEQ, int STORE, int NRC = 0, int NQC = 0>
-__global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(2, 2))) void gd_jacobian_rows_kernel(
+// BALL (round 4): the three column vertices side by side -- 45 + 9 accumulators, the point functions evaluated ONCE
+// per quadrature point instead of once per column vertex.  That is the variant that spilled 600 bytes at two waves
+// per SIMD; here it runs at ONE wave per SIMD with the whole 512-entry register file: a
+// third of the instructions per wave for half the resident waves.
+template <int NEQ, int STORE, int NRC = 0, int NQC = 0, bool BALL = false>
+__global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(BALL ? 1 : 2, BALL ? 1 : 2))) void gd_jacobian_rows_kernel(
     const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields, int nv,
     const int *__restrict__ cell_list, int n_cells, const int *__restrict__ cells,
     const double *__restrict__ coords, const int8_t *__restrict__ ftags,
@@ -588,18 +593,24 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     // of 45.  The point functions are evaluated once per column vertex -- more arithmetic, but the 45
     // accumulators next to the live coefficients did not fit the register file: 92 spilled dwords per
     // lane, re-read and re-written at every quadrature point, were what the kernel's time went into.
+    // NB column vertices per pass over the quadrature points: all three (BALL) or one (a rolled loop of three passes)
+    constexpr int NB = (BALL && STORE != 0) ? 3 : 1;
 #pragma unroll 1
-    for (int b = 0; b < (STORE == 0 ? 1 : 3); ++b) {
-    const double Gb0 = b == 0 ? c.G[0][0] : b == 1 ? c.G[1][0] : c.G[2][0];
-    const double Gb1 = b == 0 ? c.G[0][1] : b == 1 ? c.G[1][1] : c.G[2][1];
+    for (int b = 0; b < (STORE == 0 || BALL ? 1 : 3); ++b) {
     // The columns a row writes are known at compile time (energy 0, electrons ie, potential, the
     // species of the sources) except its OWN column: that one has accumulators of its own, added to
     // Jacc[.][row] after the loops -- no run-time register selection inside them.
-    double Racc[3] = {0.0, 0.0, 0.0}, Jacc[3][NEQ], Jown[3] = {0.0, 0.0, 0.0};   // [row vertex a][column field s]
+    double Racc[3] = {0.0, 0.0, 0.0}, Jacc[NB][3][NEQ], Jown[NB][3];   // [column vertex][row vertex a][column field s]
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
-        for (int s = 0; s < NEQ; ++s) Jacc[a][s] = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            Jown[bb][a] = 0.0;
+#pragma unroll
+            for (int s = 0; s < NEQ; ++s) Jacc[bb][a][s] = 0.0;
+        }
+    // the column vertex of accumulator set bb (compile-time bb; b is the rolled loop's vertex when NB = 1)
+    auto col_vertex = [&](int bb) { return NB == 3 ? bb : b; };
 
     // value and gradient of unknown s at a point (s is wave-uniform or a compile-time index)
     auto value = [&](int s, const double phi[3]) {
@@ -634,45 +645,46 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     // (source-only and flux-only forms: a product with a literal zero is not folded without fast-math)
     // s: a compile-time column where these are called (after inlining and unrolling), or OWN
     constexpr int OWN = -1;
-    auto addS = [&](int s, double W, const double phi[3], double tS) {
+    auto addS = [&](int bb, int s, double W, const double phi[3], double tS) {
         if (STORE == 0) return;
         const double w = W * tS;
         if (s == OWN) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) Jown[a] += w * phi[a];
+            for (int a = 0; a < 3; ++a) Jown[bb][a] += w * phi[a];
             return;
         }
 #pragma unroll
         for (int k = 0; k < NEQ; ++k)
             if (k == s) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Jacc[a][k] += w * phi[a];
+                for (int a = 0; a < 3; ++a) Jacc[bb][a][k] += w * phi[a];
             }
     };
-    auto addG = [&](int s, double W, double tX, double tY) {
+    auto addG = [&](int bb, int s, double W, double tX, double tY) {
         if (STORE == 0) return;
         const double wx = W * tX, wy = W * tY;
         if (s == OWN) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) Jown[a] -= wx * c.G[a][0] + wy * c.G[a][1];
+            for (int a = 0; a < 3; ++a) Jown[bb][a] -= wx * c.G[a][0] + wy * c.G[a][1];
             return;
         }
 #pragma unroll
         for (int k = 0; k < NEQ; ++k)
             if (k == s) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Jacc[a][k] -= wx * c.G[a][0] + wy * c.G[a][1];
+                for (int a = 0; a < 3; ++a) Jacc[bb][a][k] -= wx * c.G[a][0] + wy * c.G[a][1];
             }
     };
     // derivatives of the channels along the basis function of column vertex b (value w_v, gradient w_x, w_y)
     struct Seeds {
         double w_v, w_x, w_y, k1_0, k2_0, k3_0, k1_e, k2_e, k3_e;
     };
-    auto seeds = [&](const double phi[3], const GdChannels &ch) {
+    auto seeds = [&](int bb, const double phi[3], const GdChannels &ch) {
+        const int bv = col_vertex(bb);
         Seeds sd;
-        sd.w_v = b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2];
-        sd.w_x = Gb0;
-        sd.w_y = Gb1;
+        sd.w_v = bv == 0 ? phi[0] : bv == 1 ? phi[1] : phi[2];
+        sd.w_x = bv == 0 ? c.G[0][0] : bv == 1 ? c.G[1][0] : c.G[2][0];
+        sd.w_y = bv == 0 ? c.G[0][1] : bv == 1 ? c.G[1][1] : c.G[2][1];
         sd.k1_0 = ch.r0 * sd.w_v;
         sd.k2_0 = ch.c2_v0 * sd.w_v + ch.r0 * sd.w_x;
         sd.k3_0 = ch.c3_v0 * sd.w_v + ch.r0 * sd.w_y;
@@ -690,20 +702,20 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                                 (exp_table && q >= 0) ? lds_e[((size_t)q * NEQ + own) * SLICE + lc] : -1.0);
     };
     // directional derivative of a flux (column vertex b) into the flux columns of the accumulators
-    auto flux_columns = [&](const GdFluxD &Fl, int own, const Seeds &sd, double W, const double phi[3]) {
-        addG(own, W, Fl.Gx * sd.w_v + Fl.dg * sd.w_x, Fl.Gy * sd.w_v + Fl.dg * sd.w_y);
-        addG(IPHI, W, -Fl.dE * sd.w_x, -Fl.dE * sd.w_y);   // E = -grad Phi
-        addG(0, W, Fl.x_c1 * sd.k1_0 + Fl.x_c2 * sd.k2_0, Fl.y_c1 * sd.k1_0 + Fl.y_c3 * sd.k3_0);
-        addG(ie, W, Fl.x_c1 * sd.k1_e + Fl.x_c2 * sd.k2_e, Fl.y_c1 * sd.k1_e + Fl.y_c3 * sd.k3_e);
+    auto flux_columns = [&](int bb, const GdFluxD &Fl, int own, const Seeds &sd, double W, const double phi[3]) {
+        addG(bb, own, W, Fl.Gx * sd.w_v + Fl.dg * sd.w_x, Fl.Gy * sd.w_v + Fl.dg * sd.w_y);
+        addG(bb, IPHI, W, -Fl.dE * sd.w_x, -Fl.dE * sd.w_y);   // E = -grad Phi
+        addG(bb, 0, W, Fl.x_c1 * sd.k1_0 + Fl.x_c2 * sd.k2_0, Fl.y_c1 * sd.k1_0 + Fl.y_c3 * sd.k3_0);
+        addG(bb, ie, W, Fl.x_c1 * sd.k1_e + Fl.x_c2 * sd.k2_e, Fl.y_c1 * sd.k1_e + Fl.y_c3 * sd.k3_e);
     };
     // ... of factor * (w . G) (Joule heating: w = E; wall flux: w = n) into the source columns
-    auto flux_dot_columns = [&](const GdFluxD &Fl, int own, const Seeds &sd, double wx, double wy, double factor,
+    auto flux_dot_columns = [&](int bb, const GdFluxD &Fl, int own, const Seeds &sd, double wx, double wy, double factor,
                                 double W, const double phi[3]) {
-        addS(own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * sd.w_v + Fl.dg * (wx * sd.w_x + wy * sd.w_y)));
-        addS(IPHI, W, phi, -factor * Fl.dE * (wx * sd.w_x + wy * sd.w_y));
+        addS(bb, own, W, phi, factor * ((Fl.Gx * wx + Fl.Gy * wy) * sd.w_v + Fl.dg * (wx * sd.w_x + wy * sd.w_y)));
+        addS(bb, IPHI, W, phi, -factor * Fl.dE * (wx * sd.w_x + wy * sd.w_y));
         const double o1 = factor * (Fl.x_c1 * wx + Fl.y_c1 * wy), o2 = factor * Fl.x_c2 * wx, o3 = factor * Fl.y_c3 * wy;
-        addS(0, W, phi, o1 * sd.k1_0 + o2 * sd.k2_0 + o3 * sd.k3_0);
-        addS(ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e);
+        addS(bb, 0, W, phi, o1 * sd.k1_0 + o2 * sd.k2_0 + o3 * sd.k3_0);
+        addS(bb, ie, W, phi, o1 * sd.k1_e + o2 * sd.k2_e + o3 * sd.k3_e);
     };
 
     for (int q = 0; q < nqp; ++q) {
@@ -726,9 +738,18 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             for (int i = 1; i < ns; ++i) {
                 const double ni = (md->sign[i] * md->charge_over_eps) * expu(i, q, phi);
                 rho += ni;
-                addS(i, W, phi, -ni * (b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2]));
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) {
+                    const int bv = col_vertex(bb);
+                    addS(bb, i, W, phi, -ni * (bv == 0 ? phi[0] : bv == 1 ? phi[1] : phi[2]));
+                }
             }
-            addG(IPHI, W, -Gb0, -Gb1);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                const int bv = col_vertex(bb);
+                addG(bb, IPHI, W, -(bv == 0 ? c.G[0][0] : bv == 1 ? c.G[1][0] : c.G[2][0]),
+                     -(bv == 0 ? c.G[0][1] : bv == 1 ? c.G[1][1] : c.G[2][1]));
+            }
             if (b == 0) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) Racc[a] += W * (-rho * phi[a] - (Ex * c.G[a][0] + Ey * c.G[a][1]));
@@ -780,15 +801,16 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             Gy = Fw.Gy;
             const GdFluxD Fe = species_flux(ie, 1.0, ie, phi, ch, q);
             S += Fe.Gx * Ex + Fe.Gy * Ey;
-            {
-                const Seeds sd = seeds(phi, ch);
-                addS(0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0);
 #pragma unroll
-                for (int i = 1; i < ns; ++i) addS(i, W, phi, -src_v[i] * sd.w_v);
-                addS(ie, W, phi, -src_c1 * sd.k1_e);
-                flux_columns(Fw, 0, sd, W, phi);
-                flux_dot_columns(Fe, ie, sd, Ex, Ey, 1.0, W, phi);
-                addS(IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y));   // d(G . E)/dE = G, E = -grad Phi
+            for (int bb = 0; bb < NB; ++bb) {
+                const Seeds sd = seeds(bb, phi, ch);
+                addS(bb, 0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0);
+#pragma unroll
+                for (int i = 1; i < ns; ++i) addS(bb, i, W, phi, -src_v[i] * sd.w_v);
+                addS(bb, ie, W, phi, -src_c1 * sd.k1_e);
+                flux_columns(bb, Fw, 0, sd, W, phi);
+                flux_dot_columns(bb, Fe, ie, sd, Ex, Ey, 1.0, W, phi);
+                addS(bb, IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y));   // d(G . E)/dE = G, E = -grad Phi
             }
         } else {
             const bool has_flux = md->eq_type[row] != FEDM_EQ_REACTION;
@@ -798,14 +820,15 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                 Gx = Fl.Gx;
                 Gy = Fl.Gy;
             }
-            {
-                const Seeds sd = seeds(phi, ch);
-                addS(OWN, W, phi, dT * sd.w_v);
 #pragma unroll
-                for (int i = 1; i < ns; ++i) addS(i, W, phi, -src_v[i] * sd.w_v);
-                addS(0, W, phi, -src_c1 * sd.k1_0);
-                addS(ie, W, phi, -src_c1 * sd.k1_e);
-                if (has_flux) flux_columns(Fl, OWN, sd, W, phi);
+            for (int bb = 0; bb < NB; ++bb) {
+                const Seeds sd = seeds(bb, phi, ch);
+                addS(bb, OWN, W, phi, dT * sd.w_v);
+#pragma unroll
+                for (int i = 1; i < ns; ++i) addS(bb, i, W, phi, -src_v[i] * sd.w_v);
+                addS(bb, 0, W, phi, -src_c1 * sd.k1_0);
+                addS(bb, ie, W, phi, -src_c1 * sd.k1_e);
+                if (has_flux) flux_columns(bb, Fl, OWN, sd, W, phi);
             }
         }
         if (b == 0) {
@@ -849,7 +872,11 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                 double wall;
                 if (et == FEDM_EQ_DIFFUSION_REACTION) {
                     wall = fac * (0.5 * vth * dens);
-                    addS(OWN, W, phi, wall * (b == 0 ? phi[0] : b == 1 ? phi[1] : phi[2]));
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) {
+                        const int bv = col_vertex(bb);
+                        addS(bb, OWN, W, phi, wall * (bv == 0 ? phi[0] : bv == 1 ? phi[1] : phi[2]));
+                    }
                 } else {
                     const GdChannels ch = channels(phi, -1);
                     const double En = Ex * nx + Ey * ny;
@@ -859,12 +886,13 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                     const double qd = zs * (muv * En), sg = qd < 0.0 ? -1.0 : 1.0;
                     wall = fac * ((0.5 * vth + sg * qd) * dens);
                     const double k = fac * dens * sg * zs;
-                    {
-                        const Seeds sd = seeds(phi, ch);
-                        addS(OWN, W, phi, wall * sd.w_v);
-                        addS(0, W, phi, k * mub * En * sd.k1_0);
-                        addS(ie, W, phi, k * mub * En * sd.k1_e);
-                        addS(IPHI, W, phi, -k * muv * (nx * sd.w_x + ny * sd.w_y));
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) {
+                        const Seeds sd = seeds(bb, phi, ch);
+                        addS(bb, OWN, W, phi, wall * sd.w_v);
+                        addS(bb, 0, W, phi, k * mub * En * sd.k1_0);
+                        addS(bb, ie, W, phi, k * mub * En * sd.k1_e);
+                        addS(bb, IPHI, W, phi, -k * muv * (nx * sd.w_x + ny * sd.w_y));
                     }
                     if (sp == ie) {
                         // - 2 gamma / (1 + r) * sum over ions of Max(Gamma_s . n, 0), fedm-gd.py:351
@@ -875,7 +903,8 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
                             const double gn = Fs.Gx * nx + Fs.Gy * ny;
                             if (gn < 0.0) continue;
                             wall -= cI * gn;
-                            flux_dot_columns(Fs, s, seeds(phi, ch), nx, ny, -cI, W, phi);
+#pragma unroll
+                            for (int bb = 0; bb < NB; ++bb) flux_dot_columns(bb, Fs, s, seeds(bb, phi, ch), nx, ny, -cI, W, phi);
                         }
                     }
                 }
@@ -888,9 +917,11 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     }
 
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
-        for (int k = 0; k < NEQ; ++k) Jacc[a][k] += (k == row) ? Jown[a] : 0.0;
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int k = 0; k < NEQ; ++k) Jacc[bb][a][k] += (k == row) ? Jown[bb][a] : 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (b == 0) {
@@ -898,27 +929,31 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             else unsafeAtomicAdd(&F[(size_t)c.v[a] * NEQ + row], Racc[a]);
         }
         if (STORE == 0) continue;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+        const int bv = col_vertex(bb);
         if (STORE == 3) {
             // element buffer in the order of the DESTINATIONS: [row * NEQ + s][k], k = this (cell, a, b)'s place in the
             // list of contributions sorted by stored matrix position (`cell_slots` carries that table here): the gather
             // kernel then reads consecutive addresses for consecutive matrix rows, and these stores, scattered over
             // the few hundred positions around a workgroup's 64 cells, meet in the L2
             const size_t n_k = (size_t)9 * n_cells;
-            double *dst = val + (size_t)(row * NEQ) * n_k + cell_slots[(size_t)cidx * 9 + a * 3 + b];
+            double *dst = val + (size_t)(row * NEQ) * n_k + cell_slots[(size_t)cidx * 9 + a * 3 + bv];
 #pragma unroll
-            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_k] = Jacc[a][s];
+            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_k] = Jacc[bb][a][s];
             continue;
         }
         if (STORE == 2) {   // element buffer [(a * 3 + b) * NEQ2 + row * NEQ + s][cell]: lanes = cells, coalesced
-            double *dst = val + ((size_t)(a * 3 + b) * NEQ2 + row * NEQ) * n_cells + cidx;
+            double *dst = val + ((size_t)(a * 3 + bv) * NEQ2 + row * NEQ) * n_cells + cidx;
 #pragma unroll
-            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_cells] = Jacc[a][s];
+            for (int s = 0; s < NEQ; ++s) dst[(size_t)s * n_cells] = Jacc[bb][a][s];
             continue;
         }
-        const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + b];
+        const uint32_t slot = cell_slots[(size_t)cidx * 9 + a * 3 + bv];
         double *dst = val + ((size_t)(slot >> 6) * NEQ2) * SLICE + (slot & 63);
 #pragma unroll
-        for (int s = 0; s < NEQ; ++s) unsafeAtomicAdd(&dst[(size_t)(row * NEQ + s) * SLICE], Jacc[a][s]);
+        for (int s = 0; s < NEQ; ++s) unsafeAtomicAdd(&dst[(size_t)(row * NEQ + s) * SLICE], Jacc[bb][a][s]);
+        }
     }
     }   // column vertex b
     }   // pass
@@ -1006,6 +1041,7 @@ static int gd_elem_setup(Ctx &c) {
     for (size_t e = 0; e < n_e; ++e) idx[fill[c.pat.cell_slots[e]]++] = (int)e;
     std::vector<uint32_t> kpos(n_e);   // (cell, a, b) -> its place in that list (the destination-ordered buffer)
     for (size_t k = 0; k < n_e; ++k) kpos[idx[k]] = (uint32_t)k;
+
     // vertex -> (cell, local vertex): read back from the device copy of the connectivity
     std::vector<int> cells_h((size_t)c.nc * 3), vptr((size_t)c.nv + 1, 0), vidx((size_t)c.nc * 3);
     if (hipMemcpy(cells_h.data(), c.d_cells, sizeof(int) * cells_h.size(), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -1055,7 +1091,8 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         // in Poisson-only mode the other rows keep the zeros of the memset (identity rows follow)
         const int n = c.nc;
         const bool gather = hand_mode >= 3 && gd_elem_setup(c) == 0;
-        const bool dest_order = hand_mode == 3;   // (4: the buffer in cell order, round 2's layout)
+        const bool dest_order = hand_mode == 3 || hand_mode == 5;   // (4: the buffer in cell order, round 2's layout)
+        const bool ball = hand_mode == 5;
         if (!gather || mode != 0)   // (the gather writes every value of the rows it covers)
             hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * c.neq * c.neq, c.stream);
         const int cpb = SLICE, nf = c.gd_n_fields;
@@ -1083,6 +1120,17 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
             lds_attr_set = true;                                                                                  \
         }                                                                                                         \
         if (gather && dest_order) {                                                                               \
+            if (ball) {                                                                                           \
+                static bool ball_attr_set = false;                                                                \
+                if (lds_h > 64 * 1024 && !ball_attr_set) {                                                        \
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC, true>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);                  \
+                    ball_attr_set = true;                                                                         \
+                }                                                                                                 \
+                hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC, true>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
+                                   c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_gd_kpos,  \
+                                   c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \
+            } else                                                                                                \
             hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_gd_kpos,      \
                                c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \
@@ -1117,7 +1165,7 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         // residual only: the same point functions without the derivative columns, all cells in one
         // launch; element residuals summed per vertex (no atomics: fixed order)
         const int n = c.nc;
-        double *elemF = (hand_mode == 3 && gd_elem_setup(c) == 0) ? c.d_gd_elemF : nullptr;
+        double *elemF = ((hand_mode == 3 || hand_mode == 5) && gd_elem_setup(c) == 0) ? c.d_gd_elemF : nullptr;
         size_t lds_h = sizeof(double) * ((size_t)(3 * SLICE + 1) / 2 + (size_t)SLICE * c.gd_n_fields * 3 +
                                          (size_t)SLICE * 3 * c.neq);
         const size_t lds_table = sizeof(double) * (size_t)c.gd.n_qp * c.neq * SLICE;

@@ -12,10 +12,11 @@ ROOT = Path(__file__).resolve().parent.parent
 DECK = ROOT / "decks" / "glow_discharge" / "file_input" / "4_particles"
 
 
-@pytest.mark.parametrize("variant", ["3", "4", "2", "0"])
+@pytest.mark.parametrize("variant", ["5", "3", "4", "2", "0"])
 def test_gd_residual_and_jacobian_match_the_oracle(variant, monkeypatch):
-    """LMEA element Jacobian against the oracle for the device variants (csrc/gd.hip): hand-derived blocks
-    through the element buffer in the order of their destinations + gather (3, default), the buffer in cell
+    """LMEA element Jacobian against the oracle for the device variants (csrc/gd.hip): hand-derived blocks with
+    the three column vertices side by side at one wave per SIMD (5), one column vertex per pass (3), both
+    through the element buffer in the order of their destinations + gather, the buffer in cell
     order (4, round 2's layout), the same blocks added with atomics (2), and the dual-number kernel (0) that
     cross-checks the hand derivation."""
     from oracle import gd as ogd
