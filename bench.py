@@ -680,7 +680,7 @@ def main():
         import re as _re
         # the F + J pair only: element blocks (STORE = 1..3) + the gather of the matrix entries
         gtr = {k: v for k, v in gtr.items()
-               if _re.search(r"gd_jacobian_rows_kernel<\d+, ?[123],", k) or _re.search(r"gd_gather(_dest)?_kernel<", k)}
+               if _re.search(r"gd_jacobian_rows_kernel<\d+, ?[123],", k) or _re.search(r"gd_gather(_dest(_rows)?)?_kernel<", k)}
         out["glow_discharge"] = {
             "workload": "BASELINE configs[2]: argon glow discharge, LMEA (energy + 3 particle balances + Poisson), "
                         "141x141 crossed mesh, device-resident per-step pipeline (fedm_amd.cases.glow_discharge)",

@@ -1008,6 +1008,31 @@ __global__ __launch_bounds__(256) void gd_gather_dest_kernel(int n_pos, const in
         if (e / NEQ >= row_first && e / NEQ <= row_last) dst[(size_t)e * SLICE] = acc[e];
 }
 
+// The same gather with a thread per (stored position, equation row): NEQ accumulators and NEQ loads per
+// contribution and thread instead of NEQ^2 -- five times the threads in flight for the same loads, so a wave whose
+// diagonal lanes walk 6-8 contributions holds the others up for a fifth of the work (FEDM_GD_GATHER=rows).
+template <int NEQ>
+__global__ __launch_bounds__(256) void gd_gather_dest_rows_kernel(int n_pos, const int *__restrict__ inv_ptr,
+                                                                  const double *__restrict__ elem, double *__restrict__ val,
+                                                                  int row_first, int row_last, int n_cells) {
+    constexpr int NEQ2 = NEQ * NEQ;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = row_first + (int)blockIdx.y;
+    if (p >= n_pos || r > row_last) return;
+    const size_t n_k = (size_t)9 * n_cells;
+    double acc[NEQ];
+#pragma unroll
+    for (int s = 0; s < NEQ; ++s) acc[s] = 0.0;
+    const double *src = elem + (size_t)(r * NEQ) * n_k;
+    for (int k = inv_ptr[p]; k < inv_ptr[p + 1]; ++k) {
+#pragma unroll
+        for (int s = 0; s < NEQ; ++s) acc[s] += src[(size_t)s * n_k + k];
+    }
+    double *dst = val + ((size_t)(p >> 6) * NEQ2 + r * NEQ) * SLICE + (p & 63);
+#pragma unroll
+    for (int s = 0; s < NEQ; ++s) dst[(size_t)s * SLICE] = acc[s];
+}
+
 // every vertex sums the element residuals of its cells (inverse of the connectivity), fixed order
 template <int NEQ>
 __global__ __launch_bounds__(256) void gd_gather_residual_kernel(int nv, const int *__restrict__ inv_ptr,
@@ -1093,6 +1118,14 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         const bool gather = hand_mode >= 3 && gd_elem_setup(c) == 0;
         const bool dest_order = hand_mode == 3 || hand_mode == 5;   // (4: the buffer in cell order, round 2's layout)
         const bool ball = hand_mode == 5;
+        // the gather's thread mapping: a thread per (position, equation row) by default (measured at 200 k DOFs, F + J:
+        // 353 us with a thread per position, 287-296 us per (position, row), the same per (position, plane));
+        // FEDM_GD_GATHER=positions|rows
+        static const char gather_kind = [] {
+            const char *e = std::getenv("FEDM_GD_GATHER");
+            return e ? e[0] : 'r';
+        }();
+        const bool gather_rows = gather_kind == 'r';
         if (!gather || mode != 0)   // (the gather writes every value of the rows it covers)
             hipMemsetAsync(c.d_val, 0, sizeof(double) * (size_t)c.pat.total_bc * SLICE * c.neq * c.neq, c.stream);
         const int cpb = SLICE, nf = c.gd_n_fields;
@@ -1134,6 +1167,10 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
             hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_gd_kpos,      \
                                c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \
+            if (gather_rows)                                                                                      \
+                hipLaunchKernelGGL((gd_gather_dest_rows_kernel<NEQ>), dim3((n_pos + 255) / 256, row_last - row_first + 1), \
+                                   dim3(256), 0, c.stream, n_pos, c.d_gd_inv_ptr, c.d_gd_elem, c.d_val, row_first, row_last, n); \
+            else                                                                                                  \
             hipLaunchKernelGGL((gd_gather_dest_kernel<NEQ>), dim3((n_pos + 255) / 256), dim3(256), 0, c.stream, n_pos, \
                                c.d_gd_inv_ptr, c.d_gd_elem, c.d_val, row_first, row_last, n);                     \
             hipLaunchKernelGGL((gd_gather_residual_kernel<NEQ>), dim3((c.nv + 255) / 256), dim3(256), 0, c.stream, \

@@ -910,8 +910,8 @@ class DeviceProblem:
 
     def gd_assembly_kernel_name(self):
         """The LMEA F + J assembly kernels in use (bench.py's glow-discharge roofline block)."""
-        return ("gd_jacobian_rows_kernel<.., BALL> + gd_gather_dest_kernel (hand-derived element blocks of all cells, the "
-                "three column vertices side by side at one wave per SIMD; summed per stored matrix position; F + J)")
+        return ("gd_jacobian_rows_kernel<.., BALL> + gd_gather_dest_rows_kernel (hand-derived element blocks of all cells, the "
+                "three column vertices side by side at one wave per SIMD; summed per stored matrix position and row; F + J)")
 
     def sizes(self):
         v = [C.c_int64() for _ in range(6)]
