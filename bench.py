@@ -486,8 +486,13 @@ def main():
         while runner.steps < args.late_start:
             runner.step()
         t_late = runner.t
+        pol0 = runner.prob.fieldsplit_policy()
         l_elapsed, l_newton, l_gmres, l_prof, _ = timed_steps(runner, steps, barrier, torch, dist, distributed)
-        return {"what": f"{steps} accepted steps timed the same way from step {args.late_start + 1} on "
+        pol1 = runner.prob.fieldsplit_policy()
+        return {"preconditioner_sets": {"policy": pol1["policy"],
+                                        "solves_main_set": pol1["solves_main_set"] - pol0["solves_main_set"],
+                                        "solves_alternative_set": pol1["solves_alternative_set"] - pol0["solves_alternative_set"]},
+                "what": f"{steps} accepted steps timed the same way from step {args.late_start + 1} on "
                         f"(t = {t_late:.3e} s: the streamer has formed and propagates)",
                 "value": runner.total_dofs * steps / l_elapsed, "unit": "DOF-updates/s",
                 "timesteps_per_sec": steps / l_elapsed, "ms_per_step": 1e3 * l_elapsed / steps,

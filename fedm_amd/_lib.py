@@ -156,6 +156,7 @@ _SIGNATURES = {
                                                  C.POINTER(Csr), _D, C.c_int, C.c_double]),
     "fedm_set_fieldsplit": (C.c_int, [_P, C.c_int, _D]),
     "fedm_set_fieldsplit_alternative": (C.c_int, [_P, C.c_int, _D, C.c_double, C.c_double]),
+    "fedm_fieldsplit_policy": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fedm_amg_aggregate": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32)]),

@@ -799,6 +799,9 @@ static int gmres(Ctx &c, int restart, double rtol, double atol, int max_it, int 
                 if (!queued.empty()) {
                     wait_red_seq(c, queued.back());
                     queued.clear();
+                    // a dropped step that went in 'as the last one' is launched again from scratch: its skipped
+                    // update must not be made up for a second time behind the relaunch
+                    if (update_skipped_for > j) update_skipped_for = -1;
                 }
                 if (update_skipped_for == j) {   // the first Gram-Schmidt pass has not been applied to w yet
                     krylov_vector_update(c, j + 1, vp.data(), w);
@@ -1713,6 +1716,7 @@ int fedm_newton_solve(fedm_ctx *h, const fedm_newton_opts *o, fedm_newton_report
     }
     if (comm_failed(c)) rc = -1;  // the message is in fedm_last_error (Comm::error)
     if (rc == 0) c.newton_its_hint = it;
+    ++c.fs_solves[c.fs_alt_active ? 1 : 0];
     if ((c.fs_alt_sweeps > 0 || c.amg_alt) && it > 0) {
         // same counts on every rank, so every rank takes the same decision
         const double per_solve = (double)lin_total / it;
@@ -2047,10 +2051,13 @@ int fedm_debug_fieldsplit_tiles(fedm_ctx *h, int mode, int tile_slices, int dept
     iter_graphs_clear(c);   // captured Krylov steps hold the kernels of the old setting
     fs_tiles_configure(c, mode & 1, tile_slices, depth, threads);
     c.mg_tiles_off = (mode & 2) != 0;   // mode 3: species sweeps on tiles, the multigrid's finest-level sweeps not
-    if (c.amg && c.amg->graph_exec) {   // the cycle's own graph holds the kernels of the old setting
-        hipGraphExecDestroy(c.amg->graph_exec);
-        c.amg->graph_exec = nullptr;
-    }
+    // the cycles' own graphs hold the kernels (and the tile tables) of the old setting: both hierarchies, the
+    // one in use and the alternative for hard systems
+    for (Amg *a : {c.amg, c.amg_alt})
+        if (a && a->graph_exec) {
+            hipGraphExecDestroy(a->graph_exec);
+            a->graph_exec = nullptr;
+        }
     return 0;
 }
 
@@ -2212,6 +2219,16 @@ int fedm_set_fieldsplit_alternative(fedm_ctx *h, int alt_sweeps, const double *a
     for (int i = 0; i < alt_sweeps; ++i) c.fs_alt_w[i] = alt_weights[i];
     c.fs_switch_above = switch_above;
     c.fs_back_below = back_below;
+    return 0;
+}
+
+int fedm_fieldsplit_policy(fedm_ctx *h, int64_t out[4]) {
+    if (!h || !out) return -2;
+    const Ctx &c = h->c;
+    out[0] = (c.fs_measured_policy && !(c.comm && c.comm->nranks > 1)) ? 1 : 0;
+    out[1] = c.fs_alt_active ? 1 : 0;
+    out[2] = c.fs_solves[0];
+    out[3] = c.fs_solves[1];
     return 0;
 }
 

@@ -209,6 +209,7 @@ struct Ctx {
     int fs_probe_left = 0;              // > 0: probing the other set for that many more solves
     bool fs_skip_sample = false;        // the next solve re-captures its graphs: its time does not count
     int fs_probe_every = 120;
+    long fs_solves[2] = {0, 0};         // Newton solves run under the [main, alternative] set (fedm_fieldsplit_policy)
     double *d_V = nullptr;  // (restart+1) Krylov vectors
     int krylov_cap = 0;
     int krylov_steps_hint = 0;   // Krylov steps of the previous solve: how far ahead steps are queued

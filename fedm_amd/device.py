@@ -827,6 +827,13 @@ class DeviceProblem:
                                                                  float(switch_above), float(back_below)),
                         "fedm_set_fieldsplit_alternative")
 
+    def fieldsplit_policy(self):
+        """Which preconditioner set ran (``fedm_fieldsplit_policy``): policy, active set, solves under each."""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.fedm_fieldsplit_policy(self._h, out), "fedm_fieldsplit_policy")
+        return dict(policy="measured (wall time per Newton iteration)" if out[0] else "Krylov counts",
+                    alternative_active=bool(out[1]), solves_main_set=int(out[2]), solves_alternative_set=int(out[3]))
+
     def clear_multigrid(self):
         self.lib.fedm_amg_clear(self._h)
 

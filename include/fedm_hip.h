@@ -200,7 +200,7 @@ const char *fedm_last_error(void);
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
  * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields.
  * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles.
- * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]; fedm_comm_stats out[10]. */
+ * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]; fedm_comm_stats out[10]; fedm_fieldsplit_policy. */
 #define FEDM_ABI_VERSION 4
 int fedm_abi_version(void);
 
@@ -332,6 +332,11 @@ int fedm_set_fieldsplit(fedm_ctx *ctx, int sweeps, const double *weights);
  * convergence late in a run and the alternative is a cheaper one.  alt_sweeps = 0 switches the rule off. */
 int fedm_set_fieldsplit_alternative(fedm_ctx *ctx, int alt_sweeps, const double *alt_weights,
                                     double switch_above, double back_below);
+/* Which of the two sets ran: out = {policy (1: the set that is measured faster -- wall time per Newton iteration, one
+ * GPU; 0: by the Krylov counts alone), alternative set active now, Newton solves run under the main set, under the
+ * alternative set}.  The measured policy makes a run's trajectory of sets depend on the machine; bench.py prints
+ * these counts per window so that two runs can be told apart (FEDM_FS_POLICY=counts: reproducible). */
+int fedm_fieldsplit_policy(fedm_ctx *ctx, int64_t out[4]);
 /* host-side greedy aggregation on a strength graph (set-up helper, no GPU needed) */
 int fedm_amg_aggregate(int32_t n, const int64_t *indptr, const int32_t *indices,
                        const uint8_t *strong, int32_t *agg, int32_t *n_agg);

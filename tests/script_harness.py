@@ -141,8 +141,8 @@ def prepare_workdir(case, workdir):
     return workdir
 
 
-def run_reference_script(case, workdir):
-    """Execute the reference's script for `case` from /root/reference (imports redirected) until its
+def _exec_reference_script(case, workdir):
+    """(child process) the reference's script for `case` from /root/reference, imports redirected, until its
     first nonlinear solve; returns the record."""
     path = REFERENCE / SCRIPTS[case]
     text = path.read_text()
@@ -158,6 +158,29 @@ def run_reference_script(case, workdir):
         else:
             raise AssertionError(f"{path} finished without calling the nonlinear solver")
     return dict(log)
+
+
+def run_reference_script(case, workdir):
+    """Run the reference's script for `case` up to its first nonlinear solve and return the record.  The script is
+    third-party code: it runs in a CHILD process of its own (this module as a program) with a scrubbed environment,
+    its working directory inside the test's temporary directory, and hands back nothing but arrays and strings
+    (an .npz without pickles) -- not in the pytest process."""
+    import subprocess
+    import sys
+    workdir = Path(workdir)
+    workdir.mkdir(parents=True, exist_ok=True)
+    out = workdir / "record.npz"
+    env = {k: v for k, v in os.environ.items() if k in ("PATH", "HOME", "LANG", "LC_ALL", "TMPDIR", "LD_LIBRARY_PATH")}
+    env["PYTHONPATH"] = os.pathsep.join([str(ROOT), str(Path(__file__).resolve().parent)])
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--child", case, str(workdir), str(out)],
+                       env=env, cwd=str(workdir), capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise AssertionError(f"the reference's {SCRIPTS[case]} failed on the facade:\n{r.stderr[-3000:]}")
+    with np.load(out, allow_pickle=False) as z:
+        rec = {}
+        for key in z.files:
+            rec[key[2:]] = str(z[key]) if key.startswith("s_") else z[key]
+    return rec
 
 
 def run_own_example(case, workdir):
@@ -214,3 +237,11 @@ def assert_same_digest(got, want, rtol=1e-12):
             assert abs(g["sum"] - w["sum"]) <= rtol * max(abs(w["sum"]), scale * np.sqrt(max(np.prod(w["shape"]), 1))), key
             assert abs(g["sum_sq"] - w["sum_sq"]) <= rtol * max(w["sum_sq"], 1e-300), key
             np.testing.assert_allclose(g["samples"], w["samples"], rtol=rtol, atol=rtol * scale, err_msg=key)
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 5 and sys.argv[1] == "--child":
+        record = _exec_reference_script(sys.argv[2], sys.argv[3])
+        np.savez(sys.argv[4], **{("s_" if isinstance(v, str) else "a_") + k: (np.array(v) if isinstance(v, str) else np.asarray(v))
+                                  for k, v in record.items()})
