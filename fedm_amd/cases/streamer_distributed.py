@@ -48,7 +48,17 @@ class Runner(streamer.Stepper):
             several = world > 1 or bool(distributed_multigrid)
             halo_depth = int(os.environ.get("FEDM_HALO_DEPTH", "8")) if several else 1
         self.halo_depth = halo_depth
-        part = partition.partition_rcb(gmesh.coords, world, gmesh.cells)     # cuts that sever the fewest mesh edges
+        # FEDM_PARTITIONER=graph: multilevel recursive bisection of the vertex graph (fedm_amd/graph_partition.py), never
+        # worse in edge cut than the default, the coordinate bisection along the axis that severs fewer mesh edges --
+        # on the two bench meshes (a box, graded or locally refined) the two give the same cuts
+        self.partitioner = os.environ.get("FEDM_PARTITIONER", "rcb")
+        if self.partitioner == "graph":
+            from .. import graph_partition
+            part = graph_partition.partition_graph(gmesh.coords, gmesh.cells, world)
+        elif self.partitioner == "rcb":
+            part = partition.partition_rcb(gmesh.coords, world, gmesh.cells)
+        else:
+            raise ValueError(f"FEDM_PARTITIONER={self.partitioner}: 'rcb' or 'graph'")
         lm = partition.local_mesh(gmesh.coords, gmesh.cells, part, rank, depth=halo_depth)
         self.lm, self.world, self.rank = lm, world, rank
         # (True with one rank: the several-GPU solver -- distributed finest level, replicated coarse

@@ -173,3 +173,77 @@ def test_deep_halo_layers_plans_and_redundantly_assembled_rows():
         # ... and NOT those of the outermost layer (their cells beyond the local mesh are missing)
         outer = lm.layer == depth
         assert (np.abs(F_loc[outer] - F_glob[g[outer]]) / scale).max() > 1e-6
+
+
+def _u_shaped_domain(n=60):
+    """a 3 x 3 box with a slot cut out of it: the median planes of a coordinate bisection cross both arms"""
+    xs = np.linspace(0.0, 3.0, n + 1)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel()], axis=1)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    cx, cy = xs[i] + 1.5 / n, xs[j] + 1.5 / n
+    keep = ~((cx > 1.0) & (cx < 2.0) & (cy > 0.5))
+    i, j = i[keep], j[keep]
+    a, b, c, d = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+    cells = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)])
+    used = np.unique(cells)
+    lookup = np.full(coords.shape[0], -1)
+    lookup[used] = np.arange(used.size)
+    return coords[used], lookup[cells]
+
+
+def test_graph_partitioner_balances_and_never_cuts_more_than_the_planes():
+    """`north_star` names a graph partitioner (METIS); `fedm_amd/graph_partition.py` is the multilevel scheme written
+    out: balanced, deterministic, complete, and on every mesh tried its edge cut is at most the coordinate
+    bisection's (each bisection keeps the better of the multilevel split and the refined median plane)."""
+    from fedm_amd import partition, graph_partition as gp
+    from fedm_amd.cases import streamer
+    m = streamer.mesh(40, 3.0)
+    r = streamer.refined_mesh(4e-5, growth=0.15, channel=(0.0, 100.0 * 4e-5) + streamer.CHANNEL[2:])
+    cases = [(m.coords, m.cells), (r.coords, r.cells), _u_shaped_domain()]
+    for coords, cells in cases:
+        G = partition.vertex_graph(coords.shape[0], cells).astype(np.float64).tocsr()
+        for k in (2, 3, 8):
+            part = gp.partition_graph(coords, cells, k)
+            assert np.array_equal(part, gp.partition_graph(coords, cells, k))          # every rank computes the same
+            cnt = np.bincount(part, minlength=k)
+            assert cnt.sum() == coords.shape[0] and cnt.min() > 0
+            assert cnt.max() <= 1.03 * cnt.mean()
+            assert gp.edge_cut(G, part) <= gp.edge_cut(G, partition.partition_rcb(coords, k, cells)) * 1.0001
+    # where straight cuts are bad it does better: two parts of the U-shaped domain
+    coords, cells = _u_shaped_domain()
+    G = partition.vertex_graph(coords.shape[0], cells).astype(np.float64).tocsr()
+    assert gp.edge_cut(G, gp.partition_graph(coords, cells, 2)) < gp.edge_cut(G, partition.partition_rcb(coords, 2, cells))
+    # the halo plans built on a graph partition are pairwise consistent (deep halos too)
+    part = gp.partition_graph(coords, cells, 4)
+    for depth in (1, 3):
+        lms = [partition.local_mesh(coords, cells, part, q, depth=depth) for q in range(4)]
+        for p in range(4):
+            for ip, q in enumerate(lms[p].neighbours):
+                lq = lms[q]
+                iq = list(lq.neighbours).index(p)
+                sent = lms[p].vertex_global[lms[p].send_idx[lms[p].send_ptr[ip]:lms[p].send_ptr[ip + 1]]]
+                expected = lq.vertex_global[lq.n_owned + lq.recv_ptr[iq]:lq.n_owned + lq.recv_ptr[iq + 1]]
+                assert np.array_equal(sent, expected)
+
+
+def test_matching_and_refinement_steps_of_the_graph_partitioner():
+    """The pieces: heavy-edge matching halves the graph and conserves vertex and edge weight; a refinement pass never
+    raises the cut and keeps the balance it is given."""
+    from fedm_amd import partition, graph_partition as gp
+    coords, cells = _u_shaped_domain(40)
+    G = partition.vertex_graph(coords.shape[0], cells).astype(np.float64).tocsr()
+    G.sort_indices()
+    vw = np.ones(coords.shape[0])
+    Ac, vc, xc, cmap = gp._coarsen(G, vw, coords)
+    assert 0.5 * G.shape[0] <= Ac.shape[0] <= 0.62 * G.shape[0]
+    assert vc.sum() == vw.sum() and np.bincount(cmap).max() <= 2
+    inner = G.data[cmap[gp._rows(G)] == cmap[G.indices]].sum()
+    assert abs(Ac.sum() + inner - G.sum()) < 1e-9
+    rng = np.random.default_rng(3)
+    side = (coords[:, 0] + 0.05 * rng.standard_normal(coords.shape[0]) > 1.5).astype(np.int8)     # a ragged cut
+    target0 = float(np.count_nonzero(side == 0))
+    out = gp._refine(G, vw, side, target0, tol=10.0)
+    assert gp.edge_cut(G, out) < 0.7 * gp.edge_cut(G, side)
+    assert abs(np.count_nonzero(out == 0) - target0) <= 10
