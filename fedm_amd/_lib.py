@@ -62,7 +62,11 @@ class GdDesc(C.Structure):
         ("n_qp", C.c_int32), ("n_fqp", C.c_int32),
         ("qp_x", C.c_double * MAX_QP), ("qp_y", C.c_double * MAX_QP), ("qp_w", C.c_double * MAX_QP),
         ("fqp_t", C.c_double * MAX_FQP), ("fqp_w", C.c_double * MAX_FQP),
+        ("energy_Ei", C.c_double), ("mean_energy_form", C.c_int32),
     ]
+
+
+GD_ME_FORMS = {None: 0, "unknown_ratio": 1}
 
 
 class GdFieldProg(C.Structure):
@@ -198,7 +202,7 @@ EXPR_OPS = {"const": 0, "x": 1, "param": 2, "add": 3, "sub": 4, "mul": 5, "div":
 EXPR_MAX_OPS, EXPR_MAX_PARAMS, EXPR_STACK = 256, 16, 24
 
 
-ABI_VERSION = 4          # include/fedm_hip.h FEDM_ABI_VERSION
+ABI_VERSION = 5          # include/fedm_hip.h FEDM_ABI_VERSION
 
 
 def exported_symbols():

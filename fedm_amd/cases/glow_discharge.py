@@ -30,7 +30,7 @@ class Case:
 
     def __init__(self, nx=100, ny=100, file_input=DECK, device=0, T_final=1e-11,
                  relative_tolerance=1e-4, maximum_iterations=20, quiet=True, error_file=None,
-                 device_pipeline=True, mesh=None):
+                 device_pipeline=True, mesh=None, energy_loss=None, energy_Ei=0.0):
         import tempfile
         self.quiet = quiet
         model = "4_particles"
@@ -45,7 +45,10 @@ class Case:
         grad_diff = [t == "electrons" for t in species_type]
         P, L, G = file_io.reaction_matrices(path, species)
         kfiles = file_io.rate_coefficient_file_names(path)
-        self.energy_loss = file_io.read_energy_loss(path)
+        # (energy_loss: other losses than the deck's, e.g. with its sentinel values 7.77e77 / 9.99e99 for reactions
+        # that lose Ei - mean energy / the mean energy, fedm/functions.py:906-909 -- the deck itself has none)
+        self.energy_loss = file_io.read_energy_loss(path) if energy_loss is None else list(energy_loss)
+        sentinels = any(7e77 < v < 8e77 or 9e99 < v < 1e100 for v in self.energy_loss)
         self.mu_x, self.mu_y, self.mu_dep = file_io.read_transport_coefficients(names, "mobility", model)
         self.D_x, self.D_y, self.D_dep = file_io.read_transport_coefficients(names, "Diffusion", model)
         self.k_dep = file_io.read_dependences(kfiles)
@@ -72,7 +75,9 @@ class Case:
         gd_model = GdModel(n_species=ns, N0=N0, eq_type=eq_type, grad_diffusion=grad_diff,
                            is_ion=[t == "Ion" for t in species_type], sign=sign, vth=vth,
                            electron_mass=M[ns - 1], power=P.tolist(), net=(G - L).tolist(),
-                           energy_loss=self.energy_loss, ref=[ref_met, ref_met, ref_zero, ref_zero],
+                           energy_loss=self.energy_loss, energy_Ei=energy_Ei,
+                           mean_energy_form="unknown_ratio" if sentinels else None,     # u[0] / u[n - 1], fedm_gd.py:365
+                           ref=[ref_met, ref_met, ref_zero, ref_zero],
                            gamma=[0.06, 0.06, 0.0, 0.0], we_secondary=5.0, quadrature_degree=4)
         z = mesh.coords[:, 1]
         self.powered = np.nonzero(np.abs(z) <= 3e-16)[0]

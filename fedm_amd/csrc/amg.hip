@@ -923,8 +923,11 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
                                                              int upper, unsigned zs) {
     // zs: bit (r * NS + c) marks a species plane of the Jacobian that is structurally zero (the sweeps'
     // ZS): neither read here nor written to the half-precision copy, which nobody reads there
+    // A workgroup per slice, its four waves share the slice's block columns (each forms the 2x2 .. 5x5 inverse from four
+    // .. 25 loads of its own): with a wave per slice the eight or so dependent iterations of a wave kept too few bytes
+    // in flight for a kernel that only streams (r4: 31 -> see DESIGN.md section 3).
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
-    const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int slice = blockIdx.x, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int lane = threadIdx.x & 63;
     if (slice >= n_slices) return;
     double d[NS][NS];
@@ -937,12 +940,14 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
             for (int cidx = 0; cidx < NS; ++cidx)
                 A[r][cidx] = val[((size_t)(ds >> 6) * NEQ2 + r * NEQ + cidx) * SLICE + (ds & 63)];
         invert_species_block<NS>(A, d);
+        if (wave == 0) {
 #pragma unroll
-        for (int e = 0; e < NS * NS; ++e)
-            dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = d[e / NS][e % NS];
+            for (int e = 0; e < NS * NS; ++e)
+                dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = d[e / NS][e % NS];
+        }
     }
     const int b0 = boff[slice], b1 = boff[slice + 1];
-    for (int bc = b0; bc < b1; ++bc) {
+    for (int bc = b0 + wave; bc < b1; bc += n_waves) {
         const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
         double J[NS][NS];
 #pragma unroll
@@ -985,7 +990,7 @@ void fieldsplit_setup(Ctx &c) {
         c.d_val32 = nullptr;
         return;
     }
-    const dim3 gs((c.pat.n_slices + 3) / 4);
+    const dim3 gs(c.pat.n_slices);
     // the same mask the sweeps are compiled for (fs_finish_t): two species, a zero off-diagonal plane
     unsigned zs = 0u;
     if (c.ns == 2) zs = ((c.zero_plane_mask >> 1) & 1u) << 1 | ((c.zero_plane_mask >> 3) & 1u) << 2;

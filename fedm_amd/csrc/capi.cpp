@@ -1875,6 +1875,12 @@ int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) 
             launch_spmv(c, c.d_u, c.d_w, false);
         } else if (kind == 3) {
             if (c.amg) c.amg->run(c);  // one multigrid cycle on the potential block (its replayed graph)
+        } else if (kind == 4) {
+            if (c.amg && c.poisson) fieldsplit_setup(c);   // the preconditioner's species planes from the assembled Jacobian
+        } else if (kind == 5) {
+            launch_assemble(c, true, 0);                   // ... behind the assembly, as in a Newton iteration
+            c.boundary_pending = 0;
+            if (c.amg && c.poisson) fieldsplit_setup(c);
         } else {
             launch_assemble(c, false, 0);
         }

@@ -191,6 +191,9 @@ __device__ void gd_element(const fedm_gd_desc *__restrict__ md, const double *__
         Dual f[ns], f_en = mk(0.0);
 #pragma unroll
         for (int i = 0; i < ns; ++i) f[i] = mk(0.0);
+        // Energy_Source_term's mean_energy where the scripts pass u[0] / u[n - 1] (fedm-gd.py:358): the sentinel losses
+        Dual me_arg = mk(0.0);
+        if (md->mean_energy_form == FEDM_GD_ME_UNKNOWN_RATIO) me_arg = p.u[0].v / p.u[ns - 1].v;
         for (int j = 0; j < nr; ++j) {
             Dual rate = gd_rate_coefficient(fields, nv, ns, nr, j, c, phi, dme);
 #pragma unroll
@@ -198,7 +201,10 @@ __device__ void gd_element(const fedm_gd_desc *__restrict__ md, const double *__
                 for (int e = 0; e < md->power[j][i]; ++e) rate = (i == 0) ? rate * md->N0 : rate * p.n[i];
 #pragma unroll
             for (int i = 0; i < ns; ++i) f[i] = f[i] + (double)md->net[j][i] * rate;
-            f_en = f_en - md->energy_loss[j] * rate;
+            const double lj = md->energy_loss[j];   // functions.py:905-911
+            if (lj > 7e77 && lj < 8e77) f_en = f_en - (mk(md->energy_Ei) - me_arg) * rate;
+            else if (lj > 9e99 && lj < 1e100) f_en = f_en - me_arg * rate;
+            else f_en = f_en - lj * rate;
         }
         constexpr int ie = ns - 1;  // electrons are the last species
         Dual gex, gey;
@@ -536,8 +542,13 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         const double w = (wave == 0) ? -md->energy_loss[lc] : (double)md->net[lc][wave];
         int pk = 0;
         for (int i = 0; i < ns; ++i) pk |= (md->power[lc][i] & 15) << (4 * i);
+        // energy row: a loss that is a sentinel of the decks (1: Ei - mean energy, 2: mean energy, functions.py:906-909)
+        // takes the reaction out of the row's list and into a list of its own (bits 28-29: the kind), walked at the
+        // quadrature points only when the model has such reactions -- the glow-discharge deck has none
+        const int kind = wave != 0 ? 0 : (-w > 7e77 && -w < 8e77) ? 1 : (-w > 9e99 && -w < 1e100) ? 2 : 0;
         lds_rw[wave * FEDM_GD_MAX_REACTIONS + lc] = w;
-        lds_rp[wave * FEDM_GD_MAX_REACTIONS + lc] = w == 0.0 ? -1 : pk;
+        lds_rp[wave * FEDM_GD_MAX_REACTIONS + lc] = (w == 0.0 || kind) ? -1 : pk;
+        if (wave == 0) lds_rp[ns * FEDM_GD_MAX_REACTIONS + lc] = kind ? (pk | kind << 28) : -1;
     }
     if (!exp_table) __syncthreads();
     if (exp_table) {
@@ -801,13 +812,41 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
             Gy = Fw.Gy;
             const GdFluxD Fe = species_flux(ie, 1.0, ie, phi, ch, q);
             S += Fe.Gx * Ex + Fe.Gy * Ey;
+            // Sentinel losses: weight m - Ei or -m with m = u_0 / u_e at the point, the expression the scripts pass as
+            // mean_energy (fedm-gd.py:358).  sm_0, sm_e: d(-src)/du_0 and /du_e through m.
+            double sm_0 = 0.0, sm_e = 0.0;
+            if (md->mean_energy_form == FEDM_GD_ME_UNKNOWN_RATIO) {
+                const double inv_ve = 1.0 / value(ie, phi), m = value(0, phi) * inv_ve;
+                double src_m = 0.0;   // d src / d m
+                for (int j = 0; j < nr; ++j) {
+                    const int pk = __builtin_amdgcn_readfirstlane(lds_rp[ns * FEDM_GD_MAX_REACTIONS + j]);
+                    if (pk < 0) continue;
+                    const bool ei = ((pk >> 28) & 3) == 1;
+                    const double w = ei ? m - md->energy_Ei : -m;
+                    const double kv = nodal1(fl, F_K + j, phi), kd = nodal1(fl, F_KD + j, phi);
+                    double prod = 1.0;
+#pragma unroll
+                    for (int i = 0; i < ns; ++i) {
+                        const double x = (i == 0) ? md->N0 : n[i];
+                        for (int e = 0; e < ((pk >> (4 * i)) & 15); ++e) prod *= x;
+                    }
+                    const double rate = (kv + kd * ch.c1) * prod;
+                    S -= w * rate;
+                    src_c1 += w * kd * prod;
+                    src_m += ei ? rate : -rate;
+#pragma unroll
+                    for (int i = 1; i < ns; ++i) src_v[i] += w * (double)((pk >> (4 * i)) & 15) * rate;
+                }
+                sm_0 = -src_m * inv_ve;
+                sm_e = src_m * m * inv_ve;
+            }
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) {
                 const Seeds sd = seeds(bb, phi, ch);
-                addS(bb, 0, W, phi, dT * sd.w_v - src_c1 * sd.k1_0);
+                addS(bb, 0, W, phi, (dT + sm_0) * sd.w_v - src_c1 * sd.k1_0);
 #pragma unroll
                 for (int i = 1; i < ns; ++i) addS(bb, i, W, phi, -src_v[i] * sd.w_v);
-                addS(bb, ie, W, phi, -src_c1 * sd.k1_e);
+                addS(bb, ie, W, phi, sm_e * sd.w_v - src_c1 * sd.k1_e);
                 flux_columns(bb, Fw, 0, sd, W, phi);
                 flux_dot_columns(bb, Fe, ie, sd, Ex, Ey, 1.0, W, phi);
                 addS(bb, IPHI, W, phi, -(Fe.Gx * sd.w_x + Fe.Gy * sd.w_y));   // d(G . E)/dE = G, E = -grad Phi
@@ -1134,7 +1173,7 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         const size_t lds_table = sizeof(double) * (size_t)c.gd.n_qp * c.neq * cpb;
         const int exp_table = lds_h + lds_table <= 80 * 1024 ? 1 : 0;
         if (exp_table) lds_h += lds_table;
-        lds_h += (size_t)(c.neq - 1) * FEDM_GD_MAX_REACTIONS * 12 + 8;   // the rows' reaction weights and powers
+        lds_h += (size_t)(c.neq - 1) * FEDM_GD_MAX_REACTIONS * 12 + FEDM_GD_MAX_REACTIONS * 4 + 8;   // the rows' reaction weights and powers, the sentinel list
         const dim3 gh((unsigned)((n + cpb - 1) / cpb), 1), bh(SLICE * (c.neq - 1));
         const int n_pos = (int)(c.pat.total_bc * SLICE);
         const int row_first = mode == 1 ? c.neq - 1 : 0, row_last = c.neq - 1;
@@ -1208,7 +1247,7 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         const size_t lds_table = sizeof(double) * (size_t)c.gd.n_qp * c.neq * SLICE;
         const int exp_table = lds_h + lds_table <= 80 * 1024 ? 1 : 0;
         if (exp_table) lds_h += lds_table;
-        lds_h += (size_t)(c.neq - 1) * FEDM_GD_MAX_REACTIONS * 12 + 8;
+        lds_h += (size_t)(c.neq - 1) * FEDM_GD_MAX_REACTIONS * 12 + FEDM_GD_MAX_REACTIONS * 4 + 8;
         const dim3 gh((unsigned)((n + SLICE - 1) / SLICE), 1), bh(SLICE * (c.neq - 1));
         const int row_first = mode == 1 ? c.neq - 1 : 0;
 #define FEDM_GD_RES_LAUNCH(NEQ, NRC, NQC)                                                                                \

@@ -129,6 +129,10 @@ class GdModel:
     quadrature_degree: int = 4
     axisymmetric: bool = True
     poisson: bool = True
+    # Energy_Source_term's Ei and mean_energy (fedm/functions.py:855, 906-909) for the sentinel losses 7.77e77 / 9.99e99
+    # left in `energy_loss`: None (no sentinel may be present) or "unknown_ratio" = u[0] / u[n - 1] (fedm-gd.py:358)
+    energy_Ei: float = 0.0
+    mean_energy_form: Optional[str] = None
 
     @property
     def n_eq(self):
@@ -167,6 +171,11 @@ class GdModel:
             for i in range(ns):
                 md.ref[t][i] = float(self.ref[t][i])
         md.we_secondary = float(self.we_secondary)
+        sentinel = any(7e77 < v < 8e77 or 9e99 < v < 1e100 for v in self.energy_loss)
+        if sentinel and self.mean_energy_form is None:
+            raise ValueError("energy losses that depend on the mean energy need mean_energy_form")
+        md.energy_Ei = float(self.energy_Ei)
+        md.mean_energy_form = _lib.GD_ME_FORMS[self.mean_energy_form]
         xq, wq = quadrature.triangle(self.quadrature_degree)
         md.n_qp = len(wq)
         for q in range(len(wq)):

@@ -821,7 +821,7 @@ def Energy_Source_term(coupling, p_matrix, l_matrix, g_matrix, k_coeffs, u_loss,
     last = len(n) - (1 if coupling == "coupled" else 0)
     if _nodal(k_coeffs):
         from . import lmea
-        return lmea.LmeaEnergySource(p_matrix, k_coeffs, u_loss, N0)
+        return lmea.LmeaEnergySource(p_matrix, k_coeffs, u_loss, N0, mean_energy=mean_energy, Ei=Ei)
     rates = _reaction_rates(p_matrix, [N0] + [_exp(n[i]) for i in range(1, last)], k_coeffs)
     total = 0.0
     for rate, loss in zip(rates, u_loss):

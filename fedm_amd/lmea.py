@@ -80,15 +80,17 @@ class LmeaSource:
 class LmeaEnergySource:
     """-sum_j rate_j loss_j (fedm/functions.py:901-912) [+ Joule heating, fedm-gd.py:359]."""
 
-    def __init__(self, p_matrix, k_coeffs, u_loss, N0, joule=None):
+    def __init__(self, p_matrix, k_coeffs, u_loss, N0, joule=None, mean_energy=None, Ei=0):
         self.P, self.k, self.loss, self.N0, self.joule = np.asarray(p_matrix, dtype=int), list(k_coeffs), list(u_loss), float(N0), joule
+        self.mean_energy, self.Ei = mean_energy, Ei      # used by the sentinel losses only (functions.py:906-909)
 
     def __add__(self, o):
         # f_en += -dot(Flux(electrons), E)
         if isinstance(o, Sym) and o.op == "neg" and isinstance(o.args[0], Sym) and o.args[0].op == "flux_dot_field":
             if self.joule is not None:
                 _no("more than one Joule-heating term in the energy source")
-            return LmeaEnergySource(self.P, self.k, self.loss, self.N0, joule=o.args[0])
+            return LmeaEnergySource(self.P, self.k, self.loss, self.N0, joule=o.args[0],
+                                    mean_energy=self.mean_energy, Ei=self.Ei)
         if isinstance(o, (int, float)) and o == 0:
             return self
         _no("the energy source may be extended by  -dot(Flux(electrons), E)  only")
@@ -266,9 +268,29 @@ def compile_lmea(pieces, quadrature_degree):
             _no("source term f[i] must be used in the balance of species i with one set of reaction matrices")
     if abs(src0.N0 - energy.f.N0) > 0 or not np.array_equal(energy.f.P, src0.P):
         _no("particle and energy sources must share N0 and the power matrix")
+    # Energy losses; the decks' sentinel values (fedm/functions.py:906-909): 7.77e77 -> Ei - mean_energy, 9.99e99 ->
+    # mean_energy.  A numeric mean_energy is folded into the loss here; the expression the reference's scripts pass,
+    # u[0] / u[n - 1] (fedm-gd.py:358), is evaluated and differentiated on the device; anything else is refused.
     loss = [float(v) for v in energy.f.loss]
+    energy_Ei, me_form = 0.0, None
     if any(7e77 < v < 8e77 or 9e99 < v < 1e100 for v in loss):
-        _no("energy losses that depend on the mean energy (sentinel values of the decks) are not on the device path")
+        me_arg, Ei = energy.f.mean_energy, energy.f.Ei
+        if isinstance(Ei, forms.Constant):
+            Ei = Ei.value
+        if not isinstance(Ei, (int, float)):
+            _no("Energy_Source_term: Ei must be a number")
+        energy_Ei = float(Ei)
+        if isinstance(me_arg, forms.Constant):
+            me_arg = me_arg.value
+        if isinstance(me_arg, (int, float)):
+            loss = [energy_Ei - float(me_arg) if 7e77 < v < 8e77 else float(me_arg) if 9e99 < v < 1e100 else v
+                    for v in loss]
+        elif (isinstance(me_arg, Sym) and me_arg.op == "div" and all(isinstance(a, forms.Unknown) for a in me_arg.args)
+              and me_arg.args[0].index == 0 and me_arg.args[1].index == ns - 1):
+            me_form = "unknown_ratio"
+        else:
+            _no("Energy_Source_term: with mean-energy-dependent losses, mean_energy must be a number or u[0] / u[n - 1] "
+                "(examples/glow_discharge/fedm-gd.py:358)")
     if me_old is None:
         _no("no coefficient depends on the mean energy: use the LFA family")
     # ---- Poisson source: sum_i sign_i e exp(u_i) / eps0 ------------------------------------------
@@ -363,7 +385,7 @@ def compile_lmea(pieces, quadrature_degree):
     net = (src0.G - src0.L).astype(int)
     model = GdModel(n_species=ns, N0=src0.N0, eq_type=eq_type, grad_diffusion=grad_diff, is_ion=is_ion,
                     sign=sign, vth=vth, electron_mass=electron_mass, power=src0.P.tolist(), net=net.tolist(),
-                    energy_loss=loss, ref=ref, gamma=gamma,
+                    energy_loss=loss, energy_Ei=energy_Ei, mean_energy_form=me_form, ref=ref, gamma=gamma,
                     we_secondary=we_secondary if we_secondary is not None else 0.0,
                     quadrature_degree=int(quadrature_degree),
                     axisymmetric=not isinstance(energy.r, (int, float)))

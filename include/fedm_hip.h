@@ -162,14 +162,24 @@ typedef struct {
     double vth_e_coef;                        /* 16 e / (3 pi m_e): vth_e = sqrt(coef * mean energy) */
     int32_t power[FEDM_GD_MAX_REACTIONS][FEDM_GD_MAX_SPECIES];
     int32_t net[FEDM_GD_MAX_REACTIONS][FEDM_GD_MAX_SPECIES];
-    double energy_loss[FEDM_GD_MAX_REACTIONS];
+    double energy_loss[FEDM_GD_MAX_REACTIONS];   /* the decks' two sentinel values stay what they are: 7.77e77 ->
+                                                  * (energy_Ei - mean energy), 9.99e99 -> mean energy, :906-909      */
     double ref[FEDM_MAX_TAGS][FEDM_GD_MAX_SPECIES];   /* reflection coefficients         */
     double gamma[FEDM_MAX_TAGS];              /* secondary emission coefficient          */
     double we_secondary;                      /* mean energy of secondary electrons [eV] */
     int32_t n_qp, n_fqp;
     double qp_x[FEDM_MAX_QP], qp_y[FEDM_MAX_QP], qp_w[FEDM_MAX_QP];
     double fqp_t[FEDM_MAX_FQP], fqp_w[FEDM_MAX_FQP];
+    /* Energy_Source_term's `Ei` and `mean_energy` arguments (fedm/functions.py:855, 906-909), used by reactions whose
+     * energy_loss is a sentinel only.  mean_energy_form: FEDM_GD_ME_UNKNOWN_RATIO = the expression the reference's
+     * scripts pass, u[0] / u[n - 1] -- the ratio of the energy and the electron UNKNOWNS at the point, as written
+     * (examples/glow_discharge/fedm-gd.py:358) -- differentiated like every other term of the form.  A numeric
+     * mean_energy never reaches the device: the host folds it into energy_loss. */
+    double energy_Ei;
+    int32_t mean_energy_form;
 } fedm_gd_desc;
+#define FEDM_GD_ME_NONE 0
+#define FEDM_GD_ME_UNKNOWN_RATIO 1
 
 /* nodal fields of fedm_gd_set_fields, in this order, each [n_vertices]:
  *   mu[n_species], D[n_species], mu_diff[n_species], D_diff[n_species],
@@ -200,8 +210,9 @@ const char *fedm_last_error(void);
  * read past its end).  2: fedm_model_desc.linear_representation, fedm_newton_opts.watch_component,
  * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields.
  * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles.
- * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]; fedm_comm_stats out[10]; fedm_fieldsplit_policy. */
-#define FEDM_ABI_VERSION 4
+ * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]; fedm_comm_stats out[10]; fedm_fieldsplit_policy.
+ * 5: fedm_gd_desc.energy_Ei, .mean_energy_form (the sentinel energy losses on the device). */
+#define FEDM_ABI_VERSION 5
 int fedm_abi_version(void);
 
 /* mesh + model -> device: colouring, sliced block-ELL pattern, buffers.

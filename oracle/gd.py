@@ -82,6 +82,16 @@ class SG:
         return SG(e, e * self.gx, e * self.gy)
 
 
+def energy_loss_factor(loss, Ei, mean_energy):
+    """fedm/functions.py:905-911: the energy an electron loses in a reaction -- the deck's number, or for its two
+    sentinel values (Ei - mean energy) and the mean energy itself."""
+    if 7e77 < loss < 8e77:
+        return Ei - mean_energy
+    if 9e99 < loss < 1e100:
+        return mean_energy
+    return loss
+
+
 class Deck:
     """The 4_particles deck through the reference's file formats (read with numpy only)."""
 
@@ -101,6 +111,9 @@ class Deck:
         self.k6 = float(tab(rc / "k_ArStarLifetime.dat"))
         self.k_el = tab(rc / "Pelastic.dat")
         self.energy_loss = [11.55, 15.76, -11.55, 4.21, -7.34, 0.0, 1.0]      # reacscheme.cfg Uin
+        # Energy_Source_term's Ei (fedm/functions.py:855) for the sentinel losses 7.77e77 / 9.99e99 (:906-909); the deck
+        # has none -- tests put them in
+        self.energy_Ei = 0.0
         self.power = np.array([[1, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1], [0, 1, 0, 1],
                                [0, 2, 0, 0], [0, 1, 0, 0], [1, 0, 0, 1]])
         loss = np.array([[1, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 1, 0, 0],
@@ -261,7 +274,8 @@ class GlowDischarge:
                         t = t * expN[i]
                 rate.append(t)
             f = [sum(rate[j] * d.net[j, i] for j in range(7)) for i in range(4)]
-            f_en = sum(-rate[j] * d.energy_loss[j] for j in range(7))
+            # fedm/functions.py:905-911 with the mean_energy argument of the scripts, u[0] / u[n - 1] (fedm-gd.py:358)
+            f_en = sum(-rate[j] * energy_loss_factor(d.energy_loss[j], d.energy_Ei, u[0].v / u[3].v) for j in range(7))
             Ge = flux(d.sign[3], u[3], D[3], mu[3], E, True)
             f_en = f_en - (Ge[0] * E[0] + Ge[1] * E[1])                  # Joule heating, :359
             Gam = {1: None, 2: flux(d.sign[2], u[2], D[2], mu[2], E, False), 3: Ge}

@@ -152,6 +152,12 @@ def controller_and_sources():
     fen = ff.Energy_Source_term("coupled", P, L, G, k, loss, 5.0, N0, u)
     out["source_term"] = dict(u=u, k=k.tolist(), N0=N0, f=[float(v) for v in f],
                               f_energy=float(fen), mean_energy=5.0)
+    # ... and with the decks' two sentinel losses (fedm/functions.py:906-909): reaction 1 loses Ei - mean energy,
+    # reaction 6 the mean energy itself
+    loss_s = list(loss)
+    loss_s[1], loss_s[6] = 7.77e77, 9.99e99
+    fen_s = ff.Energy_Source_term("coupled", P, L, G, k, loss_s, 5.0, N0, u, Ei=15.76)
+    out["source_term"].update(energy_loss_sentinels=loss_s, Ei=15.76, f_energy_sentinels=float(fen_s))
     (OUT / "reference_values.json").write_text(json.dumps(out, indent=1, default=str))
 
 

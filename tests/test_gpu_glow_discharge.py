@@ -12,18 +12,27 @@ ROOT = Path(__file__).resolve().parent.parent
 DECK = ROOT / "decks" / "glow_discharge" / "file_input" / "4_particles"
 
 
+SENTINEL_LOSSES = [11.55, 7.77e77, -11.55, 4.21, -7.34, 0.0, 9.99e99]
+
+
+@pytest.mark.parametrize("losses", ["deck", "sentinels"])
 @pytest.mark.parametrize("variant", ["5", "3", "4", "2", "0"])
-def test_gd_residual_and_jacobian_match_the_oracle(variant, monkeypatch):
+def test_gd_residual_and_jacobian_match_the_oracle(variant, losses, monkeypatch):
     """LMEA element Jacobian against the oracle for the device variants (csrc/gd.hip): hand-derived blocks with
     the three column vertices side by side at one wave per SIMD (5), one column vertex per pass (3), both
     through the element buffer in the order of their destinations + gather, the buffer in cell
     order (4, round 2's layout), the same blocks added with atomics (2), and the dual-number kernel (0) that
-    cross-checks the hand derivation."""
+    cross-checks the hand derivation.  "sentinels": the ionisation loses Ei - mean energy and the elastic collisions
+    the mean energy itself, as the decks' sentinel loss values ask (fedm/functions.py:906-909), with the mean-energy
+    argument the scripts pass, u[0] / u[n - 1] -- two more columns in the energy row's derivative."""
     from oracle import gd as ogd
     from fedm_amd.cases import glow_discharge as gdc
     monkeypatch.setenv("FEDM_GD_HAND", variant)
-    case = gdc.Case(nx=10, ny=10, device_pipeline=False)
+    extra = dict(energy_loss=SENTINEL_LOSSES, energy_Ei=15.76) if losses == "sentinels" else {}
+    case = gdc.Case(nx=10, ny=10, device_pipeline=False, **extra)
     o = ogd.GlowDischarge(DECK, 10, 10)
+    if losses == "sentinels":
+        o.deck.energy_loss, o.deck.energy_Ei = list(SENTINEL_LOSSES), 15.76
     nv = o.mesh.nv
     assert np.array_equal(o.mesh.cells, case.mesh.cells)
     rng = np.random.default_rng(0)

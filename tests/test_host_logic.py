@@ -150,6 +150,16 @@ def test_source_terms_match_reference_values(ref):
     fen = ff.Energy_Source_term("coupled", P, L, G, s["k"], g["energy_loss"], s["mean_energy"],
                                 s["N0"], s["u"])
     assert fen == pytest.approx(s["f_energy"], rel=1e-14)
+    # the decks' sentinel losses (fedm/functions.py:906-909): the facade and the oracle's statement against the value
+    # the reference itself returned (tests/golden/make_fixtures.py)
+    fen_s = ff.Energy_Source_term("coupled", P, L, G, s["k"], s["energy_loss_sentinels"], s["mean_energy"],
+                                  s["N0"], s["u"], Ei=s["Ei"])
+    assert fen_s == pytest.approx(s["f_energy_sentinels"], rel=1e-14)
+    from oracle.gd import energy_loss_factor
+    expn = [s["N0"]] + [float(np.exp(v)) for v in s["u"][1:4]]
+    rates = [s["k"][j] * np.prod([expn[i] ** P[j, i] for i in range(4)]) for j in range(7)]
+    mine = sum(-rates[j] * energy_loss_factor(s["energy_loss_sentinels"][j], s["Ei"], s["mean_energy"]) for j in range(7))
+    assert mine == pytest.approx(s["f_energy_sentinels"], rel=1e-13)
 
 
 def test_interpolation_semantics():
@@ -524,9 +534,28 @@ def test_lmea_script_is_lowered_onto_the_device_model(tmp_path, monkeypatch):
     assert len(rows) == model.n_fields == 33
     assert rows[0] is None and all(r is not None for r in rows[1:4])          # gas has no mobility row
     assert rows[-1] is not rows[-2] and rows[-3] is not rows[-2]              # me_old, me, u_old_e
-    # a script that deviates from what the kernels implement is refused, not approximated
+    assert model.mean_energy_form is None and model.to_c().mean_energy_form == 0
     pieces = seen["F"].pieces
     energy = next(p for p in pieces if isinstance(getattr(p, "f", None), lmea.LmeaEnergySource))
+    # the decks' sentinel losses (fedm/functions.py:906-909): with the script's own mean_energy argument, u[0] / u[n - 1]
+    # (fedm-gd.py:358), they go to the device as they are; a numeric mean energy is folded into the losses; any
+    # other expression is refused
+    plain = list(energy.f.loss)
+    energy.f.loss = [11.55, 7.77e77, -11.55, 4.21, -7.34, 0.0, 9.99e99]
+    energy.f.Ei = 15.76
+    m2, _, _ = ff.compile_forms(seen["F"])
+    assert m2.energy_loss == energy.f.loss and m2.mean_energy_form == "unknown_ratio" and m2.energy_Ei == 15.76
+    c2 = m2.to_c()
+    assert c2.mean_energy_form == 1 and c2.energy_Ei == 15.76 and c2.energy_loss[1] == 7.77e77
+    script_arg = energy.f.mean_energy
+    energy.f.mean_energy = 5.0
+    m3, _, _ = ff.compile_forms(seen["F"])
+    assert m3.mean_energy_form is None and m3.energy_loss == [11.55, 15.76 - 5.0, -11.55, 4.21, -7.34, 0.0, 5.0]
+    energy.f.mean_energy = script_arg * 2.0
+    with pytest.raises(NotImplementedError, match="mean_energy must be a number or"):
+        ff.compile_forms(seen["F"])
+    energy.f.mean_energy, energy.f.loss = script_arg, plain
+    # a script that deviates from what the kernels implement is refused, not approximated
     energy.Gamma.mu = energy.Gamma.mu * 2.0
     with pytest.raises(NotImplementedError, match="factor of the electron mobility in the energy flux"):
         ff.compile_forms(seen["F"])
