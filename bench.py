@@ -69,7 +69,8 @@ def library_ready():
                          "(python3 -c 'import __graft_entry__ as g; g.build()')")
     entry.build()
     return entry
-KERNEL_SOURCES = ["kernels.hip", "assemble3.hip", "element.hpp", "element_lean.hpp", "prep.cpp", "fedm_internal.hpp"]
+KERNEL_SOURCES = ["kernels.hip", "assemble3.hip", "element.hpp", "element_lean.hpp", "prep.cpp", "fedm_internal.hpp",
+                  "species_planes.hpp"]
 
 
 def parse_args():

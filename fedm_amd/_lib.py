@@ -183,6 +183,7 @@ _SIGNATURES = {
     "fedm_fieldsplit_tiles_stats": (C.c_int, [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "fedm_debug_fieldsplit_apply": (C.c_int, [_P, _D, _D]),
     "fedm_debug_fieldsplit_tiles": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fedm_debug_species_planes_check": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "fedm_profile": (C.c_int, [_P, C.c_int]),
     "fedm_profile_read": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
     "fedm_set_assembly": (C.c_int, [_P, C.c_int]),

@@ -4,8 +4,11 @@
 // V-cycle is a sequence of coalesced, HBM/L2-bound SpMV kernels with fused epilogues.
 #include "amg.hpp"
 #include "comm.hpp"
+#include "species_planes.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <vector>
 #include <cstdlib>
 
 namespace fedm {
@@ -653,54 +656,6 @@ __global__ void fs_scatter_kernel(int nvp, const double *__restrict__ x0, double
     if (v < nvp) z[(size_t)v * (NS + 1) + NS] = x0[v];
 }
 
-// inverse of the leading NS x NS (species) part of a diagonal block (Gauss-Jordan, partial pivoting)
-template <int NS>
-__device__ __forceinline__ void invert_species_block(double (&A)[NS][NS], double (&I)[NS][NS]) {
-#pragma unroll
-    for (int r = 0; r < NS; ++r)
-#pragma unroll
-        for (int cidx = 0; cidx < NS; ++cidx) I[r][cidx] = (r == cidx) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        int piv = k;
-        double best = fabs(A[k][k]);
-#pragma unroll
-        for (int r = k + 1; r < NS; ++r)
-            if (fabs(A[r][k]) > best) {
-                best = fabs(A[r][k]);
-                piv = r;
-            }
-#pragma unroll
-        for (int r = k + 1; r < NS; ++r)
-            if (piv == r) {
-#pragma unroll
-                for (int cidx = 0; cidx < NS; ++cidx) {
-                    double t = A[k][cidx];
-                    A[k][cidx] = A[r][cidx];
-                    A[r][cidx] = t;
-                    t = I[k][cidx];
-                    I[k][cidx] = I[r][cidx];
-                    I[r][cidx] = t;
-                }
-            }
-        const double inv = 1.0 / A[k][k];
-#pragma unroll
-        for (int cidx = 0; cidx < NS; ++cidx) {
-            A[k][cidx] *= inv;
-            I[k][cidx] *= inv;
-        }
-#pragma unroll
-        for (int r = 0; r < NS; ++r) {
-            if (r == k) continue;
-            const double f = A[r][k];
-#pragma unroll
-            for (int cidx = 0; cidx < NS; ++cidx) {
-                A[r][cidx] -= f * A[k][cidx];
-                I[r][cidx] -= f * I[k][cidx];
-            }
-        }
-    }
-}
 
 // With sweeps, the first stage leaves g = Duu^-1 (alpha t_u) (weight 1) in its own vector, which
 // every sweep reads; the iterate then ping-pongs between z and the scratch vector so that the last
@@ -956,17 +911,7 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
             for (int cidx = 0; cidx < NS; ++cidx)
                 J[r][cidx] = ((zs >> (r * NS + cidx)) & 1u) ? 0.0 : vp[(size_t)(r * NEQ + cidx) * SLICE];
         _Float16 row16[NS * NS];
-#pragma unroll
-        for (int r = 0; r < NS; ++r)
-#pragma unroll
-            for (int cidx = 0; cidx < NS; ++cidx) {
-                double acc = 0.0;   // (a structurally zero plane stays zero: its J entries were set to 0 above)
-#pragma unroll
-                for (int m = 0; m < NS; ++m) acc += d[r][m] * J[m][cidx];
-                // (out-of-range entries saturate: only the preconditioner's quality is at stake)
-                const float f = fminf(fmaxf((float)acc, -65504.f), 65504.f);
-                row16[r * NS + cidx] = ((zs >> (r * NS + cidx)) & 1u) ? (_Float16)0.f : (_Float16)f;
-            }
+        species_plane_entry<NS>(d, J, zs, row16);
         // the planes of an entry side by side, [(bc * 64 + lane) * NS^2 + plane]: one 8-byte word per entry and lane
         // for two species, which the sweeps load as such
         _Float16 *dst = s16 + ((size_t)bc * SLICE + lane) * (NS * NS);
@@ -979,9 +924,72 @@ __global__ __launch_bounds__(256) void species_planes_kernel(int n_slices, const
     }
 }
 
+// The same for listed vertices only: the rows that the boundary facets and the Dirichlet values touch AFTER the
+// volume assembly, when that has formed the planes of all rows itself (assemble3.hip, Ctx::planes_fused).
+template <int NS>
+__global__ void species_planes_rows_kernel(int n_rows, const int *__restrict__ rows, const int *__restrict__ boff,
+                                           const double *__restrict__ val, const uint32_t *__restrict__ diag_slot,
+                                           double *__restrict__ dinv_uu, _Float16 *__restrict__ s16,
+                                           float *__restrict__ val32, int upper, unsigned zs) {
+    constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows) return;
+    const int vtx = rows[t], slice = vtx >> 6, lane = vtx & 63;
+    double d[NS][NS];
+    {
+        const uint32_t ds = diag_slot[vtx];
+        double A[NS][NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx)
+                A[r][cidx] = val[((size_t)(ds >> 6) * NEQ2 + r * NEQ + cidx) * SLICE + (ds & 63)];
+        invert_species_block<NS>(A, d);
+#pragma unroll
+        for (int e = 0; e < NS * NS; ++e)
+            dinv_uu[((size_t)slice * NS * NS + e) * SLICE + lane] = d[e / NS][e % NS];
+    }
+    for (int bc = boff[slice]; bc < boff[slice + 1]; ++bc) {
+        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+        double J[NS][NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx)
+                J[r][cidx] = ((zs >> (r * NS + cidx)) & 1u) ? 0.0 : vp[(size_t)(r * NEQ + cidx) * SLICE];
+        _Float16 row16[NS * NS];
+        species_plane_entry<NS>(d, J, zs, row16);
+        _Float16 *dst = s16 + ((size_t)bc * SLICE + lane) * (NS * NS);
+#pragma unroll
+        for (int e = 0; e < NS * NS; ++e) dst[e] = row16[e];
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx)
+            val32[((size_t)bc * NS + cidx) * SLICE + lane] =
+                (float)vp[(size_t)(upper ? cidx * NEQ + NS : NS * NEQ + cidx) * SLICE];
+    }
+}
+
+// zs of the species planes kernels: the same mask the sweeps are compiled for (fs_finish_t): two species, a zero
+// off-diagonal plane
+unsigned fieldsplit_zero_species_planes(const Ctx &c) {
+    if (c.ns != 2) return 0u;
+    return ((c.zero_plane_mask >> 1) & 1u) << 1 | ((c.zero_plane_mask >> 3) & 1u) << 2;
+}
+
 void fieldsplit_setup(Ctx &c) {
     const dim3 b(256);
     if (c.fs_sweeps > 1 || c.fs_main_sweeps > 1 || c.fs_alt_sweeps > 1) fs_tiles_prepare(c);
+    c.planes_last_fused = c.planes_fused;
+    if (c.planes_fused) {
+        // the volume assembly has written the planes of every row from its accumulators; what is left are the rows
+        // changed behind it
+        c.planes_fused = false;
+        if (c.n_planes_rows > 0)
+            hipLaunchKernelGGL(species_planes_rows_kernel<2>, dim3((c.n_planes_rows + 127) / 128), dim3(128), 0, c.stream,
+                               c.n_planes_rows, c.d_planes_rows, c.d_slice_boff, c.d_val, c.d_diag_slot, c.d_dinv, c.d_s16,
+                               c.d_val32, fieldsplit_upper(c) ? 1 : 0, fieldsplit_zero_species_planes(c));
+        return;
+    }
     const size_t n_entries = (size_t)c.pat.total_bc * SLICE;
     if (!c.d_val32 && (hipMalloc((void **)&c.d_val32, sizeof(float) * n_entries * c.ns) != hipSuccess ||
                        hipMalloc((void **)&c.d_s16, sizeof(_Float16) * n_entries * c.ns * c.ns) != hipSuccess)) {
@@ -991,9 +999,7 @@ void fieldsplit_setup(Ctx &c) {
         return;
     }
     const dim3 gs(c.pat.n_slices);
-    // the same mask the sweeps are compiled for (fs_finish_t): two species, a zero off-diagonal plane
-    unsigned zs = 0u;
-    if (c.ns == 2) zs = ((c.zero_plane_mask >> 1) & 1u) << 1 | ((c.zero_plane_mask >> 3) & 1u) << 2;
+    const unsigned zs = fieldsplit_zero_species_planes(c);
 #define FEDM_PLANES(NS_)                                                                                   \
     hipLaunchKernelGGL(species_planes_kernel<NS_>, gs, b, 0, c.stream, c.pat.n_slices, c.d_slice_boff, c.d_val, \
                        c.d_diag_slot, c.d_dinv, c.d_s16, c.d_val32, fieldsplit_upper(c) ? 1 : 0, zs)
@@ -1005,6 +1011,68 @@ void fieldsplit_setup(Ctx &c) {
         case 5: FEDM_PLANES(5); break;
     }
 #undef FEDM_PLANES
+}
+
+// Test hook (fedm_debug_species_planes_check): the planes as they stand -- formed by the assembly itself plus the
+// listed rows, or by the separate pass -- against that separate pass over the matrix as it stands, run into scratch
+// arrays.  out = {max |d dinv| / max |dinv|, max |d s16|, max |d val32| / max |val32|, was the last set-up the
+// fused one}.
+int fieldsplit_planes_check(Ctx &c, double *out, bool last_fused) {
+    if (!c.d_s16 || !c.d_val32 || !c.d_dinv || c.ns < 1 || c.ns > 5) {
+        set_error("fedm_debug_species_planes_check: no field split set up");
+        return -2;
+    }
+    const size_t n_entries = (size_t)c.pat.total_bc * SLICE, n_s16 = n_entries * c.ns * c.ns, n_v32 = n_entries * c.ns;
+    const size_t n_dinv = (size_t)c.pat.n_slices * c.ns * c.ns * SLICE;
+    double *t_dinv = nullptr;
+    _Float16 *t_s16 = nullptr;
+    float *t_v32 = nullptr;
+    if (hipMalloc((void **)&t_dinv, sizeof(double) * n_dinv) != hipSuccess ||
+        hipMalloc((void **)&t_s16, sizeof(_Float16) * n_s16) != hipSuccess ||
+        hipMalloc((void **)&t_v32, sizeof(float) * n_v32) != hipSuccess) {
+        set_error("fedm_debug_species_planes_check: hipMalloc failed");
+        return -1;
+    }
+    const unsigned zs = fieldsplit_zero_species_planes(c);
+#define FEDM_PLANES(NS_)                                                                                                  \
+    hipLaunchKernelGGL(species_planes_kernel<NS_>, dim3(c.pat.n_slices), dim3(256), 0, c.stream, c.pat.n_slices, c.d_slice_boff, \
+                       c.d_val, c.d_diag_slot, t_dinv, t_s16, t_v32, fieldsplit_upper(c) ? 1 : 0, zs)
+    switch (c.ns) {
+        case 1: FEDM_PLANES(1); break;
+        case 2: FEDM_PLANES(2); break;
+        case 3: FEDM_PLANES(3); break;
+        case 4: FEDM_PLANES(4); break;
+        case 5: FEDM_PLANES(5); break;
+    }
+#undef FEDM_PLANES
+    std::vector<double> a(n_dinv), b(n_dinv);
+    std::vector<_Float16> sa(n_s16), sb(n_s16);
+    std::vector<float> va(n_v32), vb(n_v32);
+    hipStreamSynchronize(c.stream);
+    hipMemcpy(a.data(), c.d_dinv, sizeof(double) * n_dinv, hipMemcpyDeviceToHost);
+    hipMemcpy(b.data(), t_dinv, sizeof(double) * n_dinv, hipMemcpyDeviceToHost);
+    hipMemcpy(sa.data(), c.d_s16, sizeof(_Float16) * n_s16, hipMemcpyDeviceToHost);
+    hipMemcpy(sb.data(), t_s16, sizeof(_Float16) * n_s16, hipMemcpyDeviceToHost);
+    hipMemcpy(va.data(), c.d_val32, sizeof(float) * n_v32, hipMemcpyDeviceToHost);
+    hipMemcpy(vb.data(), t_v32, sizeof(float) * n_v32, hipMemcpyDeviceToHost);
+    hipFree(t_dinv);
+    hipFree(t_s16);
+    hipFree(t_v32);
+    double dd = 0.0, dm = 0.0, ds = 0.0, dv = 0.0, vm = 0.0;
+    for (size_t i = 0; i < n_dinv; ++i) {
+        dd = std::max(dd, std::fabs(a[i] - b[i]));
+        dm = std::max(dm, std::fabs(b[i]));
+    }
+    for (size_t i = 0; i < n_s16; ++i) ds = std::max(ds, (double)std::fabs((float)sa[i] - (float)sb[i]));
+    for (size_t i = 0; i < n_v32; ++i) {
+        dv = std::max(dv, (double)std::fabs(va[i] - vb[i]));
+        vm = std::max(vm, (double)std::fabs(vb[i]));
+    }
+    out[0] = dm > 0.0 ? dd / dm : dd;
+    out[1] = ds;
+    out[2] = vm > 0.0 ? dv / vm : dv;
+    out[3] = last_fused ? 1.0 : 0.0;
+    return 0;
 }
 
 // z = [0, V-cycle(t_phi)] : preconditioner of the Poisson-only CG (species rows are identity

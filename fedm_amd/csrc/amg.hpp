@@ -89,6 +89,8 @@ struct Amg {
 void ell_apply(Ctx &c, const EllMat &A, int mode, const double *x, const double *b, double *y,
                double omega, double *aux = nullptr);
 void fieldsplit_setup(Ctx &c);  // species sub-block inverses into c.d_dinv
+int fieldsplit_planes_check(Ctx &c, double *out, bool last_fused);   // test hook: planes vs the separate pass
+unsigned fieldsplit_zero_species_planes(const Ctx &c);   // the structurally zero species planes, bit r * NS + c
 // z = alpha*Minv t.  scatter = false: Amg::out places the potential; with_cycle = false: stop
 // after the coupling product (the caller runs the V-cycle, whose right-hand side is ready)
 void fieldsplit_apply(Ctx &c, Amg &amg, const double *t, double *z, double alpha, bool scatter = true,

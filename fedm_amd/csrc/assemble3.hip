@@ -29,6 +29,8 @@
 
 #include "element_lean.hpp"
 #include "fedm_internal.hpp"
+#include "amg.hpp"
+#include "species_planes.hpp"
 
 namespace fedm {
 
@@ -96,6 +98,13 @@ struct Lean3Params {
     int acc_doubles, max_verts, xcd;
     const int *patch_list;
     int n_patches;         // (persistent kernels: the grid is smaller than the number of patches)
+    // the field split's planes from the accumulators (s16 = nullptr: not wanted): Ctx::planes_fused
+    _Float16 *s16;
+    float *val32;
+    double *dinv;
+    const uint32_t *diag_slot;
+    int planes_upper;
+    unsigned planes_zs;
 };
 
 __device__ __forceinline__ int lean3_xcd_contiguous(int b, int n) {
@@ -501,6 +510,88 @@ __device__ __forceinline__ void lean3_cell(const Lean3Plan<NS, NR> *__restrict__
     lean3_poisson_row<NS, NR, CMASK, JAC>(md, c, dst, Fl, lds_base);
 }
 
+// The field split's set-up (amg.hip, species_planes_kernel) from the patch's accumulators instead of from the matrix
+// just written: D_uu^-1 of the slice's rows, S = D_uu^-1 J_uu in half precision, the coupling plane in single
+// precision -- 115 MB of the Jacobian not read back behind every assembly.  A thread takes two neighbouring rows of
+// a block column (its stores are 16, 8 and 16 bytes wide); the rows' own diagonal blocks come from the accumulators
+// too.  Rows changed behind this kernel (boundary facets, Dirichlet values) are redone by
+// species_planes_rows_kernel; the padding rows of the last slice are the identity rows they will become.
+template <int NS, uint32_t CMASK, int THREADS>
+__device__ __forceinline__ void lean3_species_planes(const Lean3Params &p, const double *acc, int S, int b0, int width,
+                                                     uint2 diag) {
+    using PL = LivePlanes<NS, CMASK>;
+    constexpr int NEQ = NS + 1, NPL = PL::N, PAIRS = SLICE / 2;
+    static_assert(THREADS % PAIRS == 0, "a thread keeps its pair of rows");
+    const int pair = threadIdx.x % PAIRS;
+    const unsigned zs = p.planes_zs;
+    // a species plane of the block: the accumulator, or 0 where the plane is not formed (kept planes of the species
+    // block are structurally zero ones: launch_assemble_lean3 checks)
+    auto plane = [&](int bc, int r, int cidx, int row) {
+        return PL::live(r, cidx) ? acc[((size_t)bc * NPL + PL::index(r, cidx)) * SLICE + row] : 0.0;
+    };
+    // ... of the thread's two rows in one 16-byte read
+    auto plane2 = [&](int bc, int r, int cidx) {
+        return PL::live(r, cidx) ? reinterpret_cast<const double2 *>(acc + ((size_t)bc * NPL + PL::index(r, cidx)) * SLICE)[pair]
+                                 : make_double2(0.0, 0.0);
+    };
+    double d[2][NS][NS];
+    int dbc[2];
+    bool pad[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 2 * pair + h;
+        pad[h] = S * SLICE + row >= p.nv;
+        dbc[h] = (int)((h == 0 ? diag.x : diag.y) >> 6) - b0;
+        double A[NS][NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx)
+                A[r][cidx] = pad[h] ? (r == cidx ? 1.0 : 0.0) : plane(dbc[h], r, cidx, row);
+        invert_species_block<NS>(A, d[h]);
+    }
+    for (int bc = threadIdx.x / PAIRS; bc < width; bc += THREADS / PAIRS) {
+        _Float16 row16[2][NS * NS];
+        float cpl[NS][2];
+        double2 Jp[NS][NS], Cp[NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx) Jp[r][cidx] = plane2(bc, r, cidx);
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx) Cp[cidx] = p.planes_upper ? plane2(bc, cidx, NS) : plane2(bc, NS, cidx);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double J[NS][NS];
+#pragma unroll
+            for (int r = 0; r < NS; ++r)
+#pragma unroll
+                for (int cidx = 0; cidx < NS; ++cidx)
+                    J[r][cidx] = ((zs >> (r * NS + cidx)) & 1u) ? 0.0
+                                 : pad[h]                          ? ((r == cidx && bc == dbc[h]) ? 1.0 : 0.0)
+                                                                   : (h == 0 ? Jp[r][cidx].x : Jp[r][cidx].y);
+            species_plane_entry<NS>(d[h], J, zs, row16[h]);
+#pragma unroll
+            for (int cidx = 0; cidx < NS; ++cidx) cpl[cidx][h] = pad[h] ? 0.f : (float)(h == 0 ? Cp[cidx].x : Cp[cidx].y);
+        }
+        // [(bc * 64 + row) * NS^2 + plane]: the two rows' entries are neighbours
+        _Float16 *dst = p.s16 + ((size_t)(b0 + bc) * SLICE + 2 * pair) * (NS * NS);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < NS * NS; ++e) dst[h * NS * NS + e] = row16[h][e];
+#pragma unroll
+        for (int cidx = 0; cidx < NS; ++cidx)
+            reinterpret_cast<float2 *>(p.val32 + ((size_t)(b0 + bc) * NS + cidx) * SLICE)[pair] = make_float2(cpl[cidx][0], cpl[cidx][1]);
+        if (bc == 0) {
+#pragma unroll
+            for (int e = 0; e < NS * NS; ++e)
+                reinterpret_cast<double2 *>(p.dinv + ((size_t)S * NS * NS + e) * SLICE)[pair] =
+                    make_double2(d[0][e / NS][e % NS], d[1][e / NS][e % NS]);
+        }
+    }
+}
+
 template <int NS, int NR, int THREADS, uint32_t CMASK, bool JAC>
 __device__ __forceinline__ void assemble_lean3_body(const Lean3Plan<NS, NR> *__restrict__ plan, const Lean3Params &p) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, IPHI = NS;
@@ -533,6 +624,11 @@ __device__ __forceinline__ void assemble_lean3_body(const Lean3Plan<NS, NR> *__r
     // gives its first threads a second one
     PatchCell pc = {};
     if ((int)threadIdx.x < n_cells) pc = p.pcells[c0 + threadIdx.x];
+    // (the planes epilogue's diagonal slots of the thread's two rows: asked for now, used behind the second barrier)
+    uint2 diag = make_uint2(0u, 0u);
+    if constexpr (JAC) {
+        if (p.s16) diag = reinterpret_cast<const uint2 *>(p.diag_slot + (size_t)S * SLICE)[threadIdx.x % (SLICE / 2)];
+    }
     if constexpr (JAC) {
         double2 *acc2 = reinterpret_cast<double2 *>(acc);
         const int n2 = width * NPL * (SLICE / 2);
@@ -593,6 +689,9 @@ __device__ __forceinline__ void assemble_lean3_body(const Lean3Plan<NS, NR> *__r
     }
     double *fdst = p.F + (size_t)S * SLICE * NEQ;
     for (int k = threadIdx.x; k < SLICE * NEQ; k += THREADS) fdst[k] = Fl[k];
+    if constexpr (JAC) {
+        if (p.s16) lean3_species_planes<NS, CMASK, THREADS>(p, acc, S, b0, width, diag);
+    }
     LEAN3_T(5)   // stream-out (issue)
 }
 
@@ -981,6 +1080,12 @@ static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int 
     p.max_verts = verts;
     p.xcd = c.xcd_remap ? 1 : 0;
     p.patch_list = list;
+    p.s16 = nullptr;
+    p.val32 = nullptr;
+    p.dinv = nullptr;
+    p.diag_slot = nullptr;
+    p.planes_upper = 0;
+    p.planes_zs = 0u;
     const size_t lds = lean3_lds_bytes(c.neq, c.ns, width, verts, PL::N, jacobian);
     if (lds > 160 * 1024) return false;
     constexpr int T = 192;
@@ -1037,7 +1142,20 @@ static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             granted = lds;
         }
+        // the field split's planes from the accumulators (Ctx::planes_fused): the whole mesh in this one launch, the
+        // planes' arrays there (from the second assembly on), kept species planes structurally zero
+        const bool fuse = whole && !list && c.planes_fuse_ok && c.d_s16 && c.d_val32 && c.d_dinv && c.amg && c.poisson &&
+                          !c.comm && ((CMASK & ~(1u << 8)) & ~c.zero_plane_mask) == 0u;
+        if (fuse) {
+            p.s16 = c.d_s16;
+            p.val32 = c.d_val32;
+            p.dinv = c.d_dinv;
+            p.diag_slot = c.d_diag_slot;
+            p.planes_upper = fieldsplit_upper(c) ? 1 : 0;
+            p.planes_zs = fieldsplit_zero_species_planes(c);
+        }
         lean3_dispatch(c, whole, assemble_lean3_kernel<NS, NR, T, CMASK>, n, T, lds, plan, p);
+        c.planes_fused = fuse;
     } else {
         lean3_dispatch(c, whole, residual_lean3_kernel<NS, NR, T>, n, T, lds, plan, p);
     }

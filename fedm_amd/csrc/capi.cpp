@@ -1241,6 +1241,27 @@ static int ctx_create_impl(const fedm_mesh_desc *mesh, const fedm_model_desc *mo
             for (int a = 0; a < 3; ++a)
                 for (int sp = 0; sp < c.ns; ++sp)
                     if (is_dirichlet[(size_t)mesh->cells[3 * fcell[f] + a] * c.neq + sp]) c.boundary_rows_disjoint = false;
+        // the rows that change behind the volume assembly (Ctx::planes_fused): vertices of boundary-facet cells, of
+        // Dirichlet values, and the padding of the last slice
+        {
+            std::vector<char> touched((size_t)c.nvp, 0);
+            for (size_t f = 0; f < fcell.size(); ++f)
+                for (int a = 0; a < 3; ++a) touched[mesh->cells[3 * fcell[f] + a]] = 1;
+            for (int k = 0; k < mesh->n_dirichlet; ++k)
+                if (mesh->dirichlet_dofs[k] >= 0 && (int64_t)mesh->dirichlet_dofs[k] < (int64_t)c.nv * c.neq)
+                    touched[mesh->dirichlet_dofs[k] / c.neq] = 1;
+            for (int v = c.nv; v < c.nvp; ++v) touched[v] = 1;
+            std::vector<int> rows;
+            for (int v = 0; v < c.nvp; ++v)
+                if (touched[v]) rows.push_back(v);
+            c.n_planes_rows = (int)rows.size();
+            if (c.n_planes_rows && upload(c.d_planes_rows, rows.data(), rows.size())) return -1;
+            const char *e = getenv("FEDM_PLANES_FUSED");
+            // one GPU, whole-mesh launches: no identity rows of ghost layers, no listed part launches
+            // (opt-in, FEDM_PLANES_FUSED=1: measured -9 us per assembly back to back, nothing in the bench's step, and the
+            // dominant kernel 75 -> 89 us: DESIGN.md Appendix A)
+            c.planes_fuse_ok = (e && e[0] == '1') && mesh->n_identity_vertices == 0 && c.n_owned == c.nv;
+        }
     }
     if (upload(c.d_cell_slots, c.pat.cell_slots.data(), c.pat.cell_slots.size())) return -1;
     if (upload(c.d_colour_cells, c.pat.colour_cells.data(), c.pat.colour_cells.size())) return -1;
@@ -1364,6 +1385,7 @@ void fedm_ctx_destroy(fedm_ctx *h) {
     if (c.h_mail) hipHostFree(c.h_mail);
     if (c.d_val32) hipFree(c.d_val32);
     if (c.d_s16) hipFree(c.d_s16);
+    if (c.d_planes_rows) hipFree(c.d_planes_rows);
     if (c.d_Z) hipFree(c.d_Z);
     if (c.h_stage) hipHostFree(c.h_stage);
     if (c.d_snapshot) hipFree(c.d_snapshot);
@@ -1860,6 +1882,16 @@ int fedm_field_error(fedm_ctx *h, int component, double *rel_err) {
         return -1;
     }
     return 0;
+}
+
+int fedm_debug_species_planes_check(fedm_ctx *h, double *out) {
+    Ctx &c = h->c;
+    FEDM_HIP_CHECK(hipSetDevice(c.device));
+    if (!out) {
+        set_error("fedm_debug_species_planes_check: null argument");
+        return -2;
+    }
+    return fieldsplit_planes_check(c, out, c.planes_last_fused);
 }
 
 int fedm_time_kernel(fedm_ctx *h, int kind, int repeats, double *ms_per_launch) {

@@ -153,6 +153,13 @@ struct Ctx {
                                 // columns J_phi,u (lower-triangular order) or the species rows' potential
                                 // column J_u,phi (upper-triangular order, fs_upper)
     _Float16 *d_s16 = nullptr;  // Duu^-1 J_uu in fp16: [(bc*64 + lane)*NS*NS + r*NS + c]
+    // The one-pass assembly (assemble3.hip) forms these planes from its LDS accumulators while it streams the
+    // Jacobian out; planes_fused says the last Jacobian assembly did, and fieldsplit_setup then only redoes the rows
+    // that were changed behind the volume kernel: the vertices of boundary-facet cells, of Dirichlet values and
+    // the padding (d_planes_rows, listed once).  Opt-in (FEDM_PLANES_FUSED=1); default: the separate pass over the matrix.
+    bool planes_fused = false, planes_fuse_ok = false, planes_last_fused = false;
+    int *d_planes_rows = nullptr;
+    int n_planes_rows = 0;
     // Dirichlet
     int n_dir = 0;
     int *d_dir_dofs = nullptr;

@@ -638,6 +638,7 @@ void launch_assemble(Ctx &c, bool jacobian, int mode) {
         prof_end(c);
         return;
     }
+    if (jacobian) c.planes_fused = false;   // (set by the one-pass kernel when it forms the field split's planes itself)
     prof_begin(c, jacobian ? 0 : 2);  // the volume kernel only (all colours in variant 0)
     if (c.ns == 1 && !c.poisson) assemble_dispatch<1, false>(c, jacobian, mode);
     else if (c.ns == 1 && c.poisson) assemble_dispatch<1, true>(c, jacobian, mode);

@@ -901,6 +901,14 @@ class DeviceProblem:
         self._check(self.lib.fedm_set_fieldsplit_order(self._h, code), "fedm_set_fieldsplit_order")
 
     # -- measurement ----------------------------------------------------------
+    def species_planes_check(self):
+        """Test hook: the field split's planes as they stand against the separate pass over the Jacobian as it stands:
+        (relative difference of Duu^-1, absolute of the half-precision species planes, relative of the coupling plane,
+        whether the last set-up was the one fused into the assembly)."""
+        out = (C.c_double * 4)()
+        self._check(self.lib.fedm_debug_species_planes_check(self._h, out), "fedm_debug_species_planes_check")
+        return float(out[0]), float(out[1]), float(out[2]), bool(out[3])
+
     def time_kernel(self, kind, repeats=20):
         ms = C.c_double()
         self._check(self.lib.fedm_time_kernel(self._h, int(kind), int(repeats), C.byref(ms)),

@@ -211,7 +211,8 @@ const char *fedm_last_error(void);
  * fedm_pattern_stats out[12], fedm_debug_comm_fault out[6], fedm_pattern_info, fedm_mesh_desc's deep-halo fields.
  * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles.
  * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]; fedm_comm_stats out[10]; fedm_fieldsplit_policy.
- * 5: fedm_gd_desc.energy_Ei, .mean_energy_form (the sentinel energy losses on the device). */
+ * 5: fedm_gd_desc.energy_Ei, .mean_energy_form (the sentinel energy losses on the device); fedm_debug_species_planes_check;
+ *    fedm_time_kernel kinds 4, 5. */
 #define FEDM_ABI_VERSION 5
 int fedm_abi_version(void);
 
@@ -435,13 +436,19 @@ int fedm_debug_fieldsplit_apply(fedm_ctx *ctx, const double *t, double *z);
  * per tile, `depth` vertex layers and `threads` threads per tile (0: defaults, FEDM_FS_TILE_SLICES /
  * FEDM_FS_TILE_DEPTH / FEDM_FS_TILE_THREADS). */
 int fedm_debug_fieldsplit_tiles(fedm_ctx *ctx, int mode, int tile_slices, int depth, int threads);
+/* Test hook: the field split's species planes as they stand (formed by the one-pass assembly itself plus the rows
+ * changed behind it, or by the separate pass) against the separate pass over the Jacobian as it stands.
+ * out[4] = {max |d Duu^-1| / max |Duu^-1|, max |d S16|, max |d coupling| / max |coupling|, 1 if the last set-up was
+ * the fused one}. */
+int fedm_debug_species_planes_check(fedm_ctx *ctx, double *out);
 
 /* |new - old + eps| / |old + eps| on one component        fedm/functions.py:1062-1064 */
 int fedm_field_error(fedm_ctx *ctx, int component, double *rel_err);
 
 /* timed micro-benchmarks on the resident state (HIP events on the library's stream):
  * kind 0 = residual+Jacobian assembly, 1 = SpMV, 2 = residual only, 3 = one multigrid cycle on the
- * potential block.  ms per launch. */
+ * potential block, 4 = the field split's set-up behind an assembly (species planes), 5 = assembly + that set-up.
+ * ms per launch. */
 int fedm_time_kernel(fedm_ctx *ctx, int kind, int repeats, double *ms_per_launch);
 /* Copy rate of the device (GB/s, read + write bytes): a 16-byte-per-lane grid-stride copy between two
  * buffers of `bytes` each -- the practical HBM ceiling bench.py prints next to the specification. */

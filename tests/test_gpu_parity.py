@@ -821,3 +821,32 @@ def test_measured_choice_of_the_hard_regime_set_is_the_same_solve(monkeypatch):
     assert np.allclose(logm, logc, rtol=1e-4)
     assert np.allclose(Um, Uc, rtol=1e-5, atol=1e-5)
     assert 0.5 * lc <= lm <= 2.0 * lc
+
+
+def test_species_planes_formed_by_the_assembly_equal_the_separate_pass(monkeypatch):
+    """With FEDM_PLANES_FUSED=1 (opt-in: it did not pay in the step) the one-pass kernel forms the
+    field split's planes (Duu^-1, the half-precision species planes, the single-precision coupling plane) from its
+    LDS accumulators while it streams the Jacobian out, from the second Jacobian assembly of a run on, and `species_planes_rows_kernel` redoes the rows changed behind it (boundary facets,
+    Dirichlet values, padding): together they must leave what the separate pass over the finished matrix leaves.
+    Also: the run itself is the one FEDM_PLANES_FUSED=0 gives."""
+    from fedm_amd.cases import streamer
+    logs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("FEDM_PLANES_FUSED", fused)
+        for msh in (streamer.mesh(48, 4.0), streamer.refined_mesh(40e-6)):
+            st = streamer.Stepper(streamer.device_problem(msh.coords, msh.cells))
+            st.initialise()
+            used = []
+            for _ in range(3):
+                st.step()
+                d_inv, d_s16, d_cpl, was_fused = st.prob.species_planes_check()
+                used.append(was_fused)
+                assert d_inv <= 1e-14 and d_cpl == 0.0, (fused, d_inv, d_cpl)
+                assert d_s16 <= 2e-3, (fused, d_s16)       # (entries of Duu^-1 J_uu are O(1): half an ulp of fp16)
+            assert all(used) == (fused == "1") and any(used) == (fused == "1")
+            logs.setdefault(msh.coords.shape[0], {})[fused] = (st.newton_iterations, st.linear_iterations,
+                                                               st.prob.get_state())
+            st.prob.close()
+    for nv, by in logs.items():
+        assert by["1"][:2] == by["0"][:2], (nv, by["1"][:2], by["0"][:2])
+        assert np.abs(by["1"][2] - by["0"][2]).max() <= 1e-9 * np.abs(by["0"][2]).max()
