@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -159,15 +160,65 @@ struct Lean3Atoms {
     double P[L3_ATOMS], Q[L3_ATOMS], E, invE;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// The STRUCTURE of a model at compile time.  The reference hands every form to FFC, which generates code for exactly
+// that form; the kernels above this line take the structure from the plan at run time instead -- which equation a
+// species has, which reactions enter a row with which powers, how many terms a coefficient function has and which
+// atoms each multiplies -- as wave-uniform scalar loads, waits and ~120 scalar branches per cell.  A signature type
+// states the structure as constexpr functions; a kernel instantiated for it keeps only the NUMBERS (coefficients,
+// exponents, charges) at run time: F + J 71 -> 61 us, residual only 30 -> 24 us on the refined bench mesh (back to
+// back).  Lean3SigRuntime: any model the plan can hold.  A context takes a precompiled signature when its plan's
+// structure equals it (lean3_sig_matches); FEDM_LEAN3_SIG=0 keeps the run-time structure;
+// FEDM_LEAN3_PRINT_SIG=1 prints a plan's structure in the form of the table below.
+// Slots: [0, NR) rate coefficients, NR + s diffusion of species s, NR + NS + s mobility of species s.
+// ---------------------------------------------------------------------------------------------------------------
+struct Lean3SigRuntime {
+    static constexpr bool fixed = false;
+    static constexpr int eq_type(int) { return 0; }
+    static constexpr int has_drift_w(int) { return 0; }
+    static constexpr int nreac() { return 0; }
+    static constexpr int net(int, int) { return 0; }
+    static constexpr int power(int, int) { return 0; }
+    static constexpr int nP() { return 0; }
+    static constexpr int nQ() { return 0; }
+    static constexpr int slot_n(int) { return 0; }
+    static constexpr int slot_code(int, int) { return 0; }
+};
+// tests/integrated_tests/streamer_discharge/file_input/benchmark_model (BASELINE configs[1], [3], [4]): ions with a
+// source only, electrons drift-diffusion-reaction, one reaction e -> e + e + ion with k = alpha(E) mu_e(E) E,
+//   mu_e = c E^-0.26, D_e = c E^0.22, alpha = (c1 + c2 E^-3) exp(q / E) + c3:  atoms E^0.22, E^0.74, exp(q / E)
+struct Lean3SigBenchmark {
+    static constexpr bool fixed = true;
+    static constexpr int NS = 2, NR = 1;
+    static constexpr int eq_type(int s) { return s == 0 ? FEDM_EQ_REACTION : FEDM_EQ_DRIFT_DIFFUSION_REACTION; }
+    static constexpr int has_drift_w(int) { return 0; }
+    static constexpr int nreac() { return 1; }
+    static constexpr int net(int, int) { return 1; }
+    static constexpr int power(int, int i) { return i == 1 ? 1 : 0; }
+    static constexpr int nP() { return 2; }
+    static constexpr int nQ() { return 1; }
+    static constexpr int slot_n(int slot) { return slot == 0 ? 3 : (slot == 2 || slot == 4) ? 1 : 0; }
+    // code = power atom | exp atom << 2 | (m + 8) << 4 of  c E^m P Q  (terms in ascending code)
+    static constexpr int slot_code(int slot, int t) {
+        return slot == 0   ? (t == 0 ? (2 | 1 << 2 | 5 << 4) : t == 1 ? (2 | 8 << 4) : (2 | 1 << 2 | 8 << 4))
+               : slot == 2 ? (1 | 8 << 4)      // D_e = c E^0.22
+               : slot == 4 ? (2 | 7 << 4)      // mu_e = c E^-1 E^0.74
+                           : 0;
+    }
+};
+
+
 // value and d/dE of one coefficient function (all tests are on scalar registers: wave-uniform)
+template <class SIG, int SLOT>
 __device__ __forceinline__ void lean3_coef(const Lean3Slot *__restrict__ slot, const Lean3Atoms &at, double &val, double &der) {
     const Lean3Slot sl = *slot;    // the whole record at once: two wide scalar loads and ONE wait, not one per term and property
     val = 0.0;
     der = 0.0;
 #pragma unroll
     for (int t = 0; t < L3_TERMS; ++t) {
-        if (t >= sl.n) break;
-        const int code = sl.code[t], iP = code & 3, iQ = (code >> 2) & 3, m = ((code >> 4) & 31) - 8;
+        if (t >= (SIG::fixed ? SIG::slot_n(SLOT) : sl.n)) break;
+        const int code = SIG::fixed ? SIG::slot_code(SLOT, t) : sl.code[t];
+        const int iP = code & 3, iQ = (code >> 2) & 3, m = ((code >> 4) & 31) - 8;
         double x = sl.c[t];
         if (iP) x *= (iP == 1 ? at.P[0] : at.P[1]);
         if (iQ) x *= (iQ == 1 ? at.Q[0] : at.Q[1]);
@@ -193,7 +244,7 @@ struct Lean3Cell {
 };
 
 // Species row S (fedm/functions.py:350-368 with Flux :219-237 and the source of :777-843).
-template <int NS, int NR, uint32_t CMASK, bool JAC, int S>
+template <int NS, int NR, uint32_t CMASK, bool JAC, int S, class SIG>
 __device__ __forceinline__ void lean3_species_row(const Lean3Plan<NS, NR> *__restrict__ md, const Lean3Cell<NS, NR> &c,
                                                   const double *__restrict__ Ul, const double *__restrict__ Hl,
                                                   const StepCoef sc, const uint32_t (&dst)[9], double *__restrict__ Fl,
@@ -206,7 +257,7 @@ __device__ __forceinline__ void lean3_species_row(const Lean3Plan<NS, NR> *__res
         Us[a] = Ul[c.lv[a] * NEQ + S];
         Hs[a] = Hl[c.lv[a] * NS + S];
     }
-    const int eq = md->eq_type[S];
+    const int eq = SIG::fixed ? SIG::eq_type(S) : md->eq_type[S];
     const bool flux = eq != FEDM_EQ_REACTION;
     double Dv = 0.0, Dd = 0.0, muv = 0.0, mud = 0.0, vel[2] = {0.0, 0.0}, gradu[2] = {0.0, 0.0};
     bool fdrift = false;
@@ -217,15 +268,15 @@ __device__ __forceinline__ void lean3_species_row(const Lean3Plan<NS, NR> *__res
             gradu[0] += Us[a] * c.G[a][0];
             gradu[1] += Us[a] * c.G[a][1];
         }
-        lean3_coef(&md->D[S], c.at, Dv, Dd);
+        lean3_coef<SIG, NR + S>(&md->D[S], c.at, Dv, Dd);
         vel[0] = -Dv * gradu[0];
         vel[1] = -Dv * gradu[1];
         if (eq == FEDM_EQ_DRIFT_DIFFUSION_REACTION) {
-            if (md->has_drift_w[S]) {
+            if (SIG::fixed ? SIG::has_drift_w(S) : md->has_drift_w[S]) {
                 vel[0] += md->drift_w[S][0];
                 vel[1] += md->drift_w[S][1];
             } else {
-                lean3_coef(&md->mu[S], c.at, muv, mud);
+                lean3_coef<SIG, NR + NS + S>(&md->mu[S], c.at, muv, mud);
                 vel[0] += Z * muv * c.E[0];
                 vel[1] += Z * muv * c.E[1];
                 fdrift = true;
@@ -234,7 +285,7 @@ __device__ __forceinline__ void lean3_species_row(const Lean3Plan<NS, NR> *__res
     }
     // weighted point values: H (residual integrand), N (density), SP (d source / d|E|), Xg[i] (d integrand / d u_i)
     const double usum6 = (Us[0] + Us[1] + Us[2]) * (1.0 / 6.0), hsum6 = (Hs[0] + Hs[1] + Hs[2]) * (1.0 / 6.0);
-    const int nreac = md->nreac;
+    const int nreac = SIG::fixed ? SIG::nreac() : md->nreac;
     double XH[3], XN[3], XS[3], XG[NS][3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -246,7 +297,7 @@ __device__ __forceinline__ void lean3_species_row(const Lean3Plan<NS, NR> *__res
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             if (j >= nreac) break;
-            const double nu = (double)md->net[j][S];
+            const double nu = (double)(SIG::fixed ? SIG::net(j, S) : md->net[j][S]);
             if (nu == 0.0) continue;
             const double prod = c.rq[j][q];
             const double nk = nu * c.kv[j] * prod;
@@ -255,7 +306,7 @@ __device__ __forceinline__ void lean3_species_row(const Lean3Plan<NS, NR> *__res
             if constexpr (JAC) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    const int Pw = md->power[j][i];
+                    const int Pw = SIG::fixed ? SIG::power(j, i) : md->power[j][i];
                     if (Pw) g[i] -= nk * (double)Pw;
                 }
             }
@@ -370,15 +421,15 @@ __device__ __forceinline__ void lean3_poisson_row(const Lean3Plan<NS, NR> *__res
     }
 }
 
-template <int NS, int NR, uint32_t CMASK, bool JAC, int S>
+template <int NS, int NR, uint32_t CMASK, bool JAC, int S, class SIG>
 __device__ __forceinline__ void lean3_species_rows(const Lean3Plan<NS, NR> *__restrict__ md, const Lean3Cell<NS, NR> &c,
                                                    const double *__restrict__ Ul, const double *__restrict__ Hl,
                                                    const StepCoef sc, const uint32_t (&dst)[9], double *__restrict__ Fl,
                                                    char *__restrict__ lds_base) {
     if constexpr (S < NS) {
-        lean3_species_row<NS, NR, CMASK, JAC, S>(md, c, Ul, Hl, sc, dst, Fl, lds_base);
+        lean3_species_row<NS, NR, CMASK, JAC, S, SIG>(md, c, Ul, Hl, sc, dst, Fl, lds_base);
         __builtin_amdgcn_sched_barrier(0);   // the rows one after the other: nothing of row S + 1 lives beside row S
-        lean3_species_rows<NS, NR, CMASK, JAC, S + 1>(md, c, Ul, Hl, sc, dst, Fl, lds_base);
+        lean3_species_rows<NS, NR, CMASK, JAC, S + 1, SIG>(md, c, Ul, Hl, sc, dst, Fl, lds_base);
     }
 }
 
@@ -397,7 +448,7 @@ __device__ __forceinline__ CellIdx cell_idx(const PatchCell &pc) {
 }
 
 // One cell: everything its rows share, then the rows one after the other (straight-line code).
-template <int NS, int NR, uint32_t CMASK, bool JAC>
+template <int NS, int NR, uint32_t CMASK, bool JAC, class SIG>
 __device__ __forceinline__ void lean3_cell(const Lean3Plan<NS, NR> *__restrict__ md, const CellIdx ci,
                                            const double *__restrict__ vx, const double *__restrict__ Ul,
                                            const double *__restrict__ Hl, const double *__restrict__ Al,
@@ -444,8 +495,8 @@ __device__ __forceinline__ void lean3_cell(const Lean3Plan<NS, NR> *__restrict__
         c.at.invE = c.invEm;
 #pragma unroll
         for (int i = 0; i < L3_ATOMS; ++i) {
-            c.at.P[i] = i < md->nP ? exp(md->pf[i] * c.lnE) : 1.0;
-            c.at.Q[i] = i < md->nQ ? exp(md->qv[i] * c.invEm) : 1.0;
+            c.at.P[i] = i < (SIG::fixed ? SIG::nP() : md->nP) ? exp(md->pf[i] * c.lnE) : 1.0;
+            c.at.Q[i] = i < (SIG::fixed ? SIG::nQ() : md->nQ) ? exp(md->qv[i] * c.invEm) : 1.0;
         }
     }
 #pragma unroll
@@ -466,16 +517,17 @@ __device__ __forceinline__ void lean3_cell(const Lean3Plan<NS, NR> *__restrict__
         c.nq[i][2] = P * (a2 * a2 * a2);
     }
     {
-        const int nreac = md->nreac;
+        static_assert(NR == 1 || !SIG::fixed, "a signature's rate-coefficient slot is written for one reaction");
+        const int nreac = SIG::fixed ? SIG::nreac() : md->nreac;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             c.kv[j] = c.kd[j] = 0.0;
             c.rq[j][0] = c.rq[j][1] = c.rq[j][2] = 1.0;
             if (j < nreac) {
-                lean3_coef(&md->k[j], c.at, c.kv[j], c.kd[j]);
+                lean3_coef<SIG, 0>(&md->k[j], c.at, c.kv[j], c.kd[j]);   // (slot j; NR = 1 where this is instantiated)
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    const int Pw = md->power[j][i];
+                    const int Pw = SIG::fixed ? SIG::power(j, i) : md->power[j][i];
                     for (int e = 0; e < Pw; ++e) {
 #pragma unroll
                         for (int q = 0; q < 3; ++q) c.rq[j][q] *= c.nq[i][q];
@@ -506,7 +558,7 @@ __device__ __forceinline__ void lean3_cell(const Lean3Plan<NS, NR> *__restrict__
         unsafeAtomicAdd(&Fl[c.lv[0] & 63], sum);
         return;
     }
-    lean3_species_rows<NS, NR, CMASK, JAC, 0>(md, c, Ul, Hl, sc, dst, Fl, lds_base);
+    lean3_species_rows<NS, NR, CMASK, JAC, 0, SIG>(md, c, Ul, Hl, sc, dst, Fl, lds_base);
     lean3_poisson_row<NS, NR, CMASK, JAC>(md, c, dst, Fl, lds_base);
 }
 
@@ -592,7 +644,7 @@ __device__ __forceinline__ void lean3_species_planes(const Lean3Params &p, const
     }
 }
 
-template <int NS, int NR, int THREADS, uint32_t CMASK, bool JAC>
+template <int NS, int NR, int THREADS, uint32_t CMASK, bool JAC, class SIG>
 __device__ __forceinline__ void assemble_lean3_body(const Lean3Plan<NS, NR> *__restrict__ plan, const Lean3Params &p) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ, IPHI = NS;
     using PL = LivePlanes<NS, CMASK>;
@@ -657,7 +709,7 @@ __device__ __forceinline__ void assemble_lean3_body(const Lean3Plan<NS, NR> *__r
     LEAN3_T(1)   // staging: halo id, vertex data, exponentials, LDS writes
     __syncthreads();
     LEAN3_T(2)   // barrier 1
-    auto one_cell = [&](const PatchCell &pcx) { lean3_cell<NS, NR, CMASK, JAC>(plan, cell_idx(pcx), vx, Ul, Hl, Al, p.sc, acc, Fl); };
+    auto one_cell = [&](const PatchCell &pcx) { lean3_cell<NS, NR, CMASK, JAC, SIG>(plan, cell_idx(pcx), vx, Ul, Hl, Al, p.sc, acc, Fl); };
     // Straight-line code for the thread's cell; a second copy of it (never fetched by the other workgroups) for
     // the patches with more cells than threads.  As a loop the invariants the compiler hoists out of it cost 35
     // spilled registers.
@@ -820,10 +872,10 @@ __device__ __forceinline__ void assemble_lean3p_body(const Lean3Plan<NS, NR> *__
         const int gidn = has_next ? load_gid(t, hn) : p.nv;
         const bool has_next2 = idx + 2 * stride < end;
         const PatchHdr hn2 = has_next2 ? load_hdr(idx + 2 * stride) : hn;
-        if (!(FEDM_LEAN3_PROBE & 4) && tid < h.nc) lean3_cell<NS, NR, CMASK, JAC>(md, ci, vx, Ul, Hl, Al, p.sc, acc, Fl);
+        if (!(FEDM_LEAN3_PROBE & 4) && tid < h.nc) lean3_cell<NS, NR, CMASK, JAC, Lean3SigRuntime>(md, ci, vx, Ul, Hl, Al, p.sc, acc, Fl);
         if (tid + THREADS < h.nc) {     // (n_cells <= 2 THREADS: lean3_applies)
             const CellIdx ci2 = cell_idx(p.pcells[h.c0 + tid + THREADS]);
-            lean3_cell<NS, NR, CMASK, JAC>(md, ci2, vx, Ul, Hl, Al, p.sc, acc, Fl);
+            lean3_cell<NS, NR, CMASK, JAC, Lean3SigRuntime>(md, ci2, vx, Ul, Hl, Al, p.sc, acc, Fl);
         }
         __syncthreads();
         asm volatile("" : "+v"(t));
@@ -886,19 +938,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #ifndef FEDM_LEAN3_WAVES
 #define FEDM_LEAN3_WAVES 3
 #endif
-template <int NS, int NR, int THREADS, uint32_t CMASK>
+template <int NS, int NR, int THREADS, uint32_t CMASK, class SIG>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_LEAN3_WAVES, FEDM_LEAN3_WAVES))) void assemble_lean3_kernel(
     const Lean3Plan<NS, NR> *__restrict__ plan, const Lean3Params p) {
-    assemble_lean3_body<NS, NR, THREADS, CMASK, true>(plan, p);
+    assemble_lean3_body<NS, NR, THREADS, CMASK, true, SIG>(plan, p);
 }
 
 #ifndef FEDM_RES3_WAVES
 #define FEDM_RES3_WAVES 4
 #endif
-template <int NS, int NR, int THREADS>
+template <int NS, int NR, int THREADS, class SIG>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FEDM_RES3_WAVES, FEDM_RES3_WAVES))) void residual_lean3_kernel(
     const Lean3Plan<NS, NR> *__restrict__ plan, const Lean3Params p) {
-    assemble_lean3_body<NS, NR, THREADS, 0u, false>(plan, p);
+    assemble_lean3_body<NS, NR, THREADS, 0u, false, SIG>(plan, p);
 }
 
 // fedm_model_desc -> Lean3Plan.  false: the model's coefficient functions do not fit the plan's form.
@@ -949,15 +1001,86 @@ static bool lean3_build_plan(const fedm_model_desc &m, Lean3Plan<NS, NR> &pl) {
         }
         return true;
     };
-    for (int j = 0; j < m.n_reactions; ++j)
-        if (!slot(m.k[j], pl.k[j])) return false;
+    auto all_slots = [&]() {
+        for (int j = 0; j < m.n_reactions; ++j)
+            if (!slot(m.k[j], pl.k[j])) return false;
+        for (int s = 0; s < NS; ++s) {
+            // (only what the rows evaluate: no flux, no coefficient)
+            if (m.eq_type[s] == FEDM_EQ_REACTION) continue;
+            if (!slot(m.D[s], pl.D[s])) return false;
+            if (m.eq_type[s] == FEDM_EQ_DRIFT_DIFFUSION_REACTION && !m.has_drift_w[s] && !slot(m.mu[s], pl.mu[s])) return false;
+        }
+        return true;
+    };
+    if (!all_slots()) return false;
+    // Canonical form, so that the STRUCTURE of a plan (what a signature states) does not depend on the order in which
+    // a deck or a script happens to list terms: the atoms in ascending order, then every slot's terms by code.
+    std::sort(pl.pf, pl.pf + pl.nP);
+    std::sort(pl.qv, pl.qv + pl.nQ);
+    if (!all_slots()) return false;      // (every atom is in the lists now: the codes take their sorted positions)
+    auto sort_slot = [](Lean3Slot &sl) {
+        for (int a = 0; a < sl.n; ++a)
+            for (int b = a + 1; b < sl.n; ++b)
+                if (sl.code[b] < sl.code[a]) {
+                    std::swap(sl.code[a], sl.code[b]);
+                    std::swap(sl.c[a], sl.c[b]);
+                    std::swap(sl.p[a], sl.p[b]);
+                    std::swap(sl.q[a], sl.q[b]);
+                }
+    };
+    for (int j = 0; j < NR; ++j) sort_slot(pl.k[j]);
     for (int s = 0; s < NS; ++s) {
-        // (only what the rows evaluate: no flux, no coefficient)
-        if (m.eq_type[s] == FEDM_EQ_REACTION) continue;
-        if (!slot(m.D[s], pl.D[s])) return false;
-        if (m.eq_type[s] == FEDM_EQ_DRIFT_DIFFUSION_REACTION && !m.has_drift_w[s] && !slot(m.mu[s], pl.mu[s])) return false;
+        sort_slot(pl.D[s]);
+        sort_slot(pl.mu[s]);
     }
     return true;
+}
+
+// the slots in a signature's numbering
+template <int NS, int NR>
+static const Lean3Slot &lean3_slot(const Lean3Plan<NS, NR> &pl, int slot) {
+    return slot < NR ? pl.k[slot] : slot < NR + NS ? pl.D[slot - NR] : pl.mu[slot - NR - NS];
+}
+
+// Does the plan have exactly the structure the signature states?
+template <class SIG, int NS, int NR>
+static bool lean3_sig_matches(const Lean3Plan<NS, NR> &pl) {
+    if (!SIG::fixed) return true;
+    if (SIG::NS != NS || SIG::NR != NR) return false;
+    if (pl.nreac != SIG::nreac() || pl.nP != SIG::nP() || pl.nQ != SIG::nQ()) return false;
+    for (int s = 0; s < NS; ++s)
+        if (pl.eq_type[s] != SIG::eq_type(s) || (pl.has_drift_w[s] != 0) != (SIG::has_drift_w(s) != 0)) return false;
+    for (int j = 0; j < pl.nreac; ++j)
+        for (int s = 0; s < NS; ++s)
+            if (pl.power[j][s] != SIG::power(j, s) || pl.net[j][s] != SIG::net(j, s)) return false;
+    for (int k = 0; k < NR + 2 * NS; ++k) {
+        const Lean3Slot &sl = lean3_slot(pl, k);
+        if (sl.n != SIG::slot_n(k)) return false;
+        for (int t = 0; t < sl.n; ++t)
+            if (sl.code[t] != SIG::slot_code(k, t)) return false;
+    }
+    return true;
+}
+
+// FEDM_LEAN3_PRINT_SIG=1: the structure of this context's plan, as the signature tables state it
+template <int NS, int NR>
+static void lean3_print_signature(const Lean3Plan<NS, NR> &pl, bool precompiled) {
+    std::fprintf(stderr, "[fedm] one-pass assembly: model structure %s\n  eq_type {", precompiled ? "precompiled (Lean3SigBenchmark)" : "taken at run time");
+    for (int s = 0; s < NS; ++s) std::fprintf(stderr, "%d%s", pl.eq_type[s], s + 1 < NS ? ", " : "} has_drift_w {");
+    for (int s = 0; s < NS; ++s) std::fprintf(stderr, "%d%s", pl.has_drift_w[s], s + 1 < NS ? ", " : "}");
+    std::fprintf(stderr, " nreac %d nP %d nQ %d\n", pl.nreac, pl.nP, pl.nQ);
+    for (int j = 0; j < pl.nreac; ++j) {
+        std::fprintf(stderr, "  reaction %d: power {", j);
+        for (int s = 0; s < NS; ++s) std::fprintf(stderr, "%d%s", pl.power[j][s], s + 1 < NS ? ", " : "} net {");
+        for (int s = 0; s < NS; ++s) std::fprintf(stderr, "%d%s", pl.net[j][s], s + 1 < NS ? ", " : "}\n");
+    }
+    for (int k = 0; k < NR + 2 * NS; ++k) {
+        const Lean3Slot &sl = lean3_slot(pl, k);
+        std::fprintf(stderr, "  slot %d: n %d, codes (power atom | exp atom << 2 | (m + 8) << 4):", k, sl.n);
+        for (int t = 0; t < sl.n; ++t)
+            std::fprintf(stderr, " %d | %d << 2 | %d << 4", sl.code[t] & 3, (sl.code[t] >> 2) & 3, (sl.code[t] >> 4) & 31);
+        std::fprintf(stderr, "\n");
+    }
 }
 
 // LDS of one workgroup: live planes of its block columns + residual + staged vertex data
@@ -1047,20 +1170,31 @@ static void lean3_dispatch(Ctx &c, bool whole, K kernel, int grid, int threads, 
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, c.stream, args...);
 }
 
-template <int NS, int NR, uint32_t CMASK>
+// the compiled model in device memory, uploaded at first use (fedm_ctx_destroy frees it: lean3_release), and the
+// signature its structure selects (Ctx::lean3_sig: 0 = structure at run time, 1 = Lean3SigBenchmark)
+template <int NS, int NR>
+static bool lean3_ensure_plan(Ctx &c) {
+    if (c.d_lean3_plan) return true;
+    Lean3Plan<NS, NR> host_plan;
+    if (!lean3_build_plan<NS, NR>(c.model, host_plan)) return false;
+    if (hipMalloc(&c.d_lean3_plan, sizeof(host_plan)) != hipSuccess ||
+        hipMemcpy(c.d_lean3_plan, &host_plan, sizeof(host_plan), hipMemcpyHostToDevice) != hipSuccess) {
+        hipGetLastError();
+        c.d_lean3_plan = nullptr;
+        return false;
+    }
+    const char *e = std::getenv("FEDM_LEAN3_SIG");
+    c.lean3_sig = (!(e && e[0] == '0') && lean3_sig_matches<Lean3SigBenchmark>(host_plan)) ? 1 : 0;
+    const char *pr = std::getenv("FEDM_LEAN3_PRINT_SIG");
+    if (pr && pr[0] == '1') lean3_print_signature(host_plan, c.lean3_sig == 1);
+    return true;
+}
+
+template <int NS, int NR, uint32_t CMASK, class SIG>
 static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int width, int verts, bool whole = true) {
     using PL = LivePlanes<NS, CMASK>;
     if (n <= 0) return true;
-    // the compiled model in device memory, uploaded at first use (fedm_ctx_destroy frees it: lean3_release)
-    if (!c.d_lean3_plan) {
-        Lean3Plan<NS, NR> host_plan;
-        if (!lean3_build_plan<NS, NR>(c.model, host_plan)) return false;
-        if (hipMalloc(&c.d_lean3_plan, sizeof(host_plan)) != hipSuccess ||
-            hipMemcpy(c.d_lean3_plan, &host_plan, sizeof(host_plan), hipMemcpyHostToDevice) != hipSuccess) {
-            hipGetLastError();
-            return false;
-        }
-    }
+    if (!lean3_ensure_plan<NS, NR>(c)) return false;
     const Lean3Plan<NS, NR> *plan = static_cast<const Lean3Plan<NS, NR> *>(c.d_lean3_plan);
     Lean3Params p;
     p.nv = c.nv;
@@ -1138,7 +1272,7 @@ static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int 
     if (jacobian) {
         static size_t granted = 0;   // per instantiation: beyond the 64 KiB default the dynamic LDS is opt-in
         if (lds > 64 * 1024 && lds > granted) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_lean3_kernel<NS, NR, T, CMASK>),
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_lean3_kernel<NS, NR, T, CMASK, SIG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             granted = lds;
         }
@@ -1154,16 +1288,16 @@ static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int 
             p.planes_upper = fieldsplit_upper(c) ? 1 : 0;
             p.planes_zs = fieldsplit_zero_species_planes(c);
         }
-        lean3_dispatch(c, whole, assemble_lean3_kernel<NS, NR, T, CMASK>, n, T, lds, plan, p);
+        lean3_dispatch(c, whole, assemble_lean3_kernel<NS, NR, T, CMASK, SIG>, n, T, lds, plan, p);
         c.planes_fused = fuse;
     } else {
-        lean3_dispatch(c, whole, residual_lean3_kernel<NS, NR, T>, n, T, lds, plan, p);
+        lean3_dispatch(c, whole, residual_lean3_kernel<NS, NR, T, SIG>, n, T, lds, plan, p);
     }
     return true;
 }
 
-template <int NS, int NR, uint32_t CMASK>
-static bool lean3_launch(Ctx &c, bool jacobian, const int *list, int n) {
+template <int NS, int NR, uint32_t CMASK, class SIG>
+static bool lean3_launch_sig(Ctx &c, bool jacobian, const int *list, int n) {
     using PL = LivePlanes<NS, CMASK>;
     // the split applies to the Jacobian assembly of a whole mesh with the planes kept (the steady state of a run);
     // the listed launches of the several-GPU path and the first full assembly take one launch sized for everything
@@ -1171,11 +1305,19 @@ static bool lean3_launch(Ctx &c, bool jacobian, const int *list, int n) {
         Lean3Classes *k = lean3_classes(c, PL::N);
         if (k->split) {
             // the few large ones first: their tail overlaps nothing, so it should be short
-            return lean3_launch_one<NS, NR, CMASK>(c, true, k->d_list[1], k->n[1], k->width[1], k->verts[1], false) &&
-                   lean3_launch_one<NS, NR, CMASK>(c, true, k->d_list[0], k->n[0], k->width[0], k->verts[0], false);
+            return lean3_launch_one<NS, NR, CMASK, SIG>(c, true, k->d_list[1], k->n[1], k->width[1], k->verts[1], false) &&
+                   lean3_launch_one<NS, NR, CMASK, SIG>(c, true, k->d_list[0], k->n[0], k->width[0], k->verts[0], false);
         }
     }
-    return lean3_launch_one<NS, NR, CMASK>(c, jacobian, list, n, c.pat.max_patch_width, c.pat.max_patch_verts, list == nullptr);
+    return lean3_launch_one<NS, NR, CMASK, SIG>(c, jacobian, list, n, c.pat.max_patch_width, c.pat.max_patch_verts, list == nullptr);
+}
+
+// ... with the model's structure compiled in where a signature for it exists
+template <int NS, int NR, uint32_t CMASK>
+static bool lean3_launch(Ctx &c, bool jacobian, const int *list, int n) {
+    if (!lean3_ensure_plan<NS, NR>(c)) return false;
+    if (c.lean3_sig == 1) return lean3_launch_sig<NS, NR, CMASK, Lean3SigBenchmark>(c, jacobian, list, n);
+    return lean3_launch_sig<NS, NR, CMASK, Lean3SigRuntime>(c, jacobian, list, n);
 }
 
 // The models this generation is instantiated for: two species and one reaction (the streamer family) with the
@@ -1189,6 +1331,14 @@ bool lean3_applies(const Ctx &c) {
     if (off || c.ns != 2 || !c.poisson || c.model.n_reactions > 1 || c.pat.max_patch_cells > 2 * 192) return false;
     Lean3Plan<2, 1> plan;
     return lean3_build_plan<2, 1>(c.model, plan);
+}
+
+// Which precompiled structure signature this context's model selects (0: none -- the structure is read at run time)
+int lean3_signature(const Ctx &c) {
+    Lean3Plan<2, 1> plan;
+    if (c.ns != 2 || !lean3_build_plan<2, 1>(c.model, plan)) return 0;
+    const char *e = std::getenv("FEDM_LEAN3_SIG");
+    return (!(e && e[0] == '0') && lean3_sig_matches<Lean3SigBenchmark>(plan)) ? 1 : 0;
 }
 
 // cmask: the planes that are kept for this launch (0 on a context's first full assembly: everything is written).

@@ -2331,7 +2331,7 @@ int fedm_sizes(fedm_ctx *h, int64_t *n_vertices, int64_t *n_cells, int64_t *n_eq
     return 0;
 }
 
-int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
+int fedm_pattern_info(fedm_ctx *h, int64_t out[9]) {
     if (!h || !out) return -2;
     Ctx &c = h->c;
     out[0] = c.pat.n_slices;
@@ -2351,6 +2351,8 @@ int fedm_pattern_info(fedm_ctx *h, int64_t out[8]) {
     // 3: LDS patches, one pass over the cells (lean3 kernels, assemble3.hip)
     out[6] = c.assembly_kind == 0 ? 0 : (lean3 ? 3 : lean2 ? 2 : 1);
     out[7] = c.assembly_kind == 0 ? 0 : (c.pat.max_patch_cells <= 192 || out[6] == 3 ? 192 : (lean2 ? 256 : 320));
+    // the one-pass kernels with the model's structure compiled in (assemble3.hip, Lean3SigBenchmark)
+    out[8] = lean3 ? lean3_signature(c) : 0;
     return 0;
 }
 

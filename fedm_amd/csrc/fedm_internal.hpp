@@ -251,6 +251,7 @@ struct Ctx {
     double err_cache = 0.0;
     double *h_stage = nullptr;     // pinned staging, np doubles
     void *d_lean3_plan = nullptr;  // assemble3.hip: the model compiled for the one-pass kernels (Lean3Plan), device memory
+    int lean3_sig = 0;              // the precompiled structure signature the plan selects (assemble3.hip; 0: none)
     void *lean3_classes = nullptr; // assemble3.hip: patch lists by LDS need (Lean3Classes), built at first use
     double *d_snapshot = nullptr;  // fedm_state_snapshot: u, u_old, u_old1 (3 np doubles, allocated on first use)
 };
@@ -271,6 +272,7 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode);
 bool lean3_applies(const Ctx &c);                                   // assemble3.hip
 void lean3_release(Ctx &c);
 bool launch_assemble_lean3(Ctx &c, bool jacobian, const int *patch_list, int n, uint32_t cmask);
+int lean3_signature(const Ctx &c);   // the precompiled model structure the one-pass kernels run with (0: run-time structure)
 int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab_ptr,
                   const double *tab_x, const double *tab_y, const fedm_gd_field_prog *progs);
 int gd_prep_step(Ctx &c);

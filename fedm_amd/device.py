@@ -944,12 +944,13 @@ class DeviceProblem:
         out = dict(zip(keys, (x.value for x in v)))
         kept, zero = self.plane_masks()
         out["kept_planes"], out["zero_planes"] = bin(kept).count("1"), bin(zero).count("1")
-        info = (C.c_int64 * 8)()
+        info = (C.c_int64 * 9)()
         self._check(self.lib.fedm_pattern_info(self._h, info), "fedm_pattern_info")
         out.update(zip(("n_slices", "max_patch_cells", "max_patch_width", "max_patch_verts", "cell_visits",
                         "halo_vertices"), (int(v) for v in info[:6])))
         out["assembly_variant"] = ("global colouring", "lds-patches/unrolled", "lds-patches", "lds-patches/one-pass")[int(info[6])]
         out["patch_threads"] = int(info[7])
+        out["model_structure"] = "compiled in" if info[8] else "run time"
         return out
 
     def assembly_variant(self):

@@ -212,7 +212,7 @@ const char *fedm_last_error(void);
  * 3: fedm_fieldsplit_tiles_info, fedm_fieldsplit_tiles_stats, fedm_debug_fieldsplit_apply, fedm_debug_fieldsplit_tiles.
  * 4: fedm_state_snapshot, fedm_state_restore; fedm_fieldsplit_tiles_stats out[10]; fedm_comm_stats out[10]; fedm_fieldsplit_policy.
  * 5: fedm_gd_desc.energy_Ei, .mean_energy_form (the sentinel energy losses on the device); fedm_debug_species_planes_check;
- *    fedm_time_kernel kinds 4, 5. */
+ *    fedm_time_kernel kinds 4, 5; fedm_pattern_info out[9]. */
 #define FEDM_ABI_VERSION 5
 int fedm_abi_version(void);
 
@@ -410,8 +410,10 @@ int fedm_pattern_stats(const fedm_mesh_desc *mesh, int64_t out[12]);
 /* The same for a live context, and which volume-assembly kernels it runs: out = {slices, max cells per
  * patch, max block columns per slice, max staged vertices per patch, cell visits, halo vertices,
  * assembly variant (0 global colouring, 1 LDS patches / unrolled element routine, 2 LDS patches / one
- * equation row at a time), threads per patch workgroup}. */
-int fedm_pattern_info(fedm_ctx *ctx, int64_t out[8]);
+ * equation row at a time, 3 LDS patches / one pass over the cells), threads per patch workgroup, 1 when the one-pass
+ * kernels run with the model's STRUCTURE compiled in (a precompiled signature matches it: csrc/assemble3.hip) and only
+ * its numbers read at run time}. */
+int fedm_pattern_info(fedm_ctx *ctx, int64_t out[9]);
 /* The species sweeps of the field split (the Chebyshev polynomial in Duu^-1 Juu that stands for PETSc's
  * sub-solver of the species block; no counterpart in the scripts): on one GPU they run several per launch on
  * tiles of matrix slices whose vertex layers sit in LDS (csrc/fs_tiles.hip).  Returns 1 when this context

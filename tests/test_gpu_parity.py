@@ -430,10 +430,15 @@ def test_row_at_a_time_assembly_matches_the_unrolled_element(monkeypatch, three_
     U0 = U + 0.01 * rng.standard_normal(U.shape)
     U1 = U + 0.02 * rng.standard_normal(U.shape)
     out = {}
-    for lean in ("3", "2", "0"):      # one pass over the cells (where instantiated: the streamer family) / row phases / unrolled
-        monkeypatch.setenv("FEDM_ASSEMBLY_LEAN", lean)
+    # one pass over the cells (where instantiated: the streamer family) with the model's structure compiled in ("3":
+    # the benchmark deck has a precompiled signature) and read at run time ("3r") / row phases / unrolled
+    for lean in ("3", "3r", "2", "0"):
+        monkeypatch.setenv("FEDM_ASSEMBLY_LEAN", lean[0])
+        monkeypatch.setenv("FEDM_LEAN3_SIG", "0" if lean == "3r" else "1")
         prob = DeviceProblem(m.coords, m.cells, model, facet_tags=tags if not three_species else None,
                              dirichlet_dofs=ddofs.astype(np.int32), dirichlet_vals=dvals)
+        if not three_species and lean[0] == "3":
+            assert prob.sizes()["model_structure"] == ("compiled in" if lean == "3" else "run time")
         prob.set_state(U, U0, U1)
         prob.set_step(5e-12, 4e-12)
         prob.jacobian()
@@ -443,7 +448,7 @@ def test_row_at_a_time_assembly_matches_the_unrolled_element(monkeypatch, three_
         prob.close()
     F0, J0 = out["0"]
     rowmax = abs(J0).max(axis=1).toarray().ravel()
-    for lean in ("3", "2"):
+    for lean in ("3", "3r", "2"):
         F1, J1 = out[lean]
         assert np.abs(F1 - F0).max() <= 1e-12 * np.abs(F0).max(), lean
         d = abs(J1 - J0)
@@ -850,3 +855,69 @@ def test_species_planes_formed_by_the_assembly_equal_the_separate_pass(monkeypat
     for nv, by in logs.items():
         assert by["1"][:2] == by["0"][:2], (nv, by["1"][:2], by["0"][:2])
         assert np.abs(by["1"][2] - by["0"][2]).max() <= 1e-9 * np.abs(by["0"][2]).max()
+
+
+def test_one_pass_assembly_of_models_with_another_structure_than_the_benchmark_deck(monkeypatch):
+    """The one-pass kernels are instantiated with the benchmark deck's STRUCTURE compiled in (which equation a species
+    has, the reaction's powers, the terms of the coefficient functions and the atoms they multiply) and with the
+    structure read from the plan at run time.  Models of the same family with other structures -- constant diffusion,
+    a mobility that shares its power atom with the diffusion, an ionisation coefficient without the E^-3 term -- must
+    take the run-time kernels; the deck's terms in another order or with other exponents the compiled ones (the plan
+    is canonical, the numbers stay run-time data); all give the system of the unrolled element routine."""
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import DeviceProblem, Model, Reaction
+    from fedm_amd.mesh import Marking_boundaries, Mesh
+    from fedm_amd.termsum import TermSum, parse
+    msh = streamer.mesh(24, 2.0)
+    m = Mesh(msh.coords, msh.cells)
+    tags = Marking_boundaries(m, streamer.BOUNDARIES)
+    nv = m.coords.shape[0]
+    rng = np.random.default_rng(8)
+    x, y = m.coords[:, 0] / streamer.BOX, m.coords[:, 1] / streamer.BOX
+    ddofs, dvals = streamer.dirichlet(m.coords)
+    U = np.zeros((nv, 3))
+    U[:, 0] = 30.0 + 2.0 * np.sin(5 * x) * np.cos(3 * y)
+    U[:, 1] = 28.0 + 3.0 * np.cos(4 * x) * np.sin(6 * y)
+    U[:, 2] = streamer.U_W * y + 50.0 * np.sin(3 * x) * np.sin(np.pi * y)
+    U0 = U + 0.01 * rng.standard_normal(U.shape)
+    U1 = U + 0.02 * rng.standard_normal(U.shape)
+
+    def build(mu_e, D_e, alpha):
+        mu = parse(mu_e)
+        return Model(n_species=2, poisson=True, eq_type=["reaction", "drift-diffusion-reaction"], Z=[1.0, -1.0],
+                     mu=[TermSum.const(0.0), mu], D=[TermSum.const(0.0), parse(D_e)],
+                     reactions=[Reaction(parse(alpha) * mu * TermSum.field(), power=[0, 1], net=[1, 1])],
+                     bc_kind=streamer.BC_TYPE, quadrature_degree=2)
+    cases = {
+        "the deck": (streamer.MU_E, streamer.D_E, streamer.ALPHA, "compiled in"),
+        "the deck, alpha's terms in another order": (streamer.MU_E, streamer.D_E,
+                                                     "-340.75 + (4.3666e26*E_m**(-3) + 1.1944e6)*exp(-2.73e7/E_m)", "compiled in"),
+        "constant diffusion": (streamer.MU_E, "0.18", streamer.ALPHA, "run time"),
+        # (the same structure with other NUMBERS is the compiled one: two power atoms, the same terms)
+        "mobility with another exponent": ("2.3987*E_m**(-0.31)", streamer.D_E, streamer.ALPHA, "compiled in"),
+        "mobility and diffusion sharing their power atom": ("2.3987*E_m**(-0.78)", streamer.D_E, streamer.ALPHA, "run time"),
+        "alpha without the E^-3 term": (streamer.MU_E, streamer.D_E, "1.1944e6*exp(-2.73e7/E_m) - 340.75", "run time"),
+    }
+    for name, (mu_e, D_e, alpha, structure) in cases.items():
+        model = build(mu_e, D_e, alpha)
+        out = {}
+        for lean in ("3", "0"):
+            monkeypatch.setenv("FEDM_ASSEMBLY_LEAN", lean)
+            prob = DeviceProblem(m.coords, m.cells, model, facet_tags=tags, dirichlet_dofs=ddofs.astype(np.int32),
+                                 dirichlet_vals=dvals)
+            if lean == "3":
+                sz = prob.sizes()
+                assert sz["assembly_variant"] == "lds-patches/one-pass", name
+                assert sz["model_structure"] == structure, (name, sz["model_structure"])
+            prob.set_state(U, U0, U1)
+            prob.set_step(5e-12, 4e-12)
+            prob.jacobian()
+            F, _ = prob.residual()
+            prob.jacobian()
+            out[lean] = (F, prob.jacobian_csr())
+            prob.close()
+        F0, J0 = out["0"]
+        F1, J1 = out["3"]
+        rowmax = abs(J0).max(axis=1).toarray().ravel()
+        assert np.abs(F1 - F0).max() <= 1e-12 * np.abs(F0).max(), name
+        assert (abs(J1 - J0).max(axis=1).toarray().ravel() <= 1e-11 * rowmax + 1e-300).all(), name
