@@ -769,7 +769,7 @@ struct PatchHdr {
     int S, b0, width, c0, nc, h0, nloc;
 };
 
-template <int NS, int NR, int THREADS, uint32_t CMASK, bool JAC>
+template <int NS, int NR, int THREADS, uint32_t CMASK, bool JAC, class SIG>
 __device__ __forceinline__ void assemble_lean3p_body(const Lean3Plan<NS, NR> *__restrict__ md, double *__restrict__ gval,
                                                      double *__restrict__ gF, const Lean3Params &p) {
     constexpr int NEQ = NS + 1, NEQ2 = NEQ * NEQ;
@@ -872,10 +872,10 @@ __device__ __forceinline__ void assemble_lean3p_body(const Lean3Plan<NS, NR> *__
         const int gidn = has_next ? load_gid(t, hn) : p.nv;
         const bool has_next2 = idx + 2 * stride < end;
         const PatchHdr hn2 = has_next2 ? load_hdr(idx + 2 * stride) : hn;
-        if (!(FEDM_LEAN3_PROBE & 4) && tid < h.nc) lean3_cell<NS, NR, CMASK, JAC, Lean3SigRuntime>(md, ci, vx, Ul, Hl, Al, p.sc, acc, Fl);
+        if (!(FEDM_LEAN3_PROBE & 4) && tid < h.nc) lean3_cell<NS, NR, CMASK, JAC, SIG>(md, ci, vx, Ul, Hl, Al, p.sc, acc, Fl);
         if (tid + THREADS < h.nc) {     // (n_cells <= 2 THREADS: lean3_applies)
             const CellIdx ci2 = cell_idx(p.pcells[h.c0 + tid + THREADS]);
-            lean3_cell<NS, NR, CMASK, JAC, Lean3SigRuntime>(md, ci2, vx, Ul, Hl, Al, p.sc, acc, Fl);
+            lean3_cell<NS, NR, CMASK, JAC, SIG>(md, ci2, vx, Ul, Hl, Al, p.sc, acc, Fl);
         }
         __syncthreads();
         asm volatile("" : "+v"(t));
@@ -923,16 +923,16 @@ __device__ __forceinline__ void assemble_lean3p_body(const Lean3Plan<NS, NR> *__
     }
 }
 
-template <int NS, int NR, int THREADS, uint32_t CMASK>
+template <int NS, int NR, int THREADS, uint32_t CMASK, class SIG>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void assemble_lean3p_kernel(
     const Lean3Plan<NS, NR> *__restrict__ plan, double *__restrict__ val, double *__restrict__ F, const Lean3Params p) {
-    assemble_lean3p_body<NS, NR, THREADS, CMASK, true>(plan, val, F, p);
+    assemble_lean3p_body<NS, NR, THREADS, CMASK, true, SIG>(plan, val, F, p);
 }
 
-template <int NS, int NR, int THREADS>
+template <int NS, int NR, int THREADS, class SIG>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void residual_lean3p_kernel(
     const Lean3Plan<NS, NR> *__restrict__ plan, double *__restrict__ val, double *__restrict__ F, const Lean3Params p) {
-    assemble_lean3p_body<NS, NR, THREADS, 0u, false>(plan, val, F, p);
+    assemble_lean3p_body<NS, NR, THREADS, 0u, false, SIG>(plan, val, F, p);
 }
 
 #ifndef FEDM_LEAN3_WAVES
@@ -1260,12 +1260,12 @@ static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int 
         };
         if (jacobian) {
             static size_t granted = 0;
-            const int g = grid_for(reinterpret_cast<const void *>(&assemble_lean3p_kernel<NS, NR, T, CMASK>), granted);
-            lean3_dispatch(c, whole, assemble_lean3p_kernel<NS, NR, T, CMASK>, g, T, lds, plan, p.val, p.F, p);
+            const int g = grid_for(reinterpret_cast<const void *>(&assemble_lean3p_kernel<NS, NR, T, CMASK, SIG>), granted);
+            lean3_dispatch(c, whole, assemble_lean3p_kernel<NS, NR, T, CMASK, SIG>, g, T, lds, plan, p.val, p.F, p);
         } else {
             static size_t granted = 0;
-            const int g = grid_for(reinterpret_cast<const void *>(&residual_lean3p_kernel<NS, NR, T>), granted);
-            lean3_dispatch(c, whole, residual_lean3p_kernel<NS, NR, T>, g, T, lds, plan, p.val, p.F, p);
+            const int g = grid_for(reinterpret_cast<const void *>(&residual_lean3p_kernel<NS, NR, T, SIG>), granted);
+            lean3_dispatch(c, whole, residual_lean3p_kernel<NS, NR, T, SIG>, g, T, lds, plan, p.val, p.F, p);
         }
         return true;
     }
