@@ -577,7 +577,7 @@ def main():
         "measured_copy_ceiling_GBs": copy_gbs,
         "copy_ceiling_how": "fedm_copy_bandwidth: the fastest of six 16-byte-per-lane copy kernels (1-8 loads in flight per "
                             "lane, plain / non-temporal), 2 x 1 GiB, HIP events",
-        "run_to_reference_end_time": ("profiles/r03_refined_run_*.json: this mesh carries the streamer to the reference's "
+        "run_to_reference_end_time": ("profiles/r04_refined_run_4um_1M_dofs.json: this mesh carries the streamer to the reference's "
                                       "T_final = 1.4e-8 s (2801 accepted steps, none rejected)") if family == "unstructured" else None,
     }
     if args.late_start > 0:
