@@ -19,6 +19,22 @@
 
 namespace fedm {
 
+// -DFEDM_GD_ROW_TIMING: how long the waves of gd_jacobian_rows_kernel spend on each equation row (100 MHz wall clock,
+// lane 0 of every wave, summed over the workgroups; [NEQ]: the set-up in front of the rows): tools/gd_row_time.py
+#ifdef FEDM_GD_ROW_TIMING
+__device__ unsigned long long g_gd_row[8];
+extern "C" void fedm_debug_gd_rows(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gd_row), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_gd_row), z, sizeof(z));
+    }
+}
+#define GD_ROW_T(k) if ((threadIdx.x & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_gd_row[k], now_ - t_prev_); t_prev_ = now_; }
+#else
+#define GD_ROW_T(k)
+#endif
+
 struct Dual {
     double v, d;
 };
@@ -494,6 +510,9 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     const uint32_t *__restrict__ cell_slots, const double *__restrict__ u,
     const double *__restrict__ uold, const double *__restrict__ uold1, double dt, double dt_old,
     double *__restrict__ val, double *__restrict__ F, int mode, double *__restrict__ elemF, int exp_table) {
+#ifdef FEDM_GD_ROW_TIMING
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     constexpr int NEQ2 = NEQ * NEQ, ns = NEQ - 1, IPHI = NEQ - 1, ie = ns - 1;
     const double two_pi = 6.283185307179586476925286766559;
     const int lc = threadIdx.x & (SLICE - 1);
@@ -506,26 +525,60 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     int *lds_vtx = reinterpret_cast<int *>(gd_lds);                 // [64][3] global vertex ids (-1: no cell)
     double *lds_f = gd_lds + (3 * SLICE + 1) / 2;                   // [64][NF][3]
     double *lds_u = lds_f + (size_t)SLICE * NF * 3;                 // [3][NEQ][64]
-    for (int i = threadIdx.x; i < 3 * SLICE; i += blockDim.x) {
-        const int cc = blockIdx.x * SLICE + i / 3;
-        lds_vtx[i] = cc < n_cells ? cells[3 * (cell_list ? cell_list[cc] : cc) + i % 3] : -1;
+    // One workgroup is resident per CU (four waves of 400 registers), so nothing hides the latency of this set-up:
+    // it is ONE round trip to memory after the cell's vertex ids -- every lane reads the ids of its own cell (the waves
+    // redundantly: no LDS hop, no barrier), then the cell's coordinates, the history of the wave's row and the wave's
+    // share of the (field, vertex) pairs are all requested before the first of them is used (12.9 of the
+    // workgroup's 51 us were this set-up -- a dependent trip for the ids, per batch of fields, for the coordinates and for
+    // the history -- now 8.2 of 45: tools/gd_row_time.py; F + J 290 -> 264 us at 200 k DOFs).
+    (void)lds_vtx;
+    int vt[3] = {-1, -1, -1};
+    if (ci < n_cells) {
+        const int cc = cell_list ? cell_list[ci] : ci;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vt[a] = cells[3 * cc + a];
     }
-    __syncthreads();
+    double xy0[3][2], hist0[3][2];   // coordinates; (u_old, u_old1) of the wave's first row at the cell's vertices
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int v = vt[a] >= 0 ? vt[a] : 0;
+        xy0[a][0] = coords[2 * v];
+        xy0[a][1] = coords[2 * v + 1];
+        hist0[a][0] = uold[(size_t)v * NEQ + wave];
+        hist0[a][1] = uold1[(size_t)v * NEQ + wave];
+    }
     {
         // lane = cell, the waves share the (field, vertex) pairs: no division by a run-time number
         const int nw = blockDim.x >> 6;
-        const int vt[3] = {lds_vtx[3 * lc], lds_vtx[3 * lc + 1], lds_vtx[3 * lc + 2]};
-        double *dstf = lds_f + lc;
-        for (int f = wave; f < NF * 3; f += nw) {
-            const int fi = f / 3, a = f - 3 * fi;
-            const int vtx = a == 0 ? vt[0] : a == 1 ? vt[1] : vt[2];
-            dstf[(size_t)f * SLICE] = vtx >= 0 ? fields[(size_t)fi * nv + vtx] : 0.0;
-        }
+        constexpr int CH = 32;             // pairs requested before the first is stored (33 fields: 25 a wave)
+        constexpr int CU = (3 * NEQ + NEQ - 2) / (NEQ - 1);     // the wave's share of the unknowns
         double *dstu = lds_u + lc;
-        for (int f = wave; f < 3 * NEQ; f += nw) {
-            const int a = f / NEQ, sidx = f - a * NEQ;
+        double tmpu[CU];
+#pragma unroll
+        for (int k = 0; k < CU; ++k) {
+            const int f = wave + k * nw, a = f / NEQ, sidx = f - a * NEQ;
             const int vtx = a == 0 ? vt[0] : a == 1 ? vt[1] : vt[2];
-            dstu[(size_t)f * SLICE] = vtx >= 0 ? u[(size_t)vtx * NEQ + sidx] : 0.0;
+            tmpu[k] = (f < 3 * NEQ && vtx >= 0) ? u[(size_t)vtx * NEQ + sidx] : 0.0;
+        }
+        double *dstf = lds_f + lc;
+        for (int f0 = wave; f0 < NF * 3; f0 += nw * CH) {
+            double tmp[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int f = f0 + k * nw, fi = f / 3, a = f - 3 * fi;
+                const int vtx = a == 0 ? vt[0] : a == 1 ? vt[1] : vt[2];
+                tmp[k] = (f < NF * 3 && vtx >= 0) ? fields[(size_t)fi * nv + vtx] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int f = f0 + k * nw;
+                if (f < NF * 3) dstf[(size_t)f * SLICE] = tmp[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CU; ++k) {
+            const int f = wave + k * nw;
+            if (f < 3 * NEQ) dstu[(size_t)f * SLICE] = tmpu[k];
         }
     }
     __syncthreads();
@@ -571,9 +624,9 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     {
         double x[3][2];   // (not kept: the facet terms read the two coordinates they need again)
         for (int a = 0; a < 3; ++a) {
-            c.v[a] = lds_vtx[3 * lc + a];
-            x[a][0] = coords[2 * c.v[a]];
-            x[a][1] = coords[2 * c.v[a] + 1];
+            c.v[a] = vt[a];
+            x[a][0] = xy0[a][0];
+            x[a][1] = xy0[a][1];
             c.rn[a] = md->axisymmetric ? x[a][0] : 0.5 / 3.14159265358979323846;
         }
         const double d1x = x[1][0] - x[0][0], d1y = x[1][1] - x[0][1];
@@ -593,13 +646,17 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     // One wave per species/energy row; the (cheap) Poisson row is a second pass of wave 1, so that a
     // workgroup is NEQ - 1 waves (four for the glow-discharge model: two workgroups per CU at two waves
     // per SIMD; five-wave workgroups left three of eight wave slots empty).
+    GD_ROW_T(NEQ)
     for (int pass = 0; pass < 2; ++pass) {
     const int row = pass == 0 ? wave : IPHI;
     if (pass == 1 && wave != (ns > 1 ? 1 : 0)) break;
     if (mode == 1 && row != IPHI) continue;   // Poisson-only: the other rows are identity rows
     double Hrow[3];
-    for (int a = 0; a < 3; ++a)
-        Hrow[a] = (-(trp1 * trp1) * uold[(size_t)c.v[a] * NEQ + row] + (tr * tr) * uold1[(size_t)c.v[a] * NEQ + row]) / trp1;
+    for (int a = 0; a < 3; ++a) {
+        const double ho = pass == 0 ? hist0[a][0] : uold[(size_t)c.v[a] * NEQ + row];
+        const double ho1 = pass == 0 ? hist0[a][1] : uold1[(size_t)c.v[a] * NEQ + row];
+        Hrow[a] = (-(trp1 * trp1) * ho + (tr * tr) * ho1) / trp1;
+    }
     // One column vertex b at a time (a rolled loop around the quadrature loop): 15 accumulators instead
     // of 45.  The point functions are evaluated once per column vertex -- more arithmetic, but the 45
     // accumulators next to the live coefficients did not fit the register file: 92 spilled dwords per
@@ -995,6 +1052,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         }
     }
     }   // column vertex b
+    GD_ROW_T(row)
     }   // pass
 }
 
