@@ -129,7 +129,9 @@ class Runner(streamer.Stepper):
         self.transport = transport
         self.total_dofs = gmesh.num_vertices() * 3
         shape = f"{n}x{n}" if n else f"unstructured, {gmesh.num_vertices()} vertices"
-        self.partition_name = (f"RCB vertex partition (cuts severing the fewest edges), {world} parts, global mesh {shape}, "
+        kind = ("multilevel graph partition (heavy-edge matching, FM refinement)" if self.partitioner == "graph"
+                else "RCB vertex partition (cuts severing the fewest edges)")
+        self.partition_name = (f"{kind}, {world} parts, global mesh {shape}, "
                                f"{lm.n_owned} owned + {lm.n_ghost} ghost vertices in {halo_depth} layer(s) on rank {rank}, "
                                f"{len(lm.neighbours)} neighbours, transport {transport}")
 
