@@ -15,11 +15,12 @@ struct GdPrep {
     fedm_gd_field_prog *d_progs = nullptr;
     std::vector<fedm_gd_field_prog> progs;
     double *d_redE = nullptr, *d_b = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
+    double *d_cg = nullptr;     // the CG's scalars on the device: r.z, p.q, r.z of the new residual, r.r
     int nvp = 0;
     void release() {
         M.release();
         for (void *p : {(void *)d_tab_ptr, (void *)d_tab_x, (void *)d_tab_y, (void *)d_progs, (void *)d_redE,
-                        (void *)d_b, (void *)d_r, (void *)d_p, (void *)d_q})
+                        (void *)d_b, (void *)d_r, (void *)d_p, (void *)d_q, (void *)d_cg})
             if (p) hipFree(p);
     }
 };
@@ -89,58 +90,77 @@ __global__ void sreduce_kernel(const double *__restrict__ partials, int nblocks,
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (threadIdx.x == 0) out[i] = s;
 }
-__global__ void saxpy2_kernel(int n, double a, const double *__restrict__ x, double *__restrict__ y,
-                              double b, const double *__restrict__ x2, double *__restrict__ y2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        y[i] += a * x[i];
-        y2[i] += b * x2[i];
-    }
-}
-__global__ void sxpby_kernel(int n, const double *__restrict__ dinv, const double *__restrict__ r,
-                             double beta, double *__restrict__ p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = dinv[i] * r[i] + beta * p[i];
-}
 __global__ void smul_kernel(int n, const double *__restrict__ dinv, const double *__restrict__ r,
                             double *__restrict__ z) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) z[i] = dinv[i] * r[i];
 }
 
-// M x = b by Jacobi-preconditioned CG, rtol on |r|
+// The CG's updates with their scalars read from the device (s = {r.z, p.q, r.z of the new residual, r.r}): the host
+// forms neither alpha nor beta and so has nothing to wait for inside an iteration
+__global__ void saxpy2_dev_kernel(int n, const double *__restrict__ s, const double *__restrict__ p, double *__restrict__ x,
+                                  const double *__restrict__ q, double *__restrict__ r) {
+    const double alpha = s[1] != 0.0 ? s[0] / s[1] : 0.0;     // (p.q = 0: the residual is exactly zero already)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        x[i] += alpha * p[i];
+        r[i] -= alpha * q[i];
+    }
+}
+__global__ void sxpby_dev_kernel(int n, const double *__restrict__ s, const double *__restrict__ dinv,
+                                 const double *__restrict__ r, double *__restrict__ p) {
+    const double beta = s[0] != 0.0 ? s[2] / s[0] : 0.0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = dinv[i] * r[i] + beta * p[i];
+}
+__global__ void cg_shift_kernel(double *s) { s[0] = s[2]; }
+
+// M x = b by Jacobi-preconditioned CG, rtol on |r|.  An iteration is seven launches and no wait: its scalars stay on
+// the device, its |r|^2 goes to the host mailbox, and the host reads the publication of iteration k - 1 after it has
+// queued iteration k -- the iteration that runs while the convergence of the previous one is being looked at is the
+// only one that may be superfluous (it improves x a little further).  (Until round 4 the host formed alpha and beta:
+// two round trips per iteration, 26 per time step of the glow-discharge case, a tenth of its step.)
 static int mass_solve(Ctx &c, GdPrep &g, const double *b, double *x, double rtol, int max_it) {
     const int n = c.nv, np = g.nvp;
     const dim3 gv((np + 255) / 256), bv(256);
     int grid = (n + 255) / 256;
     if (grid > RED_BLOCKS) grid = RED_BLOCKS;
-    auto dots = [&](const double *a, const double *bb, const double *cc, const double *dd) {
+    double *s = g.d_cg;
+    auto dots = [&](const double *a, const double *bb, const double *cc, const double *dd, double *out) {
         hipLaunchKernelGGL(sdot2_kernel, dim3(grid), dim3(256), 0, c.stream, n, a, bb, cc, dd, c.d_partials);
-        hipLaunchKernelGGL(sreduce_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, c.d_red);
-        read_red(c, 2);
+        hipLaunchKernelGGL(sreduce_kernel, dim3(2), dim3(64), 0, c.stream, c.d_partials, grid, out);
     };
+    auto publish = [&](const double *src) { return publish_values(c, src, 2); };
     hipMemsetAsync(x, 0, sizeof(double) * np, c.stream);
     hipMemcpyAsync(g.d_r, b, sizeof(double) * np, hipMemcpyDeviceToDevice, c.stream);
     hipLaunchKernelGGL(smul_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, g.d_p);  // p = z = Dinv r
-    dots(g.d_r, g.d_p, g.d_r, g.d_r);
-    double rz = c.h_red[0];
+    dots(g.d_r, g.d_p, g.d_r, g.d_r, s);          // s[0] = r.z, s[1] = r.r (p.q of the first iteration overwrites it)
+    wait_red_seq(c, publish(s));
     const double r0 = std::sqrt(c.h_red[1]);
     if (r0 == 0.0) return 0;
+    if (!std::isfinite(r0)) return FEDM_DIVERGED_NAN;
+    unsigned long long previous = 0;
     for (int it = 0; it < max_it; ++it) {
         ell_apply(c, g.M, 0, g.d_p, nullptr, g.d_q, 0.0);
-        dots(g.d_p, g.d_q, g.d_p, g.d_q);
-        const double alpha = rz / c.h_red[0];
-        hipLaunchKernelGGL(saxpy2_kernel, gv, bv, 0, c.stream, n, alpha, g.d_p, x, -alpha, g.d_q, g.d_r);
-        hipLaunchKernelGGL(smul_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, g.d_q);  // z in q
-        dots(g.d_r, g.d_q, g.d_r, g.d_r);
-        const double rz_new = c.h_red[0], rn = std::sqrt(c.h_red[1]);
-        if (!std::isfinite(rn)) return FEDM_DIVERGED_NAN;
-        if (rn <= rtol * r0) return 0;
-        const double beta = rz_new / rz;
-        rz = rz_new;
-        hipLaunchKernelGGL(sxpby_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, beta, g.d_p);
+        dots(g.d_p, g.d_q, g.d_p, g.d_q, s + 1);                                                       // s[1] = p.q
+        hipLaunchKernelGGL(saxpy2_dev_kernel, gv, bv, 0, c.stream, n, s, g.d_p, x, g.d_q, g.d_r);
+        hipLaunchKernelGGL(smul_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, g.d_q);               // z in q
+        dots(g.d_r, g.d_q, g.d_r, g.d_r, s + 2);                                                       // s[2] = r.z, s[3] = r.r
+        const unsigned long long mine = publish(s + 2);
+        hipLaunchKernelGGL(sxpby_dev_kernel, gv, bv, 0, c.stream, n, s, g.M.dinv, g.d_r, g.d_p);
+        hipLaunchKernelGGL(cg_shift_kernel, dim3(1), dim3(1), 0, c.stream, s);
+        if (previous) {
+            wait_red_seq(c, previous);
+            const double rn = std::sqrt(c.h_red[1]);
+            if (!std::isfinite(rn)) return FEDM_DIVERGED_NAN;
+            if (rn <= rtol * r0) return 0;
+        }
+        previous = mine;
     }
-    return FEDM_DIVERGED_LINEAR;
+    wait_red_seq(c, previous);
+    const double rn = std::sqrt(c.h_red[1]);
+    if (!std::isfinite(rn)) return FEDM_DIVERGED_NAN;
+    return rn <= rtol * r0 ? 0 : FEDM_DIVERGED_LINEAR;
 }
 
 // np.interp(x, xp, fp): clamped ends, slope*(x - xp[j]) + fp[j] inside
@@ -217,6 +237,8 @@ int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab
         FEDM_HIP_CHECK(hipMalloc((void **)p, sizeof(double) * g->nvp));
         FEDM_HIP_CHECK(hipMemset(*p, 0, sizeof(double) * g->nvp));
     }
+    FEDM_HIP_CHECK(hipMalloc((void **)&g->d_cg, sizeof(double) * 8));
+    FEDM_HIP_CHECK(hipMemset(g->d_cg, 0, sizeof(double) * 8));
     c.gd_prep = g;
     return 0;
 }

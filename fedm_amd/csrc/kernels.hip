@@ -1787,6 +1787,12 @@ void norm2_read(Ctx &c, const double *x, int slot, int k) {
     wait_red(c);
 }
 
+// src[0 .. k) into the mailbox without the wait; the publication's sequence number (wait_red_seq)
+unsigned long long publish_values(Ctx &c, const double *src, int k) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, src, k, c.h_mail, c.d_mail_seq);
+    return ++c.mail_seq;
+}
+
 void read_red(Ctx &c, int k) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_mail, c.d_mail_seq);
     ++c.mail_seq;
