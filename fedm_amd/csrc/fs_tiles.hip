@@ -61,7 +61,7 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int xcd) {
 // registers (two halves a word, as they lie in memory), its local column numbers go to LDS, the arithmetic is single
 // precision with the half-precision entry as an operand of the fused multiply-add (v_fma_mix_f32: no conversions).
 template <int NS, int W, int SLOTS>
-__global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void fs_tile_sweeps_kernel(
+__global__ __launch_bounds__(512, (NS > 2 ? 3 : SLOTS <= 3 ? 6 : 4)) void fs_tile_sweeps_kernel(
     const int *__restrict__ tiles, int record, int lds_vertices, int lds_rows, int width, const int *__restrict__ vertex,
     const uint32_t *__restrict__ cols, const int *__restrict__ boff, const _Float16 *__restrict__ s16, unsigned zmask,
     const float *__restrict__ g32, const float *__restrict__ zin, float *__restrict__ zout32,
@@ -502,7 +502,7 @@ void fs_tiles_release(Ctx &c) {
 }
 
 // The tiles of this context (built at first use); nullptr where the fused sweeps do not apply: several GPUs with
-// an exchange before every sweep (one-layer halos), other than two species (the instantiations), rows too long or
+// an exchange before every sweep (one-layer halos), other than two or four species (the instantiations), rows too long or
 // layers too wide for the kernel's instantiations, or FEDM_FS_TILES=0.
 static FsTiles *fs_tiles_get(Ctx &c) {
     if (c.fs_tiles_state < 0) return nullptr;
@@ -513,13 +513,16 @@ static FsTiles *fs_tiles_get(Ctx &c) {
     const char *e = std::getenv("FEDM_FS_TILES");
     // (instantiated for two species; several GPUs: only with deep halos, where nothing is exchanged between the sweeps
     // and the ghost layers are rows of the local matrix like any other)
-    if ((e && e[0] == '0') || (c.comm && !deep_halo_active(c)) || c.ns != 2) return nullptr;
+    if ((e && e[0] == '0') || (c.comm && !deep_halo_active(c)) || (c.ns != 2 && c.ns != 4)) return nullptr;
     // 8 slices (512 vertices) and 3 layers a tile, 512 threads: on the 576 x 576 bench mesh 651 workgroups of up to
     // 973 rows, two rows a thread, all resident at once (three workgroups of eight waves per CU); Chebyshev(6) is two
     // launches, 3 + 2 sweeps: 32 us instead of 44 us for five launches.  Measured alternatives (tools/fs_tiles_probe.py):
     // 5 layers in one launch 40 us (1462 rows, three a thread at 80 registers: spills, and 1.9 x the rows), 2 layers
     // in three launches 39 us, 256 threads a tile 38 us, tiles of 4 slices 52 us
     int tile_slices = 8, depth = 3, threads = 512;
+    // four unknowns a vertex (the LMEA species block): a row's 16 half-precision planes are eight registers an entry,
+    // so a thread keeps ONE row and a tile is three slices (192 vertices + three layers: 430 rows on the 141 x 141 crossed mesh)
+    if (c.ns == 4) tile_slices = 3;
     if (const char *ts = std::getenv("FEDM_FS_TILE_SLICES")) tile_slices = std::atoi(ts);
     if (const char *td = std::getenv("FEDM_FS_TILE_DEPTH")) depth = std::atoi(td);
     if (const char *tt = std::getenv("FEDM_FS_TILE_THREADS")) threads = std::atoi(tt);
@@ -531,7 +534,7 @@ static FsTiles *fs_tiles_get(Ctx &c) {
     threads = std::max(64, std::min(512, (threads + 63) / 64 * 64));
     FsTiles *ft = new FsTiles();
     ft->threads = threads;
-    bool ok = FsTiles_build(*ft, c.pat, tile_slices, depth) && ft->width <= 12 && ft->max_rows <= 8 * threads;
+    bool ok = FsTiles_build(*ft, c.pat, tile_slices, depth) && ft->width <= 12 && ft->max_rows <= (c.ns == 4 ? 1 : 8) * threads;
     if (ok) {
         // the species kernel must fit the workgroup's LDS budget (the multigrid kernel is checked at its launch:
         // it is an extra on the same tiles)
@@ -614,7 +617,9 @@ static void fs_tiles_launch(Ctx &c, FsTiles &ft, unsigned zmask, const float *g3
                            ft.max_rows, ft.width, ft.d_vertex, ft.d_cols, c.d_slice_boff, c.d_s16, zmask, g32, in, out32, z, wt, last ? 1 : 0, \
                            x0, cpl32, b0, tile_xcd);                                                             \
     } while (0)
-    if (slots <= 2) FEDM_TILE_SWEEPS(2, 0);
+    if constexpr (NS > 2) {
+        FEDM_TILE_SWEEPS(1, 0);          // (fs_tiles_get: a row a thread)
+    } else if (slots <= 2) FEDM_TILE_SWEEPS(2, 0);
     else if (slots <= 3) FEDM_TILE_SWEEPS(3, 1);
     else if (slots <= 4) FEDM_TILE_SWEEPS(4, 2);
     else if (slots <= 6) FEDM_TILE_SWEEPS(6, 3);
@@ -649,7 +654,8 @@ bool fs_tiles_sweeps(Ctx &c, int n_sweeps, unsigned zmask, const float *g32, flo
         else if (ft->width <= 9) fs_tiles_launch<NS_, 9>(c, *ft, zmask, g32, in, out, z, wt, last, x0, cpl32, b0); \
         else fs_tiles_launch<NS_, 12>(c, *ft, zmask, g32, in, out, z, wt, last, x0, cpl32, b0);                 \
     } while (0)
-        FEDM_TILE_W(2);
+        if (c.ns == 4) FEDM_TILE_W(4);
+        else FEDM_TILE_W(2);
 #undef FEDM_TILE_W
         if (hipPeekAtLastError() != hipSuccess) {
             // a refused launch (not seen on the meshes tried): no tiles from now on; outside a capture the caller

@@ -88,3 +88,30 @@ def test_polynomial_smoother_sweeps_on_the_same_tiles(kind):
     assert np.array_equal(z[:, :2], z_ref[:, :2])
     assert not np.array_equal(z[:, 2], z_ref[:, 2])          # (it did take the other path)
     assert np.abs(z[:, 2] - z_ref[:, 2]).max() < 1e-5 * np.abs(z_ref[:, 2]).max()
+
+
+def test_tiled_sweeps_with_four_unknowns_per_vertex_equal_the_sweeps_one_by_one():
+    """The glow-discharge case: the species block has four unknowns a vertex (energy + three species), a row's sixteen
+    half-precision planes are eight registers an entry, a thread keeps one row (tiles of three slices).  Same operands,
+    same order of the sums: bit for bit the sweeps one by one."""
+    import contextlib, io
+    from fedm_amd.cases import glow_discharge as gdc
+    with contextlib.redirect_stdout(io.StringIO()):
+        case = gdc.Case(nx=60, ny=60, T_final=1.0)
+    for _ in range(3):
+        case.step()
+    prob = case.prob
+    prob.jacobian()
+    t = np.random.default_rng(3).standard_normal(prob.n)
+    prob.configure_fieldsplit_tiles(False)
+    assert prob.fieldsplit_tiles() is None
+    z_ref = prob.fieldsplit_apply(t)
+    assert np.isfinite(z_ref).all() and np.abs(z_ref).max() > 0
+    assert np.array_equal(prob.fieldsplit_apply(t), z_ref)
+    for slices, layers, threads in ((0, 0, 0), (2, 3, 512), (3, 2, 512), (1, 4, 256)):
+        prob.configure_fieldsplit_tiles(True, slices, layers, threads, multigrid=False)
+        info = prob.fieldsplit_tiles()
+        assert info is not None and info["slices_per_tile"] == (slices or 3) and info["max_rows"] <= info["threads"]
+        z = prob.fieldsplit_apply(t)
+        assert np.array_equal(z, z_ref), (slices, layers, threads, np.abs(z - z_ref).max())
+    prob.close()
