@@ -311,6 +311,7 @@ void launch_field_error(Ctx &c, int comp);  // d_red[0]=|new-old+eps|^2, d_red[1
 void launch_field_error_slots34(Ctx &c, int comp);
 void launch_set_dirichlet_state(Ctx &c);    // u[dof] = g
 unsigned long long publish_values(Ctx &c, const double *src, int k);   // src[0..k) into the host mailbox, no wait
+void publish_values_queued(Ctx &c, const double *src, int k);            // ... the launch alone (stream captures)
 void wait_red_seq(Ctx &c, unsigned long long seq);  // a particular publication (steps launched ahead)
 void read_red(Ctx &c, int k);
 void norm2_read(Ctx &c, const double *x, int slot, int k);  // launch_norm2 + read_red, one kernel fewer on one GPU               // publish d_red[0..k) to h_red and wait for it

@@ -16,11 +16,20 @@ struct GdPrep {
     std::vector<fedm_gd_field_prog> progs;
     double *d_redE = nullptr, *d_b = nullptr, *d_r = nullptr, *d_p = nullptr, *d_q = nullptr;
     double *d_cg = nullptr;     // the CG's scalars on the device: r.z, p.q, r.z of the new residual, r.r
+    hipGraphExec_t cg_graph = nullptr;   // one CG iteration (its nine launches), replayed
+    const double *cg_graph_x = nullptr;  // ... recorded for this solution vector
+    bool cg_graph_ok = true;
+    unsigned *d_cg_counter = nullptr;    // the single-launch CG: barrier counter, the workgroups' partial sums
+    double *d_cg_partials = nullptr;
+    bool cg_one_launch_ok = true;
     int nvp = 0;
     void release() {
+        if (cg_graph) hipGraphExecDestroy(cg_graph);
+        cg_graph = nullptr;
         M.release();
         for (void *p : {(void *)d_tab_ptr, (void *)d_tab_x, (void *)d_tab_y, (void *)d_progs, (void *)d_redE,
-                        (void *)d_b, (void *)d_r, (void *)d_p, (void *)d_q, (void *)d_cg})
+                        (void *)d_b, (void *)d_r, (void *)d_p, (void *)d_q, (void *)d_cg, (void *)d_cg_counter,
+                        (void *)d_cg_partials})
             if (p) hipFree(p);
     }
 };
@@ -96,6 +105,142 @@ __global__ void smul_kernel(int n, const double *__restrict__ dinv, const double
     if (i < n) z[i] = dinv[i] * r[i];
 }
 
+// ---- the whole CG as ONE launch ---------------------------------------------------------------------------------
+// The mass matrix of the glow-discharge mesh has 40 000 rows: a CG iteration is a few microseconds of work in nine
+// dependent launches, each of which costs its 5-8 us launch-to-drain floor whether or not the step is replayed as a
+// graph (72 us an iteration, 1 ms a time step, a quarter of the step).  Here a small grid of resident workgroups runs
+// all iterations itself, with a counter barrier in device memory between the three phases of an iteration (1.7-3.4 us
+// for 8-32 workgroups, tools/grid_barrier_bench): the product with its partial p.q | the updates with the partial sums
+// r.z, r.r | the new direction.  Every workgroup sums the partials itself, in a fixed order (reproducible); the spin
+// of the barrier is bounded (a barrier that gives up sets info[1] and the caller repeats the solve launch by launch).
+__device__ __forceinline__ bool cg_grid_barrier(unsigned *counter, unsigned target) {
+    __shared__ int ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22))
+            __builtin_amdgcn_s_sleep(1);
+        ok = spins < (1u << 22);
+        __threadfence();
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+// the two sums of a phase: this workgroup's into partials[2 * block + {0, 1}]
+__device__ __forceinline__ void cg_block_sums(double s0, double s1, double *partials) {
+    __shared__ double sm[2][16];
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (lane == 0) {
+        sm[0][wave] = s0;
+        sm[1][wave] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += sm[threadIdx.x][w];
+        partials[2 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+// ... and of all workgroups (after a barrier): every thread gets both totals
+__device__ __forceinline__ void cg_grid_sums(const double *partials, double &t0, double &t1) {
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < (int)gridDim.x; ++g) {       // (at most 64 workgroups: a broadcast read each, the same order everywhere)
+        a += partials[2 * g];
+        b += partials[2 * g + 1];
+    }
+    t0 = a;
+    t1 = b;
+}
+
+__global__ __launch_bounds__(512) void mass_cg_kernel(int n, int n_slices, int log2_split, int width,
+                                                      const int *__restrict__ boff, const int *__restrict__ col,
+                                                      const double *__restrict__ val, const double *__restrict__ dinv,
+                                                      const double *__restrict__ b, double *__restrict__ x,
+                                                      double *__restrict__ r, double *__restrict__ p, double *__restrict__ q,
+                                                      double rtol, int max_it, unsigned *counter, double *partials,
+                                                      double *info) {
+    const int T = blockDim.x, G = gridDim.x, tid = blockIdx.x * T + threadIdx.x, nt = G * T;
+    const int lane = threadIdx.x & 63, wave_g = tid >> 6, n_waves = nt >> 6;
+    double *pa = partials, *pb = partials + 2 * G;      // (p.q | r.z, r.r: two arrays, see the barriers)
+    unsigned done = 0;
+    bool fine = true;
+    // x = 0, r = b, p = Dinv r; r.z and r.r
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = tid; i < n; i += nt) {
+        const double ri = b[i], zi = dinv[i] * ri;
+        x[i] = 0.0;
+        r[i] = ri;
+        p[i] = zi;
+        s0 += ri * zi;
+        s1 += ri * ri;
+    }
+    cg_block_sums(s0, s1, pb);
+    fine = cg_grid_barrier(counter, ++done * G) && fine;
+    double rz, rr0;
+    cg_grid_sums(pb, rz, rr0);
+    double rr = rr0;
+    int it = 0;
+    if (rr0 > 0.0 && isfinite(rr0)) {
+        for (; it < max_it && fine; ++it) {
+            // q = M p (a wave per slice of 64 lanes, as ell_spmv_kernel<0>) and p.q
+            s0 = 0.0;
+            for (int slice = wave_g; slice < n_slices; slice += n_waves) {
+                const int b0 = width > 0 ? slice * width : boff[slice], b1 = width > 0 ? b0 + width : boff[slice + 1];
+                const size_t row = ((size_t)slice * SLICE + lane) >> log2_split;
+                double acc = 0.0;
+                for (int bc = b0; bc < b1; ++bc) {
+                    const size_t k = (size_t)bc * SLICE + lane;
+                    acc += val[k] * p[col[k]];
+                }
+                for (int off = (1 << log2_split) >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if ((lane & ((1 << log2_split) - 1)) == 0 && row < (size_t)n) {
+                    q[row] = acc;
+                    s0 += p[row] * acc;
+                }
+            }
+            cg_block_sums(s0, 0.0, pa);
+            fine = cg_grid_barrier(counter, ++done * G) && fine;
+            double pq, unused;
+            cg_grid_sums(pa, pq, unused);
+            const double alpha = pq != 0.0 ? rz / pq : 0.0;
+            // x += alpha p, r -= alpha q; r.z and r.r with z = Dinv r
+            s0 = s1 = 0.0;
+            for (int i = tid; i < n; i += nt) {
+                const double ri = r[i] - alpha * q[i];
+                x[i] += alpha * p[i];
+                r[i] = ri;
+                s0 += ri * dinv[i] * ri;
+                s1 += ri * ri;
+            }
+            cg_block_sums(s0, s1, pb);
+            fine = cg_grid_barrier(counter, ++done * G) && fine;
+            double rz_new;
+            cg_grid_sums(pb, rz_new, rr);
+            if (!(rr > rtol * rtol * rr0) || !isfinite(rr)) {     // converged (or not a number: the host looks at rr)
+                ++it;
+                break;
+            }
+            const double beta = rz != 0.0 ? rz_new / rz : 0.0;
+            rz = rz_new;
+            for (int i = tid; i < n; i += nt) p[i] = dinv[i] * r[i] + beta * p[i];
+            fine = cg_grid_barrier(counter, ++done * G) && fine;
+        }
+    }
+    if (tid == 0) {
+        info[0] = (double)it;
+        info[1] = fine ? 0.0 : 1.0;
+        info[2] = rr0;
+        info[3] = rr;
+    }
+}
+
 // The CG's updates with their scalars read from the device (s = {r.z, p.q, r.z of the new residual, r.r}): the host
 // forms neither alpha nor beta and so has nothing to wait for inside an iteration
 __global__ void saxpy2_dev_kernel(int n, const double *__restrict__ s, const double *__restrict__ p, double *__restrict__ x,
@@ -120,7 +265,33 @@ __global__ void cg_shift_kernel(double *s) { s[0] = s[2]; }
 // queued iteration k -- the iteration that runs while the convergence of the previous one is being looked at is the
 // only one that may be superfluous (it improves x a little further).  (Until round 4 the host formed alpha and beta:
 // two round trips per iteration, 26 per time step of the glow-discharge case, a tenth of its step.)
+static int mass_solve_launches(Ctx &c, GdPrep &g, const double *b, double *x, double rtol, int max_it);
+
 static int mass_solve(Ctx &c, GdPrep &g, const double *b, double *x, double rtol, int max_it) {
+    // small systems: the whole CG in one launch (above); FEDM_GD_CG=launches keeps one launch per operation
+    static const bool one_launch = [] {
+        const char *e = std::getenv("FEDM_GD_CG");
+        return !(e && e[0] == 'l');
+    }();
+    if (one_launch && g.cg_one_launch_ok && !c.capturing && c.nv <= 400000 && g.M.val && g.M.n_slices > 0) {
+        const int G = std::max(8, std::min(32, (g.M.n_slices + 15) / 16));
+        hipMemsetAsync(g.d_cg_counter, 0, sizeof(unsigned), c.stream);
+        hipLaunchKernelGGL(mass_cg_kernel, dim3(G), dim3(512), 0, c.stream, c.nv, g.M.n_slices, g.M.log2_split, g.M.width,
+                           g.M.boff, g.M.col, g.M.val, g.M.dinv, b, x, g.d_r, g.d_p, g.d_q, rtol, max_it, g.d_cg_counter,
+                           g.d_cg_partials, g.d_cg + 4);
+        wait_red_seq(c, publish_values(c, g.d_cg + 4, 4));
+        const double its = c.h_red[0], gave_up = c.h_red[1], rr0 = c.h_red[2], rr = c.h_red[3];
+        if (gave_up == 0.0) {
+            if (!std::isfinite(rr0) || !std::isfinite(rr)) return FEDM_DIVERGED_NAN;
+            if (rr0 == 0.0 || rr <= rtol * rtol * rr0) return 0;
+            return its >= max_it ? FEDM_DIVERGED_LINEAR : 0;
+        }
+        g.cg_one_launch_ok = false;   // a barrier gave up (never seen): launch by launch from now on
+    }
+    return mass_solve_launches(c, g, b, x, rtol, max_it);
+}
+
+static int mass_solve_launches(Ctx &c, GdPrep &g, const double *b, double *x, double rtol, int max_it) {
     const int n = c.nv, np = g.nvp;
     const dim3 gv((np + 255) / 256), bv(256);
     int grid = (n + 255) / 256;
@@ -139,16 +310,51 @@ static int mass_solve(Ctx &c, GdPrep &g, const double *b, double *x, double rtol
     const double r0 = std::sqrt(c.h_red[1]);
     if (r0 == 0.0) return 0;
     if (!std::isfinite(r0)) return FEDM_DIVERGED_NAN;
-    unsigned long long previous = 0;
-    for (int it = 0; it < max_it; ++it) {
+    // one iteration: nine launches on vectors of 40 000 entries, 3 us of work and 5 us of launch each -- replayed as a
+    // graph (recorded once per context; a capture that fails leaves the plain launches)
+    auto iteration = [&]() {
         ell_apply(c, g.M, 0, g.d_p, nullptr, g.d_q, 0.0);
         dots(g.d_p, g.d_q, g.d_p, g.d_q, s + 1);                                                       // s[1] = p.q
         hipLaunchKernelGGL(saxpy2_dev_kernel, gv, bv, 0, c.stream, n, s, g.d_p, x, g.d_q, g.d_r);
         hipLaunchKernelGGL(smul_kernel, gv, bv, 0, c.stream, n, g.M.dinv, g.d_r, g.d_q);               // z in q
         dots(g.d_r, g.d_q, g.d_r, g.d_r, s + 2);                                                       // s[2] = r.z, s[3] = r.r
-        const unsigned long long mine = publish(s + 2);
+        publish_values_queued(c, s + 2, 2);              // (the host counts the publication itself: a replay has no host code)
         hipLaunchKernelGGL(sxpby_dev_kernel, gv, bv, 0, c.stream, n, s, g.M.dinv, g.d_r, g.d_p);
         hipLaunchKernelGGL(cg_shift_kernel, dim3(1), dim3(1), 0, c.stream, s);
+    };
+    if (g.cg_graph && g.cg_graph_x != x) {
+        hipGraphExecDestroy(g.cg_graph);
+        g.cg_graph = nullptr;
+    }
+    if (!g.cg_graph && g.cg_graph_ok && !c.capturing && !(c.prof.on && c.prof.all_kinds)) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            c.capturing = true;
+            iteration();
+            c.capturing = false;
+            const bool ok = hipStreamEndCapture(c.stream, &graph) == hipSuccess && graph &&
+                            hipGraphInstantiate(&g.cg_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) hipGraphDestroy(graph);
+            if (!ok) g.cg_graph = nullptr;
+        }
+        if (!g.cg_graph) {
+            hipGetLastError();
+            g.cg_graph_ok = false;
+        }
+        g.cg_graph_x = x;
+    }
+    unsigned long long previous = 0;
+    for (int it = 0; it < max_it; ++it) {
+        if (g.cg_graph && hipGraphLaunch(g.cg_graph, c.stream) != hipSuccess) {
+            hipGetLastError();
+            hipGraphExecDestroy(g.cg_graph);
+            g.cg_graph = nullptr;
+            g.cg_graph_ok = false;
+            iteration();
+        } else if (!g.cg_graph) {
+            iteration();
+        }
+        const unsigned long long mine = ++c.mail_seq;
         if (previous) {
             wait_red_seq(c, previous);
             const double rn = std::sqrt(c.h_red[1]);
@@ -239,6 +445,8 @@ int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab
     }
     FEDM_HIP_CHECK(hipMalloc((void **)&g->d_cg, sizeof(double) * 8));
     FEDM_HIP_CHECK(hipMemset(g->d_cg, 0, sizeof(double) * 8));
+    FEDM_HIP_CHECK(hipMalloc((void **)&g->d_cg_counter, sizeof(unsigned) * 4));
+    FEDM_HIP_CHECK(hipMalloc((void **)&g->d_cg_partials, sizeof(double) * 4 * 64));
     c.gd_prep = g;
     return 0;
 }

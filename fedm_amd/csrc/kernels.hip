@@ -1792,6 +1792,10 @@ unsigned long long publish_values(Ctx &c, const double *src, int k) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, src, k, c.h_mail, c.d_mail_seq);
     return ++c.mail_seq;
 }
+// ... the launch alone (inside a stream capture: whoever replays the graph advances Ctx::mail_seq per replay)
+void publish_values_queued(Ctx &c, const double *src, int k) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, src, k, c.h_mail, c.d_mail_seq);
+}
 
 void read_red(Ctx &c, int k) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, k, c.h_mail, c.d_mail_seq);

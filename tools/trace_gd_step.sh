@@ -22,6 +22,16 @@ for s, e, n in half:
 print(f"second half of the trace: {len(half)} kernels, span {span:.0f} us, busy {busy:.0f} us ({100 * busy / span:.0f} %)")
 for n, v in tot.most_common(30):
     print(f"{v:10.1f} us {cnt[n]:6d} x {v / cnt[n]:7.2f}  {n}")
+# the gaps: which kernel starts after how long an idle time
+gaps = collections.Counter(); gcnt = collections.Counter()
+for (s0, e0, n0), (s1, e1, n1) in zip(half, half[1:]):
+    g = (s1 - e0) / 1e3
+    if g > 3.0:
+        key = re.sub(r"\(.*", "", n0)[:40] + "  ->  " + re.sub(r"\(.*", "", n1)[:40]
+        gaps[key] += g; gcnt[key] += 1
+print("idle times over 3 us, by the kernels on either side:")
+for k, v in gaps.most_common(14):
+    print(f"{v:10.1f} us {gcnt[k]:5d} x {v / gcnt[k]:7.1f}  {k}")
 PY
 rm -f $(find "$OUT" -name "q_kernel_trace.csv")
-cat "$OUT/out.txt"; head -40 gpurun_out/gd_step_kernels.txt
+cat "$OUT/out.txt"; head -60 gpurun_out/gd_step_kernels.txt
