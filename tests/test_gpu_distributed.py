@@ -48,16 +48,19 @@ def _worker(rank, world, port, q, restart=30, halo_depth=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("restart,halo_depth", [(30, None), (3, None), (30, 1), (30, 3)])
-def test_two_ranks_match_single_gpu(restart, halo_depth):
+@pytest.mark.parametrize("restart,halo_depth,partitioner", [(30, None, "rcb"), (3, None, "rcb"), (30, 1, "rcb"), (30, 3, "rcb"),
+                                                            (30, None, "graph")])
+def test_two_ranks_match_single_gpu(restart, halo_depth, partitioner, monkeypatch):
     """restart = 3 makes every linear solve run through several GMRES cycles: the restarted
     residual rhs - J delta (halo exchange of delta, plain product) and the accumulated update.
     halo_depth: None = the default of eight ghost layers (one exchange per Krylov step: the input
     vector on all layers; sweeps, smoothings and product on redundantly assembled ghost rows),
     1 = the one-layer halo with an exchange before every operator, 3 = ghost layers that do NOT
-    cover a preconditioner application (the library must fall back to the exchanges)."""
+    cover a preconditioner application (the library must fall back to the exchanges).  partitioner: the coordinate
+    bisection, or the multilevel graph partitioner (FEDM_PARTITIONER=graph, fedm_amd/graph_partition.py)."""
     import torch.multiprocessing as mp
     from fedm_amd.cases import streamer
+    monkeypatch.setenv("FEDM_PARTITIONER", partitioner)     # (the spawned ranks inherit it)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
