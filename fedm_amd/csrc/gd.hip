@@ -502,7 +502,7 @@ __device__ __forceinline__ GdFluxD gd_flux_partials(const double *fl, int f_mu, 
 // per quadrature point instead of once per column vertex.  That is the variant that spilled 600 bytes at two waves
 // per SIMD; here it runs at ONE wave per SIMD with the whole 512-entry register file: a
 // third of the instructions per wave for half the resident waves.
-template <int NEQ, int STORE, int NRC = 0, int NQC = 0, bool BALL = false>
+template <int NEQ, int STORE, int NRC = 0, int NQC = 0, bool BALL = false, int WV = 0>
 __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(BALL ? 1 : 2, BALL ? 1 : 2))) void gd_jacobian_rows_kernel(
     const fedm_gd_desc *__restrict__ md, const double *__restrict__ fields, int nv,
     const int *__restrict__ cell_list, int n_cells, const int *__restrict__ cells,
@@ -514,6 +514,10 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     unsigned long long t_prev_ = wall_clock64();
 #endif
     constexpr int NEQ2 = NEQ * NEQ, ns = NEQ - 1, IPHI = NEQ - 1, ie = ns - 1;
+    // waves of a workgroup: one per species/energy row (WV = 0), or WV waves that take the rows w, w + WV, ... in turn
+    // (two for the glow-discharge model: the set-up is shared by two rows a wave, two workgroups fit a CU, and the
+    // rows balance: energy + ion against metastables + electrons + Poisson)
+    constexpr int NWV = WV > 0 ? WV : NEQ - 1;
     const double two_pi = 6.283185307179586476925286766559;
     const int lc = threadIdx.x & (SLICE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         // lane = cell, the waves share the (field, vertex) pairs: no division by a run-time number
         const int nw = blockDim.x >> 6;
         constexpr int CH = 32;             // pairs requested before the first is stored (33 fields: 25 a wave)
-        constexpr int CU = (3 * NEQ + NEQ - 2) / (NEQ - 1);     // the wave's share of the unknowns
+        constexpr int CU = (3 * NEQ + NWV - 1) / NWV;           // the wave's share of the unknowns
         double *dstu = lds_u + lc;
         double tmpu[CU];
 #pragma unroll
@@ -592,16 +596,18 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     double *lds_rw = lds_e + (exp_table ? (size_t)nqp * NEQ * SLICE : 0);
     int *lds_rp = reinterpret_cast<int *>(lds_rw + ns * FEDM_GD_MAX_REACTIONS);
     if (lc < nr) {
-        const double w = (wave == 0) ? -md->energy_loss[lc] : (double)md->net[lc][wave];
         int pk = 0;
         for (int i = 0; i < ns; ++i) pk |= (md->power[lc][i] & 15) << (4 * i);
-        // energy row: a loss that is a sentinel of the decks (1: Ei - mean energy, 2: mean energy, functions.py:906-909)
-        // takes the reaction out of the row's list and into a list of its own (bits 28-29: the kind), walked at the
-        // quadrature points only when the model has such reactions -- the glow-discharge deck has none
-        const int kind = wave != 0 ? 0 : (-w > 7e77 && -w < 8e77) ? 1 : (-w > 9e99 && -w < 1e100) ? 2 : 0;
-        lds_rw[wave * FEDM_GD_MAX_REACTIONS + lc] = w;
-        lds_rp[wave * FEDM_GD_MAX_REACTIONS + lc] = (w == 0.0 || kind) ? -1 : pk;
-        if (wave == 0) lds_rp[ns * FEDM_GD_MAX_REACTIONS + lc] = kind ? (pk | kind << 28) : -1;
+        for (int rw = wave; rw < ns; rw += NWV) {     // (the rows of this wave)
+            const double w = (rw == 0) ? -md->energy_loss[lc] : (double)md->net[lc][rw];
+            // energy row: a loss that is a sentinel of the decks (1: Ei - mean energy, 2: mean energy, functions.py:906-909)
+            // takes the reaction out of the row's list and into a list of its own (bits 28-29: the kind), walked at the
+            // quadrature points only when the model has such reactions -- the glow-discharge deck has none
+            const int kind = rw != 0 ? 0 : (-w > 7e77 && -w < 8e77) ? 1 : (-w > 9e99 && -w < 1e100) ? 2 : 0;
+            lds_rw[rw * FEDM_GD_MAX_REACTIONS + lc] = w;
+            lds_rp[rw * FEDM_GD_MAX_REACTIONS + lc] = (w == 0.0 || kind) ? -1 : pk;
+            if (rw == 0) lds_rp[ns * FEDM_GD_MAX_REACTIONS + lc] = kind ? (pk | kind << 28) : -1;
+        }
     }
     if (!exp_table) __syncthreads();
     if (exp_table) {
@@ -609,7 +615,8 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
         const int f_ueo = 4 * ns + 2 * nr + 2;
         for (int q = 0; q < nqp; ++q) {
             const double p0 = 1.0 - md->qp_x[q] - md->qp_y[q], p1 = md->qp_x[q], p2 = md->qp_y[q];
-            lds_e[((size_t)q * NEQ + wave) * SLICE + lc] = exp(ulw[wave * SLICE] * p0 + ulw[(NEQ + wave) * SLICE] * p1 + ulw[(2 * NEQ + wave) * SLICE] * p2);
+            for (int sw = wave; sw < ns; sw += NWV)
+                lds_e[((size_t)q * NEQ + sw) * SLICE + lc] = exp(ulw[sw * SLICE] * p0 + ulw[(NEQ + sw) * SLICE] * p1 + ulw[(2 * NEQ + sw) * SLICE] * p2);
             if (wave == 0)
                 lds_e[((size_t)q * NEQ + ns) * SLICE + lc] =
                     exp(-(flw[(3 * f_ueo) * SLICE] * p0 + flw[(3 * f_ueo + 1) * SLICE] * p1 + flw[(3 * f_ueo + 2) * SLICE] * p2));
@@ -647,9 +654,10 @@ __global__ __launch_bounds__(64 * (NEQ - 1)) __attribute__((amdgpu_waves_per_eu(
     // workgroup is NEQ - 1 waves (four for the glow-discharge model: two workgroups per CU at two waves
     // per SIMD; five-wave workgroups left three of eight wave slots empty).
     GD_ROW_T(NEQ)
-    for (int pass = 0; pass < 2; ++pass) {
-    const int row = pass == 0 ? wave : IPHI;
-    if (pass == 1 && wave != (ns > 1 ? 1 : 0)) break;
+    const int n_own = (ns - wave + NWV - 1) / NWV;                            // species/energy rows of this wave
+    const int n_pass = n_own + (wave == (ns > 1 && NWV > 1 ? 1 : 0) ? 1 : 0);   // ... and the Poisson row
+    for (int pass = 0; pass < n_pass; ++pass) {
+    const int row = pass < n_own ? wave + pass * NWV : IPHI;
     if (mode == 1 && row != IPHI) continue;   // Poisson-only: the other rows are identity rows
     double Hrow[3];
     for (int a = 0; a < 3; ++a) {
@@ -1218,6 +1226,10 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         // the gather's thread mapping: a thread per (position, equation row) by default (measured at 200 k DOFs, F + J:
         // 353 us with a thread per position, 287-296 us per (position, row), the same per (position, plane));
         // FEDM_GD_GATHER=positions|rows
+        static const char gd_waves_mode = [] {
+            const char *e = std::getenv("FEDM_GD_WAVES");
+            return e ? e[0] : 'a';
+        }();
         static const char gather_kind = [] {
             const char *e = std::getenv("FEDM_GD_GATHER");
             return e ? e[0] : 'r';
@@ -1251,6 +1263,22 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         }                                                                                                         \
         if (gather && dest_order) {                                                                               \
             if (ball) {                                                                                           \
+                /* two waves a workgroup, each taking two rows in turn, two workgroups a CU: the set-up is paid once for two   \
+                 * rows and the rows balance -- 509 against 558 us at 402 k DOFs (2 500 workgroups), 268 against 260 us at      \
+                 * 200 k (1 243: the rounds of workgroups quantise the same way): from six workgroups a CU on                  \
+                 * (FEDM_GD_WAVES=rows / two: a wave per row / two waves, whatever the size) */                                 \
+                constexpr int WV2 = (NEQ - 1) % 2 == 0 && NEQ > 3 ? 2 : 0;                                        \
+                if (WV2 && (gd_waves_mode == 't' || (gd_waves_mode != 'r' && (long long)gh.x >= 6LL * 256))) {   \
+                    static bool ball2_attr_set = false;                                                           \
+                    if (lds_h > 64 * 1024 && !ball2_attr_set) {                                                   \
+                        hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC, true, WV2>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);              \
+                        ball2_attr_set = true;                                                                    \
+                    }                                                                                             \
+                    hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC, true, WV2>), gh, dim3(SLICE * (WV2 ? WV2 : 1)), lds_h, c.stream, c.d_gd, c.d_gd_fields, \
+                                       c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_gd_kpos, \
+                                       c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \
+                } else {                                                                                          \
                 static bool ball_attr_set = false;                                                                \
                 if (lds_h > 64 * 1024 && !ball_attr_set) {                                                        \
                     hipFuncSetAttribute(reinterpret_cast<const void *>(&gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC, true>), \
@@ -1260,6 +1288,7 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
                 hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC, true>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                    c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_gd_kpos,  \
                                    c.d_u, c.d_uold, c.d_uold1, c.dt, c.dt_old, c.d_gd_elem, c.d_F, mode, c.d_gd_elemF, exp_table); \
+                }                                                                                                 \
             } else                                                                                                \
             hipLaunchKernelGGL((gd_jacobian_rows_kernel<NEQ, 3, NRC, NQC>), gh, bh, lds_h, c.stream, c.d_gd, c.d_gd_fields, \
                                c.nv, (const int *)nullptr, n, c.d_cells, c.d_coords, c.d_ftags, c.d_gd_kpos,      \

@@ -28,6 +28,9 @@ def test_gd_residual_and_jacobian_match_the_oracle(variant, losses, monkeypatch)
     from oracle import gd as ogd
     from fedm_amd.cases import glow_discharge as gdc
     monkeypatch.setenv("FEDM_GD_HAND", variant)
+    # (variant 5 on a mesh of this size runs a wave per row; "sentinels" also takes its two-wave workgroups, which
+    # large meshes get: two rows a wave in turn)
+    monkeypatch.setenv("FEDM_GD_WAVES", "two" if losses == "sentinels" else "auto")
     extra = dict(energy_loss=SENTINEL_LOSSES, energy_Ei=15.76) if losses == "sentinels" else {}
     case = gdc.Case(nx=10, ny=10, device_pipeline=False, **extra)
     o = ogd.GlowDischarge(DECK, 10, 10)
