@@ -1464,6 +1464,10 @@ int fedm_state_snapshot(fedm_ctx *h) {
         FEDM_HIP_CHECK(hipMemcpyAsync(c.d_snapshot + (size_t)k * c.np, src[k], sizeof(double) * c.np,
                                       hipMemcpyDeviceToDevice, c.stream));
     FEDM_HIP_CHECK(hipStreamSynchronize(c.stream));
+    // ... and what the solver has learnt from the steps before (how many Krylov steps to queue ahead, at which Newton
+    // iteration the final check is expected): steps repeated from the checkpoint then run as they did the first time
+    c.snap_krylov_steps_hint = c.krylov_steps_hint;
+    c.snap_newton_its_hint = c.newton_its_hint;
     return 0;
 }
 
@@ -1474,6 +1478,8 @@ int fedm_state_restore(fedm_ctx *h) {
         return -2;
     }
     c.err_cache_comp = -1;
+    c.krylov_steps_hint = c.snap_krylov_steps_hint;
+    c.newton_its_hint = c.snap_newton_its_hint;
     FEDM_HIP_CHECK(hipSetDevice(c.device));
     c.halo_pending = false;   // the snapshot was taken with exchanged ghosts
     double *dst[3] = {c.d_u, c.d_uold, c.d_uold1};

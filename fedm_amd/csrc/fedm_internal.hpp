@@ -245,6 +245,7 @@ struct Ctx {
     bool iter_graphs_ok = true;   // false after a failed capture: plain launches from then on
     bool capturing = false;
     int newton_its_hint = -1;     // Newton iterations of the previous converged solve
+    int snap_krylov_steps_hint = 0, snap_newton_its_hint = -1;   // ... as of fedm_state_snapshot
     // relative change of one component, computed with the final residual check of the last Newton solve
     // (fedm_newton_opts::watch_component); dropped by anything that touches the state
     int err_cache_comp = -1;
