@@ -323,8 +323,8 @@ def test_several_gpu_solver_on_one_rank_over_rccl_matches_single_gpu():
     p.start()
     res = mp_results.collect([p], q, 1, 600)[0]
     p.join(timeout=60)
-    assert p.exitcode == 0
-    assert res[5] == "rccl" and res[6]["transport"] == "rccl" and not res[6]["failed"] and res[6]["allreduces"] > 0
+    assert p.exitcode == 0, p.exitcode
+    assert res[5] == "rccl" and res[6]["transport"] == "rccl" and not res[6]["failed"] and res[6]["allreduces"] > 0, (res[5], res[6])
     msh = streamer.mesh(res[4], 2.0)
     prob = streamer.device_problem(msh.coords, msh.cells)
     st = streamer.Stepper(prob, **TOL)
@@ -335,7 +335,8 @@ def test_several_gpu_solver_on_one_rank_over_rccl_matches_single_gpu():
     U_ref = prob.get_state()
     U = np.zeros_like(U_ref)
     U[res[1]] = res[2]
-    assert (np.abs(U - U_ref) / np.abs(U_ref).max(axis=0)).max() < 1e-8
+    diff = (np.abs(U - U_ref) / np.abs(U_ref).max(axis=0)).max()
+    assert diff < 1e-8, (diff, res[3], st.log_rows())
 
 
 def test_two_ranks_over_rccl_match_single_gpu():
