@@ -75,7 +75,7 @@ static int check_model(const fedm_model_desc &m) {
     if (m.n_qp < 1 || m.n_qp > FEDM_MAX_QP || m.n_fqp < 0 || m.n_fqp > FEDM_MAX_FQP) return 1;
     if (m.n_tags < 0 || m.n_tags > FEDM_MAX_TAGS) return 1;
     const int ns = m.n_species, po = m.poisson ? 1 : 0;
-    const bool ok = (ns == 1) || (ns == 2) || (ns == 3 && po);
+    const bool ok = (ns == 1) || (ns == 2) || ((ns == 3 || ns == 4) && po);
     if (!ok) return 1;
     for (int s = 0; s < ns; ++s) {
         if (m.eq_type[s] < 0 || m.eq_type[s] > 2) return 1;
@@ -1018,11 +1018,11 @@ int fedm_ctx_create(const fedm_mesh_desc *mesh, const fedm_model_desc *model, in
         return -2;
     }
     if (check_model(*model)) {
-        // refused, never truncated: the LFA kernels are instantiated for 1-2 species without and 1-3 species
+        // refused, never truncated: the LFA kernels are instantiated for 1-2 species without and 1-4 species
         // with a Poisson equation (fedm_model_desc's arrays hold FEDM_MAX_SPECIES = 4 and FEDM_MAX_REACTIONS = 8)
         set_error("unsupported LFA model: " + std::to_string(model->n_species) + " species" +
                   (model->poisson ? " + Poisson" : "") + ", " + std::to_string(model->n_reactions) +
-                  " reactions, " + std::to_string(model->n_qp) + " quadrature points (supported: 1-2 species, or 1-3 "
+                  " reactions, " + std::to_string(model->n_qp) + " quadrature points (supported: 1-2 species, or 1-4 "
                   "with a Poisson equation; at most " + std::to_string(FEDM_MAX_REACTIONS) + " reactions, " +
                   std::to_string(FEDM_MAX_TERMS) + " terms per coefficient, " + std::to_string(FEDM_MAX_QP) +
                   " quadrature points)");

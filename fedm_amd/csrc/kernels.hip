@@ -585,6 +585,7 @@ static void launch_boundary_range(Ctx &c, bool jacobian, int f0, int n) {
         case 1: hipLaunchKernelGGL((boundary_kernel<1, ATOMIC>), g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
         case 2: hipLaunchKernelGGL((boundary_kernel<2, ATOMIC>), g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
         case 3: hipLaunchKernelGGL((boundary_kernel<3, ATOMIC>), g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
+        case 4: hipLaunchKernelGGL((boundary_kernel<4, ATOMIC>), g, b, 0, c.stream, c.d_model, n, fl, c.d_cells, c.d_coords, c.d_cell_slots, c.d_u, c.d_val, c.d_F, jacobian ? 1 : 0); break;
     }
 }
 
@@ -645,6 +646,7 @@ void launch_assemble(Ctx &c, bool jacobian, int mode) {
     else if (c.ns == 2 && c.poisson) assemble_dispatch<2, true>(c, jacobian, mode);
     else if (c.ns == 2 && !c.poisson) assemble_dispatch<2, false>(c, jacobian, mode);
     else if (c.ns == 3 && c.poisson) assemble_dispatch<3, true>(c, jacobian, mode);
+    else if (c.ns == 4 && c.poisson) assemble_dispatch<4, true>(c, jacobian, mode);
     prof_end(c);
     if (mode == 0) {
         static const bool fuse_off = [] {
@@ -654,7 +656,7 @@ void launch_assemble(Ctx &c, bool jacobian, int mode) {
         // one GPU, patch assembly (the facets in one launch, with atomics), no row shared with a Dirichlet dof: the
         // facets go into launch_finalize's launch
         if (!fuse_off && !c.comm && c.n_owned == c.nv && !c.d_identity && c.assembly_kind == 1 && c.poisson &&
-            c.n_bfacets > 0 && c.boundary_rows_disjoint && c.ns >= 1 && c.ns <= 3)
+            c.n_bfacets > 0 && c.boundary_rows_disjoint && c.ns >= 1 && c.ns <= 4)
             c.boundary_pending = jacobian ? 2 : 1;
         else
             launch_boundary(c, jacobian);
@@ -812,7 +814,8 @@ void launch_finalize(Ctx &c, bool jacobian, int mode) {
                        c.d_dir_dofs, c.d_dir_vals, c.d_slice_boff, c.d_diag_slot, c.nv, n_id)
             if (c.ns == 1) FEDM_BD(1);
             else if (c.ns == 2) FEDM_BD(2);
-            else FEDM_BD(3);
+            else if (c.ns == 3) FEDM_BD(3);
+            else FEDM_BD(4);
 #undef FEDM_BD
             return;
         }

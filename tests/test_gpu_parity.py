@@ -921,3 +921,90 @@ def test_one_pass_assembly_of_models_with_another_structure_than_the_benchmark_d
         rowmax = abs(J0).max(axis=1).toarray().ravel()
         assert np.abs(F1 - F0).max() <= 1e-12 * np.abs(F0).max(), name
         assert (abs(J1 - J0).max(axis=1).toarray().ravel() <= 1e-11 * rowmax + 1e-300).all(), name
+
+
+@pytest.mark.parametrize("lean", ["2", "0"])
+def test_four_species_and_poisson_against_the_oracle(monkeypatch, lean):
+    """The largest model `fedm_model_desc` holds (FEDM_MAX_SPECIES = 4 + Poisson, five equations): a metastable that only
+    diffuses, an ion that drifts, a negative ion drifting with a prescribed velocity, electrons with field-dependent
+    coefficients; three reactions with field-dependent, constant and quadratic rates.  Residual, Jacobian, product and
+    a Newton step of the device path (row-phase kernels / unrolled element routine) against the numpy oracle
+    (oracle/forms.py restates fedm/functions.py:240-401 for any number of species)."""
+    from oracle import streamer as ost
+    from oracle.forms import LFAModel, TermSum as OTermSum
+    from oracle.mesh import Mesh as OMesh, mark_boundaries
+    from fedm_amd.cases import streamer
+    from fedm_amd.device import DeviceProblem, Model, Reaction
+    from fedm_amd.mesh import Marking_boundaries, Mesh
+    from fedm_amd.termsum import TermSum, parse
+    monkeypatch.setenv("FEDM_ASSEMBLY_LEAN", lean)
+    msh = streamer.mesh(20, 2.0)
+    m = Mesh(msh.coords, msh.cells)
+    tags = Marking_boundaries(m, streamer.BOUNDARIES)
+    nv = m.coords.shape[0]
+    eq = ["diffusion-reaction", "drift-diffusion-reaction", "drift-diffusion-reaction", "drift-diffusion-reaction"]
+    Z = [0.0, 1.0, -1.0, -1.0]
+    bc = [[kind[0]] * 3 + [kind[1]] for kind in streamer.BC_TYPE]        # the electrons keep the deck's wall types
+    mu_e = parse(streamer.MU_E)
+    ionisation = parse(streamer.ALPHA) * mu_e * TermSum.field()
+    model = Model(n_species=4, poisson=True, eq_type=eq, Z=Z,
+                  mu=[TermSum.const(0.0), TermSum.const(2e-4), TermSum.const(0.0), mu_e],
+                  D=[TermSum.const(5e-4), TermSum.const(3e-6), TermSum.const(2e-3), parse(streamer.D_E)],
+                  reactions=[Reaction(ionisation, power=[0, 0, 0, 1], net=[0, 1, 0, 1]),
+                             Reaction(TermSum.const(3e-17), power=[1, 0, 0, 1], net=[-1, 1, 0, 1]),
+                             Reaction(TermSum.const(1e-19), power=[0, 1, 1, 0], net=[1, -1, -1, 0])],
+                  drift_w=[None, None, (1.0e3, -2.0e3), None], bc_kind=bc, quadrature_degree=2)
+    ddofs, dvals = streamer.dirichlet(m.coords)
+    ddofs = (ddofs // 3) * 5 + 4
+    prob = DeviceProblem(m.coords, m.cells, model, facet_tags=tags, dirichlet_dofs=ddofs.astype(np.int32), dirichlet_vals=dvals)
+    assert prob.assembly_variant() == ("lds-patches" if lean == "2" else "lds-patches/unrolled")
+    omesh = OMesh(msh.coords, msh.cells)
+    om = LFAModel(omesh, 4, True, eq, Z,
+                  mu=[0.0, 2e-4, 0.0, ost.MU_E], D=[5e-4, 3e-6, 2e-3, ost.D_E],
+                  drift_w=[None, None, (1.0e3, -2.0e3), None],
+                  reactions=[(ost.K_ION, [0, 0, 0, 1], [0, 1, 0, 1]), (3e-17, [1, 0, 0, 1], [-1, 1, 0, 1]),
+                             (1e-19, [0, 1, 1, 0], [1, -1, -1, 0])],
+                  facet_tags=mark_boundaries(omesh, ost.BOUNDARIES), bc_type=bc, qdeg=2)
+    om.dirichlet_dofs, om.dirichlet_vals = ddofs.astype(np.int64), dvals
+    rng = np.random.default_rng(4)
+    x, y = m.coords[:, 0] / streamer.BOX, m.coords[:, 1] / streamer.BOX
+    U = np.zeros((nv, 5))
+    U[:, 0] = 27.0 + np.sin(4 * x) * np.cos(2 * y)
+    U[:, 1] = 30.0 + 2.0 * np.sin(5 * x) * np.cos(3 * y)
+    U[:, 2] = 25.0 + np.sin(3 * x + 2 * y)
+    U[:, 3] = 29.0 + 2.0 * np.cos(4 * x) * np.sin(6 * y)
+    U[:, 4] = streamer.U_W * y + 50.0 * np.sin(3 * x) * np.sin(np.pi * y)
+    U.ravel()[ddofs] = dvals
+    Uo = U + 0.01 * rng.standard_normal(U.shape)
+    Uo1 = U + 0.02 * rng.standard_normal(U.shape)
+    dt, dt_old = 5e-12, 4e-12
+    prob.set_state(U, Uo, Uo1)
+    prob.set_step(dt, dt_old)
+    F_gpu, fnorm = prob.residual()
+    F_cpu, J_cpu = om.residual_jacobian(U, Uo, Uo1, dt, dt_old)
+    scale = np.abs(F_cpu).reshape(-1, 5).max(axis=0)
+    assert (np.abs(F_gpu - F_cpu).reshape(-1, 5) / scale).max() < 1e-11
+    assert fnorm == pytest.approx(np.linalg.norm(F_cpu), rel=1e-11)
+    prob.jacobian()
+    J_gpu = prob.jacobian_csr()
+    assert _rel_rows(J_gpu, J_cpu) < 1e-10
+    xv = rng.normal(size=prob.n)
+    yv, yc = prob.spmv(xv), J_cpu @ xv
+    assert np.abs(yv - yc).max() / np.abs(yc).max() < 1e-11
+    # a Newton solve of one time step (point-block Jacobi GMRES here; then with the field split: species polynomial +
+    # multigrid on the potential block) against the oracle's Newton with direct solves
+    from oracle.newton import newton_solve
+    from fedm_amd.device import chebyshev_weights
+    U_cpu = Uo.copy()
+    its_cpu, _ = newton_solve(om, U_cpu, Uo, Uo1, dt, dt_old, 1e-8, 25)
+    for split in (False, True):
+        prob.set_state(Uo, Uo, Uo1)
+        prob.set_step(dt, dt_old)
+        if split:
+            prob.setup_multigrid(**streamer.MULTIGRID)
+            prob.set_fieldsplit(chebyshev_weights(6))
+        its, _ = prob.newton_solve(rtol=1e-8, max_it=25, ksp_rtol=1e-10, ksp_max_it=2000)
+        assert its == its_cpu, (split, its, its_cpu)
+        d = np.abs(prob.get_state() - U_cpu).max(axis=0) / np.abs(U_cpu).max(axis=0)
+        assert d.max() < 1e-8, (split, d)
+    prob.close()

@@ -1012,9 +1012,10 @@ def test_dolfin_like_names_of_the_star_import(tmp_path):
 
 def test_models_beyond_the_instantiated_kernels_are_refused_not_truncated():
     """The descriptors are fixed-size structs and the LFA kernels are instantiated for 1-2 species without
-    and 1-3 species with a Poisson equation: a larger deck is refused with a message that names the limits
-    -- by the Python descriptor (5 species do not fit the struct) and by fedm_ctx_create (4 species fit the
-    struct but no kernel exists), before any device is touched."""
+    and 1-4 species with a Poisson equation (the four-species model on the device: tests/test_gpu_parity.py): a deck
+    beyond that is refused with a message that names the limits -- by the Python descriptor (5 species do not fit
+    the struct) and by fedm_ctx_create (3 species without a Poisson equation fit the struct but no kernel exists),
+    before any device is touched."""
     import ctypes as C
     from fedm_amd import _lib
     from fedm_amd.device import Model, Reaction
@@ -1022,7 +1023,7 @@ def test_models_beyond_the_instantiated_kernels_are_refused_not_truncated():
     big = Model(n_species=5, poisson=True, eq_type=["reaction"] * 5, Z=[0.0] * 5)
     with pytest.raises(ValueError, match="n_species must be 1..4"):
         big.to_c()
-    four = Model(n_species=4, poisson=True, eq_type=["reaction"] * 4, Z=[1.0, -1.0, 0.0, 0.0])
+    three = Model(n_species=3, poisson=False, eq_type=["reaction"] * 3, Z=[1.0, -1.0, 0.0])
     many = Model(n_species=2, poisson=True, eq_type=["reaction"] * 2, Z=[1.0, -1.0],
                  reactions=[Reaction(TermSum.const(1.0), power=[1, 0], net=[0, 1])] * 9)
     with pytest.raises(ValueError, match="at most 8 reactions"):
@@ -1035,10 +1036,10 @@ def test_models_beyond_the_instantiated_kernels_are_refused_not_truncated():
     mesh.coords = coords.ctypes.data_as(C.POINTER(C.c_double))
     mesh.cells = cells.ctypes.data_as(C.POINTER(C.c_int32))
     handle = C.c_void_p()
-    md = four.to_c()
+    md = three.to_c()
     assert lib.fedm_ctx_create(C.byref(mesh), C.byref(md), 0, C.byref(handle)) == -2 and not handle
     msg = _lib.last_error()
-    assert "4 species + Poisson" in msg and "1-3 with a Poisson equation" in msg
+    assert "unsupported LFA model: 3 species," in msg and "1-4 with a Poisson equation" in msg
 
 
 def test_binding_brings_torch_in_before_the_hip_library():
