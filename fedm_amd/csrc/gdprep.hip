@@ -268,12 +268,8 @@ __global__ void cg_shift_kernel(double *s) { s[0] = s[2]; }
 static int mass_solve_launches(Ctx &c, GdPrep &g, const double *b, double *x, double rtol, int max_it);
 
 static int mass_solve(Ctx &c, GdPrep &g, const double *b, double *x, double rtol, int max_it) {
-    // small systems: the whole CG in one launch (above); FEDM_GD_CG=launches keeps one launch per operation
-    static const bool one_launch = [] {
-        const char *e = std::getenv("FEDM_GD_CG");
-        return !(e && e[0] == 'l');
-    }();
-    if (one_launch && g.cg_one_launch_ok && !c.capturing && c.nv <= 400000 && g.M.val && g.M.n_slices > 0) {
+    // small systems: the whole CG in one launch (above); FEDM_GD_CG=launches (read at set-up) keeps one launch per operation
+    if (g.cg_one_launch_ok && !c.capturing && c.nv <= 400000 && g.M.val && g.M.n_slices > 0) {
         const int G = std::max(8, std::min(32, (g.M.n_slices + 15) / 16));
         hipMemsetAsync(g.d_cg_counter, 0, sizeof(unsigned), c.stream);
         hipLaunchKernelGGL(mass_cg_kernel, dim3(G), dim3(512), 0, c.stream, c.nv, g.M.n_slices, g.M.log2_split, g.M.width,
@@ -445,6 +441,10 @@ int gd_prep_setup(Ctx &c, const fedm_csr *mass, int n_tables, const int32_t *tab
     }
     FEDM_HIP_CHECK(hipMalloc((void **)&g->d_cg, sizeof(double) * 8));
     FEDM_HIP_CHECK(hipMemset(g->d_cg, 0, sizeof(double) * 8));
+    {
+        const char *e = std::getenv("FEDM_GD_CG");     // (read when the pipeline is set up)
+        g->cg_one_launch_ok = !(e && e[0] == 'l');
+    }
     FEDM_HIP_CHECK(hipMalloc((void **)&g->d_cg_counter, sizeof(unsigned) * 4));
     FEDM_HIP_CHECK(hipMalloc((void **)&g->d_cg_partials, sizeof(double) * 4 * 64));
     c.gd_prep = g;

@@ -82,10 +82,14 @@ def test_gd_residual_and_jacobian_match_the_oracle(variant, losses, monkeypatch)
     assert (sp.diags(1.0 / rs) @ D).max() < 1e-9
 
 
-def test_gd_device_pipeline_matches_host_pipeline():
+@pytest.mark.parametrize("cg", ["one launch", "launches"])
+def test_gd_device_pipeline_matches_host_pipeline(cg, monkeypatch):
     """fedm-gd.py:424-443,452 on the device (projection CG, np.interp look-ups, ESR, mean
-    energy) against the same steps with the façade's host functions."""
+    energy) against the same steps with the façade's host functions.  cg: the projection's Jacobi-CG as ONE launch of
+    a resident grid with counter barriers (the default for meshes of this size) and launch by launch with its scalars
+    on the device (FEDM_GD_CG=launches: larger meshes, and where a barrier of the single launch should ever give up)."""
     from fedm_amd.cases import glow_discharge as gdc
+    monkeypatch.setenv("FEDM_GD_CG", "launches" if cg == "launches" else "one")
     host = gdc.Case(nx=24, ny=24, device_pipeline=False, T_final=1.0)
     dev = gdc.Case(nx=24, ny=24, device_pipeline=True, T_final=1.0)
     # A self-comparison of two PIPELINES, so the solves in between must not add a Krylov-path dependent
