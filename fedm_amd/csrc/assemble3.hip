@@ -1227,14 +1227,10 @@ static bool lean3_launch_one(Ctx &c, bool jacobian, const int *list, int n, int 
     // one workgroup per patch (default) or the persistent, software-pipelined kernels (FEDM_LEAN3_PERSISTENT=1:
     // measured equal on the refined mesh, 79.4 against 79.5 us in the bench, and slower on the tensor-product mesh,
     // 88.8 against 66.5 us, whose 5 203 patches leave 1 024 resident workgroups with six or five patches each)
-    static const bool persistent = [] {
-        const char *e = std::getenv("FEDM_LEAN3_PERSISTENT");
-        return e && e[0] == '1';
-    }();
-    static const int wgs_per_cu_env = [] {
-        const char *e = std::getenv("FEDM_LEAN3_WGS_PER_CU");
-        return e ? std::atoi(e) : 0;
-    }();
+    // (read per launch, not once per process: the tests compare the two forms in one process)
+    const char *env_persistent = std::getenv("FEDM_LEAN3_PERSISTENT"), *env_wgs = std::getenv("FEDM_LEAN3_WGS_PER_CU");
+    const bool persistent = env_persistent && env_persistent[0] == '1';
+    const int wgs_per_cu_env = env_wgs ? std::atoi(env_wgs) : 0;
     if (persistent && verts <= T) {
         // as many workgroups as the chip holds at once (a multiple of 8: the XCDs' shares), each taking its patches
         // one after the other
@@ -1324,11 +1320,8 @@ static bool lean3_launch(Ctx &c, bool jacobian, const int *list, int n) {
 // planes the model keeps -- potential-potential alone, or together with a structurally zero species plane.
 // Everything else stays on the second generation (kernels.hip).
 bool lean3_applies(const Ctx &c) {
-    static const bool off = [] {
-        const char *e = std::getenv("FEDM_ASSEMBLY_LEAN");
-        return e && std::atoi(e) < 3;
-    }();
-    if (off || c.ns != 2 || !c.poisson || c.model.n_reactions > 1 || c.pat.max_patch_cells > 2 * 192) return false;
+    // (FEDM_ASSEMBLY_LEAN below 3 keeps the earlier generations: Ctx::assembly_lean, read when the context is created)
+    if (c.assembly_lean < 3 || c.ns != 2 || !c.poisson || c.model.n_reactions > 1 || c.pat.max_patch_cells > 2 * 192) return false;
     Lean3Plan<2, 1> plan;
     return lean3_build_plan<2, 1>(c.model, plan);
 }

@@ -1226,10 +1226,8 @@ void launch_assemble_gd(Ctx &c, bool jacobian, int mode) {
         // the gather's thread mapping: a thread per (position, equation row) by default (measured at 200 k DOFs, F + J:
         // 353 us with a thread per position, 287-296 us per (position, row), the same per (position, plane));
         // FEDM_GD_GATHER=positions|rows
-        static const char gd_waves_mode = [] {
-            const char *e = std::getenv("FEDM_GD_WAVES");
-            return e ? e[0] : 'a';
-        }();
+        const char *gd_waves_env = std::getenv("FEDM_GD_WAVES");     // (per launch: the tests switch it)
+        const char gd_waves_mode = gd_waves_env ? gd_waves_env[0] : 'a';
         static const char gather_kind = [] {
             const char *e = std::getenv("FEDM_GD_GATHER");
             return e ? e[0] : 'r';
