@@ -29,15 +29,17 @@ struct FsTiles {
     int threads = 512;            // per tile: a thread carries max_rows / threads rows in registers
     int *d_tile = nullptr;        // per tile: [vertex offset, column offset, row stride, cnt[0..depth]] (cnt[L]: vertices of layers <= L)
     int *d_vertex = nullptr;      // vertex numbers, tile by tile
+    uint32_t *d_rowinfo = nullptr; // beside them: first entry of the vertex's matrix row (block column * 64 + lane) | entries << 26
     uint32_t *d_cols = nullptr;   // [column offset + (entry / 2) * row stride + row]: two 16-bit local columns a word
     long long total_rows = 0, total_vertices = 0;
     size_t bytes = 0;
     size_t lds_limit = 64 * 1024;   // dynamic LDS a workgroup may ask for on this device (fs_tiles_get)
     bool usable = false;
     void release() {
-        for (void *p : {(void *)d_tile, (void *)d_vertex, (void *)d_cols})
+        for (void *p : {(void *)d_tile, (void *)d_vertex, (void *)d_cols, (void *)d_rowinfo})
             if (p) hipFree(p);
         d_tile = d_vertex = nullptr;
+        d_rowinfo = nullptr;
         d_cols = nullptr;
         usable = false;
     }
@@ -63,7 +65,7 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int xcd) {
 template <int NS, int W, int SLOTS>
 __global__ __launch_bounds__(512, (NS > 2 ? 3 : SLOTS <= 3 ? 6 : 4)) void fs_tile_sweeps_kernel(
     const int *__restrict__ tiles, int record, int lds_vertices, int lds_rows, int width, const int *__restrict__ vertex,
-    const uint32_t *__restrict__ cols, const int *__restrict__ boff, const _Float16 *__restrict__ s16, unsigned zmask,
+    const uint32_t *__restrict__ rowinfo, const uint32_t *__restrict__ cols, const int *__restrict__ boff, const _Float16 *__restrict__ s16, unsigned zmask,
     const float *__restrict__ g32, const float *__restrict__ zin, float *__restrict__ zout32,
     double *__restrict__ zout, FsTileWeights wt, int last, const double *__restrict__ x0,
     const float *__restrict__ cpl32, double *__restrict__ b0, int xcd) {
@@ -90,19 +92,21 @@ __global__ __launch_bounds__(512, (NS > 2 ? 3 : SLOTS <= 3 ? 6 : 4)) void fs_til
 #pragma unroll
     for (int q = 0; q < PW; ++q)
         pmask[q] = (((zmask >> (2 * q)) & 1u) ? 0u : 0xffffu) | ((2 * q + 1 < PL && !((zmask >> (2 * q + 1)) & 1u)) ? 0xffff0000u : 0u);
+    uint32_t rinfo[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {   // (the address chains of all rows first, side by side)
         const int r = tid + s * T;
         vglob[s] = vertex[voff + (r < n_rows ? r : 0)];
+        rinfo[s] = rowinfo[voff + (r < n_rows ? r : 0)];
     }
     const int width2 = (width + 1) >> 1;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int r = tid + s * T;
         const int rr = r < n_rows ? r : 0;
-        const int v = vglob[s], slice = v >> 6;
-        const int bb0 = boff[slice], wrow = (boff[slice + 1] - bb0) & (r < n_rows ? -1 : 0);
-        const _Float16 *base = s16 + ((size_t)bb0 * SLICE + (v & 63)) * PL;
+        const int v = vglob[s];
+        const int wrow = (int)(rinfo[s] >> 26) & (r < n_rows ? -1 : 0);
+        const _Float16 *base = s16 + (size_t)(rinfo[s] & 0x3ffffffu) * PL;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const uint32_t have = k < wrow ? 0xffffffffu : 0u;
@@ -319,7 +323,7 @@ struct FsTileTables {
     int tile_slices = 0, depth = 0, n_tiles = 0, width = 0, record = 0, max_vertices = 0, max_rows = 0;
     long long total_rows = 0, total_vertices = 0;
     std::vector<int> tiles, vertices;
-    std::vector<uint32_t> cols;
+    std::vector<uint32_t> cols, rowinfo;
 };
 
 static bool fs_tile_tables(const Pattern &pat, int tile_slices, int depth, FsTileTables &tt) {
@@ -378,6 +382,16 @@ static bool fs_tile_tables(const Pattern &pat, int tile_slices, int depth, FsTil
         tt.total_vertices += (long long)list.size();
     }
     if (tt.max_vertices > 65535) return false;
+    // the matrix row of every listed vertex at a glance: the kernels ask for it together with the vertex number, so
+    // the row's planes do not wait for a trip through the slice offsets
+    tt.rowinfo.resize(tt.vertices.size());
+    for (size_t i = 0; i < tt.vertices.size(); ++i) {
+        const int v = tt.vertices[i], slice = v >> 6;
+        const long long first = (long long)pat.slice_boff[slice] * SLICE + (v & 63);
+        const int w = pat.slice_boff[slice + 1] - pat.slice_boff[slice];
+        if (first >= (1LL << 26) || w > 63) return false;
+        tt.rowinfo[i] = (uint32_t)first | ((uint32_t)w << 26);
+    }
     // pass 2: local column numbers of the rows of the layers < depth
     tt.cols.assign(n_cols, 0u);
     for (int t = 0; t < tt.n_tiles; ++t) {
@@ -479,10 +493,11 @@ bool FsTiles_build(FsTiles &ft, const Pattern &pat, int tile_slices, int depth) 
     ft.max_rows = tt.max_rows;
     ft.total_rows = tt.total_rows;
     ft.total_vertices = tt.total_vertices;
-    ft.bytes = sizeof(int) * (tt.tiles.size() + tt.vertices.size()) + sizeof(uint32_t) * tt.cols.size();
+    ft.bytes = sizeof(int) * (tt.tiles.size() + tt.vertices.size()) + sizeof(uint32_t) * (tt.cols.size() + tt.rowinfo.size());
     if (hipMalloc((void **)&ft.d_tile, sizeof(int) * tt.tiles.size()) != hipSuccess ||
         hipMalloc((void **)&ft.d_vertex, sizeof(int) * tt.vertices.size()) != hipSuccess ||
-        hipMalloc((void **)&ft.d_cols, sizeof(uint32_t) * std::max<size_t>(tt.cols.size(), 1)) != hipSuccess) {
+        hipMalloc((void **)&ft.d_cols, sizeof(uint32_t) * std::max<size_t>(tt.cols.size(), 1)) != hipSuccess ||
+        hipMalloc((void **)&ft.d_rowinfo, sizeof(uint32_t) * std::max<size_t>(tt.rowinfo.size(), 1)) != hipSuccess) {
         hipGetLastError();
         ft.release();
         return false;
@@ -490,6 +505,7 @@ bool FsTiles_build(FsTiles &ft, const Pattern &pat, int tile_slices, int depth) 
     hipMemcpy(ft.d_tile, tt.tiles.data(), sizeof(int) * tt.tiles.size(), hipMemcpyHostToDevice);
     hipMemcpy(ft.d_vertex, tt.vertices.data(), sizeof(int) * tt.vertices.size(), hipMemcpyHostToDevice);
     hipMemcpy(ft.d_cols, tt.cols.data(), sizeof(uint32_t) * tt.cols.size(), hipMemcpyHostToDevice);
+    hipMemcpy(ft.d_rowinfo, tt.rowinfo.data(), sizeof(uint32_t) * tt.rowinfo.size(), hipMemcpyHostToDevice);
     ft.usable = true;
     return true;
 }
@@ -614,7 +630,7 @@ static void fs_tiles_launch(Ctx &c, FsTiles &ft, unsigned zmask, const float *g3
             lds_granted[IDX] = lds;                                                                              \
         }                                                                                                        \
         hipLaunchKernelGGL((fs_tile_sweeps_kernel<NS, W, SL>), g, b, lds, c.stream, ft.d_tile, ft.record, ft.max_vertices, \
-                           ft.max_rows, ft.width, ft.d_vertex, ft.d_cols, c.d_slice_boff, c.d_s16, zmask, g32, in, out32, z, wt, last ? 1 : 0, \
+                           ft.max_rows, ft.width, ft.d_vertex, ft.d_rowinfo, ft.d_cols, c.d_slice_boff, c.d_s16, zmask, g32, in, out32, z, wt, last ? 1 : 0, \
                            x0, cpl32, b0, tile_xcd);                                                             \
     } while (0)
     if constexpr (NS > 2) {
