@@ -239,7 +239,7 @@ struct MgTileWeights {
 template <int W, int SLOTS>
 __global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void mg_tile_sweeps_kernel(
     const int *__restrict__ tiles, int record, int lds_vertices, int lds_rows, int width, const int *__restrict__ vertex,
-    const uint32_t *__restrict__ cols, const int *__restrict__ boff, const double *__restrict__ val, int neq2, int plane,
+    const uint32_t *__restrict__ rowinfo, const uint32_t *__restrict__ cols, const int *__restrict__ boff, const double *__restrict__ val, int neq2, int plane,
     const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ xin, MgTileWeights wt,
     double *__restrict__ out, int ostride, int ooff, int xcd) {
     constexpr int W2 = (W + 1) / 2;
@@ -254,19 +254,22 @@ __global__ __launch_bounds__(512, (SLOTS <= 3 ? 6 : 4)) void mg_tile_sweeps_kern
     const int n_vertices = cnt[n], n_rows = cnt[n - 1], n_own = cnt[0];
     double a[SLOTS][W], dv[SLOTS], bv[SLOTS];
     int vglob[SLOTS];
+    uint32_t rinfo[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int r = tid + s * T;
         vglob[s] = vertex[voff + (r < n_rows ? r : 0)];
+        rinfo[s] = rowinfo[voff + (r < n_rows ? r : 0)];
     }
     const int width2 = (width + 1) >> 1;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int r = tid + s * T;
         const int rr = r < n_rows ? r : 0;
-        const int v = vglob[s], slice = v >> 6;
-        const int bb0 = boff[slice], wrow = (boff[slice + 1] - bb0) & (r < n_rows ? -1 : 0);
-        const double *base = val + ((size_t)bb0 * neq2 + plane) * SLICE + (v & 63);
+        const int v = vglob[s];
+        const uint32_t first = rinfo[s] & 0x3ffffffu;      // (block column * 64 + lane of the row's first entry)
+        const int wrow = (int)(rinfo[s] >> 26) & (r < n_rows ? -1 : 0);
+        const double *base = val + ((size_t)(first >> 6) * neq2 + plane) * SLICE + (first & 63u);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             // (branch-free, as in fs_tile_sweeps_kernel: a valid address always, a select on the value)
@@ -720,7 +723,7 @@ bool mg_tiles_sweeps(Ctx &c, const EllMat &A, const double *b, const double *xin
         }                                                                                                         \
         hipLaunchKernelGGL((mg_tile_sweeps_kernel<WW, SL>), g, bl, mg_lds,                                        \
                            c.stream, ft->d_tile, ft->record, ft->max_vertices, ft->max_rows, ft->width, ft->d_vertex, \
-                           ft->d_cols, c.d_slice_boff, c.d_val, neq2, neq2 - 1, A.dinv, b, xin, wt, out, ostride, ooff, 1); \
+                           ft->d_rowinfo, ft->d_cols, c.d_slice_boff, c.d_val, neq2, neq2 - 1, A.dinv, b, xin, wt, out, ostride, ooff, 1); \
     } while (0)
 #define FEDM_MG_TILE_S(WW, BASE)                                                                                  \
     do {                                                                                                          \
