@@ -16,7 +16,12 @@ import mp_results  # noqa: E402
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 N_PER_GPU, STEPS = 16, 3
-TOL = dict(relative_tolerance=1e-9)
+# Newton's relative tolerance of these comparisons.  It was 1e-9 until a step of the two-rank run failed once in ~25
+# runs: "maximum number of Newton iterations reached" at |F| = 4.07e5 from |F0| = 2.13e14, i.e. the residual stalls at
+# 1.9e-9 |F0| -- the rounding floor of the assembled residual (sums of 1e14-sized terms in an order the LDS atomics do
+# not fix) sits ABOVE 1e-9 |F0| in some runs; adaptive_solver then halves the step and the histories differ.  1e-8 is
+# five times that floor; the states still agree to 1e-8 x (a step's change) << the 1e-8 asked of them below.
+TOL = dict(relative_tolerance=1e-8)
 
 
 def _free_port():
@@ -37,13 +42,22 @@ def _worker(rank, world, port, q, restart=30, halo_depth=None):
         run.solver.parameters["krylov_relative_tolerance"] = 1e-11
         run.solver.parameters["krylov_restart"] = restart
         run.initialise()
+        raised, solve = [], run.solver.solve      # (what adaptive_solver's catch-all swallows, for the failure message)
+
+        def logged(*a, **k):
+            try:
+                return solve(*a, **k)
+            except Exception as e:
+                raised.append((repr(e), run.prob.last_report))
+                raise
+        run.solver.solve = logged
         for _ in range(STEPS):
             run.step()
         U = run.prob.get_state()[:run.lm.n_owned]
         stats = run.prob.comm_stats()
         q.put((rank, run.lm.vertex_global[:run.lm.n_owned], U, run.log_rows(), run.global_n,
                (stats["halo_exchanges"], stats["allreduces"], run.linear_iterations, int(run.lm.n_ghost),
-                run.prob.fieldsplit_tiles() is not None)))
+                run.prob.fieldsplit_tiles() is not None, [str(r) for r in raised])))
     finally:
         dist.destroy_process_group()
 
@@ -84,13 +98,18 @@ def test_two_ranks_match_single_gpu(restart, halo_depth, partitioner, monkeypatc
     for _, gids, Uloc, _, _, _ in res:
         U[gids] = Uloc
     scale = np.abs(U_ref).max(axis=0)
-    assert (np.abs(U - U_ref) / scale).max() < 1e-8
+    diff = (np.abs(U - U_ref) / scale).max()
+    if diff >= 1e-8:        # (what a failure is made of, in full: pytest shortens assertion messages)
+        print("per-field max |U - U_ref|:", np.abs(U - U_ref).max(axis=0), "mean signed:", (U - U_ref).mean(axis=0))
+        print("two ranks: log", res[0][3], "stats", res[0][5], "| rank 1 log", res[1][3], "stats", res[1][5])
+        print("one GPU: log", st.log_rows(), "newton", st.newton_iterations, "krylov", st.linear_iterations)
+    assert diff < 1e-8, diff
     ref_log = np.array(st.log_rows())
     for r in res:
         assert np.allclose(np.array(r[3]), ref_log, rtol=1e-6)
     # the deep halo saves the exchanges (Krylov counts at this 1e-11 tolerance end in rounding and vary by tens
     # of per cent between any two runs; at the default tolerances they are those of one GPU: tools/rehearse_multi_rank.sh)
-    halos, _, krylov, n_ghost, tiled = res[0][5]
+    halos, _, krylov, n_ghost, tiled = res[0][5][:5]
     # deep halos: nothing is exchanged between the species sweeps, so they run several per launch on tiles as on
     # one GPU (csrc/fs_tiles.hip); with an exchange before every sweep they cannot
     assert tiled == (halo_depth is None)
