@@ -74,8 +74,9 @@ text = [f"rocprofv3 --pmc (two passes, 8 SQ counters each) on `python3 bench.py 
         f"--family <mesh> --no-cpu-baseline --late-start 0 --second-mesh off --big-mesh 0 --no-glow-discharge`, averages per "
         f"launch; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md).  kernel sources "
         f"{bench.kernel_source_sha()}", ""]
-for W in ("unstructured", "tensor"):
-    for kern in ("assemble_lean3", "residual_lean3"):
+def sq_section(W, kern, title, text):
+    """SQ counters of the kernels whose name contains `kern` on mesh family W, appended to `text`"""
+    if True:
         rows = []
         for d in ("sq1", "sq2"):
             try:
@@ -90,9 +91,9 @@ for W in ("unstructured", "tensor"):
                 v = list(dd.values())
                 rows.append((cname, sum(v) / len(v), len(v)))
         if not rows:
-            continue
+            return
         c = {n: v for n, v, _ in rows}
-        text.append(f"== {kern} kernel on the {W} mesh")
+        text.append(title)
         if "SQ_WAVE_CYCLES" in c:
             wc = c["SQ_WAVE_CYCLES"]
             pct = lambda k: 100.0 * c.get(k, 0.0) / wc
@@ -100,11 +101,23 @@ for W in ("unstructured", "tensor"):
                         f"{pct('SQ_WAIT_INST_ANY'):.1f} % (LDS {pct('SQ_WAIT_INST_LDS'):.1f} %), instruction in flight "
                         f"{pct('SQ_ACTIVE_INST_ANY'):.1f} % (VALU {pct('SQ_ACTIVE_INST_VALU'):.1f} %, LDS {pct('SQ_ACTIVE_INST_LDS'):.1f} %, "
                         f"scalar {pct('SQ_ACTIVE_INST_SCA'):.1f} %)")
-        if "SQ_LDS_IDX_ACTIVE" in c:
+        if c.get("SQ_LDS_IDX_ACTIVE", 0.0) > 0.0:
             text.append(f"LDS bank conflicts: {100.0 * c.get('SQ_LDS_BANK_CONFLICT', 0.0) / c['SQ_LDS_IDX_ACTIVE']:.1f} % of the LDS-array cycles")
         text += [f"{n:32s} {v:16.1f}  (n={k})" for n, v, k in rows]
         text.append("")
+
+
+for W in ("unstructured", "tensor"):
+    for kern in ("assemble_lean3", "residual_lean3"):
+        sq_section(W, kern, f"== {kern} kernel on the {W} mesh", text)
 (prof / f"{tag}_pmc_assembly_sq.txt").write_text("\n".join(text) + "\n")
+# the other kernels of a time step, same passes (the headline mesh)
+step = [text[0].replace("assembly", "step"), "The kernels of a time step besides the assembly, largest shares of the step first (profiles/*_step_sequence.txt).", ""]
+for kern, what in (("fs_tile_sweeps", "species sweeps on tiles (three sweeps a launch)"), ("ell_spmv_kernel", "multigrid cycle: products, sweeps, composite levels"),
+                   ("spmv_dots_kernel", "Jacobian product fused with the Krylov step's dot products"), ("species_planes", "field split set-up behind an assembly"),
+                   ("dense_gemv", "coarsest level: dense inverse"), ("boundary_dirichlet", "boundary facets + Dirichlet rows")):
+    sq_section("unstructured", kern, f"== {kern}: {what}", step)
+(prof / f"{tag}_pmc_step_kernels_sq.txt").write_text("\n".join(step) + "\n")
 for W, block in res["workloads"].items():
     top = sorted(block["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes_corrected"])[:6]
     for k, v in top:
