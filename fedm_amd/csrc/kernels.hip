@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
                                                    int fs_compact32 = 0, int xcd = 0) {
     constexpr int NEQ2 = NEQ * NEQ;
     // xcd: consecutive slices (neighbours in the Z-curve, sharing most of their x entries) on one XCD
-    const int blk = xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int blk = (xcd & 1) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int wave_id = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave_id >= n_slices) return;  // n_slices: number of slices this launch covers
@@ -970,18 +970,31 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
     double acc[NEQ];
 #pragma unroll
     for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
-    for (int bc = b0; bc < b1; ++bc) {
-        const int col = colidx[(size_t)bc * SLICE + lane];
-        double xj[NEQ];
+    // xcd bit 1: the matrix values by non-temporal loads (launch_spmv: matrices beyond half the Infinity Cache).  Read
+    // once per product, they then neither go through the cache nor push the vectors, the preconditioner's planes and
+    // the multigrid out of it: the 4 M-DOF product 136 -> 123 us (69 -> 76 % of the HBM peak), the 1 M-DOF time step
+    // -2.7 % and the developed streamer's -3.6 % although the product by itself, back to back, slows from 28 to 35 us
+    // there (its 177 MB would have stayed in the cache if nothing else ran).
+    auto products = [&](auto nt_c) {
+        constexpr bool NT = decltype(nt_c)::value;
+        for (int bc = b0; bc < b1; ++bc) {
+            const int col = colidx[(size_t)bc * SLICE + lane];
+            double xj[NEQ];
 #pragma unroll
-        for (int cc = 0; cc < NEQ; ++cc) xj[cc] = x[(size_t)col * NEQ + cc];
-        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+            for (int cc = 0; cc < NEQ; ++cc) xj[cc] = x[(size_t)col * NEQ + cc];
+            const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
 #pragma unroll
-        for (int r = 0; r < NEQ; ++r)
+            for (int r = 0; r < NEQ; ++r)
 #pragma unroll
-            for (int cc = 0; cc < NEQ; ++cc)
-                if (!((ZMASK >> (r * NEQ + cc)) & 1u)) acc[r] += vp[(size_t)(r * NEQ + cc) * SLICE] * xj[cc];
-    }
+                for (int cc = 0; cc < NEQ; ++cc)
+                    if (!((ZMASK >> (r * NEQ + cc)) & 1u)) {
+                        const double *ap = &vp[(size_t)(r * NEQ + cc) * SLICE];
+                        acc[r] += (NT ? __builtin_nontemporal_load(ap) : *ap) * xj[cc];
+                    }
+        }
+    };
+    if (xcd & 2) products(std::true_type{});
+    else products(std::false_type{});
     const size_t vtx = (size_t)slice * SLICE + lane;
     if ((int)vtx >= n_owned) {  // ghost / padding rows belong to someone else (or to nobody)
 #pragma unroll
@@ -1018,6 +1031,18 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n_slices, int n_owned,
     }
 }
 
+// bit 1 of the products' `xcd` argument: the Jacobian's values by non-temporal loads when the matrix is larger than half
+// the Infinity Cache (256 MiB) -- see spmv_kernel; FEDM_SPMV_NT=0 / 1 forces it off / on
+static int spmv_nontemporal(const Ctx &c) {
+    static const int forced = [] {
+        const char *e = std::getenv("FEDM_SPMV_NT");
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    if (forced >= 0) return forced ? 2 : 0;
+    const double bytes = (double)c.pat.total_bc * SLICE * c.neq * c.neq * sizeof(double);
+    return bytes > 128.0 * 1024.0 * 1024.0 ? 2 : 0;
+}
+
 // slice_list != nullptr: only those n_list matrix slices (interior / boundary halves across GPUs)
 void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int *slice_list, int n_list) {
     const int n = slice_list ? n_list : c.pat.n_slices;
@@ -1027,7 +1052,7 @@ void launch_spmv(Ctx &c, const double *x, double *y, bool scale_dinv, const int 
 #define FEDM_SPMV_Z(NEQ, Z)                                                                           \
     hipLaunchKernelGGL((spmv_kernel<NEQ, false, Z>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
                        c.d_colidx, c.d_val, x, y, dinv, (double *)nullptr, (double *)nullptr, 0.0,         \
-                       slice_list, 0, (c.xcd_remap && !slice_list) ? 1 : 0)
+                       slice_list, 0, ((c.xcd_remap && !slice_list) ? 1 : 0) | spmv_nontemporal(c))
 #define FEDM_SPMV(NEQ) FEDM_SPMV_Z(NEQ, 0u)
     switch (c.neq) {
         case 1: FEDM_SPMV(1); break;
@@ -1058,7 +1083,7 @@ void launch_spmv_fieldsplit(Ctx &c, const double *x, double *t, double *z, doubl
 #define FEDM_SPMV_Z(NEQ, Z)                                                                          \
     hipLaunchKernelGGL((spmv_kernel<NEQ, true, Z>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, \
                        c.d_colidx, c.d_val, x, t, c.d_dinv, z, b0, scale, slice_list, compact32 ? 1 : 0,      \
-                       (c.xcd_remap && !slice_list) ? 1 : 0)
+                       ((c.xcd_remap && !slice_list) ? 1 : 0) | spmv_nontemporal(c))
 #define FEDM_SPMV(NEQ) FEDM_SPMV_Z(NEQ, 0u)
     switch (c.neq) {
         case 2: FEDM_SPMV(2); break;
@@ -1307,7 +1332,7 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int n_slices, int n_owne
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         PtrPack8 xs, double *__restrict__ partials, int xcd) {
     constexpr int NEQ2 = NEQ * NEQ;
-    const int blk = xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int blk = (xcd & 1) ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int wave_id = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const bool live = wave_id < n_slices;          // (no early return: the workgroup reduces together)
@@ -1316,18 +1341,31 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int n_slices, int n_owne
     double acc[NEQ];
 #pragma unroll
     for (int r = 0; r < NEQ; ++r) acc[r] = 0.0;
-    for (int bc = b0; bc < b1; ++bc) {
-        const int col = colidx[(size_t)bc * SLICE + lane];
-        double xj[NEQ];
+    // xcd bit 1: the matrix values by non-temporal loads (launch_spmv: matrices beyond half the Infinity Cache).  Read
+    // once per product, they then neither go through the cache nor push the vectors, the preconditioner's planes and
+    // the multigrid out of it: the 4 M-DOF product 136 -> 123 us (69 -> 76 % of the HBM peak), the 1 M-DOF time step
+    // -2.7 % and the developed streamer's -3.6 % although the product by itself, back to back, slows from 28 to 35 us
+    // there (its 177 MB would have stayed in the cache if nothing else ran).
+    auto products = [&](auto nt_c) {
+        constexpr bool NT = decltype(nt_c)::value;
+        for (int bc = b0; bc < b1; ++bc) {
+            const int col = colidx[(size_t)bc * SLICE + lane];
+            double xj[NEQ];
 #pragma unroll
-        for (int cc = 0; cc < NEQ; ++cc) xj[cc] = x[(size_t)col * NEQ + cc];
-        const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
+            for (int cc = 0; cc < NEQ; ++cc) xj[cc] = x[(size_t)col * NEQ + cc];
+            const double *vp = val + (size_t)bc * NEQ2 * SLICE + lane;
 #pragma unroll
-        for (int r = 0; r < NEQ; ++r)
+            for (int r = 0; r < NEQ; ++r)
 #pragma unroll
-            for (int cc = 0; cc < NEQ; ++cc)
-                if (!((ZMASK >> (r * NEQ + cc)) & 1u)) acc[r] += vp[(size_t)(r * NEQ + cc) * SLICE] * xj[cc];
-    }
+                for (int cc = 0; cc < NEQ; ++cc)
+                    if (!((ZMASK >> (r * NEQ + cc)) & 1u)) {
+                        const double *ap = &vp[(size_t)(r * NEQ + cc) * SLICE];
+                        acc[r] += (NT ? __builtin_nontemporal_load(ap) : *ap) * xj[cc];
+                    }
+        }
+    };
+    if (xcd & 2) products(std::true_type{});
+    else products(std::false_type{});
     const size_t vtx = (size_t)slice * SLICE + lane;
     const bool owned = live && (int)vtx < n_owned;
     double d[K];
@@ -1522,7 +1560,7 @@ bool launch_spmv_dots(Ctx &c, const double *x, double *y, const double *const *x
     const dim3 g((n + 3) / 4), b(256);
     PtrPack8 pk;
     for (int i = 0; i < 8; ++i) pk.p[i] = xs[i < k - 1 ? i : 0];
-    const int xcd = c.xcd_remap ? 1 : 0;
+    const int xcd = (c.xcd_remap ? 1 : 0) | spmv_nontemporal(c);
 #define FEDM_SD(Z, K)                                                                                       \
     hipLaunchKernelGGL((spmv_dots_kernel<3, Z, K>), g, b, 0, c.stream, n, c.n_owned, c.d_slice_boff, c.d_colidx, \
                        c.d_val, x, y, pk, c.d_partials_wide, xcd)
